@@ -1,0 +1,242 @@
+/*
+ * sarpro_hip.h -- C ABI of libsarpro_hip.so: the MI355X (gfx950) replacement for
+ * sarpro's per-pixel raster core (reference: bogwi/sarpro v0.3.0, src/core/processing).
+ *
+ * The reference has no FFI layer: its seam is ordinary Rust calls from save.rs /
+ * api/mod.rs / io/sentinel1.rs into core::processing::{pipeline,autoscale,ops,
+ * synthetic_rgb}.  Each entry point below names the Rust function it replaces
+ * (file:line in the reference tree) -- a Rust `extern "C"` crate binding these
+ * (rust/sarpro-hip-sys) gives save.rs the same call surface.
+ *
+ * Conventions
+ *   - every call returns a status (0 = ok, <0 = error); message via sarpro_hip_last_error
+ *   - rasters are row-major (rows, cols), the layout of ndarray::Array2 / GDAL read_as
+ *     (io/gdal.rs:123-131); all sizes in ELEMENTS; outputs are caller-allocated
+ *   - enum integers are the declaration order of src/types.rs
+ *   - host entry points take HOST pointers (pageable or pinned) and are synchronous;
+ *     `_dev` entry points take DEVICE pointers (+ pitch in elements) and run on the
+ *     context's stream; they return after the result is complete on the device
+ *   - one context per host thread; contexts are independent (no global state)
+ *   - nothing here falls back to a CPU implementation: without a usable HIP device
+ *     ctx_create fails with SARPRO_HIP_ERR_NO_DEVICE
+ *   - `sarpro_hip_host_*` functions are the host half of the path (statistics, LUT and
+ *     CDF construction from device-produced histograms); they need no GPU and are
+ *     exported so the multi-GPU driver and the tests can call them directly
+ */
+#ifndef SARPRO_HIP_H
+#define SARPRO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (reference: infallible fns; callers wrap panics/errors as
+ *      Error::External / Error::Processing, src/error.rs:39-46) ---- */
+#define SARPRO_HIP_OK 0
+#define SARPRO_HIP_ERR_INVALID_ARG (-1)
+#define SARPRO_HIP_ERR_SHAPE_MISMATCH (-2)
+#define SARPRO_HIP_ERR_UNSUPPORTED_SHAPE (-3) /* CLAHE tile underflow sizes where the reference panics (autoscale.rs:250,254) */
+#define SARPRO_HIP_ERR_HIP (-4)
+#define SARPRO_HIP_ERR_RCCL (-5)
+#define SARPRO_HIP_ERR_OOM (-6)
+#define SARPRO_HIP_ERR_NO_DEVICE (-7)
+
+/* ---- src/types.rs discriminants ---- */
+typedef enum { /* types.rs:115-123 */
+    SARPRO_STRATEGY_STANDARD = 0,
+    SARPRO_STRATEGY_ROBUST = 1,
+    SARPRO_STRATEGY_ADAPTIVE = 2,
+    SARPRO_STRATEGY_EQUALIZED = 3,
+    SARPRO_STRATEGY_CLAHE = 4,
+    SARPRO_STRATEGY_TAMED = 5,
+    SARPRO_STRATEGY_DEFAULT = 6
+} sarpro_strategy;
+typedef enum { SARPRO_BITDEPTH_U8 = 0, SARPRO_BITDEPTH_U16 = 1 } sarpro_bitdepth; /* types.rs:170-173 */
+typedef enum { /* types.rs:8-14 */
+    SARPRO_OP_SUM = 0,
+    SARPRO_OP_DIFF = 1,
+    SARPRO_OP_RATIO = 2,
+    SARPRO_OP_NDIFF = 3,
+    SARPRO_OP_LOGRATIO = 4
+} sarpro_polop;
+typedef enum { /* types.rs:177-182 */
+    SARPRO_SYNRGB_DEFAULT = 0,
+    SARPRO_SYNRGB_RGB_RATIO = 1,
+    SARPRO_SYNRGB_SAR_URBAN = 2,
+    SARPRO_SYNRGB_ENHANCED = 3
+} sarpro_synrgb_mode;
+
+/* HistogramStats (autoscale.rs:7-24) + the window the reference only logs
+ * (autoscale.rs:398-401,431-434,485-488,566-569). */
+typedef struct {
+    uint64_t valid_count;
+    double min_db, max_db, mean_db, std_db, median_db;
+    double p01, p02, p05, p10, p25, p75, p90, p95, p98, p99;
+    double low_clip, high_clip, gamma;
+    double skew_factor, tail_heaviness; /* Adaptive only (autoscale.rs:503-504) */
+} sarpro_hip_stats;
+
+typedef struct sarpro_hip_ctx sarpro_hip_ctx;
+
+/* ---- context ---- */
+int sarpro_hip_ctx_create(int device, unsigned flags, sarpro_hip_ctx **ctx_out);
+void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx);
+const char *sarpro_hip_last_error(const sarpro_hip_ctx *ctx); /* ctx may be NULL: last ctx_create error */
+const char *sarpro_hip_version(void);
+/* raw hipStream_t of the context (for callers that enqueue their own work / events) */
+void *sarpro_hip_ctx_stream(sarpro_hip_ctx *ctx);
+int sarpro_hip_ctx_synchronize(sarpro_hip_ctx *ctx);
+
+/* ================= host-pointer entry points (the drop-in seam) ================= */
+
+/* process_scalar_data_pipeline (pipeline.rs:42-67) for an f32 band as GDAL hands it over
+ * (io/gdal.rs:123-131).  U8: fills out_u8 (out_u16 may be NULL); U16: fills out_u16.
+ * The dB buffer / mask the reference also returns are not materialised (callers only
+ * use their dims, save.rs:331; see sarpro_hip_db_mask_f32 for the buffers themselves).
+ * stats_out may be NULL. */
+int sarpro_hip_autoscale_band_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols,
+                                  int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16,
+                                  sarpro_hip_stats *stats_out);
+/* Same function for the u16 DN samples of a full-resolution GRD read (io/gdal.rs:107-141
+ * reads u16 as f32; values are integral), the fast flavour. */
+int sarpro_hip_autoscale_band_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols,
+                                  int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16,
+                                  sarpro_hip_stats *stats_out);
+
+/* process_scalar_data_inplace (pipeline.rs:8-40): db = 10*log10(max(v,1e-10)) as f64,
+ * mask = db > -50.  Either output may be NULL.  db is within 1 ulp(f64) of glibc's. */
+int sarpro_hip_db_mask_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols,
+                           double *db_out, uint8_t *mask_out);
+
+/* autoscale_db_image_tamed_synrgb_u8 (autoscale.rs:710-742); takes the band itself
+ * (the dB buffer is recomputed on the device, never shipped). */
+int sarpro_hip_tamed_synrgb_u8_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols,
+                                   int is_copol, uint8_t *out_u8);
+int sarpro_hip_tamed_synrgb_u8_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols,
+                                   int is_copol, uint8_t *out_u8);
+
+/* sum_arrays / difference_arrays / ratio_arrays / normalized_diff_arrays /
+ * log_ratio_arrays (ops.rs:4-44). */
+int sarpro_hip_polop_f32(sarpro_hip_ctx *ctx, int op, const float *a, const float *b, size_t n,
+                         float *out);
+
+/* create_synthetic_rgb_by_mode_and_strategy (synthetic_rgb.rs:182-197): interleaved RGB,
+ * rgb_out holds 3*n bytes. */
+int sarpro_hip_synrgb_u8(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *band1,
+                         const uint8_t *band2, size_t n, uint8_t *rgb_out);
+
+/* The JPEG/multiband branch of save_processed_multiband_image_sequential at native
+ * resolution (save.rs:317-367): pipeline(band1,U8) -> [Tamed: tamed_synrgb(copol)] ->
+ * pipeline(band2,U8) -> [Tamed: tamed_synrgb(cross-pol)] -> synRGB by strategy, fused on the
+ * device.  rgb_out holds 3*rows*cols bytes; u8_band1/u8_band2 (optional) receive the
+ * per-band u8 rasters that feed the composition; stats_out (optional) is [2]. */
+int sarpro_hip_dualpol_synrgb_u16(sarpro_hip_ctx *ctx, const uint16_t *band1, const uint16_t *band2,
+                                  size_t rows, size_t cols, int strategy, int mode,
+                                  uint8_t *rgb_out, uint8_t *u8_band1, uint8_t *u8_band2,
+                                  sarpro_hip_stats *stats_out);
+int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *band1, const float *band2,
+                                  size_t rows, size_t cols, int strategy, int mode,
+                                  uint8_t *rgb_out, uint8_t *u8_band1, uint8_t *u8_band2,
+                                  sarpro_hip_stats *stats_out);
+
+/* ================= device-pointer entry points ================= */
+/* Same operations on rasters already resident in HBM.  pitch = row stride in elements
+ * (>= cols).  The vectorised kernels need base pointers aligned to 16 bytes and
+ * pitch % 8 == 0; other layouts take the scalar kernels (same results). */
+int sarpro_hip_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows,
+                                      size_t cols, size_t in_pitch, int strategy, int bit_depth,
+                                      void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out);
+int sarpro_hip_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, const float *d_in, size_t rows,
+                                      size_t cols, size_t in_pitch, int strategy, int bit_depth,
+                                      void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out);
+int sarpro_hip_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1,
+                                      const uint16_t *d_band2, size_t rows, size_t cols,
+                                      size_t in_pitch, int strategy, int mode, uint8_t *d_rgb,
+                                      size_t rgb_pitch_px, uint8_t *d_u8_band1, uint8_t *d_u8_band2,
+                                      size_t u8_pitch, sarpro_hip_stats *stats_out);
+int sarpro_hip_polop_f32_dev(sarpro_hip_ctx *ctx, int op, const float *d_a, const float *d_b,
+                             size_t n, float *d_out);
+int sarpro_hip_synrgb_u8_dev(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *d_band1,
+                             const uint8_t *d_band2, size_t n, uint8_t *d_rgb);
+
+/* ---- per-kernel timing of the last *_dev / host call on this context (HIP events on the
+ * context's stream).  names_out receives up to max_entries pointers to static strings. */
+int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **names_out, float *ms_out,
+                                 int max_entries);
+
+/* ================= row-stripe (multi-GPU) protocol ================= */
+/* One scene split into row stripes, one per rank.  Each phase
+ * ends in a small integer reduction that the caller merges across ranks (RCCL
+ * all-reduce(sum) on the returned DEVICE buffers, or sarpro_hip_comm_* below), so the
+ * N-rank result is bit-identical to the 1-rank result. */
+typedef struct sarpro_hip_stripe sarpro_hip_stripe;
+/* rows_total x cols scene; this rank owns rows [row0, row0+rows_local).  d_band1/2 are the
+ * local stripe (rows_local x cols, pitch in elements). */
+int sarpro_hip_stripe_begin_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2,
+                                size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                                size_t in_pitch, int strategy, int mode, sarpro_hip_stripe **out);
+/* phase 1: local DN histograms.  *d_buf: device u64 buffer to all-reduce(sum), *count its length. */
+int sarpro_hip_stripe_phase1(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *count);
+/* phase 2 (CLAHE only; no-op otherwise): local per-tile bin histograms -> all-reduce(sum). */
+int sarpro_hip_stripe_phase2(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *count);
+/* phase 3: apply; local histogram of the pre-rescale u8 levels -> all-reduce(sum). */
+int sarpro_hip_stripe_phase3(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *count);
+/* phase 4: compose the local stripe of the RGB raster (rows_local x cols x 3). */
+int sarpro_hip_stripe_phase4(sarpro_hip_stripe *s, uint8_t *d_rgb, size_t rgb_pitch_px,
+                             sarpro_hip_stats *stats_out);
+void sarpro_hip_stripe_end(sarpro_hip_stripe *s);
+
+/* RCCL communicator owned by the library (optional: callers may reduce the phase buffers
+ * with their own communicator, e.g. torch.distributed's).  uid is the 128-byte
+ * ncclUniqueId produced by sarpro_hip_comm_unique_id on rank 0 and shipped to all ranks. */
+int sarpro_hip_comm_unique_id(uint8_t uid_out[128]);
+int sarpro_hip_comm_init(sarpro_hip_ctx *ctx, int nranks, int rank, const uint8_t uid[128]);
+int sarpro_hip_comm_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);
+void sarpro_hip_comm_destroy(sarpro_hip_ctx *ctx);
+
+/* ================= host half of the path (no GPU needed) ================= */
+/* compute_histogram_stats (autoscale.rs:35-160) from the exact 65536-bin DN histogram of a
+ * u16 band (valid <=> DN >= 1, pipeline.rs:19-22). */
+int sarpro_hip_host_stats_from_dn_hist(const uint64_t dn_hist[65536], sarpro_hip_stats *out);
+/* Strategy window (autoscale.rs:404-429 Standard; :491-564 advanced; :721-729 tamed-synrgb
+ * when tamed_synrgb = 1 copol / 2 crosspol) -> fills low_clip/high_clip/gamma in *stats. */
+int sarpro_hip_host_window(sarpro_hip_stats *stats, int strategy, int tamed_synrgb);
+/* Level of every DN under the window: the u16 the reference's map loop yields
+ * (autoscale.rs:437-447 / :647-655; tamed :731-741), max_val 255 or 65535.  lut[0] = 0. */
+int sarpro_hip_host_level_lut_u16(const sarpro_hip_stats *stats, int bit_depth, int tamed_synrgb,
+                                  uint16_t lut_out[65536]);
+/* CLAHE bin of every DN (autoscale.rs:583-591 then :262-265): 0..255. */
+int sarpro_hip_host_clahe_bin_lut_u16(const sarpro_hip_stats *stats, uint8_t lut_out[65536]);
+/* Clip / redistribute / CDF for all tiles (autoscale.rs:271-302).  tile_hists is
+ * [8*8][256] counts in tile order ty*8+tx; cdfs_out is [64][256] f64. */
+int sarpro_hip_host_clahe_cdfs(const uint64_t *tile_hists, size_t rows, size_t cols,
+                               double *cdfs_out);
+/* scale_u16_to_u8 (autoscale.rs:348-364) as a 256-entry map for levels 0..255 given the
+ * global min / max of the level raster. */
+int sarpro_hip_host_u8_rescale_lut(unsigned min_level, unsigned max_level, uint8_t lut_out[256]);
+/* LUTs of create_synthetic_rgb (synthetic_rgb.rs:20-51) / _suppressed (:92-155, from the
+ * combined 256-bin histogram of both u8 bands).  luts_out = lut_r[256] | lut_g[256] |
+ * lut_b[65536]; floor_out = floor_with_cushion (suppressed) or -1. */
+int sarpro_hip_host_synrgb_luts(int strategy, const uint64_t combined_hist[256], uint64_t n_per_band,
+                                uint8_t *luts_out, int *floor_out);
+/* CLAHE shape check: 0 when the reference's tile arithmetic underflows (autoscale.rs:250,254). */
+int sarpro_hip_host_clahe_shape_ok(size_t rows, size_t cols);
+/* Row-stripe plan: stripes aligned to CLAHE tile rows (tile_h = ceil(rows/8)).
+ * row0_out / nrows_out hold nranks entries. */
+int sarpro_hip_host_stripe_plan(size_t rows, int nranks, size_t *row0_out, size_t *nrows_out);
+
+/* ================= synthetic scene generator (bench / tests) ================= */
+/* counter-based (splitmix64) dual-pol GRD-like scene written
+ * straight into HBM.  q_tables: 2 bands x 4 classes x 65536 u16 inverse-CDF tables
+ * (host pointer).  band in {0,1}. */
+int sarpro_hip_synth_scene_u16_dev(sarpro_hip_ctx *ctx, uint64_t seed, int band,
+                                   const uint16_t *q_tables_host, size_t rows_total, size_t cols,
+                                   size_t row0, size_t rows_local, uint16_t *d_out, size_t pitch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SARPRO_HIP_H */

@@ -1,0 +1,11 @@
+"""sarpro_amd -- MI355X-native (gfx950) per-pixel raster core of bogwi/sarpro.
+
+Product code: HIP kernels + C ABI in csrc/ (libsarpro_hip.so) and this thin host-side
+mirror of the reference interface.  No CPU fallback; the oracle under oracle/ is test
+infrastructure and is never imported from here.
+"""
+from .types import AutoscaleStrategy, BitDepth, PolarizationOperation, SyntheticRgbMode  # noqa: F401
+from .api import (Context, SarproHipError, Stripe, comm_unique_id, host_clahe_bin_lut_u16,  # noqa: F401
+                  host_clahe_cdfs, host_clahe_shape_ok, host_level_lut_u16, host_stats_from_dn_hist,
+                  host_stripe_plan, host_synrgb_luts, host_u8_rescale_lut, host_window)
+from ._lib import Stats  # noqa: F401

@@ -1,0 +1,108 @@
+"""Loads libsarpro_hip.so (the C-ABI boundary) and declares its prototypes.
+
+There is no Python or CPU fallback: if the shared library has not been built the import
+fails, and every raster entry point needs a HIP device (ctx_create fails without one).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsarpro_hip.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_SHAPE_MISMATCH, ERR_UNSUPPORTED_SHAPE = -1, -2, -3
+ERR_HIP, ERR_RCCL, ERR_OOM, ERR_NO_DEVICE = -4, -5, -6, -7
+
+
+class Stats(C.Structure):
+    _fields_ = [("valid_count", C.c_uint64)] + [
+        (n, C.c_double)
+        for n in ("min_db", "max_db", "mean_db", "std_db", "median_db", "p01", "p02", "p05", "p10",
+                  "p25", "p75", "p90", "p95", "p98", "p99", "low_clip", "high_clip", "gamma",
+                  "skew_factor", "tail_heaviness")
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/sarpro_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "sarpro_hip_ctx_create", "sarpro_hip_ctx_destroy", "sarpro_hip_last_error", "sarpro_hip_version",
+    "sarpro_hip_ctx_stream", "sarpro_hip_ctx_synchronize",
+    "sarpro_hip_autoscale_band_f32", "sarpro_hip_autoscale_band_u16", "sarpro_hip_db_mask_f32",
+    "sarpro_hip_tamed_synrgb_u8_f32", "sarpro_hip_tamed_synrgb_u8_u16", "sarpro_hip_polop_f32",
+    "sarpro_hip_synrgb_u8", "sarpro_hip_dualpol_synrgb_u16", "sarpro_hip_dualpol_synrgb_f32",
+    "sarpro_hip_autoscale_band_u16_dev", "sarpro_hip_autoscale_band_f32_dev",
+    "sarpro_hip_dualpol_synrgb_u16_dev", "sarpro_hip_polop_f32_dev", "sarpro_hip_synrgb_u8_dev",
+    "sarpro_hip_last_kernel_times",
+    "sarpro_hip_stripe_begin_u16", "sarpro_hip_stripe_phase1", "sarpro_hip_stripe_phase2",
+    "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end",
+    "sarpro_hip_comm_unique_id", "sarpro_hip_comm_init", "sarpro_hip_comm_allreduce_sum_u64",
+    "sarpro_hip_comm_destroy",
+    "sarpro_hip_host_stats_from_dn_hist", "sarpro_hip_host_window", "sarpro_hip_host_level_lut_u16",
+    "sarpro_hip_host_clahe_bin_lut_u16", "sarpro_hip_host_clahe_cdfs", "sarpro_hip_host_u8_rescale_lut",
+    "sarpro_hip_host_synrgb_luts", "sarpro_hip_host_clahe_shape_ok", "sarpro_hip_host_stripe_plan",
+    "sarpro_hip_synth_scene_u16_dev",
+]
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+        "or make -C sarpro_amd/csrc). sarpro_amd has no fallback implementation.")
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+_S = C.POINTER(Stats)
+
+
+def _proto(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+
+
+_proto("sarpro_hip_ctx_create", _i, _i, C.c_uint, C.POINTER(_vp))
+_proto("sarpro_hip_ctx_destroy", None, _vp)
+_proto("sarpro_hip_last_error", C.c_char_p, _vp)
+_proto("sarpro_hip_version", C.c_char_p)
+_proto("sarpro_hip_ctx_stream", _vp, _vp)
+_proto("sarpro_hip_ctx_synchronize", _i, _vp)
+_proto("sarpro_hip_autoscale_band_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _S)
+_proto("sarpro_hip_autoscale_band_u16", _i, _vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _S)
+_proto("sarpro_hip_db_mask_f32", _i, _vp, _vp, _sz, _sz, _vp, _vp)
+_proto("sarpro_hip_tamed_synrgb_u8_f32", _i, _vp, _vp, _sz, _sz, _i, _vp)
+_proto("sarpro_hip_tamed_synrgb_u8_u16", _i, _vp, _vp, _sz, _sz, _i, _vp)
+_proto("sarpro_hip_polop_f32", _i, _vp, _i, _vp, _vp, _sz, _vp)
+_proto("sarpro_hip_synrgb_u8", _i, _vp, _i, _i, _vp, _vp, _sz, _vp)
+_proto("sarpro_hip_dualpol_synrgb_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _vp, _S)
+_proto("sarpro_hip_dualpol_synrgb_f32", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _vp, _S)
+_proto("sarpro_hip_autoscale_band_u16_dev", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
+_proto("sarpro_hip_autoscale_band_f32_dev", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
+_proto("sarpro_hip_dualpol_synrgb_u16_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _sz, _vp, _vp, _sz, _S)
+_proto("sarpro_hip_polop_f32_dev", _i, _vp, _i, _vp, _vp, _sz, _vp)
+_proto("sarpro_hip_synrgb_u8_dev", _i, _vp, _i, _i, _vp, _vp, _sz, _vp)
+_proto("sarpro_hip_last_kernel_times", _i, _vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i)
+_proto("sarpro_hip_stripe_begin_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, C.POINTER(_vp))
+_proto("sarpro_hip_stripe_phase1", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
+_proto("sarpro_hip_stripe_phase2", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
+_proto("sarpro_hip_stripe_phase3", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
+_proto("sarpro_hip_stripe_phase4", _i, _vp, _vp, _sz, _S)
+_proto("sarpro_hip_stripe_end", None, _vp)
+_proto("sarpro_hip_comm_unique_id", _i, _vp)
+_proto("sarpro_hip_comm_init", _i, _vp, _i, _i, _vp)
+_proto("sarpro_hip_comm_allreduce_sum_u64", _i, _vp, _vp, _sz)
+_proto("sarpro_hip_comm_destroy", None, _vp)
+_proto("sarpro_hip_host_stats_from_dn_hist", _i, _vp, _S)
+_proto("sarpro_hip_host_window", _i, _S, _i, _i)
+_proto("sarpro_hip_host_level_lut_u16", _i, _S, _i, _i, _vp)
+_proto("sarpro_hip_host_clahe_bin_lut_u16", _i, _S, _vp)
+_proto("sarpro_hip_host_clahe_cdfs", _i, _vp, _sz, _sz, _vp)
+_proto("sarpro_hip_host_u8_rescale_lut", _i, C.c_uint, C.c_uint, _vp)
+_proto("sarpro_hip_host_synrgb_luts", _i, _i, _vp, _u64, _vp, C.POINTER(_i))
+_proto("sarpro_hip_host_clahe_shape_ok", _i, _sz, _sz)
+_proto("sarpro_hip_host_stripe_plan", _i, _sz, _i, _vp, _vp)
+_proto("sarpro_hip_synth_scene_u16_dev", _i, _vp, _u64, _i, _vp, _sz, _sz, _sz, _sz, _vp, _sz)

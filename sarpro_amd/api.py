@@ -1,0 +1,358 @@
+"""Host-side mirror of the reference's raster-core interface, over the C ABI.
+
+Function names, argument meaning and error behaviour follow the Rust functions they
+replace (file:line in the reference tree):
+
+    process_scalar_data_pipeline               src/core/processing/pipeline.rs:42
+    process_scalar_data_inplace                pipeline.rs:8
+    autoscale_db_image_tamed_synrgb_u8         autoscale.rs:710
+    sum_arrays / difference_arrays / ratio_arrays /
+    normalized_diff_arrays / log_ratio_arrays  ops.rs:4-44
+    create_synthetic_rgb_by_mode_and_strategy  synthetic_rgb.rs:182
+    save_multiband JPEG branch (native res)    save.rs:317-367  -> dualpol_synrgb
+
+numpy arrays in, numpy arrays out (host entry points).  `Context.dev_*` methods take device
+pointers (e.g. torch.Tensor.data_ptr()) for rasters already resident in HBM.
+All raster work runs in libsarpro_hip.so on the GPU; nothing here computes pixels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Stats, lib
+from .types import AutoscaleStrategy, BitDepth, PolarizationOperation, SyntheticRgbMode
+
+
+class SarproHipError(RuntimeError):
+    """Maps a non-zero C-ABI status (reference: Error::Processing / Error::External, src/error.rs:39-46)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"sarpro_hip status {code}: {msg}")
+        self.code = code
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))
+
+
+class Context:
+    """One sarpro_hip_ctx: a device, a stream, a grow-only workspace.  One per host thread."""
+
+    def __init__(self, device: int = 0, timing: bool = False):
+        h = C.c_void_p()
+        rc = lib.sarpro_hip_ctx_create(device, 1 if timing else 0, C.byref(h))
+        if rc != _lib.OK:
+            raise SarproHipError(rc, (lib.sarpro_hip_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sarpro_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc: int):
+        if rc != _lib.OK:
+            raise SarproHipError(rc, (lib.sarpro_hip_last_error(self._h) or b"").decode())
+
+    @property
+    def stream(self) -> int:
+        return lib.sarpro_hip_ctx_stream(self._h) or 0
+
+    def synchronize(self):
+        self._chk(lib.sarpro_hip_ctx_synchronize(self._h))
+
+    def last_kernel_times(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = lib.sarpro_hip_last_kernel_times(self._h, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
+
+    # ------------------------------------------------------------------ pipeline.rs:42
+    def process_scalar_data_pipeline(self, processed: np.ndarray, bit_depth: BitDepth,
+                                     strategy: AutoscaleStrategy, want_stats: bool = False):
+        """Returns (scaled_u8, scaled_u16) like the reference's last two tuple members:
+        U8 -> (u8[rows,cols], None); U16 -> (empty u8, u16[rows,cols]).  The dB buffer and
+        mask the reference also returns are not materialised (see process_scalar_data_inplace)."""
+        if processed.ndim != 2:
+            raise ValueError("processed must be 2-D (rows, cols)")
+        rows, cols = processed.shape
+        st = Stats()
+        out8 = np.empty((rows, cols), np.uint8) if bit_depth == BitDepth.U8 else None
+        out16 = np.empty((rows, cols), np.uint16) if bit_depth == BitDepth.U16 else None
+        if processed.dtype == np.uint16:
+            x = np.ascontiguousarray(processed)
+            fn = lib.sarpro_hip_autoscale_band_u16
+        else:
+            x = np.ascontiguousarray(processed, np.float32)
+            fn = lib.sarpro_hip_autoscale_band_f32
+        self._chk(fn(self._h, _vp(x), rows, cols, int(strategy), int(bit_depth), _vp(out8), _vp(out16), C.byref(st)))
+        res = (out8, None) if bit_depth == BitDepth.U8 else (np.empty(0, np.uint8), out16)
+        return res + (st,) if want_stats else res
+
+    # ------------------------------------------------------------------ pipeline.rs:8
+    def process_scalar_data_inplace(self, processed: np.ndarray):
+        x = np.ascontiguousarray(processed, np.float32)
+        rows, cols = x.shape
+        db = np.empty((rows, cols), np.float64)
+        mask = np.empty((rows, cols), np.uint8)
+        self._chk(lib.sarpro_hip_db_mask_f32(self._h, _vp(x), rows, cols, _vp(db), _vp(mask)))
+        return db, mask.astype(bool)
+
+    # ------------------------------------------------------------------ autoscale.rs:710
+    def autoscale_db_image_tamed_synrgb_u8(self, band: np.ndarray, is_copol: bool) -> np.ndarray:
+        """Takes the band (u16 or f32), not the dB buffer: dB is recomputed on the device."""
+        rows, cols = band.shape
+        out = np.empty((rows, cols), np.uint8)
+        if band.dtype == np.uint16:
+            self._chk(lib.sarpro_hip_tamed_synrgb_u8_u16(self._h, _vp(np.ascontiguousarray(band)), rows, cols, int(is_copol), _vp(out)))
+        else:
+            x = np.ascontiguousarray(band, np.float32)
+            self._chk(lib.sarpro_hip_tamed_synrgb_u8_f32(self._h, _vp(x), rows, cols, int(is_copol), _vp(out)))
+        return out
+
+    # ------------------------------------------------------------------ ops.rs
+    def _polop(self, op: PolarizationOperation, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        if a.shape != b.shape:
+            raise SarproHipError(_lib.ERR_SHAPE_MISMATCH, "operand shapes differ")
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        out = np.empty(a.shape, np.float32)
+        self._chk(lib.sarpro_hip_polop_f32(self._h, int(op), _vp(a), _vp(b), a.size, _vp(out)))
+        return out
+
+    def sum_arrays(self, a, b):
+        return self._polop(PolarizationOperation.Sum, a, b)
+
+    def difference_arrays(self, a, b):
+        return self._polop(PolarizationOperation.Diff, a, b)
+
+    def ratio_arrays(self, a, b):
+        return self._polop(PolarizationOperation.Ratio, a, b)
+
+    def normalized_diff_arrays(self, a, b):
+        return self._polop(PolarizationOperation.NDiff, a, b)
+
+    def log_ratio_arrays(self, a, b):
+        return self._polop(PolarizationOperation.LogRatio, a, b)
+
+    # ------------------------------------------------------------------ synthetic_rgb.rs:182
+    def create_synthetic_rgb_by_mode_and_strategy(self, mode: SyntheticRgbMode, strategy: AutoscaleStrategy,
+                                                  band1_data: np.ndarray, band2_data: np.ndarray) -> np.ndarray:
+        if band1_data.size != band2_data.size:
+            raise SarproHipError(_lib.ERR_SHAPE_MISMATCH, "band lengths differ")  # debug_assert_eq!, synthetic_rgb.rs:11,89
+        b1 = np.ascontiguousarray(band1_data, np.uint8)
+        b2 = np.ascontiguousarray(band2_data, np.uint8)
+        rgb = np.empty(b1.shape + (3,), np.uint8)
+        self._chk(lib.sarpro_hip_synrgb_u8(self._h, int(mode), int(strategy), _vp(b1), _vp(b2), b1.size, _vp(rgb)))
+        return rgb
+
+    # ------------------------------------------------------------------ save.rs:317-367
+    def dualpol_synrgb(self, band1: np.ndarray, band2: np.ndarray, strategy: AutoscaleStrategy,
+                       mode: SyntheticRgbMode = SyntheticRgbMode.Default, want_u8: bool = False,
+                       want_stats: bool = False):
+        if band1.shape != band2.shape or band1.ndim != 2:
+            raise SarproHipError(_lib.ERR_SHAPE_MISMATCH, "band shapes differ")
+        rows, cols = band1.shape
+        rgb = np.empty((rows, cols, 3), np.uint8)
+        u1 = np.empty((rows, cols), np.uint8) if want_u8 else None
+        u2 = np.empty((rows, cols), np.uint8) if want_u8 else None
+        st = (Stats * 2)()
+        if band1.dtype == np.uint16 and band2.dtype == np.uint16:
+            fn, dt = lib.sarpro_hip_dualpol_synrgb_u16, np.uint16
+        else:
+            fn, dt = lib.sarpro_hip_dualpol_synrgb_f32, np.float32
+        b1 = np.ascontiguousarray(band1, dt)
+        b2 = np.ascontiguousarray(band2, dt)
+        self._chk(fn(self._h, _vp(b1), _vp(b2), rows, cols, int(strategy), int(mode), _vp(rgb), _vp(u1), _vp(u2), st))
+        out = (rgb,)
+        if want_u8:
+            out += (u1, u2)
+        if want_stats:
+            out += ([st[0], st[1]],)
+        return out if len(out) > 1 else rgb
+
+    # ------------------------------------------------------------------ device-pointer variants
+    def dev_autoscale_band_u16(self, d_in: int, rows: int, cols: int, in_pitch: int, strategy, bit_depth,
+                               d_out: int, out_pitch: int) -> Stats:
+        st = Stats()
+        self._chk(lib.sarpro_hip_autoscale_band_u16_dev(self._h, _vp(d_in), rows, cols, in_pitch, int(strategy),
+                                                        int(bit_depth), _vp(d_out), out_pitch, C.byref(st)))
+        return st
+
+    def dev_autoscale_band_f32(self, d_in: int, rows: int, cols: int, in_pitch: int, strategy, bit_depth,
+                               d_out: int, out_pitch: int) -> Stats:
+        st = Stats()
+        self._chk(lib.sarpro_hip_autoscale_band_f32_dev(self._h, _vp(d_in), rows, cols, in_pitch, int(strategy),
+                                                        int(bit_depth), _vp(d_out), out_pitch, C.byref(st)))
+        return st
+
+    def dev_dualpol_synrgb_u16(self, d_b1: int, d_b2: int, rows: int, cols: int, in_pitch: int, strategy, mode,
+                               d_rgb: int, rgb_pitch_px: int, d_u8_1: int | None = None, d_u8_2: int | None = None,
+                               u8_pitch: int = 0):
+        st = (Stats * 2)()
+        self._chk(lib.sarpro_hip_dualpol_synrgb_u16_dev(self._h, _vp(d_b1), _vp(d_b2), rows, cols, in_pitch,
+                                                        int(strategy), int(mode), _vp(d_rgb), rgb_pitch_px,
+                                                        _vp(d_u8_1), _vp(d_u8_2), u8_pitch, st))
+        return [st[0], st[1]]
+
+    def dev_polop_f32(self, op, d_a: int, d_b: int, n: int, d_out: int):
+        self._chk(lib.sarpro_hip_polop_f32_dev(self._h, int(op), _vp(d_a), _vp(d_b), n, _vp(d_out)))
+
+    def dev_synrgb_u8(self, mode, strategy, d_b1: int, d_b2: int, n: int, d_rgb: int):
+        self._chk(lib.sarpro_hip_synrgb_u8_dev(self._h, int(mode), int(strategy), _vp(d_b1), _vp(d_b2), n, _vp(d_rgb)))
+
+    def dev_synth_scene_u16(self, seed: int, band: int, q_tables: np.ndarray, rows_total: int, cols: int,
+                            row0: int, rows_local: int, d_out: int, pitch: int):
+        q = np.ascontiguousarray(q_tables, np.uint16)
+        assert q.shape == (2, 4, 65536)
+        self._chk(lib.sarpro_hip_synth_scene_u16_dev(self._h, seed, band, _vp(q), rows_total, cols, row0, rows_local,
+                                                     _vp(d_out), pitch))
+
+    # ------------------------------------------------------------------ row-stripe protocol
+    def stripe_begin_u16(self, d_b1: int, d_b2: int, rows_total: int, cols: int, row0: int, rows_local: int,
+                         in_pitch: int, strategy, mode) -> "Stripe":
+        h = C.c_void_p()
+        self._chk(lib.sarpro_hip_stripe_begin_u16(self._h, _vp(d_b1), _vp(d_b2), rows_total, cols, row0, rows_local,
+                                                  in_pitch, int(strategy), int(mode), C.byref(h)))
+        return Stripe(self, h)
+
+    def comm_init(self, nranks: int, rank: int, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._chk(lib.sarpro_hip_comm_init(self._h, nranks, rank, buf))
+
+    def comm_allreduce_sum_u64(self, d_buf: int, count: int):
+        self._chk(lib.sarpro_hip_comm_allreduce_sum_u64(self._h, _vp(d_buf), count))
+
+
+class Stripe:
+    """sarpro_hip_stripe: phases of one row stripe; the caller all-reduces between phases."""
+
+    def __init__(self, ctx: Context, h):
+        self.ctx, self._h = ctx, h
+
+    def _phase(self, fn):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx._chk(fn(self._h, C.byref(p), C.byref(n)))
+        return (p.value or 0), n.value
+
+    def phase1(self):
+        return self._phase(lib.sarpro_hip_stripe_phase1)
+
+    def phase2(self):
+        return self._phase(lib.sarpro_hip_stripe_phase2)
+
+    def phase3(self):
+        return self._phase(lib.sarpro_hip_stripe_phase3)
+
+    def phase4(self, d_rgb: int, rgb_pitch_px: int):
+        st = (Stats * 2)()
+        self.ctx._chk(lib.sarpro_hip_stripe_phase4(self._h, _vp(d_rgb), rgb_pitch_px, st))
+        return [st[0], st[1]]
+
+    def end(self):
+        if self._h:
+            lib.sarpro_hip_stripe_end(self._h)
+            self._h = None
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    rc = lib.sarpro_hip_comm_unique_id(buf)
+    if rc != _lib.OK:
+        raise SarproHipError(rc, "ncclGetUniqueId failed")
+    return bytes(buf)
+
+
+# ---------------------------------------------------------------------- host half (no GPU)
+def host_stats_from_dn_hist(dn_hist: np.ndarray) -> Stats:
+    h = np.ascontiguousarray(dn_hist, np.uint64)
+    assert h.size == 65536
+    st = Stats()
+    rc = lib.sarpro_hip_host_stats_from_dn_hist(_vp(h), C.byref(st))
+    if rc:
+        raise SarproHipError(rc, "host_stats_from_dn_hist")
+    return st
+
+
+def host_window(st: Stats, strategy, tamed_synrgb: int = 0) -> Stats:
+    rc = lib.sarpro_hip_host_window(C.byref(st), int(strategy), tamed_synrgb)
+    if rc:
+        raise SarproHipError(rc, "host_window")
+    return st
+
+
+def host_level_lut_u16(st: Stats, bit_depth, tamed_synrgb: int = 0) -> np.ndarray:
+    lut = np.empty(65536, np.uint16)
+    rc = lib.sarpro_hip_host_level_lut_u16(C.byref(st), int(bit_depth), tamed_synrgb, _vp(lut))
+    if rc:
+        raise SarproHipError(rc, "host_level_lut_u16")
+    return lut
+
+
+def host_clahe_bin_lut_u16(st: Stats) -> np.ndarray:
+    lut = np.empty(65536, np.uint8)
+    rc = lib.sarpro_hip_host_clahe_bin_lut_u16(C.byref(st), _vp(lut))
+    if rc:
+        raise SarproHipError(rc, "host_clahe_bin_lut_u16")
+    return lut
+
+
+def host_clahe_cdfs(tile_hists: np.ndarray, rows: int, cols: int) -> np.ndarray:
+    th = np.ascontiguousarray(tile_hists, np.uint64)
+    assert th.size == 64 * 256
+    cdfs = np.empty((64, 256), np.float64)
+    rc = lib.sarpro_hip_host_clahe_cdfs(_vp(th), rows, cols, _vp(cdfs))
+    if rc:
+        raise SarproHipError(rc, "host_clahe_cdfs")
+    return cdfs
+
+
+def host_u8_rescale_lut(min_level: int, max_level: int) -> np.ndarray:
+    lut = np.empty(256, np.uint8)
+    rc = lib.sarpro_hip_host_u8_rescale_lut(min_level, max_level, _vp(lut))
+    if rc:
+        raise SarproHipError(rc, "host_u8_rescale_lut")
+    return lut
+
+
+def host_synrgb_luts(strategy, combined_hist: np.ndarray | None = None, n_per_band: int = 0):
+    luts = np.empty(66048, np.uint8)
+    fl = C.c_int(-1)
+    h = None if combined_hist is None else np.ascontiguousarray(combined_hist, np.uint64)
+    rc = lib.sarpro_hip_host_synrgb_luts(int(strategy), _vp(h), n_per_band, _vp(luts), C.byref(fl))
+    if rc:
+        raise SarproHipError(rc, "host_synrgb_luts")
+    return luts[:256].copy(), luts[256:512].copy(), luts[512:].reshape(256, 256).copy(), fl.value
+
+
+def host_clahe_shape_ok(rows: int, cols: int) -> bool:
+    return bool(lib.sarpro_hip_host_clahe_shape_ok(rows, cols))
+
+
+def host_stripe_plan(rows: int, nranks: int):
+    r0 = np.empty(nranks, np.uint64)
+    nr = np.empty(nranks, np.uint64)
+    rc = lib.sarpro_hip_host_stripe_plan(rows, nranks, _vp(r0), _vp(nr))
+    if rc:
+        raise SarproHipError(rc, "host_stripe_plan")
+    return [int(x) for x in r0], [int(x) for x in nr]

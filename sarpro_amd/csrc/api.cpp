@@ -1,0 +1,895 @@
+// api.cpp -- C ABI of libsarpro_hip.so: context, work planning and the pass orchestration of
+// the u16 (integer-DN) flavour.  See include/sarpro_hip.h for the reference functions each
+// entry point replaces.  No CPU fallback exists anywhere in this file: every raster result is
+// produced by the kernels in kernels.hip.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "context.h"
+#include "internal.h"
+
+using namespace sarpro;
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+            return e__ == hipErrorOutOfMemory ? SARPRO_HIP_ERR_OOM : SARPRO_HIP_ERR_HIP;          \
+        }                                                                                         \
+    } while (0)
+
+#define RETCHK(expr)                                   \
+    do {                                               \
+        int rc__ = (expr);                             \
+        if (rc__ != SARPRO_HIP_OK) return rc__;        \
+    } while (0)
+
+static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------
+// timing helpers (HIP events on the context's stream)
+// ---------------------------------------------------------------------------------------
+namespace sarpro {
+
+void timing_reset(sarpro_hip_ctx *ctx) {
+    ctx->times.clear();
+    ctx->events_used = 0;
+}
+
+static hipEvent_t next_event(sarpro_hip_ctx *ctx) {
+    if (ctx->events_used == ctx->event_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->event_pool.push_back(e);
+    }
+    return ctx->event_pool[ctx->events_used++];
+}
+
+KernelTimer::KernelTimer(sarpro_hip_ctx *c, const char *name) : ctx(c) {
+    if (!ctx->timing) return;
+    KernelTime t{name, next_event(ctx), next_event(ctx)};
+    if (!t.start || !t.stop) return;
+    (void)hipEventRecord(t.start, ctx->stream);
+    ctx->times.push_back(t);
+    active = true;
+}
+KernelTimer::~KernelTimer() {
+    if (active) (void)hipEventRecord(ctx->times.back().stop, ctx->stream);
+}
+
+size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+} // namespace sarpro
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+extern "C" const char *sarpro_hip_version(void) { return "sarpro-hip 0.1 (gfx950)"; }
+
+extern "C" int sarpro_hip_ctx_create(int device, unsigned flags, sarpro_hip_ctx **out) {
+    if (!out) return SARPRO_HIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return SARPRO_HIP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return SARPRO_HIP_ERR_INVALID_ARG; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = hipGetErrorString(e); return SARPRO_HIP_ERR_HIP; }
+    sarpro_hip_ctx *ctx = new sarpro_hip_ctx();
+    ctx->device = device;
+    ctx->flags = flags;
+    ctx->timing = (flags & 1u) != 0;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_err = hipGetErrorString(e);
+        delete ctx;
+        return SARPRO_HIP_ERR_HIP;
+    }
+    (void)db_table_u16(); // build the constant dB table once, outside any timed region
+    *out = ctx;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" void sarpro_hip_comm_destroy(sarpro_hip_ctx *ctx);
+
+extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    sarpro_hip_comm_destroy(ctx);
+    for (auto &kv : ctx->plans) {
+        StripePlan *p = kv.second;
+        p->d_hist_rects_tiled.release(); p->d_hist_rects_flat.release(); p->d_apply_rects.release();
+        p->d_row_w.release(); p->d_col_w.release();
+        delete p;
+    }
+    for (int b = 0; b < kMaxBands; ++b) { ctx->tile_hist[b].release(); ctx->levels[b].release(); ctx->stage_in[b].release(); }
+    for (auto &b : ctx->stage_out) b.release();
+    ctx->ghist.release(); ctx->tile_bins.release(); ctx->cdfs.release(); ctx->luts.release();
+    ctx->level_hist.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
+    ctx->h_ghist.release(); ctx->h_small.release(); ctx->h_upload.release();
+    for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *sarpro_hip_last_error(const sarpro_hip_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+extern "C" void *sarpro_hip_ctx_stream(sarpro_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int sarpro_hip_ctx_synchronize(sarpro_hip_ctx *ctx) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **names, float *ms, int max_entries) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    int n = 0;
+    for (const KernelTime &t : ctx->times) {
+        if (n >= max_entries) break;
+        float v = 0.f;
+        if (hipEventSynchronize(t.stop) != hipSuccess || hipEventElapsedTime(&v, t.start, t.stop) != hipSuccess) v = -1.f;
+        if (names) names[n] = t.name;
+        if (ms) ms[n] = v;
+        ++n;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------
+// planning: split a stripe into work items
+// ---------------------------------------------------------------------------------------
+namespace sarpro {
+
+static void add_rects(std::vector<Rect> &out, const StripePlan &P, size_t gr0, size_t gr1, size_t c0, size_t c1,
+                      const int ids[4], size_t chunk_rows, int vecw) {
+    const size_t lo = std::max(gr0, P.row0), hi = std::min(gr1, P.row0 + P.rows_local);
+    if (lo >= hi || c0 >= c1) return;
+    const size_t strip = 64 * (size_t)vecw;
+    for (size_t cs = c0 / vecw * vecw; cs < c1; cs += strip) {
+        Rect r{};
+        r.c0 = (int32_t)std::max(c0, cs);
+        r.c1 = (int32_t)std::min(c1, cs + strip);
+        r.cstart = (int32_t)cs;
+        for (int k = 0; k < 4; ++k) r.id[k] = ids[k];
+        for (size_t rr = lo; rr < hi; rr += chunk_rows) {
+            r.r0 = (int32_t)(rr - P.row0);
+            r.r1 = (int32_t)(std::min(rr + chunk_rows, hi) - P.row0);
+            out.push_back(r);
+        }
+    }
+}
+
+static int upload_vec(sarpro_hip_ctx *ctx, DevBuf &d, const void *src, size_t bytes) {
+    if (!bytes) return SARPRO_HIP_OK;
+    HIPCHK(ctx, d.reserve(bytes));
+    HIPCHK(ctx, hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // src may be a temporary
+    return SARPRO_HIP_OK;
+}
+
+int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, bool vec,
+             StripePlan **out) {
+    auto key = std::make_tuple(rows_total, cols, row0, rows_local, vec);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) { *out = it->second; return SARPRO_HIP_OK; }
+    if (ctx->plans.size() > 16) { // bounded cache
+        for (auto &kv : ctx->plans) {
+            StripePlan *p = kv.second;
+            p->d_hist_rects_tiled.release(); p->d_hist_rects_flat.release(); p->d_apply_rects.release();
+            p->d_row_w.release(); p->d_col_w.release();
+            delete p;
+        }
+        ctx->plans.clear();
+    }
+    StripePlan *P = new StripePlan();
+    P->rows_total = rows_total; P->cols = cols; P->row0 = row0; P->rows_local = rows_local; P->vec = vec;
+    build_clahe_geometry(rows_total, cols, &P->geom);
+    const int vecw = vec ? 8 : 1;
+    const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
+    const size_t target_items = 4096;
+    const size_t chunk_rows = std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items);
+    const ClaheGeometry &g = P->geom;
+    for (size_t ty = 0; ty < (size_t)kTiles; ++ty) {
+        const size_t r0 = std::min(ty * g.tile_h, rows_total), r1 = std::min((ty + 1) * g.tile_h, rows_total);
+        for (size_t tx = 0; tx < (size_t)kTiles; ++tx) {
+            const size_t c0 = std::min(tx * g.tile_w, cols), c1 = std::min((tx + 1) * g.tile_w, cols);
+            const int ids[4] = {(int)(ty * kTiles + tx), 0, 0, 0};
+            add_rects(P->hist_rects_tiled, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
+        }
+    }
+    {
+        const int ids[4] = {0, 0, 0, 0};
+        add_rects(P->hist_rects_flat, *P, 0, rows_total, 0, cols, ids, chunk_rows, vecw);
+    }
+    for (size_t ri = 0; ri + 1 < g.row_cell_start.size(); ++ri) {
+        const size_t r0 = g.row_cell_start[ri], r1 = g.row_cell_start[ri + 1];
+        const RowWeight &rw = g.row_w[r0];
+        for (size_t ci = 0; ci + 1 < g.col_cell_start.size(); ++ci) {
+            const size_t c0 = g.col_cell_start[ci], c1 = g.col_cell_start[ci + 1];
+            const RowWeight &cw = g.col_w[c0];
+            const int ids[4] = {rw.t0 * kTiles + cw.t0, rw.t0 * kTiles + cw.t1, rw.t1 * kTiles + cw.t0,
+                                rw.t1 * kTiles + cw.t1};
+            add_rects(P->apply_rects, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
+        }
+    }
+    int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_row_w, g.row_w.data(), g.row_w.size() * sizeof(RowWeight));
+    if (!rc) rc = upload_vec(ctx, P->d_col_w, g.col_w.data(), g.col_w.size() * sizeof(RowWeight));
+    if (rc) {
+        P->d_hist_rects_tiled.release(); P->d_hist_rects_flat.release(); P->d_apply_rects.release();
+        P->d_row_w.release(); P->d_col_w.release();
+        delete P;
+        return rc;
+    }
+    ctx->plans[key] = P;
+    *out = P;
+    return SARPRO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The u16 pipeline as explicit phases (also the row-stripe protocol: each phase ends in a
+// small integer reduction that a multi-rank driver all-reduces before the next phase).
+// ---------------------------------------------------------------------------------------
+struct U16Job {
+    sarpro_hip_ctx *ctx = nullptr;
+    int nbands = 1;
+    const uint16_t *d_in[kMaxBands] = {nullptr, nullptr};
+    size_t rows_total = 0, cols = 0, row0 = 0, rows_local = 0, in_pitch = 0;
+    int strategy = 0, bit_depth = 0, mode = 0;
+    bool synrgb = false; // dual-pol JPEG branch (save.rs:317-367): always U8, Tamed uses tamed_synrgb
+    int tamed_force = 0; // single band tamed_synrgb entry point: 1 copol, 2 crosspol
+    bool vec = false;
+    StripePlan *plan = nullptr;
+    // host-side state between phases
+    sarpro_hip_stats stats[kMaxBands];
+    DnLut lut[kMaxBands];
+    uint8_t resc[kMaxBands][256];
+    bool resc_identity[kMaxBands] = {true, true};
+    uint64_t level_hist_h[kMaxBands][256];
+    int floor_with_cushion = -1;
+    // level rasters (u8) when an intermediate is needed
+    uint8_t *d_levels[kMaxBands] = {nullptr, nullptr};
+    size_t lvl_pitch = 0;
+
+    bool clahe() const { return strategy == SARPRO_STRATEGY_CLAHE; }
+    int tamed_kind(int band) const {
+        if (tamed_force) return tamed_force;
+        if (synrgb && strategy == SARPRO_STRATEGY_TAMED) return band == 0 ? kTamedCopol : kTamedCrosspol;
+        return kNotTamedSynrgb;
+    }
+    bool u8_out() const { return synrgb || tamed_force || bit_depth == SARPRO_BITDEPTH_U8; }
+};
+
+static bool ptr_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int job_init(U16Job &J) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    if (J.strategy < 0 || J.strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (J.bit_depth != SARPRO_BITDEPTH_U8 && J.bit_depth != SARPRO_BITDEPTH_U16)
+        return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if (J.mode < 0 || J.mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
+    if (J.in_pitch < J.cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    if (J.rows_total > 0x7FFFFFFFull || J.cols > 0x7FFFFFFFull) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "raster too large");
+    if (J.row0 + J.rows_local > J.rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "stripe outside the scene");
+    if (J.clahe() && !clahe_shape_ok(J.rows_total, J.cols))
+        return fail(ctx, SARPRO_HIP_ERR_UNSUPPORTED_SHAPE,
+                    "CLAHE tile arithmetic underflows for this shape (reference panics: autoscale.rs:250,254)");
+    J.vec = J.in_pitch % 8 == 0;
+    for (int b = 0; b < J.nbands; ++b) J.vec = J.vec && ptr_aligned16(J.d_in[b]);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return get_plan(ctx, J.rows_total, J.cols, J.row0, J.rows_local, J.vec, &J.plan);
+}
+
+// phase 1: local DN histograms -> ctx->ghist (u64 [nbands][65536]) on the device
+static int job_phase1(U16Job &J) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    const bool tiled = J.clahe();
+    const int ntiles = tiled ? kTiles * kTiles : 1;
+    HIPCHK(ctx, ctx->ghist.reserve(sizeof(uint64_t) * 65536 * kMaxBands));
+    DnHistArgs a{};
+    for (int b = 0; b < J.nbands; ++b) {
+        HIPCHK(ctx, ctx->tile_hist[b].reserve(sizeof(uint32_t) * 65536 * (size_t)ntiles));
+        HIPCHK(ctx, hipMemsetAsync(ctx->tile_hist[b].p, 0, sizeof(uint32_t) * 65536 * (size_t)ntiles, ctx->stream));
+        a.in[b] = J.d_in[b];
+        a.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+    }
+    a.pitch = J.in_pitch;
+    a.rects = (tiled ? J.plan->d_hist_rects_tiled : J.plan->d_hist_rects_flat).as<Rect>();
+    a.lds_bins = 8192;
+    const int nrects = (int)(tiled ? J.plan->hist_rects_tiled.size() : J.plan->hist_rects_flat.size());
+    {
+        KernelTimer t(ctx, "dn_hist_u16");
+        HIPCHK(ctx, launch_dn_hist_u16(a, nrects, J.nbands, J.vec, ctx->stream));
+    }
+    for (int b = 0; b < J.nbands; ++b) {
+        KernelTimer t(ctx, "sum_tile_hists");
+        HIPCHK(ctx, launch_sum_tile_hists(ctx->tile_hist[b].as<uint32_t>(), ntiles,
+                                          ctx->ghist.as<unsigned long long>() + (size_t)b * 65536, ctx->stream));
+    }
+    return SARPRO_HIP_OK;
+}
+
+// after the (optional) all-reduce of ghist: stats, window, DN tables
+static int job_after_phase1(U16Job &J) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    const size_t bytes = sizeof(uint64_t) * 65536 * (size_t)J.nbands;
+    HIPCHK(ctx, ctx->h_ghist.reserve(sizeof(uint64_t) * 65536 * kMaxBands));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_ghist.p, ctx->ghist.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
+    HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
+    for (int b = 0; b < J.nbands; ++b) {
+        const uint64_t *h = ctx->h_ghist.as<uint64_t>() + (size_t)b * 65536;
+        RETCHK(stats_from_dn_hist(h, &J.stats[b]));
+        RETCHK(select_window(&J.stats[b], J.strategy, J.tamed_kind(b)));
+        if (J.clahe()) build_clahe_bin_lut_u16(J.stats[b], &J.lut[b]);
+        else build_level_lut_u16(J.stats[b], J.u8_out() ? SARPRO_BITDEPTH_U8 : SARPRO_BITDEPTH_U16, J.tamed_kind(b), &J.lut[b]);
+
+        if (!J.clahe() && J.u8_out()) {
+            // levels are a function of DN: their histogram, min and max follow from the DN histogram
+            std::memset(J.level_hist_h[b], 0, sizeof(J.level_hist_h[b]));
+            for (uint32_t dn = 0; dn < 65536; ++dn)
+                if (h[dn]) J.level_hist_h[b][dn ? J.lut[b].full[dn] : 0] += h[dn];
+        }
+    }
+    return SARPRO_HIP_OK;
+}
+
+// u8 rescale (autoscale.rs:348-364) from the level histogram; tamed_synrgb has none (:731-741)
+static void job_rescale_from_level_hist(U16Job &J, int b) {
+    if (J.tamed_kind(b) != kNotTamedSynrgb) {
+        for (int i = 0; i < 256; ++i) J.resc[b][i] = (uint8_t)i;
+        J.resc_identity[b] = true;
+        return;
+    }
+    unsigned mn = 0, mx = 0;
+    bool any = false;
+    for (unsigned i = 0; i < 256; ++i)
+        if (J.level_hist_h[b][i]) { if (!any) mn = i; mx = i; any = true; }
+    u8_rescale_lut(mn, mx, J.resc[b]);
+    J.resc_identity[b] = true;
+    for (unsigned i = 0; i < 256; ++i)
+        if (J.level_hist_h[b][i] && J.resc[b][i] != i) J.resc_identity[b] = false;
+}
+
+// phase 2 (CLAHE): per-tile bin histograms -> ctx->tile_bins (u64 [nbands][64][256])
+static int job_phase2(U16Job &J) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    if (!J.clahe()) return SARPRO_HIP_OK;
+    HIPCHK(ctx, ctx->tile_bins.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands));
+    for (int b = 0; b < J.nbands; ++b) {
+        uint8_t *stage = ctx->h_upload.as<uint8_t>() + (size_t)b * 65536;
+        for (int i = 0; i < 65536; ++i) stage[i] = (uint8_t)J.lut[b].full[i];
+        HIPCHK(ctx, hipMemcpyAsync(ctx->luts.as<uint8_t>() + (size_t)b * 131072, stage, 65536, hipMemcpyHostToDevice, ctx->stream));
+        KernelTimer t(ctx, "tile_bin_hist");
+        HIPCHK(ctx, launch_tile_bin_hist(ctx->tile_hist[b].as<uint32_t>(), kTiles * kTiles,
+                                         ctx->luts.as<uint8_t>() + (size_t)b * 131072,
+                                         ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256, ctx->stream));
+    }
+    return SARPRO_HIP_OK;
+}
+
+static int ensure_levels(U16Job &J) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    J.lvl_pitch = round_up(J.cols, 64);
+    for (int b = 0; b < J.nbands; ++b) {
+        HIPCHK(ctx, ctx->levels[b].reserve(J.lvl_pitch * std::max<size_t>(J.rows_local, 1)));
+        J.d_levels[b] = ctx->levels[b].as<uint8_t>();
+    }
+    return SARPRO_HIP_OK;
+}
+
+// phase 3: apply.  d_out[b] (+ out_pitch) receive the per-band raster when the caller wants it
+// (single-band entry points: the final raster; dual-pol: optional u8 copies, may be null).
+// Leaves the u8 level histogram in ctx->level_hist (CLAHE u8) for the reduction.
+static int job_phase3(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    const bool u8o = J.u8_out();
+    HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
+    if (J.clahe()) {
+        // CDFs from the (reduced) tile histograms
+        const size_t tb_bytes = sizeof(uint64_t) * 64 * 256 * (size_t)J.nbands;
+        HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_small.p, ctx->tile_bins.p, tb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, ctx->cdfs.reserve(sizeof(double) * 64 * 256 * kMaxBands));
+        double *h_cdfs = reinterpret_cast<double *>(ctx->h_upload.as<uint8_t>() + 2 * 131072);
+        for (int b = 0; b < J.nbands; ++b)
+            RETCHK(clahe_cdfs(ctx->h_small.as<uint64_t>() + (size_t)b * 64 * 256, J.rows_total, J.cols, h_cdfs + (size_t)b * 64 * 256));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->cdfs.p, h_cdfs, sizeof(double) * 64 * 256 * (size_t)J.nbands, hipMemcpyHostToDevice, ctx->stream));
+
+        ClaheApplyArgs a{};
+        const bool direct = !J.synrgb && d_out[0] != nullptr; // single band: write the caller's raster
+        if (!direct) RETCHK(ensure_levels(J));
+        size_t win_max = 0;
+        for (int b = 0; b < J.nbands; ++b) {
+            a.in[b] = J.d_in[b];
+            a.out[b] = direct ? d_out[b] : (void *)J.d_levels[b];
+            a.cdfs[b] = ctx->cdfs.as<double>() + (size_t)b * 64 * 256;
+            a.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+            a.win_lo[b] = J.lut[b].win_lo;
+            a.win_hi[b] = J.lut[b].win_hi;
+            win_max = std::max<size_t>(win_max, J.lut[b].win_hi - J.lut[b].win_lo + 1);
+            a.level_hist[b] = u8o ? ctx->level_hist.as<unsigned long long>() + (size_t)b * 256 : nullptr;
+        }
+        a.in_pitch = J.in_pitch;
+        a.out_pitch = direct ? out_pitch : J.lvl_pitch;
+        a.rects = J.plan->d_apply_rects.as<Rect>();
+        a.lut_in_lds = win_max <= kLutLdsMaxBytes;
+        a.row_w = J.plan->d_row_w.as<RowWeight>();
+        a.col_w = J.plan->d_col_w.as<RowWeight>();
+        a.row_off = (int32_t)J.row0;
+        a.max_val = u8o ? 255.0 : 65535.0;
+        if (u8o) HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
+        const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out[0]) && (J.nbands < 2 || ptr_aligned16(a.out[1]));
+        if (vec != J.vec) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
+        KernelTimer t(ctx, "clahe_apply_u16");
+        HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, J.vec, !u8o, ctx->stream));
+        return SARPRO_HIP_OK;
+    }
+    // percentile strategies: the level histogram is known on the host already; publish it on the
+    // device too so the stripe protocol reduces the same buffer in both modes
+    if (u8o) {
+        uint64_t *stage = reinterpret_cast<uint64_t *>(ctx->h_upload.as<uint8_t>() + 2 * 131072);
+        for (int b = 0; b < J.nbands; ++b) std::memcpy(stage + (size_t)b * 256, J.level_hist_h[b], sizeof(uint64_t) * 256);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->level_hist.p, stage, sizeof(uint64_t) * 256 * (size_t)J.nbands, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return SARPRO_HIP_OK;
+}
+
+// phase 4: finish.  Single band: final raster into d_out[0].  Dual-pol: RGB into d_rgb and
+// (optionally) the per-band u8 rasters into d_out[b].
+static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
+                      bool level_hist_reduced_on_device) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    const bool u8o = J.u8_out();
+    const uint32_t rows = (uint32_t)J.rows_local, cols = (uint32_t)J.cols;
+
+    if (u8o && (J.clahe() || level_hist_reduced_on_device)) {
+        HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
+        uint64_t *h = ctx->h_small.as<uint64_t>() + 64 * 256 * kMaxBands;
+        HIPCHK(ctx, hipMemcpyAsync(h, ctx->level_hist.p, sizeof(uint64_t) * 256 * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < J.nbands; ++b) std::memcpy(J.level_hist_h[b], h + (size_t)b * 256, sizeof(uint64_t) * 256);
+    }
+    if (u8o) for (int b = 0; b < J.nbands; ++b) job_rescale_from_level_hist(J, b);
+
+    uint8_t *up = ctx->h_upload.as<uint8_t>();
+    if (!J.clahe()) {
+        // table apply: final = resc[level[DN]] (u8) or level[DN] (u16)
+        const bool need_levels = J.synrgb && (d_out[0] == nullptr || d_out[1] == nullptr);
+        if (need_levels) RETCHK(ensure_levels(J));
+        for (int b = 0; b < J.nbands; ++b) {
+            LutApplyArgs a{};
+            a.in = J.d_in[b];
+            a.in_pitch = J.in_pitch;
+            a.rows = rows; a.cols = cols;
+            if (d_out[b]) { a.out = d_out[b]; a.out_pitch = out_pitch; }
+            else { a.out = J.d_levels[b]; a.out_pitch = J.lvl_pitch; }
+            a.win_lo = J.lut[b].win_lo; a.win_hi = J.lut[b].win_hi;
+            const size_t esz = u8o ? 1 : 2;
+            a.lut_in_lds = (size_t)(a.win_hi - a.win_lo + 1) * esz <= kLutLdsMaxBytes;
+            uint8_t *stage = up + (size_t)b * 131072;
+            if (u8o) for (int i = 0; i < 65536; ++i) stage[i] = J.resc[b][J.lut[b].full[i] & 0xFF];
+            else std::memcpy(stage, J.lut[b].full.data(), 131072);
+            if (u8o) stage[0] = J.resc[b][0];
+            void *d_lut = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+            HIPCHK(ctx, hipMemcpyAsync(d_lut, stage, 65536 * esz, hipMemcpyHostToDevice, ctx->stream));
+            a.lut = d_lut;
+            const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out);
+            KernelTimer t(ctx, "lut_apply_u16");
+            HIPCHK(ctx, launch_lut_apply_u16(a, vec, !u8o, ctx->stream));
+        }
+    }
+    if (!J.synrgb) {
+        if (J.clahe() && u8o && !J.resc_identity[0]) { // rare: CLAHE levels did not span 0..255
+            HIPCHK(ctx, ctx->tables.reserve(66048));
+            std::memcpy(up, J.resc[0], 256);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, up, 256, hipMemcpyHostToDevice, ctx->stream));
+            KernelTimer t(ctx, "remap_u8");
+            HIPCHK(ctx, launch_remap_u8(reinterpret_cast<uint8_t *>(d_out[0]), out_pitch, rows, cols, ctx->tables.as<uint8_t>(), ctx->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return SARPRO_HIP_OK;
+    }
+
+    // ---- dual-pol composition (synthetic_rgb.rs:182-197) ----
+    // combined histogram of the FINAL u8 bands = level histograms pushed through each band's rescale
+    uint64_t combined[256];
+    std::memset(combined, 0, sizeof(combined));
+    for (int b = 0; b < 2; ++b)
+        for (int i = 0; i < 256; ++i) combined[J.resc[b][i]] += J.level_hist_h[b][i];
+    std::vector<uint8_t> luts(66048), tables(66048);
+    const bool suppressed = J.strategy == SARPRO_STRATEGY_TAMED || J.strategy == SARPRO_STRATEGY_CLAHE;
+    if (suppressed) {
+        J.floor_with_cushion = synrgb_floor_from_hist(combined, (uint64_t)J.rows_total * J.cols);
+        synrgb_luts_suppressed(J.floor_with_cushion, luts.data());
+    } else {
+        J.floor_with_cushion = -1;
+        synrgb_luts_default(luts.data());
+    }
+    uint8_t ident[256];
+    for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
+    // CLAHE: the compose kernel reads LEVELS, so the rescale is folded into the tables.
+    // Percentile strategies: the table-apply pass already wrote final u8 values.
+    const uint8_t *r1 = J.clahe() ? J.resc[0] : ident, *r2 = J.clahe() ? J.resc[1] : ident;
+    fold_compose_tables(luts.data(), J.floor_with_cushion, r1, r2, tables.data());
+    HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
+    uint8_t *tstage = up + 2 * 131072 + 2 * 64 * 256 * 8;
+    std::memcpy(tstage, tables.data(), 66048);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tstage, 66048, hipMemcpyHostToDevice, ctx->stream));
+
+    ComposeArgs c{};
+    if (J.clahe()) { c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch; }
+    else if (d_out[0] && d_out[1]) { c.b1 = (const uint8_t *)d_out[0]; c.b2 = (const uint8_t *)d_out[1]; c.in_pitch = out_pitch; }
+    else {
+        // percentile strategies wrote into d_out[b] when given, else into the level rasters; compose
+        // needs one pitch for both bands, so mixed destinations are not offered by the entry points
+        c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch;
+    }
+    c.rgb = d_rgb; c.rgb_pitch_px = rgb_pitch_px; c.rows = rows; c.cols = cols;
+    c.tables = ctx->tables.as<uint8_t>();
+    const int cvec = (c.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(c.b1) && ptr_aligned16(c.b2) && ptr_aligned16(d_rgb)) ? 16 : 1;
+    {
+        KernelTimer t(ctx, "compose_u8");
+        HIPCHK(ctx, launch_compose_u8(c, cvec, ctx->stream));
+    }
+    if (J.clahe()) { // optional per-band u8 rasters: levels pushed through the rescale
+        for (int b = 0; b < 2; ++b) {
+            if (!d_out[b]) continue;
+            HIPCHK(ctx, hipMemcpy2DAsync(d_out[b], out_pitch, J.d_levels[b], J.lvl_pitch, cols, rows, hipMemcpyDeviceToDevice, ctx->stream));
+            if (!J.resc_identity[b]) {
+                uint8_t *m = tstage + 66048 + (size_t)b * 256;
+                std::memcpy(m, J.resc[b], 256);
+                HIPCHK(ctx, hipMemcpyAsync(ctx->tables.as<uint8_t>() + 66048 + (size_t)b * 256, m, 256, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, launch_remap_u8(reinterpret_cast<uint8_t *>(d_out[b]), out_pitch, rows, cols,
+                                            ctx->tables.as<uint8_t>() + 66048 + (size_t)b * 256, ctx->stream));
+            }
+        }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
+                       sarpro_hip_stats *stats_out) {
+    timing_reset(J.ctx);
+    RETCHK(job_init(J));
+    if (J.rows_local == 0 || J.cols == 0) {
+        if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out) * (size_t)J.nbands);
+        return SARPRO_HIP_OK;
+    }
+    RETCHK(job_phase1(J));
+    RETCHK(job_after_phase1(J));
+    RETCHK(job_phase2(J));
+    RETCHK(job_phase3(J, d_out, out_pitch));
+    RETCHK(job_phase4(J, d_out, out_pitch, d_rgb, rgb_pitch_px, false));
+    if (stats_out) for (int b = 0; b < J.nbands; ++b) stats_out[b] = J.stats[b];
+    return SARPRO_HIP_OK;
+}
+
+} // namespace sarpro
+
+// ---------------------------------------------------------------------------------------
+// device-pointer entry points (u16)
+// ---------------------------------------------------------------------------------------
+extern "C" int sarpro_hip_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols,
+                                                 size_t in_pitch, int strategy, int bit_depth, void *d_out,
+                                                 size_t out_pitch, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if ((!d_in || !d_out) && rows * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (out_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "out_pitch < cols");
+    U16Job J;
+    J.ctx = ctx; J.nbands = 1; J.d_in[0] = d_in;
+    J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = in_pitch;
+    J.strategy = strategy; J.bit_depth = bit_depth;
+    void *outs[kMaxBands] = {d_out, nullptr};
+    return job_run_all(J, outs, out_pitch, nullptr, 0, stats_out);
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2,
+                                                 size_t rows, size_t cols, size_t in_pitch, int strategy, int mode,
+                                                 uint8_t *d_rgb, size_t rgb_pitch_px, uint8_t *d_u8_band1,
+                                                 uint8_t *d_u8_band2, size_t u8_pitch, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if ((!d_band1 || !d_band2 || !d_rgb) && rows * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (rgb_pitch_px < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "rgb_pitch_px < cols");
+    if ((d_u8_band1 == nullptr) != (d_u8_band2 == nullptr))
+        return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pass both per-band u8 outputs or neither");
+    if (d_u8_band1 && u8_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "u8_pitch < cols");
+    U16Job J;
+    J.ctx = ctx; J.nbands = 2; J.d_in[0] = d_band1; J.d_in[1] = d_band2;
+    J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = in_pitch;
+    J.strategy = strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.mode = mode; J.synrgb = true;
+    void *outs[kMaxBands] = {d_u8_band1, d_u8_band2};
+    return job_run_all(J, outs, u8_pitch, d_rgb, rgb_pitch_px, stats_out);
+}
+
+extern "C" int sarpro_hip_polop_f32_dev(sarpro_hip_ctx *ctx, int op, const float *d_a, const float *d_b, size_t n,
+                                        float *d_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (op < SARPRO_OP_SUM || op > SARPRO_OP_LOGRATIO) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad polarization operation");
+    if ((!d_a || !d_b || !d_out) && n) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null array");
+    timing_reset(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        KernelTimer t(ctx, "polop_f32");
+        HIPCHK(ctx, launch_polop_f32(op, d_a, d_b, n, d_out, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_synrgb_u8_dev(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *d_b1,
+                                        const uint8_t *d_b2, size_t n, uint8_t *d_rgb) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if ((!d_b1 || !d_b2 || !d_rgb) && n) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null array");
+    timing_reset(ctx);
+    if (n == 0) return SARPRO_HIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // view the flat arrays as rows of 4096 px (+ one short row) so the 2-D kernels apply
+    const size_t W = 4096;
+    const size_t full_rows = n / W, tail = n - full_rows * W;
+    const bool suppressed = strategy == SARPRO_STRATEGY_TAMED || strategy == SARPRO_STRATEGY_CLAHE;
+    std::vector<uint8_t> luts(66048), tables(66048);
+    int fwc = -1;
+    if (suppressed) {
+        HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
+        HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256, ctx->stream));
+        for (const uint8_t *p : {d_b1, d_b2}) {
+            KernelTimer t(ctx, "hist256_u8");
+            if (full_rows) HIPCHK(ctx, launch_hist256_u8(p, W, (uint32_t)full_rows, (uint32_t)W, ctx->level_hist.as<unsigned long long>(), ctx->stream));
+            if (tail) HIPCHK(ctx, launch_hist256_u8(p + full_rows * W, W, 1, (uint32_t)tail, ctx->level_hist.as<unsigned long long>(), ctx->stream));
+        }
+        uint64_t h[256];
+        HIPCHK(ctx, hipMemcpyAsync(h, ctx->level_hist.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        fwc = synrgb_floor_from_hist(h, n);
+        synrgb_luts_suppressed(fwc, luts.data());
+    } else {
+        synrgb_luts_default(luts.data());
+    }
+    uint8_t ident[256];
+    for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
+    fold_compose_tables(luts.data(), fwc, ident, ident, tables.data());
+    HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tables.data(), 66048, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const bool al = ptr_aligned16(d_b1) && ptr_aligned16(d_b2) && ptr_aligned16(d_rgb);
+    ComposeArgs c{};
+    c.tables = ctx->tables.as<uint8_t>();
+    c.in_pitch = W; c.rgb_pitch_px = W;
+    if (full_rows) {
+        c.b1 = d_b1; c.b2 = d_b2; c.rgb = d_rgb; c.rows = (uint32_t)full_rows; c.cols = (uint32_t)W;
+        KernelTimer t(ctx, "compose_u8");
+        HIPCHK(ctx, launch_compose_u8(c, al ? 16 : 1, ctx->stream));
+    }
+    if (tail) {
+        c.b1 = d_b1 + full_rows * W; c.b2 = d_b2 + full_rows * W; c.rgb = d_rgb + full_rows * W * 3;
+        c.rows = 1; c.cols = (uint32_t)tail;
+        KernelTimer t(ctx, "compose_u8");
+        HIPCHK(ctx, launch_compose_u8(c, al ? 16 : 1, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-pointer entry points: stage through pitched device buffers, run the device path
+// ---------------------------------------------------------------------------------------
+namespace sarpro {
+
+int stage_in_2d(sarpro_hip_ctx *ctx, DevBuf &buf, const void *host, size_t rows, size_t cols, size_t esz, size_t *pitch_elems) {
+    const size_t pitch = round_up(std::max<size_t>(cols, 1), 64);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, buf.reserve(std::max<size_t>(rows, 1) * pitch * esz));
+    if (rows && cols)
+        HIPCHK(ctx, hipMemcpy2DAsync(buf.p, pitch * esz, host, cols * esz, cols * esz, rows, hipMemcpyHostToDevice, ctx->stream));
+    *pitch_elems = pitch;
+    return SARPRO_HIP_OK;
+}
+
+int fetch_out_2d(sarpro_hip_ctx *ctx, void *host, const void *dev, size_t pitch_bytes, size_t row_bytes, size_t rows) {
+    if (rows && row_bytes) {
+        HIPCHK(ctx, hipMemcpy2DAsync(host, row_bytes, dev, pitch_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SARPRO_HIP_OK;
+}
+
+} // namespace sarpro
+
+static int host_band_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols, int strategy, int bit_depth,
+                         int tamed_force, uint8_t *out_u8, uint16_t *out_u16, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const bool u8o = tamed_force || bit_depth == SARPRO_BITDEPTH_U8;
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if (rows * cols && (!in || (u8o ? (void *)out_u8 : (void *)out_u16) == nullptr)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    size_t pitch = 0;
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[0], in, rows, cols, 2, &pitch));
+    const size_t osz = u8o ? 1 : 2;
+    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max<size_t>(rows, 1) * pitch * osz));
+    U16Job J;
+    J.ctx = ctx; J.nbands = 1; J.d_in[0] = ctx->stage_in[0].as<uint16_t>();
+    J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = pitch;
+    J.strategy = tamed_force ? SARPRO_STRATEGY_TAMED : strategy;
+    J.bit_depth = u8o ? SARPRO_BITDEPTH_U8 : SARPRO_BITDEPTH_U16;
+    J.tamed_force = tamed_force;
+    if (!tamed_force && (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    void *outs[kMaxBands] = {ctx->stage_out[0].p, nullptr};
+    RETCHK(job_run_all(J, outs, pitch, nullptr, 0, stats_out));
+    return fetch_out_2d(ctx, u8o ? (void *)out_u8 : (void *)out_u16, ctx->stage_out[0].p, pitch * osz, cols * osz, rows);
+}
+
+extern "C" int sarpro_hip_autoscale_band_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols,
+                                             int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16,
+                                             sarpro_hip_stats *stats_out) {
+    return host_band_u16(ctx, in, rows, cols, strategy, bit_depth, 0, out_u8, out_u16, stats_out);
+}
+
+extern "C" int sarpro_hip_tamed_synrgb_u8_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols,
+                                              int is_copol, uint8_t *out_u8) {
+    return host_band_u16(ctx, in, rows, cols, SARPRO_STRATEGY_TAMED, SARPRO_BITDEPTH_U8,
+                         is_copol ? kTamedCopol : kTamedCrosspol, out_u8, nullptr, nullptr);
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_u16(sarpro_hip_ctx *ctx, const uint16_t *band1, const uint16_t *band2,
+                                             size_t rows, size_t cols, int strategy, int mode, uint8_t *rgb_out,
+                                             uint8_t *u8_band1, uint8_t *u8_band2, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (rows * cols && (!band1 || !band2 || !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    size_t pitch = 0;
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[0], band1, rows, cols, 2, &pitch));
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[1], band2, rows, cols, 2, &pitch));
+    const size_t r1 = std::max<size_t>(rows, 1);
+    HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * pitch * 3));
+    const bool want_u8 = u8_band1 || u8_band2;
+    if (want_u8) { HIPCHK(ctx, ctx->stage_out[1].reserve(r1 * pitch)); HIPCHK(ctx, ctx->stage_out[2].reserve(r1 * pitch)); }
+    int rc = sarpro_hip_dualpol_synrgb_u16_dev(ctx, ctx->stage_in[0].as<uint16_t>(), ctx->stage_in[1].as<uint16_t>(), rows, cols,
+                                               pitch, strategy, mode, ctx->stage_out[0].as<uint8_t>(), pitch,
+                                               want_u8 ? ctx->stage_out[1].as<uint8_t>() : nullptr,
+                                               want_u8 ? ctx->stage_out[2].as<uint8_t>() : nullptr, pitch, stats_out);
+    if (rc) return rc;
+    RETCHK(fetch_out_2d(ctx, rgb_out, ctx->stage_out[0].p, pitch * 3, cols * 3, rows));
+    if (u8_band1) RETCHK(fetch_out_2d(ctx, u8_band1, ctx->stage_out[1].p, pitch, cols, rows));
+    if (u8_band2) RETCHK(fetch_out_2d(ctx, u8_band2, ctx->stage_out[2].p, pitch, cols, rows));
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_polop_f32(sarpro_hip_ctx *ctx, int op, const float *a, const float *b, size_t n, float *out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (op < SARPRO_OP_SUM || op > SARPRO_OP_LOGRATIO) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad polarization operation");
+    if ((!a || !b || !out) && n) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null array");
+    if (!n) return SARPRO_HIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->stage_in[0].reserve(n * 4));
+    HIPCHK(ctx, ctx->stage_in[1].reserve(n * 4));
+    HIPCHK(ctx, ctx->stage_out[0].reserve(n * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_in[0].p, a, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_in[1].p, b, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RETCHK(sarpro_hip_polop_f32_dev(ctx, op, ctx->stage_in[0].as<float>(), ctx->stage_in[1].as<float>(), n, ctx->stage_out[0].as<float>()));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_out[0].p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_synrgb_u8(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *band1, const uint8_t *band2,
+                                    size_t n, uint8_t *rgb_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if ((!band1 || !band2 || !rgb_out) && n) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null array");
+    if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (!n) return SARPRO_HIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->stage_in[0].reserve(n));
+    HIPCHK(ctx, ctx->stage_in[1].reserve(n));
+    HIPCHK(ctx, ctx->stage_out[0].reserve(n * 3));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_in[0].p, band1, n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_in[1].p, band2, n, hipMemcpyHostToDevice, ctx->stream));
+    RETCHK(sarpro_hip_synrgb_u8_dev(ctx, mode, strategy, ctx->stage_in[0].as<uint8_t>(), ctx->stage_in[1].as<uint8_t>(), n,
+                                    ctx->stage_out[0].as<uint8_t>()));
+    HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->stage_out[0].p, n * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// synthetic scene
+// ---------------------------------------------------------------------------------------
+extern "C" int sarpro_hip_synth_scene_u16_dev(sarpro_hip_ctx *ctx, uint64_t seed, int band, const uint16_t *q_tables_host,
+                                              size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                                              uint16_t *d_out, size_t pitch) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (band < 0 || band > 1 || !q_tables_host || (!d_out && rows_local * cols) || pitch < cols)
+        return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synthetic scene arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t qbytes = sizeof(uint16_t) * 4 * 65536;
+    HIPCHK(ctx, ctx->qtab.reserve(qbytes));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->qtab.p, q_tables_host + (size_t)band * 4 * 65536, qbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, launch_synth_scene_u16(seed, band, ctx->qtab.as<uint16_t>(), rows_total, cols, row0, rows_local, d_out, pitch, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// row-stripe protocol
+// ---------------------------------------------------------------------------------------
+struct sarpro_hip_stripe {
+    U16Job job;
+    int phase = 0;
+};
+
+extern "C" int sarpro_hip_stripe_begin_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2,
+                                           size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t in_pitch,
+                                           int strategy, int mode, sarpro_hip_stripe **out) {
+    if (!ctx || !out) return SARPRO_HIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if ((!d_band1 || !d_band2) && rows_local * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    sarpro_hip_stripe *s = new sarpro_hip_stripe();
+    U16Job &J = s->job;
+    J.ctx = ctx; J.nbands = 2; J.d_in[0] = d_band1; J.d_in[1] = d_band2;
+    J.rows_total = rows_total; J.cols = cols; J.row0 = row0; J.rows_local = rows_local; J.in_pitch = in_pitch;
+    J.strategy = strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.mode = mode; J.synrgb = true;
+    timing_reset(ctx);
+    int rc = job_init(J);
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_phase1(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *count) {
+    if (!s || !d_buf || !count || s->phase != 0) return SARPRO_HIP_ERR_INVALID_ARG;
+    RETCHK(job_phase1(s->job));
+    *d_buf = s->job.ctx->ghist.as<uint64_t>();
+    *count = 65536 * 2;
+    s->phase = 1;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_phase2(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *count) {
+    if (!s || !d_buf || !count || s->phase != 1) return SARPRO_HIP_ERR_INVALID_ARG;
+    RETCHK(job_after_phase1(s->job));
+    RETCHK(job_phase2(s->job));
+    if (s->job.clahe()) { *d_buf = s->job.ctx->tile_bins.as<uint64_t>(); *count = 64 * 256 * 2; }
+    else { *d_buf = nullptr; *count = 0; }
+    s->phase = 2;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_phase3(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *count) {
+    if (!s || !d_buf || !count || s->phase != 2) return SARPRO_HIP_ERR_INVALID_ARG;
+    void *outs[kMaxBands] = {nullptr, nullptr};
+    RETCHK(job_phase3(s->job, outs, 0));
+    if (s->job.clahe()) { *d_buf = s->job.ctx->level_hist.as<uint64_t>(); *count = 256 * 2; }
+    else { *d_buf = nullptr; *count = 0; } // percentile strategies: level histogram follows from the reduced DN histogram
+    s->phase = 3;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_phase4(sarpro_hip_stripe *s, uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
+    if (!s || s->phase != 3) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (!d_rgb && s->job.rows_local * s->job.cols) return fail(s->job.ctx, SARPRO_HIP_ERR_INVALID_ARG, "null rgb raster");
+    if (rgb_pitch_px < s->job.cols) return fail(s->job.ctx, SARPRO_HIP_ERR_INVALID_ARG, "rgb_pitch_px < cols");
+    void *outs[kMaxBands] = {nullptr, nullptr};
+    if (s->job.rows_local * s->job.cols) RETCHK(job_phase4(s->job, outs, 0, d_rgb, rgb_pitch_px, false));
+    if (stats_out) { stats_out[0] = s->job.stats[0]; stats_out[1] = s->job.stats[1]; }
+    s->phase = 4;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" void sarpro_hip_stripe_end(sarpro_hip_stripe *s) { delete s; }

@@ -1,0 +1,90 @@
+// context.h -- sarpro_hip_ctx: device, streams, grow-only workspace, cached plans.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "kernels.h"
+
+namespace sarpro {
+
+struct DevBuf { // grow-only device allocation
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct PinnedBuf { // grow-only pinned host allocation
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Work decomposition for one (scene shape, stripe) -- built once, cached on the context.
+struct StripePlan {
+    size_t rows_total = 0, cols = 0, row0 = 0, rows_local = 0;
+    bool vec = false;
+    ClaheGeometry geom;                 // of the WHOLE scene (rows_total x cols)
+    std::vector<Rect> hist_rects_tiled; // per-tile DN histogram items
+    std::vector<Rect> hist_rects_flat;  // single-histogram items (non-CLAHE)
+    std::vector<Rect> apply_rects;      // interpolation-cell items
+    DevBuf d_hist_rects_tiled, d_hist_rects_flat, d_apply_rects, d_row_w, d_col_w;
+};
+
+struct KernelTime { const char *name; hipEvent_t start, stop; };
+
+} // namespace sarpro
+
+struct sarpro_hip_ctx {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // workspace (device)
+    sarpro::DevBuf tile_hist[sarpro::kMaxBands]; // u32 [ntiles][65536]
+    sarpro::DevBuf ghist;                        // u64 [2][65536]
+    sarpro::DevBuf tile_bins;                    // u64 [2][64][256]
+    sarpro::DevBuf cdfs;                         // f64 [2][64][256]
+    sarpro::DevBuf luts;                         // 2 x 128 KiB: per-band DN table (u8 or u16 entries)
+    sarpro::DevBuf level_hist;                   // u64 [2][256]
+    sarpro::DevBuf tables;                       // compose tables 66048 B
+    sarpro::DevBuf levels[sarpro::kMaxBands];    // u8 level rasters (intermediate)
+    sarpro::DevBuf stage_in[sarpro::kMaxBands];  // host API staging
+    sarpro::DevBuf stage_out[3];
+    sarpro::DevBuf qtab;                         // synthetic scene tables
+    sarpro::DevBuf f32ws;                        // f32-path workspace
+    // pinned host mirrors
+    sarpro::PinnedBuf h_ghist, h_small, h_upload;
+
+    std::map<std::tuple<size_t, size_t, size_t, size_t, bool>, sarpro::StripePlan *> plans;
+
+    // per-kernel timing of the last call
+    bool timing = false;
+    std::vector<sarpro::KernelTime> times;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+
+    // RCCL (lazy)
+    void *rccl_lib = nullptr;
+    void *comm = nullptr;
+};

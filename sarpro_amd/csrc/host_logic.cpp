@@ -1,0 +1,514 @@
+// host_logic.cpp -- see host_logic.h.  Built with g++ -O2 -ffp-contract=off (no fast-math):
+// the arithmetic below must round exactly like the reference's Rust/libm evaluation.
+#include "host_logic.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace sarpro {
+
+// ---- Rust `as` casts from float: truncate, saturate, NaN -> 0 ----
+static inline uint64_t as_u64(double x) {
+    if (!(x == x) || x <= 0.0) return 0;
+    if (x >= 18446744073709551615.0) return UINT64_MAX;
+    return (uint64_t)x;
+}
+static inline int64_t as_i64(double x) {
+    if (!(x == x)) return 0;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    if (x >= 9223372036854775807.0) return INT64_MAX;
+    return (int64_t)x;
+}
+static inline uint32_t as_u32(double x) {
+    if (!(x == x) || x <= 0.0) return 0;
+    if (x >= 4294967295.0) return UINT32_MAX;
+    return (uint32_t)x;
+}
+static inline uint16_t as_u16(double x) {
+    if (!(x == x) || x <= 0.0) return 0;
+    if (x >= 65535.0) return 65535;
+    return (uint16_t)x;
+}
+static inline uint8_t f32_as_u8(float x) {
+    if (!(x == x) || x <= 0.0f) return 0;
+    if (x >= 255.0f) return 255;
+    return (uint8_t)x;
+}
+// Rust clamp: NaN stays NaN
+static inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+const double *db_table_u16() {
+    static double table[65536];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t dn = 0; dn < 65536; ++dn) // pipeline.rs:19-20 with v = DN exactly
+            table[dn] = 10.0 * std::log10(std::fmax((double)dn, 1e-10));
+    });
+    return table;
+}
+
+// percentile inversion, autoscale.rs:120-140
+static double percentile_from_bins(const uint64_t *hist, uint64_t n, double min_db, double max_db,
+                                   double span, double p) {
+    uint64_t target = as_u64(std::floor(p * (double)n));
+    if (target >= n) target = n - 1;
+    uint64_t cumsum = 0;
+    for (int b = 0; b < kStatBins; ++b) {
+        uint64_t h = hist[b], next = cumsum + h;
+        if (target < next) {
+            uint64_t within = target >= cumsum ? target - cumsum : 0;
+            double frac = h > 0 ? (double)within / (double)h : 0.0;
+            double bin_width = span / (double)kStatBins;
+            double bin_start = min_db + (double)b * bin_width;
+            return bin_start + frac * bin_width;
+        }
+        cumsum = next;
+    }
+    return max_db;
+}
+
+int stats_from_bins4096(uint64_t count, double min_db, double max_db, double mean, double std_db,
+                        const uint64_t *hist, sarpro_hip_stats *s) {
+    std::memset(s, 0, sizeof(*s));
+    if (count == 0) return SARPRO_HIP_OK; // autoscale.rs:57-76
+    s->valid_count = count;
+    s->min_db = min_db;
+    s->max_db = max_db;
+    s->mean_db = mean;
+    s->std_db = std_db;
+    if (std::fabs(max_db - min_db) < DBL_EPSILON) { // autoscale.rs:81-100
+        s->median_db = s->p01 = s->p02 = s->p05 = s->p10 = s->p25 = min_db;
+        s->p75 = s->p90 = s->p95 = s->p98 = s->p99 = max_db;
+        return SARPRO_HIP_OK;
+    }
+    double span = max_db - min_db;
+    s->median_db = percentile_from_bins(hist, count, min_db, max_db, span, 0.5);
+    s->p01 = percentile_from_bins(hist, count, min_db, max_db, span, 0.01);
+    s->p02 = percentile_from_bins(hist, count, min_db, max_db, span, 0.02);
+    s->p05 = percentile_from_bins(hist, count, min_db, max_db, span, 0.05);
+    s->p10 = percentile_from_bins(hist, count, min_db, max_db, span, 0.10);
+    s->p25 = percentile_from_bins(hist, count, min_db, max_db, span, 0.25);
+    s->p75 = percentile_from_bins(hist, count, min_db, max_db, span, 0.75);
+    s->p90 = percentile_from_bins(hist, count, min_db, max_db, span, 0.90);
+    s->p95 = percentile_from_bins(hist, count, min_db, max_db, span, 0.95);
+    s->p98 = percentile_from_bins(hist, count, min_db, max_db, span, 0.98);
+    s->p99 = percentile_from_bins(hist, count, min_db, max_db, span, 0.99);
+    return SARPRO_HIP_OK;
+}
+
+// compute_histogram_stats (autoscale.rs:35-160) re-expressed over the exact DN histogram:
+// every valid pixel with the same DN has the same dB value, so min/max/count and the 4096-bin
+// histogram are exact; mean/std are the same quantities summed per DN instead of by Welford's
+// sequential update (they agree to ~1e-12 relative; they feed only the log lines and the two
+// discrete Adaptive tests).
+int stats_from_dn_hist(const uint64_t *h, sarpro_hip_stats *out) {
+    const double *db = db_table_u16();
+    uint64_t count = 0;
+    uint32_t min_dn = 0, max_dn = 0;
+    for (uint32_t dn = 1; dn < 65536; ++dn) { // valid <=> db > -50 <=> DN >= 1
+        if (h[dn]) {
+            if (!count) min_dn = dn;
+            max_dn = dn;
+            count += h[dn];
+        }
+    }
+    if (count == 0) { std::memset(out, 0, sizeof(*out)); return SARPRO_HIP_OK; }
+    long double sum = 0.0L;
+    for (uint32_t dn = min_dn; dn <= max_dn; ++dn) sum += (long double)h[dn] * (long double)db[dn];
+    long double meanl = sum / (long double)count;
+    long double m2 = 0.0L;
+    for (uint32_t dn = min_dn; dn <= max_dn; ++dn) {
+        long double d = (long double)db[dn] - meanl;
+        m2 += (long double)h[dn] * d * d;
+    }
+    double mean = (double)meanl;
+    double std_db = count > 1 ? std::sqrt((double)(m2 / (long double)count)) : 0.0;
+
+    double min_db = db[min_dn], max_db = db[max_dn];
+    uint64_t hist[kStatBins];
+    std::memset(hist, 0, sizeof(hist));
+    if (!(std::fabs(max_db - min_db) < DBL_EPSILON)) {
+        double span = max_db - min_db, inv_span = 1.0 / span; // autoscale.rs:105-106
+        for (uint32_t dn = min_dn; dn <= max_dn; ++dn) {
+            if (!h[dn]) continue;
+            double t = clampd((db[dn] - min_db) * inv_span, 0.0, 1.0); // :113
+            uint64_t idx = as_u64(t * (double)kStatBins);               // :114
+            if (idx >= (uint64_t)kStatBins) idx = kStatBins - 1;
+            hist[idx] += h[dn];
+        }
+    }
+    return stats_from_bins4096(count, min_db, max_db, mean, std_db, hist, out);
+}
+
+int select_window(sarpro_hip_stats *s, int strategy, int tamed_synrgb) {
+    s->skew_factor = s->tail_heaviness = 0.0;
+    if (s->valid_count == 0) { s->low_clip = s->high_clip = 0.0; s->gamma = 1.0; return SARPRO_HIP_OK; }
+    if (tamed_synrgb != kNotTamedSynrgb) { // autoscale.rs:721-729
+        s->low_clip = tamed_synrgb == kTamedCopol ? std::fmin(s->p02, s->p05) : s->p05;
+        s->high_clip = s->p99;
+        s->gamma = 1.0;
+        return SARPRO_HIP_OK;
+    }
+    double dynamic_range = s->max_db - s->min_db;
+    double iqr = s->p75 - s->p25;
+    double low, high, gamma;
+    switch (strategy) {
+    case SARPRO_STRATEGY_STANDARD: // pipeline.rs:49-52 -> autoscale.rs:404-429
+        if (dynamic_range < 15.0) {
+            double range = std::fmax(20.0, dynamic_range * 0.8);
+            low = s->median_db - range / 2.0; high = s->median_db + range / 2.0; gamma = 1.1;
+        } else if (iqr < 5.0) {
+            low = s->p25 - 2.5 * iqr; high = s->p75 + 2.5 * iqr; gamma = 1.0;
+        } else if (dynamic_range > 40.0) {
+            low = std::fmax(s->p02, s->min_db + 0.02 * dynamic_range);
+            high = std::fmin(s->p98, s->max_db - 0.02 * dynamic_range);
+            gamma = 0.9;
+        } else {
+            low = s->p02; high = s->p98; gamma = 1.0;
+        }
+        low = std::fmax(low, s->min_db);
+        high = std::fmin(high, s->max_db);
+        break;
+    case SARPRO_STRATEGY_ROBUST: { // autoscale.rs:492-499
+        double thr = 2.5 * iqr;
+        low = std::fmax(std::fmax(s->p25 - thr, s->p01), s->min_db);
+        high = std::fmin(std::fmin(s->p75 + thr, s->p99), s->max_db);
+        gamma = 1.0;
+        break;
+    }
+    case SARPRO_STRATEGY_ADAPTIVE: { // autoscale.rs:500-538
+        double skew = (s->mean_db - s->median_db) / std::fmax(std::fabs(s->std_db), 1.0);
+        double tail = (s->p99 - s->p95) / std::fmax(s->p95 - s->p75, 1.0);
+        s->skew_factor = skew;
+        s->tail_heaviness = tail;
+        if (std::fabs(skew) > 0.5) {
+            if (skew > 0.0) { low = s->p02; high = s->p98; gamma = 0.9; }
+            else { low = s->p05; high = s->p95; gamma = 1.1; }
+        } else if (tail > 2.0) {
+            low = s->p10; high = s->p90; gamma = 0.8;
+        } else {
+            low = s->p05; high = s->p95; gamma = 1.0;
+        }
+        break;
+    }
+    case SARPRO_STRATEGY_EQUALIZED: // :539-543
+    case SARPRO_STRATEGY_CLAHE:     // :544-548
+        low = s->p01; high = s->p99; gamma = 1.0; break;
+    case SARPRO_STRATEGY_TAMED: // :549-553
+        low = s->p25; high = s->p99; gamma = 1.0; break;
+    case SARPRO_STRATEGY_DEFAULT: // :558-561
+        low = s->p05; high = s->p95; gamma = 1.0; break;
+    default:
+        return SARPRO_HIP_ERR_INVALID_ARG;
+    }
+    s->low_clip = low; s->high_clip = high; s->gamma = gamma;
+    return SARPRO_HIP_OK;
+}
+
+uint16_t level_of_db(double db, double low_clip, double high_clip, double gamma, double max_val) {
+    double range = std::fmax(high_clip - low_clip, 1.0); // autoscale.rs:429 / 564 / 729
+    double clipped = std::fmin(std::fmax(db, low_clip), high_clip);
+    double normalized = std::pow((clipped - low_clip) / range, gamma);
+    return as_u16(clampd(normalized * max_val, 0.0, max_val));
+}
+
+uint8_t clahe_bin_of_db(double db, double low_clip, double high_clip) {
+    double range = std::fmax(high_clip - low_clip, 1.0);
+    double clipped = std::fmin(std::fmax(db, low_clip), high_clip);
+    double n = (clipped - low_clip) / range;                                // autoscale.rs:585-586
+    double v = clampd(n, 0.0, 1.0);                                         // :262 / :320
+    int64_t bin = as_i64(std::round(v * ((double)kClaheBins - 1.0)));       // :263
+    if (bin < 0) bin = 0;
+    if (bin >= kClaheBins) bin = kClaheBins - 1;
+    return (uint8_t)bin;
+}
+
+// Fill a per-DN table of a function that is constant for db <= low_clip and for db >= high_clip.
+template <typename F>
+static void fill_windowed(double low_clip, double high_clip, F f, DnLut *out) {
+    const double *db = db_table_u16();
+    out->full.assign(65536, 0);
+    // a = first DN >= 1 with db > low_clip; b = first DN >= 1 with db >= high_clip
+    uint32_t a = (uint32_t)(std::upper_bound(db + 1, db + 65536, low_clip) - db);
+    uint32_t b = (uint32_t)(std::lower_bound(db + 1, db + 65536, high_clip) - db);
+    uint32_t m = std::max(a, b);
+    if (a > 1) {
+        uint16_t v1 = f(db[1]);
+        std::fill(out->full.begin() + 1, out->full.begin() + a, v1);
+    }
+    for (uint32_t dn = a; dn < m; ++dn) out->full[dn] = f(db[dn]);
+    if (m <= 65535) {
+        uint16_t vm = f(db[m]);
+        std::fill(out->full.begin() + m, out->full.end(), vm);
+    }
+    out->win_lo = a > 1 ? a - 1 : 1;
+    out->win_hi = std::min<uint32_t>(m, 65535);
+    if (out->win_lo > out->win_hi) out->win_lo = out->win_hi;
+}
+
+void build_level_lut_u16(const sarpro_hip_stats &s, int bit_depth, int tamed_synrgb, DnLut *out) {
+    double max_val = (bit_depth == SARPRO_BITDEPTH_U8 || tamed_synrgb) ? 255.0 : 65535.0;
+    if (s.valid_count == 0) { out->full.assign(65536, 0); out->win_lo = out->win_hi = 1; return; }
+    double lo = s.low_clip, hi = s.high_clip, g = s.gamma;
+    fill_windowed(lo, hi, [=](double d) { return level_of_db(d, lo, hi, g, max_val); }, out);
+}
+
+void build_clahe_bin_lut_u16(const sarpro_hip_stats &s, DnLut *out) {
+    if (s.valid_count == 0) { out->full.assign(65536, 0); out->win_lo = out->win_hi = 1; return; }
+    double lo = s.low_clip, hi = s.high_clip;
+    fill_windowed(lo, hi, [=](double d) { return (uint16_t)clahe_bin_of_db(d, lo, hi); }, out);
+}
+
+bool clahe_shape_ok(size_t rows, size_t cols) {
+    if (rows == 0 || cols == 0) return true; // early-out clone (autoscale.rs:231-233)
+    size_t tile_h = (rows + kTiles - 1) / kTiles, tile_w = (cols + kTiles - 1) / kTiles;
+    for (size_t t = 0; t < (size_t)kTiles; ++t)
+        if (t * tile_h > rows || t * tile_w > cols) return false; // r1 - r0 underflow (:250,:254)
+    return true;
+}
+
+static void axis_weights(size_t n, size_t tile, std::vector<RowWeight> *w, std::vector<size_t> *cells) {
+    w->resize(n);
+    cells->clear();
+    for (size_t i = 0; i < n; ++i) { // autoscale.rs:308-318
+        double f = (double)i / (double)tile - 0.5;
+        int64_t t = as_i64(std::fmax(std::floor(f), 0.0));
+        double d = f - (double)t;
+        int64_t last = kTiles - 1;
+        RowWeight rw;
+        rw.d = d;
+        rw.omd = 1.0 - d;
+        rw.t0 = (int32_t)std::min(std::max<int64_t>(t, 0), last);
+        rw.t1 = (int32_t)std::min(std::max<int64_t>(t + 1, 0), last);
+        if (i == 0 || rw.t0 != (*w)[i - 1].t0 || rw.t1 != (*w)[i - 1].t1) cells->push_back(i);
+        (*w)[i] = rw;
+    }
+    cells->push_back(n);
+}
+
+void build_clahe_geometry(size_t rows, size_t cols, ClaheGeometry *g) {
+    g->rows = rows; g->cols = cols;
+    g->tile_h = (rows + kTiles - 1) / kTiles; // autoscale.rs:235
+    g->tile_w = (cols + kTiles - 1) / kTiles; // :236
+    axis_weights(rows, g->tile_h, &g->row_w, &g->row_cell_start);
+    axis_weights(cols, g->tile_w, &g->col_w, &g->col_cell_start);
+}
+
+// autoscale.rs:271-302.  The reference holds the counts in u32: the casts saturate like Rust's.
+void clahe_tile_cdf(uint64_t *hist, size_t tile_rows, size_t tile_cols, double *cdf) {
+    const double nb = (double)kClaheBins;
+    double avg = (double)(tile_rows * tile_cols) / nb;
+    double thr = std::fmax(kClipLimit * avg, 1.0);
+    double excess = 0.0;
+    for (int i = 0; i < kClaheBins; ++i) {
+        if ((double)hist[i] > thr) {
+            excess += (double)hist[i] - thr;
+            hist[i] = as_u32(thr);
+        }
+    }
+    double add = std::floor(excess / nb);
+    uint64_t remainder = as_u64(std::round(excess - add * nb));
+    for (int i = 0; i < kClaheBins; ++i) hist[i] = as_u32((double)hist[i] + add);
+    for (size_t b = 0; remainder > 0; --remainder, b = (b + 1) % kClaheBins) hist[b] += 1;
+    double total = 0.0;
+    for (int i = 0; i < kClaheBins; ++i) total += (double)hist[i];
+    total = std::fmax(total, 1.0);
+    double acc = 0.0;
+    for (int i = 0; i < kClaheBins; ++i) {
+        acc += (double)hist[i];
+        cdf[i] = clampd(acc / total, 0.0, 1.0);
+    }
+}
+
+int clahe_cdfs(const uint64_t *tile_hists, size_t rows, size_t cols, double *cdfs_out) {
+    if (rows == 0 || cols == 0) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (!clahe_shape_ok(rows, cols)) return SARPRO_HIP_ERR_UNSUPPORTED_SHAPE;
+    size_t tile_h = (rows + kTiles - 1) / kTiles, tile_w = (cols + kTiles - 1) / kTiles;
+    uint64_t hist[kClaheBins];
+    for (size_t ty = 0; ty < (size_t)kTiles; ++ty) {
+        size_t r0 = ty * tile_h, r1 = std::min((ty + 1) * tile_h, rows);
+        for (size_t tx = 0; tx < (size_t)kTiles; ++tx) {
+            size_t c0 = tx * tile_w, c1 = std::min((tx + 1) * tile_w, cols);
+            size_t t = ty * kTiles + tx;
+            std::memcpy(hist, tile_hists + t * kClaheBins, sizeof(hist));
+            clahe_tile_cdf(hist, r1 - r0, c1 - c0, cdfs_out + t * kClaheBins);
+        }
+    }
+    return SARPRO_HIP_OK;
+}
+
+void u8_rescale_lut(unsigned min_level, unsigned max_level, uint8_t *lut) {
+    float mn = (float)min_level, mx = (float)max_level; // autoscale.rs:352-356
+    float scale = mx > mn ? 255.0f / (mx - mn) : 1.0f;
+    for (unsigned x = 0; x < 256; ++x) {
+        float val = std::round(((float)x - mn) * scale); // :360
+        lut[x] = f32_as_u8(clampf(val, 0.0f, 255.0f));
+    }
+}
+
+static void blue_lut(const uint8_t *lut_r, const uint8_t *lut_g, bool dflt, uint8_t *lut_b) {
+    for (unsigned x1 = 0; x1 < 256; ++x1) {
+        for (unsigned x2 = 0; x2 < 256; ++x2) {
+            float r = (float)lut_r[x1], g = (float)lut_g[x2];
+            uint8_t blue;
+            if (dflt) { // synthetic_rgb.rs:38-49
+                if (x2 == 0) blue = 0;
+                else {
+                    float ratio = r / g;
+                    blue = f32_as_u8(std::round(clampf(std::pow(ratio, 0.1f) * 255.0f * 0.24f, 0.0f, 255.0f)));
+                }
+            } else { // :146-152
+                float ratio = (r + 8.0f) / (g + 8.0f);
+                blue = f32_as_u8(std::round(clampf(std::pow(ratio, 0.1f) * 255.0f * 0.18f, 0.0f, 255.0f)));
+            }
+            lut_b[(x1 << 8) | x2] = blue;
+        }
+    }
+}
+
+void synrgb_luts_default(uint8_t *luts) {
+    uint8_t *lut_r = luts, *lut_g = luts + 256, *lut_b = luts + 512;
+    for (unsigned v = 0; v < 256; ++v) { // synthetic_rgb.rs:22-29
+        float vf = (float)v / 255.0f;
+        lut_r[v] = f32_as_u8(clampf(std::round(std::pow(vf, 0.7f) * 255.0f), 0.0f, 255.0f));
+        lut_g[v] = f32_as_u8(clampf(std::round(std::pow(vf, 0.9f) * 255.0f), 0.0f, 255.0f));
+    }
+    blue_lut(lut_r, lut_g, true, lut_b);
+}
+
+int synrgb_floor_from_hist(const uint64_t *hist, uint64_t n_per_band) {
+    // synthetic_rgb.rs:92-113; the reference's counters are saturating u32
+    uint32_t total = (uint32_t)(n_per_band + n_per_band);              // `as u32` wraps
+    uint32_t target = as_u32(std::round((double)total * 0.05));
+    uint32_t cumulative = 0;
+    size_t floor_value = 0;
+    for (size_t i = 0; i < 256; ++i) {
+        uint64_t hi = std::min<uint64_t>(hist[i], UINT32_MAX);
+        uint64_t c = (uint64_t)cumulative + hi;
+        cumulative = c > UINT32_MAX ? UINT32_MAX : (uint32_t)c;
+        if (cumulative >= target) { floor_value = i; break; }
+    }
+    return (int)std::min<size_t>(floor_value + 3, 40);
+}
+
+void synrgb_luts_suppressed(int fwc, uint8_t *luts) {
+    uint8_t *lut_r = luts, *lut_g = luts + 256, *lut_b = luts + 512;
+    float floor_f = (float)fwc;
+    float denom = std::fmax(255.0f - floor_f, 1.0f); // synthetic_rgb.rs:119-120
+    for (unsigned v = 0; v < 256; ++v) {              // :124-135
+        if ((int)v <= fwc) { lut_r[v] = 0; lut_g[v] = 0; continue; }
+        float shifted = ((float)v - floor_f) / denom;
+        lut_r[v] = f32_as_u8(clampf(std::round(std::pow(shifted, 1.15f) * 255.0f), 0.0f, 255.0f));
+        lut_g[v] = f32_as_u8(clampf(std::round(std::pow(shifted, 1.10f) * 255.0f), 0.0f, 255.0f));
+    }
+    blue_lut(lut_r, lut_g, false, lut_b);
+}
+
+void fold_compose_tables(const uint8_t *luts, int fwc, const uint8_t *resc1, const uint8_t *resc2,
+                         uint8_t *tables) {
+    const uint8_t *lut_r = luts, *lut_g = luts + 256, *lut_b = luts + 512;
+    uint8_t *R2 = tables, *G2 = tables + 256, *B2 = tables + 512;
+    for (unsigned v = 0; v < 256; ++v) {
+        R2[v] = lut_r[resc1[v]];
+        G2[v] = lut_g[resc2[v]];
+    }
+    for (unsigned v1 = 0; v1 < 256; ++v1) {
+        unsigned r1 = resc1[v1];
+        for (unsigned v2 = 0; v2 < 256; ++v2) {
+            unsigned r2 = resc2[v2];
+            bool water = fwc >= 0 && (int)r1 <= fwc && (int)r2 <= fwc; // synthetic_rgb.rs:161-166
+            B2[(v1 << 8) | v2] = water ? 0 : lut_b[(r1 << 8) | r2];
+        }
+    }
+    if (fwc >= 0) { // the short-circuit also zeroes R and G; lut_r/lut_g are already 0 at <= floor
+        for (unsigned v = 0; v < 256; ++v) {
+            if ((int)resc1[v] <= fwc) R2[v] = 0;
+            if ((int)resc2[v] <= fwc) G2[v] = 0;
+        }
+    }
+}
+
+int stripe_plan(size_t rows, int nranks, size_t *row0, size_t *nrows) {
+    if (nranks <= 0) return SARPRO_HIP_ERR_INVALID_ARG;
+    for (int k = 0; k < nranks; ++k) {
+        size_t a = (size_t)(((unsigned __int128)rows * (unsigned)k) / (unsigned)nranks);
+        size_t b = (size_t)(((unsigned __int128)rows * (unsigned)(k + 1)) / (unsigned)nranks);
+        row0[k] = a;
+        nrows[k] = b - a;
+    }
+    return SARPRO_HIP_OK;
+}
+
+} // namespace sarpro
+
+// ---------------- C ABI: host half ----------------
+using namespace sarpro;
+
+extern "C" {
+
+int sarpro_hip_host_stats_from_dn_hist(const uint64_t dn_hist[65536], sarpro_hip_stats *out) {
+    if (!dn_hist || !out) return SARPRO_HIP_ERR_INVALID_ARG;
+    return stats_from_dn_hist(dn_hist, out);
+}
+
+int sarpro_hip_host_window(sarpro_hip_stats *stats, int strategy, int tamed_synrgb) {
+    if (!stats || tamed_synrgb < 0 || tamed_synrgb > 2) return SARPRO_HIP_ERR_INVALID_ARG;
+    return select_window(stats, strategy, tamed_synrgb);
+}
+
+int sarpro_hip_host_level_lut_u16(const sarpro_hip_stats *stats, int bit_depth, int tamed_synrgb,
+                                  uint16_t lut_out[65536]) {
+    if (!stats || !lut_out || (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16))
+        return SARPRO_HIP_ERR_INVALID_ARG;
+    DnLut lut;
+    build_level_lut_u16(*stats, bit_depth, tamed_synrgb, &lut);
+    std::memcpy(lut_out, lut.full.data(), 65536 * sizeof(uint16_t));
+    return SARPRO_HIP_OK;
+}
+
+int sarpro_hip_host_clahe_bin_lut_u16(const sarpro_hip_stats *stats, uint8_t lut_out[65536]) {
+    if (!stats || !lut_out) return SARPRO_HIP_ERR_INVALID_ARG;
+    DnLut lut;
+    build_clahe_bin_lut_u16(*stats, &lut);
+    for (int i = 0; i < 65536; ++i) lut_out[i] = (uint8_t)lut.full[i];
+    return SARPRO_HIP_OK;
+}
+
+int sarpro_hip_host_clahe_cdfs(const uint64_t *tile_hists, size_t rows, size_t cols, double *cdfs_out) {
+    if (!tile_hists || !cdfs_out) return SARPRO_HIP_ERR_INVALID_ARG;
+    return clahe_cdfs(tile_hists, rows, cols, cdfs_out);
+}
+
+int sarpro_hip_host_u8_rescale_lut(unsigned min_level, unsigned max_level, uint8_t lut_out[256]) {
+    if (!lut_out || min_level > 65535 || max_level > 65535) return SARPRO_HIP_ERR_INVALID_ARG;
+    u8_rescale_lut(min_level, max_level, lut_out);
+    return SARPRO_HIP_OK;
+}
+
+int sarpro_hip_host_synrgb_luts(int strategy, const uint64_t combined_hist[256], uint64_t n_per_band,
+                                uint8_t *luts_out, int *floor_out) {
+    if (!luts_out || strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (strategy == SARPRO_STRATEGY_TAMED || strategy == SARPRO_STRATEGY_CLAHE) { // synthetic_rgb.rs:188-194
+        if (!combined_hist) return SARPRO_HIP_ERR_INVALID_ARG;
+        int fwc = synrgb_floor_from_hist(combined_hist, n_per_band);
+        synrgb_luts_suppressed(fwc, luts_out);
+        if (floor_out) *floor_out = fwc;
+    } else {
+        synrgb_luts_default(luts_out);
+        if (floor_out) *floor_out = -1;
+    }
+    return SARPRO_HIP_OK;
+}
+
+int sarpro_hip_host_clahe_shape_ok(size_t rows, size_t cols) { return clahe_shape_ok(rows, cols) ? 1 : 0; }
+
+int sarpro_hip_host_stripe_plan(size_t rows, int nranks, size_t *row0_out, size_t *nrows_out) {
+    if (!row0_out || !nrows_out) return SARPRO_HIP_ERR_INVALID_ARG;
+    return stripe_plan(rows, nranks, row0_out, nrows_out);
+}
+
+} // extern "C"

@@ -1,0 +1,80 @@
+// host_logic.h -- host half of the MI355X raster core: everything that happens between
+// kernels (statistics from device-produced histograms, window selection, LUT / CDF /
+// geometry tables).  Pure C++ + glibc libm, no HIP: runs (and is tested) without a GPU.
+//
+// The device never evaluates log10/pow for integer-DN input: every per-pixel transcendental
+// of the reference collapses into tables built here with the host's glibc, exactly as the
+// Rust reference evaluates them (f64::log10 / f64::powf / f32::powf lower to libm).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/sarpro_hip.h"
+
+namespace sarpro {
+
+constexpr int kTiles = 8;          // CLAHE tiles per axis (autoscale.rs:593)
+constexpr int kClaheBins = 256;    // autoscale.rs:593
+constexpr double kClipLimit = 2.0; // autoscale.rs:593
+constexpr int kStatBins = 4096;    // autoscale.rs:103
+
+// db[DN] = 10*log10(max(DN,1e-10)) for every u16 DN (pipeline.rs:18-23); db[0] = -100.
+const double *db_table_u16();
+
+// 0 = not tamed-synrgb, 1 = co-pol, 2 = cross-pol (autoscale.rs:721-727)
+enum TamedSynrgb { kNotTamedSynrgb = 0, kTamedCopol = 1, kTamedCrosspol = 2 };
+
+int stats_from_dn_hist(const uint64_t *dn_hist, sarpro_hip_stats *out);
+// stats over arbitrary sorted distinct (value-in-dB, count) support; used by the f32 path
+int stats_from_bins4096(uint64_t count, double min_db, double max_db, double mean, double std_db,
+                        const uint64_t *hist4096, sarpro_hip_stats *out);
+int select_window(sarpro_hip_stats *s, int strategy, int tamed_synrgb);
+
+// level of one dB value under the window (autoscale.rs:440-442 / 649-651 / 734-736)
+uint16_t level_of_db(double db, double low_clip, double high_clip, double gamma, double max_val);
+// CLAHE bin of one dB value (autoscale.rs:585-586 then 262-265 / 320)
+uint8_t clahe_bin_of_db(double db, double low_clip, double high_clip);
+
+// A per-DN table plus the DN window outside which it is constant:
+// value(DN) = full[clamp(DN, win_lo, win_hi)] for DN >= 1, and 0 for DN = 0.
+struct DnLut {
+    std::vector<uint16_t> full; // 65536 entries; full[0] = 0
+    uint32_t win_lo = 1, win_hi = 1;
+};
+void build_level_lut_u16(const sarpro_hip_stats &s, int bit_depth, int tamed_synrgb, DnLut *out);
+void build_clahe_bin_lut_u16(const sarpro_hip_stats &s, DnLut *out);
+
+// CLAHE geometry (autoscale.rs:235-236, 307-318)
+struct RowWeight { double d, omd; int32_t t0, t1; }; // d = dy (or dx), omd = 1.0 - d
+struct ClaheGeometry {
+    size_t rows = 0, cols = 0, tile_h = 0, tile_w = 0;
+    std::vector<RowWeight> row_w, col_w;
+    // cells: maximal row (col) ranges with constant (t0,t1)
+    std::vector<size_t> row_cell_start, col_cell_start; // size = ncells+1
+};
+bool clahe_shape_ok(size_t rows, size_t cols);
+void build_clahe_geometry(size_t rows, size_t cols, ClaheGeometry *g);
+void clahe_tile_cdf(uint64_t *hist /*[256], clobbered*/, size_t tile_rows, size_t tile_cols,
+                    double *cdf /*[256]*/);
+int clahe_cdfs(const uint64_t *tile_hists, size_t rows, size_t cols, double *cdfs_out);
+
+void u8_rescale_lut(unsigned min_level, unsigned max_level, uint8_t *lut256);
+
+// luts = lut_r[256] | lut_g[256] | lut_b[65536]
+void synrgb_luts_default(uint8_t *luts);
+int synrgb_floor_from_hist(const uint64_t *combined_hist256, uint64_t n_per_band);
+void synrgb_luts_suppressed(int floor_with_cushion, uint8_t *luts);
+
+// Compose tables with the per-band u8 rescale folded in:
+// R2[v1] = lut_r[resc1[v1]], G2[v2] = lut_g[resc2[v2]],
+// B2[v1<<8|v2] = lut_b[resc1[v1]<<8 | resc2[v2]] (with the suppressed water short-circuit
+// synthetic_rgb.rs:161-166 folded into all three: when both rescaled values <= floor the
+// pixel is (0,0,0); lut_r/lut_g are already 0 there, B2 is forced to 0).
+// tables = R2[256] | G2[256] | B2[65536]
+void fold_compose_tables(const uint8_t *luts, int floor_with_cushion /* -1: none */,
+                         const uint8_t *resc1, const uint8_t *resc2, uint8_t *tables);
+
+int stripe_plan(size_t rows, int nranks, size_t *row0, size_t *nrows);
+
+} // namespace sarpro

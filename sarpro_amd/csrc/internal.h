@@ -1,0 +1,22 @@
+// internal.h -- helpers shared by the translation units of libsarpro_hip.so.
+#pragma once
+#include "context.h"
+
+namespace sarpro {
+
+// Records a start/stop event pair around a launch when the context was created with flag 1.
+struct KernelTimer {
+    sarpro_hip_ctx *ctx;
+    bool active = false;
+    KernelTimer(sarpro_hip_ctx *c, const char *name);
+    ~KernelTimer();
+};
+void timing_reset(sarpro_hip_ctx *ctx);
+size_t round_up(size_t x, size_t m);
+int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, bool vec,
+             StripePlan **out);
+int stage_in_2d(sarpro_hip_ctx *ctx, DevBuf &buf, const void *host, size_t rows, size_t cols, size_t esz,
+                size_t *pitch_elems);
+int fetch_out_2d(sarpro_hip_ctx *ctx, void *host, const void *dev, size_t pitch_bytes, size_t row_bytes, size_t rows);
+
+} // namespace sarpro

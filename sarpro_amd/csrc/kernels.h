@@ -1,0 +1,90 @@
+// kernels.h -- launch interface of the gfx950 kernels (kernels.hip).  Plain structs and
+// device pointers; every launcher enqueues on the given stream and returns hipError_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "host_logic.h"
+
+namespace sarpro {
+
+constexpr int kMaxBands = 2;
+
+// Work item of the position-dependent kernels: a column strip x row range that lies inside
+// one CLAHE tile (histogram pass) or one interpolation cell (apply pass).  Rows/cols are in
+// LOCAL raster coordinates (the stripe this rank holds).
+struct Rect {
+    int32_t r0, r1;         // rows [r0, r1)
+    int32_t c0, c1;         // columns [c0, c1) this item owns
+    int32_t cstart;         // c0 rounded down to the vector width: lane l starts at cstart + l*VEC
+    int32_t id[4];          // hist: id[0] = tile index;  apply: tile indices t00, t01, t10, t11
+    int32_t pad[3];
+};
+static_assert(sizeof(Rect) == 48, "Rect layout");
+
+struct DnHistArgs {
+    const uint16_t *in[kMaxBands];
+    uint32_t *tile_hist[kMaxBands]; // [ntiles][65536], zeroed by the caller
+    size_t pitch;                   // elements
+    const Rect *rects;
+    uint32_t lds_bins;              // DN < lds_bins are privatised in LDS
+};
+
+struct ClaheApplyArgs {
+    const uint16_t *in[kMaxBands];
+    void *out[kMaxBands];                   // u8 (levels 0..255) or u16
+    size_t in_pitch, out_pitch;             // elements
+    const Rect *rects;
+    const double *cdfs[kMaxBands];          // [64][256]
+    const uint8_t *binlut[kMaxBands];       // full 65536-entry DN -> bin table
+    uint32_t win_lo[kMaxBands], win_hi[kMaxBands];
+    uint32_t lut_in_lds;                    // window staged in LDS (else gathered from global)
+    const RowWeight *row_w;                 // indexed by GLOBAL row (row_off + local row)
+    const RowWeight *col_w;                 // indexed by column
+    unsigned long long *level_hist[kMaxBands]; // [256] histogram of u8 levels, or null
+    int32_t row_off;
+    double max_val;                         // 255.0 or 65535.0
+};
+
+struct LutApplyArgs {
+    const uint16_t *in;
+    void *out;                  // u8 or u16
+    size_t in_pitch, out_pitch; // elements
+    uint32_t rows, cols;
+    const void *lut;            // full 65536-entry table of u8 (OUT16 = false) or u16 entries
+    uint32_t win_lo, win_hi;
+    uint32_t lut_in_lds;
+};
+
+struct ComposeArgs {
+    const uint8_t *b1, *b2;
+    uint8_t *rgb;
+    size_t in_pitch, rgb_pitch_px; // elements / pixels
+    uint32_t rows, cols;
+    const uint8_t *tables;         // R2[256] | G2[256] | B2[65536]
+};
+
+hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);
+hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned long long *out,
+                                 hipStream_t s);
+hipError_t launch_tile_bin_hist(const uint32_t *tile_hist, int ntiles, const uint8_t *binlut,
+                                unsigned long long *out, hipStream_t s);
+hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,
+                                  hipStream_t s);
+hipError_t launch_lut_apply_u16(const LutApplyArgs &a, bool vec, bool out16, hipStream_t s);
+hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s);
+hipError_t launch_polop_f32(int op, const float *a, const float *b, size_t n, float *out, hipStream_t s);
+hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q /*[4][65536]*/,
+                                  size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                                  uint16_t *d_out, size_t pitch, hipStream_t s);
+hipError_t launch_remap_u8(uint8_t *buf, size_t pitch, uint32_t rows, uint32_t cols, const uint8_t *d_map256,
+                           hipStream_t s);
+hipError_t launch_hist256_u8(const uint8_t *in, size_t pitch, uint32_t rows, uint32_t cols,
+                             unsigned long long *hist, hipStream_t s);
+
+size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands);
+constexpr uint32_t kLutLdsMaxBytes = 48 * 1024; // per-band window budget in LDS
+
+} // namespace sarpro

@@ -1,0 +1,575 @@
+// kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the SAR raster core.
+//
+// All of these are HBM-bound integer / gather work (no MFMA: the path is pointwise +
+// histogram).  Common shape: 64-lane waves read 16 B per lane (8 u16 samples) from
+// row-major rasters, so one wave instruction covers 1 KiB of a row; per-pixel
+// transcendental math is replaced by host-built tables that live in LDS.
+//
+// Built with -ffp-contract=off: the CLAHE blend must round like the reference's separate
+// f64 multiplies and adds (autoscale.rs:327-329), never as FMAs.
+#include "kernels.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace sarpro {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;           // 4 waves: one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+template <int VEC> struct U16Vec;
+template <> struct U16Vec<8> {
+    uint4 v;
+    __device__ static U16Vec load(const uint16_t *p) { U16Vec r; r.v = *reinterpret_cast<const uint4 *>(p); return r; }
+    __device__ uint32_t get(int j) const {
+        uint32_t w = j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w));
+        return (j & 1) ? (w >> 16) : (w & 0xFFFFu);
+    }
+};
+template <> struct U16Vec<1> {
+    uint32_t v;
+    __device__ static U16Vec load(const uint16_t *p) { U16Vec r; r.v = *p; return r; }
+    __device__ uint32_t get(int) const { return v; }
+};
+
+__device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+
+// ------------------------------------------------------------------------------------
+// 1. Per-tile DN histogram (pass 1).  One work item = a column strip x row range inside
+//    one CLAHE tile.  Counts of DN < lds_bins are privatised in LDS (ds_add_u32), the
+//    bright tail goes straight to the tile's global histogram, DN = 0 (no-data) is counted
+//    in a register so the no-data wedge does not serialise on one LDS word.
+//    Algorithmic traffic: 2 B/px read.
+// ------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_dn_hist_u16(DnHistArgs a) {
+    extern __shared__ uint32_t lds_hist[];
+    const Rect rc = a.rects[blockIdx.x];
+    const int band = blockIdx.y;
+    const uint16_t *__restrict__ in = a.in[band];
+    uint32_t *__restrict__ gh = a.tile_hist[band] + (size_t)rc.id[0] * 65536u;
+    const uint32_t W = a.lds_bins;
+
+    for (uint32_t i = threadIdx.x; i < W; i += kBlock) lds_hist[i] = 0;
+    __syncthreads();
+
+    const int col = rc.cstart + lane_id() * VEC;
+    const bool lane_on = col < rc.c1 && col + VEC > rc.c0;
+    uint32_t zeros = 0;
+
+    auto consume = [&](const U16Vec<VEC> &v) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = col + j;
+            if (c >= rc.c0 && c < rc.c1) {
+                const uint32_t d = v.get(j);
+                if (d == 0) ++zeros;
+                else if (d < W) atomicAdd(&lds_hist[d], 1u);
+                else atomicAdd(&gh[d], 1u);
+            }
+        }
+    };
+
+    if (lane_on) {
+        const int step = kWavesPerBlock;
+        int r = rc.r0 + wave_id();
+        // two rows in flight per wave: the loads of row r+step issue before row r is consumed
+        for (; r + step < rc.r1; r += 2 * step) {
+            const U16Vec<VEC> v0 = U16Vec<VEC>::load(in + (size_t)r * a.pitch + col);
+            const U16Vec<VEC> v1 = U16Vec<VEC>::load(in + (size_t)(r + step) * a.pitch + col);
+            consume(v0);
+            consume(v1);
+        }
+        if (r < rc.r1) consume(U16Vec<VEC>::load(in + (size_t)r * a.pitch + col));
+    }
+    if (zeros) atomicAdd(&lds_hist[0], zeros); // slot 0 is otherwise unused (d == 0 never lands in LDS)
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < W; i += kBlock) {
+        const uint32_t n = lds_hist[i];
+        if (n) atomicAdd(&gh[i], n);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 2. Sum the per-tile histograms into the band's global 65536-bin histogram (u64).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sum_tile_hists(const uint32_t *__restrict__ th, int ntiles,
+                                                           unsigned long long *__restrict__ out) {
+    const uint32_t dn = blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long s = 0;
+    for (int t = 0; t < ntiles; ++t) s += th[(size_t)t * 65536u + dn];
+    out[dn] = s;
+}
+
+// ------------------------------------------------------------------------------------
+// 3. Per-tile 256-bin CLAHE histogram from the per-tile DN histogram and the DN -> bin table
+//    (autoscale.rs:259-268 without touching the pixels again).  One block per tile.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tile_bin_hist(const uint32_t *__restrict__ th,
+                                                          const uint8_t *__restrict__ binlut,
+                                                          unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long h[256];
+    const uint32_t *__restrict__ t = th + (size_t)blockIdx.x * 65536u;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t dn = threadIdx.x; dn < 65536u; dn += kBlock) {
+        const uint32_t n = t[dn];
+        if (n && dn) atomicAdd(&h[binlut[dn]], (unsigned long long)n); // DN = 0 is invalid: not counted
+    }
+    __syncthreads();
+    out[(size_t)blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------
+// 4. CLAHE apply (pass 2): DN -> bin (windowed table in LDS) -> bilinear blend of the four
+//    neighbouring tile CDFs in exact IEEE f64 (autoscale.rs:307-330) -> level
+//    (autoscale.rs:600-606), plus the 256-bin histogram of the u8 levels that the u8 rescale
+//    (autoscale.rs:348-364) and the suppressed-synRGB floor (synthetic_rgb.rs:92-113) need.
+//    One work item = a 64*VEC-column strip x row range inside one interpolation cell, so the
+//    four CDFs are fixed per block and the per-column weights (dx, 1-dx) stay in registers;
+//    the per-row weights (dy, 1-dy) are wave-uniform.
+//    Algorithmic traffic: 2 B/px read + 1 (u8) or 2 (u16) B/px written.
+// ------------------------------------------------------------------------------------
+template <int VEC, bool OUT16>
+__global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *cdf4 = reinterpret_cast<double *>(lds_raw);                        // [256][4]
+    uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_raw + 256 * 4 * 8);  // [256]
+    uint8_t *lds_lut = lds_raw + 256 * 4 * 8 + 256 * 4;                        // window
+
+    const Rect rc = a.rects[blockIdx.x];
+    const int band = blockIdx.y;
+    const uint16_t *__restrict__ in = a.in[band];
+    const double *__restrict__ cdfs = a.cdfs[band];
+    const uint8_t *__restrict__ glut = a.binlut[band];
+    const uint32_t win_lo = a.win_lo[band], win_hi = a.win_hi[band];
+    const bool lut_lds = a.lut_in_lds != 0;
+    unsigned long long *ghist = a.level_hist[band];
+
+    {   // stage the four CDFs interleaved per bin: one pixel gathers 32 contiguous bytes
+        const int b = threadIdx.x; // kBlock == 256 bins
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cdf4[b * 4 + k] = cdfs[(size_t)rc.id[k] * 256 + b];
+        lds_hist[b] = 0;
+        if (lut_lds)
+            for (uint32_t i = threadIdx.x; i <= win_hi - win_lo; i += kBlock) lds_lut[i] = glut[win_lo + i];
+    }
+    __syncthreads();
+
+    const int col = rc.cstart + lane_id() * VEC;
+    const bool lane_on = col < rc.c1 && col + VEC > rc.c0;
+    const bool full = col >= rc.c0 && col + VEC <= rc.c1;
+    uint32_t zeros = 0;
+
+    double dx[VEC], omdx[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = col + j;
+        const bool in_rng = c >= rc.c0 && c < rc.c1;
+        const RowWeight w = a.col_w[in_rng ? c : rc.c0];
+        dx[j] = w.d;
+        omdx[j] = w.omd;
+    }
+
+    auto process_row = [&](int r, const U16Vec<VEC> &v) {
+        const RowWeight rw = a.row_w[a.row_off + r]; // wave-uniform
+        const double dy = rw.d, omdy = rw.omd;
+        uint32_t lv[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t d = v.get(j);
+            const uint32_t dc = min(max(d, win_lo), win_hi);
+            const uint32_t bin = lut_lds ? (uint32_t)lds_lut[dc - win_lo] : (uint32_t)glut[dc];
+            const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
+            const double top = c4.x * omdx[j] + c4.y * dx[j];
+            const double bottom = c4.z * omdx[j] + c4.w * dx[j];
+            double o = top * omdy + bottom * dy;
+            o = fmin(fmax(o, 0.0), 1.0);
+            const uint32_t level = (uint32_t)(o * a.max_val); // truncation, o*max_val in [0, max_val]
+            lv[j] = d ? level : 0u;                           // invalid (DN = 0) -> 0
+        }
+        if (!OUT16 && ghist) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = col + j;
+                if (c >= rc.c0 && c < rc.c1) {
+                    if (lv[j] == 0) ++zeros;
+                    else atomicAdd(&lds_hist[lv[j]], 1u);
+                }
+            }
+        }
+        if (OUT16) {
+            uint16_t *o16 = reinterpret_cast<uint16_t *>(a.out[band]) + (size_t)r * a.out_pitch + col;
+            if (VEC == 8 && full) {
+                uint4 pk;
+                pk.x = lv[0] | (lv[1] << 16); pk.y = lv[2] | (lv[3] << 16);
+                pk.z = lv[4] | (lv[5] << 16); pk.w = lv[6] | (lv[7] << 16);
+                *reinterpret_cast<uint4 *>(o16) = pk;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (col + j >= rc.c0 && col + j < rc.c1) o16[j] = (uint16_t)lv[j];
+            }
+        } else {
+            uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out[band]) + (size_t)r * a.out_pitch + col;
+            if (VEC == 8 && full) {
+                uint2 pk;
+                pk.x = lv[0] | (lv[1] << 8) | (lv[2] << 16) | (lv[3] << 24);
+                pk.y = lv[4] | (lv[5] << 8) | (lv[6] << 16) | (lv[7] << 24);
+                *reinterpret_cast<uint2 *>(o8) = pk;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (col + j >= rc.c0 && col + j < rc.c1) o8[j] = (uint8_t)lv[j];
+            }
+        }
+    };
+
+    if (lane_on) {
+        const int step = kWavesPerBlock;
+        int r = rc.r0 + wave_id();
+        for (; r + step < rc.r1; r += 2 * step) {
+            const U16Vec<VEC> v0 = U16Vec<VEC>::load(in + (size_t)r * a.in_pitch + col);
+            const U16Vec<VEC> v1 = U16Vec<VEC>::load(in + (size_t)(r + step) * a.in_pitch + col);
+            process_row(r, v0);
+            process_row(r + step, v1);
+        }
+        if (r < rc.r1) process_row(r, U16Vec<VEC>::load(in + (size_t)r * a.in_pitch + col));
+    }
+
+    if (!OUT16 && ghist) {
+        if (zeros) atomicAdd(&lds_hist[0], zeros);
+        __syncthreads();
+        const uint32_t n = lds_hist[threadIdx.x];
+        if (n) atomicAdd(&ghist[threadIdx.x], (unsigned long long)n);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 5. Table apply for the percentile strategies: out = LUT[DN] (the table already folds
+//    dB, clip, gamma, quantisation and -- for u8 -- the global rescale).  Flat over
+//    (row, vector) pairs.  Algorithmic traffic: 2 B/px read + 1 or 2 B/px written.
+// ------------------------------------------------------------------------------------
+template <int VEC, bool OUT16>
+__global__ __launch_bounds__(kBlock) void k_lut_apply_u16(LutApplyArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using Entry = typename std::conditional<OUT16, uint16_t, uint8_t>::type;
+    Entry *lds_lut = reinterpret_cast<Entry *>(lds_raw);
+    const Entry *__restrict__ glut = reinterpret_cast<const Entry *>(a.lut);
+    const uint32_t win_lo = a.win_lo, win_hi = a.win_hi;
+    const bool lut_lds = a.lut_in_lds != 0;
+    if (lut_lds) {
+        for (uint32_t i = threadIdx.x; i <= win_hi - win_lo; i += kBlock) lds_lut[i] = glut[win_lo + i];
+        __syncthreads();
+    }
+    const uint32_t vpr = (a.cols + VEC - 1) / VEC;
+    const uint64_t total = (uint64_t)a.rows * vpr;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t r = (uint32_t)(idx / vpr);
+        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
+        const U16Vec<VEC> v = U16Vec<VEC>::load(a.in + (size_t)r * a.in_pitch + col);
+        uint32_t lv[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t d = v.get(j);
+            const uint32_t dc = min(max(d, win_lo), win_hi);
+            const uint32_t l = lut_lds ? (uint32_t)lds_lut[dc - win_lo] : (uint32_t)glut[dc];
+            lv[j] = d ? l : 0u;
+        }
+        const bool full = col + VEC <= a.cols;
+        if (OUT16) {
+            uint16_t *o = reinterpret_cast<uint16_t *>(a.out) + (size_t)r * a.out_pitch + col;
+            if (VEC == 8 && full) {
+                uint4 pk;
+                pk.x = lv[0] | (lv[1] << 16); pk.y = lv[2] | (lv[3] << 16);
+                pk.z = lv[4] | (lv[5] << 16); pk.w = lv[6] | (lv[7] << 16);
+                *reinterpret_cast<uint4 *>(o) = pk;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) if (col + j < a.cols) o[j] = (uint16_t)lv[j];
+            }
+        } else {
+            uint8_t *o = reinterpret_cast<uint8_t *>(a.out) + (size_t)r * a.out_pitch + col;
+            if (VEC == 8 && full) {
+                uint2 pk;
+                pk.x = lv[0] | (lv[1] << 8) | (lv[2] << 16) | (lv[3] << 24);
+                pk.y = lv[4] | (lv[5] << 8) | (lv[6] << 16) | (lv[7] << 24);
+                *reinterpret_cast<uint2 *>(o) = pk;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) if (col + j < a.cols) o[j] = (uint8_t)lv[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 6. Synthetic-RGB compose (synthetic_rgb.rs:55-64 / 158-175) from two u8 level rasters.
+//    Tables (with each band's u8 rescale and the water short-circuit folded in) live in LDS:
+//    R2[256] | G2[256] | B2[65536].  16 px per lane: 2 x 16 B loads, 3 x 16 B stores.
+//    Algorithmic traffic: 2 B/px read + 3 B/px written.
+// ------------------------------------------------------------------------------------
+constexpr int kComposeBlock = 1024; // 66 KiB of tables per block -> 2 blocks (32 waves) per CU
+constexpr int kComposeTableBytes = 512 + 65536;
+
+template <int VEC>
+__global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < kComposeTableBytes / 16; i += kComposeBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint8_t *R2 = lds_raw, *G2 = lds_raw + 256, *B2 = lds_raw + 512;
+    const uint32_t vpr = (a.cols + VEC - 1) / VEC;
+    const uint64_t total = (uint64_t)a.rows * vpr;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kComposeBlock + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * kComposeBlock) {
+        const uint32_t r = (uint32_t)(idx / vpr);
+        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
+        const uint8_t *p1 = a.b1 + (size_t)r * a.in_pitch + col;
+        const uint8_t *p2 = a.b2 + (size_t)r * a.in_pitch + col;
+        uint8_t *po = a.rgb + ((size_t)r * a.rgb_pitch_px + col) * 3;
+        if (VEC == 16 && col + VEC <= a.cols) {
+            const uint4 q1 = *reinterpret_cast<const uint4 *>(p1);
+            const uint4 q2 = *reinterpret_cast<const uint4 *>(p2);
+            const uint32_t w1[4] = {q1.x, q1.y, q1.z, q1.w}, w2[4] = {q2.x, q2.y, q2.z, q2.w};
+            uint32_t o[12];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { // 4 px -> 12 bytes -> 3 dwords
+                uint32_t px[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t v1 = (w1[g] >> (8 * j)) & 0xFF, v2 = (w2[g] >> (8 * j)) & 0xFF;
+                    px[j][0] = R2[v1]; px[j][1] = G2[v2]; px[j][2] = B2[(v1 << 8) | v2];
+                }
+                o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
+                o[3 * g + 1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
+                o[3 * g + 2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+            }
+            uint4 *d = reinterpret_cast<uint4 *>(po);
+            d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            d[2] = make_uint4(o[8], o[9], o[10], o[11]);
+        } else {
+            for (int j = 0; j < VEC && col + j < a.cols; ++j) {
+                const uint32_t v1 = p1[j], v2 = p2[j];
+                po[3 * j + 0] = R2[v1]; po[3 * j + 1] = G2[v2]; po[3 * j + 2] = B2[(v1 << 8) | v2];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 7. Polarisation operations (ops.rs:4-44), IEEE f32, correctly rounded division.
+// ------------------------------------------------------------------------------------
+__device__ inline float polop_one(int op, float x, float y) {
+    switch (op) {
+    case SARPRO_OP_SUM: return x + y;
+    case SARPRO_OP_DIFF: return x - y;
+    case SARPRO_OP_RATIO:
+    case SARPRO_OP_LOGRATIO: return fabsf(y) > 1e-10f ? x / y : 0.0f;
+    default: { const float d = x + y; return fabsf(d) > 1e-10f ? (x - y) / d : 0.0f; }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_polop_f32(int op, const float *__restrict__ a,
+                                                      const float *__restrict__ b, size_t n,
+                                                      float *__restrict__ out, int vec_ok) {
+    const size_t nv = vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
+        float4 o;
+        o.x = polop_one(op, x.x, y.x); o.y = polop_one(op, x.y, y.y);
+        o.z = polop_one(op, x.z, y.z); o.w = polop_one(op, x.w, y.w);
+        reinterpret_cast<float4 *>(out)[i] = o;
+    }
+    for (size_t i = nv * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = polop_one(op, a[i], b[i]);
+}
+
+// ------------------------------------------------------------------------------------
+// 8. 256-bin histogram of a u8 raster (standalone suppressed synRGB, synthetic_rgb.rs:92-98).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_hist256_u8(const uint8_t *__restrict__ in, size_t pitch,
+                                                       uint32_t rows, uint32_t cols,
+                                                       unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t h[kWavesPerBlock][256]; // one copy per wave: fewer same-address collisions
+    for (int i = threadIdx.x; i < kWavesPerBlock * 256; i += kBlock) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *mine = h[threadIdx.x >> 6];
+    const uint64_t total = (uint64_t)rows * cols;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t r = (uint32_t)(idx / cols);
+        const uint32_t c = (uint32_t)(idx - (uint64_t)r * cols);
+        atomicAdd(&mine[in[(size_t)r * pitch + c]], 1u);
+    }
+    __syncthreads();
+    uint32_t n = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) n += h[w][threadIdx.x];
+    if (n) atomicAdd(&hist[threadIdx.x], (unsigned long long)n);
+}
+
+// ------------------------------------------------------------------------------------
+// 8b. In-place u8 -> u8 remap (the rare case where scale_u16_to_u8 of a CLAHE level raster is
+//     not the identity and the caller wants the per-band u8 raster itself).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_remap_u8(uint8_t *__restrict__ buf, size_t pitch, uint32_t rows,
+                                                     uint32_t cols, const uint8_t *__restrict__ map) {
+    __shared__ uint8_t m[256];
+    m[threadIdx.x] = map[threadIdx.x];
+    __syncthreads();
+    const uint64_t total = (uint64_t)rows * cols;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t r = (uint32_t)(idx / cols);
+        const uint32_t c = (uint32_t)(idx - (uint64_t)r * cols);
+        uint8_t *p = buf + (size_t)r * pitch + c;
+        *p = m[*p];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 9. Synthetic scene generator (bench / tests; mirrors sarpro_amd/synth.py exactly).
+// ------------------------------------------------------------------------------------
+__device__ inline uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void k_synth_scene_u16(uint64_t key, const uint16_t *__restrict__ q,
+                                                            uint64_t rows_total, uint64_t cols, uint64_t row0,
+                                                            uint64_t rows_local, uint64_t block,
+                                                            uint16_t *__restrict__ out, size_t pitch) {
+    const uint64_t total = rows_local * cols;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t rl = i / cols, c = i - rl * cols, r = row0 + rl;
+        const uint64_t h = splitmix64((r * cols + c) ^ key);
+        const uint64_t cls = ((r / block) + 3 * (c / block)) & 3;
+        uint32_t dn = q[cls * 65536 + (h >> 48)];
+        if (((h >> 20) % 10000ull) == 0) dn = (uint32_t)((20000ull + (h & 0x7FFFull)) & 0xFFFFull);
+        const bool left = c * rows_total * 100ull < 3ull * cols * (rows_total - r);
+        const bool right = (cols - 1 - c) * rows_total * 100ull < 3ull * cols * r;
+        if (left || right) dn = 0;
+        out[rl * pitch + c] = (uint16_t)dn;
+    }
+}
+
+inline int stream_grid(uint64_t work_items, int block, int per_cu = 8) {
+    const uint64_t want = (work_items + block - 1) / block;
+    const uint64_t cap = 256ull * per_cu;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+} // namespace
+
+hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s) {
+    if (nrects <= 0) return hipSuccess;
+    const size_t lds = (size_t)a.lds_bins * sizeof(uint32_t);
+    dim3 grid(nrects, nbands);
+    if (vec) hipLaunchKernelGGL(k_dn_hist_u16<8>, grid, dim3(kBlock), lds, s, a);
+    else hipLaunchKernelGGL(k_dn_hist_u16<1>, grid, dim3(kBlock), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_tile_hists, dim3(65536 / kBlock), dim3(kBlock), 0, s, tile_hist, ntiles, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_bin_hist(const uint32_t *tile_hist, int ntiles, const uint8_t *binlut,
+                                unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_bin_hist, dim3(ntiles), dim3(kBlock), 0, s, tile_hist, binlut, out);
+    return hipGetLastError();
+}
+
+size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands) {
+    size_t win = 0;
+    if (a.lut_in_lds)
+        for (int b = 0; b < nbands; ++b) win = std::max<size_t>(win, a.win_hi[b] - a.win_lo[b] + 1);
+    return 256 * 4 * 8 + 256 * 4 + ((win + 15) & ~(size_t)15);
+}
+
+hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,
+                                  hipStream_t s) {
+    if (nrects <= 0) return hipSuccess;
+    const size_t lds = clahe_apply_lds_bytes(a, nbands);
+    dim3 grid(nrects, nbands);
+    if (vec) {
+        if (out16) hipLaunchKernelGGL((k_clahe_apply_u16<8, true>), grid, dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_clahe_apply_u16<8, false>), grid, dim3(kBlock), lds, s, a);
+    } else {
+        if (out16) hipLaunchKernelGGL((k_clahe_apply_u16<1, true>), grid, dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_clahe_apply_u16<1, false>), grid, dim3(kBlock), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lut_apply_u16(const LutApplyArgs &a, bool vec, bool out16, hipStream_t s) {
+    if (a.rows == 0 || a.cols == 0) return hipSuccess;
+    const size_t esz = out16 ? 2 : 1;
+    const size_t lds = a.lut_in_lds ? (((size_t)(a.win_hi - a.win_lo + 1) * esz + 15) & ~(size_t)15) : 0;
+    const int V = vec ? 8 : 1;
+    const uint64_t items = (uint64_t)a.rows * ((a.cols + V - 1) / V);
+    dim3 grid(stream_grid(items, kBlock));
+    if (vec) {
+        if (out16) hipLaunchKernelGGL((k_lut_apply_u16<8, true>), grid, dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_lut_apply_u16<8, false>), grid, dim3(kBlock), lds, s, a);
+    } else {
+        if (out16) hipLaunchKernelGGL((k_lut_apply_u16<1, true>), grid, dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_lut_apply_u16<1, false>), grid, dim3(kBlock), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s) {
+    if (a.rows == 0 || a.cols == 0) return hipSuccess;
+    const uint64_t items = (uint64_t)a.rows * ((a.cols + vec - 1) / vec);
+    dim3 grid(stream_grid(items, kComposeBlock, 2));
+    if (vec == 16) hipLaunchKernelGGL(k_compose_u8<16>, grid, dim3(kComposeBlock), kComposeTableBytes, s, a);
+    else hipLaunchKernelGGL(k_compose_u8<1>, grid, dim3(kComposeBlock), kComposeTableBytes, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_polop_f32(int op, const float *a, const float *b, size_t n, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                         reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    hipLaunchKernelGGL(k_polop_f32, dim3(stream_grid(n / 4 + 1, kBlock)), dim3(kBlock), 0, s, op, a, b, n, out, vec_ok);
+    return hipGetLastError();
+}
+
+hipError_t launch_remap_u8(uint8_t *buf, size_t pitch, uint32_t rows, uint32_t cols, const uint8_t *d_map256,
+                           hipStream_t s) {
+    if (rows == 0 || cols == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_remap_u8, dim3(stream_grid((uint64_t)rows * cols, kBlock)), dim3(kBlock), 0, s, buf, pitch, rows,
+                       cols, d_map256);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist256_u8(const uint8_t *in, size_t pitch, uint32_t rows, uint32_t cols,
+                             unsigned long long *hist, hipStream_t s) {
+    if (rows == 0 || cols == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hist256_u8, dim3(stream_grid((uint64_t)rows * cols, kBlock)), dim3(kBlock), 0, s, in, pitch,
+                       rows, cols, hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q, size_t rows_total, size_t cols,
+                                  size_t row0, size_t rows_local, uint16_t *d_out, size_t pitch, hipStream_t s) {
+    if (rows_local == 0 || cols == 0) return hipSuccess;
+    const uint64_t key = seed ^ ((uint64_t)band << 60);
+    const uint64_t block = std::max<uint64_t>((rows_total + 15) / 16, 1);
+    hipLaunchKernelGGL(k_synth_scene_u16, dim3(stream_grid((uint64_t)rows_local * cols, kBlock)), dim3(kBlock), 0, s,
+                       key, d_q, (uint64_t)rows_total, (uint64_t)cols, (uint64_t)row0, (uint64_t)rows_local, block,
+                       d_out, pitch);
+    return hipGetLastError();
+}
+
+} // namespace sarpro

@@ -1,0 +1,161 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle, u16 (integer-DN) flavour.
+
+Bar: bit-exact for every u8/u16 raster.  Sizes are small enough that the oracle runs in
+seconds.  Mirrors how the reference's own tests would read: call the reference-named
+function, compare the raster.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, SyntheticRgbMode as Mode
+from sarpro_amd import SarproHipError, synth
+from sarpro_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(257, 300), (64, 64), (100, 333), (512, 640), (7, 8), (43, 1000)]
+
+
+def scene(rows, cols, band, **kw):
+    return synth.scene_u16(rows, cols, band, **kw)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("strategy", list(St))
+@pytest.mark.parametrize("bit_depth", list(Bd))
+def test_pipeline_u16_matches_oracle(ctx, shape, strategy, bit_depth):
+    rows, cols = shape
+    for band in (0, 1):
+        dn = scene(rows, cols, band)
+        u8, u16, st = ctx.process_scalar_data_pipeline(dn, bit_depth, strategy, want_stats=True)
+        rc, ref, so = oracle.pipeline(dn.astype(np.float32), int(bit_depth), int(strategy), want_stats=True)
+        assert rc == 0
+        got = u8 if bit_depth == Bd.U8 else u16
+        assert got.dtype == ref.dtype and got.shape == ref.shape
+        assert np.array_equal(got, ref), f"{(got != ref).sum()} px differ"
+        # statistics: exact except Welford mean/std (summed per DN instead)
+        for k in ("valid_count", "min_db", "max_db", "median_db", "p01", "p02", "p05", "p10", "p25", "p75",
+                  "p90", "p95", "p98", "p99", "low_clip", "high_clip", "gamma"):
+            assert getattr(st, k) == getattr(so, k), k
+        assert abs(st.mean_db - so.mean_db) <= 1e-9 * max(1.0, abs(so.mean_db))
+        assert abs(st.std_db - so.std_db) <= 1e-9 * max(1.0, abs(so.std_db))
+
+
+@pytest.mark.parametrize("shape", [(257, 300), (96, 1031), (512, 640)])
+@pytest.mark.parametrize("strategy", list(St))
+def test_dualpol_synrgb_u16_matches_oracle(ctx, shape, strategy):
+    rows, cols = shape
+    b1, b2 = scene(rows, cols, 0), scene(rows, cols, 1)
+    rgb, u1, u2 = ctx.dualpol_synrgb(b1, b2, strategy, Mode.Default, want_u8=True)
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1.astype(np.float32), b2.astype(np.float32), int(strategy))
+    assert rc == 0
+    assert np.array_equal(u1, r1), f"band1 {(u1 != r1).sum()} px differ"
+    assert np.array_equal(u2, r2), f"band2 {(u2 != r2).sum()} px differ"
+    assert np.array_equal(rgb, rrgb), f"rgb {(rgb != rrgb).any(axis=2).sum()} px differ"
+    # without the per-band outputs the composition must be the same
+    rgb2 = ctx.dualpol_synrgb(b1, b2, strategy, Mode.SarUrban)  # mode is ignored by the reference (synthetic_rgb.rs:72-79)
+    assert np.array_equal(rgb2, rrgb)
+
+
+@pytest.mark.parametrize("is_copol", [True, False])
+def test_tamed_synrgb_u8(ctx, is_copol):
+    dn = scene(200, 264, 0 if is_copol else 1)
+    got = ctx.autoscale_db_image_tamed_synrgb_u8(dn, is_copol)
+    ref = oracle.tamed_synrgb_u8(dn.astype(np.float32), is_copol)
+    assert np.array_equal(got, ref)
+
+
+def test_flat_scene_takes_iqr_arm(ctx):
+    # single-class Rayleigh: IQR ~3.4 dB < 5 -> Standard's `iqr < 5` arm (autoscale.rs:409-413)
+    q = synth.q_tables(flat=True)
+    dn = synth.scene_u16(300, 300, 0, q=q)
+    u8, _, st = ctx.process_scalar_data_pipeline(dn, Bd.U8, St.Standard, want_stats=True)
+    rc, ref, so = oracle.pipeline(dn.astype(np.float32), 0, 0, want_stats=True)
+    assert (st.p75 - st.p25) < 5.0 and (st.max_db - st.min_db) >= 15.0 and st.gamma == 1.0
+    assert np.array_equal(u8, ref)
+
+
+@pytest.mark.parametrize("strategy", list(St))
+@pytest.mark.parametrize("bit_depth", list(Bd))
+def test_degenerate_inputs(ctx, strategy, bit_depth):
+    for dn in (np.zeros((50, 70), np.uint16),              # no valid pixel -> zero raster (autoscale.rs:376-378)
+               np.full((50, 70), 1234, np.uint16),         # constant -> degenerate stats branch (:81-100)
+               np.where(np.arange(3500).reshape(50, 70) % 2 == 0, 7, 65535).astype(np.uint16)):
+        u8, u16 = ctx.process_scalar_data_pipeline(dn, bit_depth, strategy)
+        rc, ref = oracle.pipeline(dn.astype(np.float32), int(bit_depth), int(strategy))
+        assert rc == 0
+        assert np.array_equal(u8 if bit_depth == Bd.U8 else u16, ref)
+
+
+def test_low_contrast_arm(ctx):
+    # dynamic range < 15 dB -> Standard's median-window arm with gamma 1.1 (autoscale.rs:404-408)
+    rng = np.random.default_rng(5)
+    dn = rng.integers(1000, 4000, size=(120, 168)).astype(np.uint16)
+    u16 = ctx.process_scalar_data_pipeline(dn, Bd.U16, St.Standard)[1]
+    rc, ref, so = oracle.pipeline(dn.astype(np.float32), 1, 0, want_stats=True)
+    assert so.gamma == 1.1
+    assert np.array_equal(u16, ref)
+
+
+def test_uniform_dn_exercises_global_atomics_and_big_window(ctx):
+    # DN uniform over the whole u16 range: the histogram's bright tail path (DN >= LDS window)
+    # and a table window too large for LDS (gathered from global memory instead)
+    rng = np.random.default_rng(11)
+    dn = rng.integers(0, 65536, size=(256, 512)).astype(np.uint16)
+    for strategy in (St.Clahe, St.Robust, St.Adaptive):
+        for bd in Bd:
+            u8, u16 = ctx.process_scalar_data_pipeline(dn, bd, strategy)
+            rc, ref = oracle.pipeline(dn.astype(np.float32), int(bd), int(strategy))
+            assert np.array_equal(u8 if bd == Bd.U8 else u16, ref)
+
+
+def test_clahe_unsupported_shapes(ctx):
+    # shapes where the reference's tile arithmetic underflows (autoscale.rs:250,254): it panics,
+    # the oracle and the library both refuse
+    for rows, cols in ((9, 64), (64, 13), (3, 3), (34, 100)):
+        assert not oracle.clahe_shape_ok(rows, cols)
+        dn = scene(rows, cols, 0)
+        with pytest.raises(SarproHipError) as ei:
+            ctx.process_scalar_data_pipeline(dn, Bd.U8, St.Clahe)
+        assert ei.value.code == _lib.ERR_UNSUPPORTED_SHAPE
+        rc, _ = oracle.pipeline(dn.astype(np.float32), 0, int(St.Clahe))
+        assert rc == oracle.ERR_UNSUPPORTED_SHAPE
+        # the other strategies do not tile and must still work
+        u8, _ = ctx.process_scalar_data_pipeline(dn, Bd.U8, St.Robust)
+        assert np.array_equal(u8, oracle.pipeline(dn.astype(np.float32), 0, int(St.Robust))[1])
+
+
+def test_empty_raster(ctx):
+    dn = np.zeros((0, 0), np.uint16)
+    u8, _ = ctx.process_scalar_data_pipeline(dn, Bd.U8, St.Clahe)
+    assert u8.shape == (0, 0)
+
+
+@pytest.mark.parametrize("op", range(5))
+def test_polops_match_oracle(ctx, op):
+    rng = np.random.default_rng(op)
+    a = (rng.standard_normal((123, 457)) * 300).astype(np.float32)
+    b = (rng.standard_normal((123, 457)) * 300).astype(np.float32)
+    # zero handling / tiny denominators / specials
+    b.ravel()[:7] = [0.0, 1e-10, -1e-10, 1.0000001e-10, np.inf, np.nan, -0.0]
+    a.ravel()[7:10] = [np.inf, -np.inf, np.nan]
+    b.ravel()[10:13] = -a.ravel()[10:13]  # a + b == 0 for the normalized difference
+    fn = [ctx.sum_arrays, ctx.difference_arrays, ctx.ratio_arrays, ctx.normalized_diff_arrays, ctx.log_ratio_arrays][op]
+    got = fn(a, b)
+    ref = oracle.polop(op, a, b)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("strategy", [St.Robust, St.Clahe, St.Tamed])
+@pytest.mark.parametrize("n", [1, 4095, 4096, 100003])
+def test_synrgb_matches_oracle(ctx, strategy, n):
+    rng = np.random.default_rng(n)
+    b1 = rng.integers(0, 256, n).astype(np.uint8)
+    b2 = rng.integers(0, 256, n).astype(np.uint8)
+    if n > 100:
+        b1[: n // 3] = 0  # a dark wedge moves the suppressed floor (synthetic_rgb.rs:100-113)
+        b2[: n // 3] = 0
+    got = ctx.create_synthetic_rgb_by_mode_and_strategy(Mode.Default, strategy, b1, b2)
+    ref = oracle.synrgb(0, int(strategy), b1, b2)
+    assert np.array_equal(got, ref)
