@@ -144,7 +144,11 @@ def test_polops_match_oracle(ctx, op):
     fn = [ctx.sum_arrays, ctx.difference_arrays, ctx.ratio_arrays, ctx.normalized_diff_arrays, ctx.log_ratio_arrays][op]
     got = fn(a, b)
     ref = oracle.polop(op, a, b)
-    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # bit-exact wherever the result is a number; NaN sign/payload is not defined by IEEE-754 for
+    # invalid operations (x86 yields 0xFFC00000, gfx950 0x7FC00000), so NaNs match by position
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan])
 
 
 @pytest.mark.parametrize("strategy", [St.Robust, St.Clahe, St.Tamed])
