@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mpix/s calibrate+CLAHE+synRGB on a 400 MP dual-pol scene.
+
+One "step" = one pass of the hot path (save.rs:317-367 at native resolution: per-band dB +
+CLAHE autoscale to u8, then suppressed synthetic-RGB composition) over one synthetic
+20000 x 20000 dual-pol u16 scene that is already resident in HBM.  Output: the interleaved
+RGB raster in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode batch|stripe]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU:
+  batch  (default, weak scaling): every rank processes its own scene, no collective
+         (BASELINE.json config 5 style sharding; pixel data never leaves a GPU)
+  stripe (strong scaling): ONE scene split into row stripes; the three small histogram
+         reductions of the path are RCCL all-reduces (BASELINE.json config 4)
+
+Prints ONE JSON line on rank 0 (see the task contract), including
+  roofline     -- dominant kernel, algorithmic bytes / HIP-event time vs 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (single thread, = the reference's behaviour) on a bounded
+                  sample of the same workload, timed on this box's host cores (N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["batch", "stripe"], default="batch")
+    ap.add_argument("--rows", type=int, default=20000)
+    ap.add_argument("--cols", type=int, default=20000)
+    ap.add_argument("--strategy", default="clahe")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=7000, help="side of the square CPU-baseline sample scene")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import sarpro_amd
+    from sarpro_amd import AutoscaleStrategy, SyntheticRgbMode, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    strategy = {s.name.lower(): s for s in AutoscaleStrategy}[args.strategy.lower()]
+    rows, cols = args.rows, args.cols
+    pitch = (cols + 63) // 64 * 64
+    ctx = sarpro_amd.Context(local_rank, timing=True)
+    q = synth.q_tables()
+
+    if args.mode == "stripe" and world > 1:
+        r0s, nrs = sarpro_amd.host_stripe_plan(rows, world)
+        row0, rows_local = r0s[rank], nrs[rank]
+        seed = synth.SEED_SCENE_A
+    else:
+        row0, rows_local = 0, rows
+        seed = synth.SEED_SCENE_A + rank  # batch: one scene per rank
+
+    band = [torch.empty((max(rows_local, 1), pitch), dtype=torch.int16, device=dev) for _ in range(2)]
+    rgb = torch.empty((max(rows_local, 1), pitch * 3), dtype=torch.uint8, device=dev)
+    for b in range(2):
+        ctx.dev_synth_scene_u16(seed, b, q, rows, cols, row0, rows_local, band[b].data_ptr(), pitch)
+
+    if args.mode == "stripe" and world > 1:
+        # library-owned RCCL communicator (xGMI): rank 0 makes the id, everyone joins
+        uid = [sarpro_amd.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+
+    def allreduce(ptr, count):
+        ctx.comm_allreduce_sum_u64(ptr, count)  # RCCL all-reduce(sum, u64) on the library's stream
+
+    def step():
+        if args.mode == "stripe" and world > 1:
+            s = ctx.stripe_begin_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, row0, rows_local, pitch,
+                                     strategy, SyntheticRgbMode.Default)
+            try:
+                allreduce(*s.phase1())
+                allreduce(*s.phase2())
+                allreduce(*s.phase3())
+                s.phase4(rgb.data_ptr(), pitch)
+            finally:
+                s.end()
+        else:
+            ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, strategy,
+                                       SyntheticRgbMode.Default, rgb.data_ptr(), pitch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ktimes: dict[str, list[float]] = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, ms in ctx.last_kernel_times():  # HIP events on the library's stream
+            ktimes.setdefault(name, []).append(ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        scenes_per_step = world if not (args.mode == "stripe" and world > 1) else 1
+        px = rows * cols * scenes_per_step * args.steps
+        value = px / elapsed / 1e6
+        # dominant kernel = largest total event time; one launch covers both bands of the local rows
+        per_launch = {k: float(np.mean(v)) for k, v in ktimes.items()}
+        launches = {k: len(v) / args.steps for k, v in ktimes.items()}
+        total_ms = {k: per_launch[k] * launches[k] for k in per_launch}
+        dom = max(total_ms, key=total_ms.get) if total_ms else None
+        # algorithmic bytes per pixel PER LAUNCH (both bands), DESIGN.md section 4
+        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0}
+        roofline = None
+        if dom:
+            local_px = rows_local * cols
+            bytes_launch = alg_bpp.get(dom, 0.0) * local_px
+            achieved = bytes_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "ms_per_launch": round(per_launch[dom], 4),
+                        "kernels_ms_per_step": {k: round(total_ms[k], 4) for k in sorted(total_ms)}}
+        out = {
+            "metric": "Mpix/s calibrate+CLAHE+synRGB, 400MP dual-pol scene; % HBM roofline",
+            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if (args.mode == "stripe" and world > 1) else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"dual-pol u16 {rows}x{cols} scene resident in HBM -> dB + {strategy.name} autoscale u8 x2 "
+                                   f"-> synRGB (suppressed) interleaved u8, native resolution (save.rs:317-367)",
+                       "mode": args.mode if world > 1 else "single", "rows": rows, "cols": cols,
+                       "scenes_per_step": scenes_per_step},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, q, args.cpu_sample, int(strategy), torch, dev)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(ctx, q, side, strategy, torch, dev):
+    """Time the CPU oracle (single thread -- the reference's hot path has no threads)
+    on a bounded side x side sample of the same synthetic workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from sarpro_amd import synth
+
+    pitch = (side + 63) // 64 * 64
+    bands = []
+    for b in range(2):
+        t = torch.empty((side, pitch), dtype=torch.int16, device=dev)
+        ctx.dev_synth_scene_u16(synth.SEED_SCENE_A, b, q, side, side, 0, side, t.data_ptr(), pitch)
+        bands.append(t[:, :side].contiguous().cpu().numpy().view(np.uint16).astype(np.float32))
+    oracle.lib()
+    t0 = time.perf_counter()
+    rc, rgb, _, _ = oracle.dualpol_synrgb(bands[0], bands[1], strategy)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": round(side * side / dt / 1e6, 2), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": f"{side}x{side} dual-pol scene (same generator), whole path, {dt:.1f} s on 1 of {os.cpu_count()} host threads"}
+
+
+if __name__ == "__main__":
+    main()
