@@ -117,16 +117,20 @@ int stats_from_dn_hist(const uint64_t *h, sarpro_hip_stats *out) {
         }
     }
     if (count == 0) { std::memset(out, 0, sizeof(*out)); return SARPRO_HIP_OK; }
-    long double sum = 0.0L;
-    for (uint32_t dn = min_dn; dn <= max_dn; ++dn) sum += (long double)h[dn] * (long double)db[dn];
-    long double meanl = sum / (long double)count;
-    long double m2 = 0.0L;
-    for (uint32_t dn = min_dn; dn <= max_dn; ++dn) {
-        long double d = (long double)db[dn] - meanl;
-        m2 += (long double)h[dn] * d * d;
-    }
-    double mean = (double)meanl;
-    double std_db = count > 1 ? std::sqrt((double)(m2 / (long double)count)) : 0.0;
+    // mean / M2 over the distinct DN values, Neumaier-compensated (error ~1e-16 relative)
+    auto csum = [&](auto term) {
+        double sum = 0.0, comp = 0.0;
+        for (uint32_t dn = min_dn; dn <= max_dn; ++dn) {
+            if (!h[dn]) continue;
+            const double x = term(dn), t = sum + x;
+            comp += std::fabs(sum) >= std::fabs(x) ? (sum - t) + x : (x - t) + sum;
+            sum = t;
+        }
+        return sum + comp;
+    };
+    const double mean = csum([&](uint32_t dn) { return (double)h[dn] * db[dn]; }) / (double)count;
+    const double m2 = csum([&](uint32_t dn) { const double d = db[dn] - mean; return (double)h[dn] * d * d; });
+    double std_db = count > 1 ? std::sqrt(m2 / (double)count) : 0.0;
 
     double min_db = db[min_dn], max_db = db[max_dn];
     uint64_t hist[kStatBins];
@@ -350,23 +354,38 @@ void u8_rescale_lut(unsigned min_level, unsigned max_level, uint8_t *lut) {
     }
 }
 
-static void blue_lut(const uint8_t *lut_r, const uint8_t *lut_g, bool dflt, uint8_t *lut_b) {
-    for (unsigned x1 = 0; x1 < 256; ++x1) {
-        for (unsigned x2 = 0; x2 < 256; ++x2) {
-            float r = (float)lut_r[x1], g = (float)lut_g[x2];
-            uint8_t blue;
-            if (dflt) { // synthetic_rgb.rs:38-49
-                if (x2 == 0) blue = 0;
-                else {
+// Blue depends on the pair of gamma-mapped u8 values (r, g) only, so both variants are
+// constant 256x256 tables of powf results, built once per process.
+static const uint8_t *blue_pair_table(bool dflt) {
+    static uint8_t tab[2][65536];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (unsigned ri = 0; ri < 256; ++ri) {
+            for (unsigned gi = 0; gi < 256; ++gi) {
+                float r = (float)ri, g = (float)gi;
+                { // default, synthetic_rgb.rs:43-48 (g == 0 gives ratio = inf or NaN exactly as in the reference)
                     float ratio = r / g;
-                    blue = f32_as_u8(std::round(clampf(std::pow(ratio, 0.1f) * 255.0f * 0.24f, 0.0f, 255.0f)));
+                    tab[0][(ri << 8) | gi] =
+                        f32_as_u8(std::round(clampf(std::pow(ratio, 0.1f) * 255.0f * 0.24f, 0.0f, 255.0f)));
                 }
-            } else { // :146-152
-                float ratio = (r + 8.0f) / (g + 8.0f);
-                blue = f32_as_u8(std::round(clampf(std::pow(ratio, 0.1f) * 255.0f * 0.18f, 0.0f, 255.0f)));
+                { // suppressed, synthetic_rgb.rs:146-152
+                    float ratio = (r + 8.0f) / (g + 8.0f);
+                    tab[1][(ri << 8) | gi] =
+                        f32_as_u8(std::round(clampf(std::pow(ratio, 0.1f) * 255.0f * 0.18f, 0.0f, 255.0f)));
+                }
             }
-            lut_b[(x1 << 8) | x2] = blue;
         }
+    });
+    return tab[dflt ? 0 : 1];
+}
+
+static void blue_lut(const uint8_t *lut_r, const uint8_t *lut_g, bool dflt, uint8_t *lut_b) {
+    const uint8_t *pair = blue_pair_table(dflt);
+    for (unsigned x1 = 0; x1 < 256; ++x1) {
+        const uint8_t *row = pair + ((unsigned)lut_r[x1] << 8);
+        uint8_t *out = lut_b + (x1 << 8);
+        for (unsigned x2 = 0; x2 < 256; ++x2) out[x2] = row[lut_g[x2]];
+        if (dflt) out[0] = 0; // `if b2 == 0 { blue = 0 }` on the raw band value (synthetic_rgb.rs:38-40)
     }
 }
 

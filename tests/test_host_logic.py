@@ -1,0 +1,104 @@
+"""CPU suite: the product's host half (C ABI `sarpro_hip_host_*`) composed with numpy stand-ins
+for the kernels (tests/emul.py) must reproduce the oracle bit for bit.  No GPU needed."""
+import numpy as np
+import pytest
+
+import emul
+import oracle
+import sarpro_amd as S
+from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, synth
+
+
+@pytest.mark.parametrize("shape", [(257, 300), (64, 64), (100, 333)])
+@pytest.mark.parametrize("strategy", list(St))
+@pytest.mark.parametrize("bit_depth", list(Bd))
+def test_host_half_reproduces_oracle_pipeline(shape, strategy, bit_depth):
+    for band in (0, 1):
+        dn = synth.scene_u16(*shape, band)
+        got, st = emul.pipeline(dn, bit_depth, strategy)
+        rc, ref, so = oracle.pipeline(dn.astype(np.float32), int(bit_depth), int(strategy), want_stats=True)
+        assert rc == 0 and np.array_equal(got, ref)
+        for k in ("valid_count", "min_db", "max_db", "median_db", "p01", "p25", "p75", "p99", "low_clip", "high_clip", "gamma"):
+            assert getattr(st, k) == getattr(so, k), k
+        assert abs(st.mean_db - so.mean_db) < 1e-9 and abs(st.std_db - so.std_db) < 1e-9
+
+
+@pytest.mark.parametrize("strategy", list(St))
+def test_host_half_reproduces_oracle_dualpol(strategy):
+    b1, b2 = synth.scene_u16(130, 200, 0), synth.scene_u16(130, 200, 1)
+    rgb, u1, u2 = emul.dualpol_synrgb(b1, b2, strategy)
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1.astype(np.float32), b2.astype(np.float32), int(strategy))
+    assert rc == 0
+    assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb)
+
+
+def test_level_lut_equals_per_pixel_formula_for_every_dn():
+    # the windowed table construction must agree with evaluating the reference formula at every DN
+    dn = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    for strategy in St:
+        for bd in Bd:
+            got, _ = emul.pipeline(dn, bd, strategy) if strategy != St.Clahe else (None, None)
+            if got is None:
+                continue
+            rc, ref = oracle.pipeline(dn.astype(np.float32), int(bd), int(strategy))
+            assert np.array_equal(got, ref), (strategy, bd)
+
+
+def test_synrgb_luts_match_oracle():
+    r, g, b, fl = S.host_synrgb_luts(St.Robust)
+    orr, og, ob, _ = oracle.synrgb_luts(False)
+    assert fl == -1 and np.array_equal(r, orr) and np.array_equal(g, og) and np.array_equal(b, ob)
+    rng = np.random.default_rng(3)
+    for dark in (0.0, 0.04, 0.3, 0.9):
+        b1 = rng.integers(0, 256, 5000).astype(np.uint8)
+        b2 = rng.integers(0, 256, 5000).astype(np.uint8)
+        b1[: int(5000 * dark)] = 0
+        b2[: int(5000 * dark)] = rng.integers(0, 30, int(5000 * dark))
+        h = (np.bincount(b1, minlength=256) + np.bincount(b2, minlength=256)).astype(np.uint64)
+        r, g, b, fl = S.host_synrgb_luts(St.Clahe, h, 5000)
+        orr, og, ob, ofl = oracle.synrgb_luts(True, b1, b2)
+        assert fl == ofl and np.array_equal(r, orr) and np.array_equal(g, og) and np.array_equal(b, ob)
+
+
+def test_u8_rescale_lut_matches_oracle():
+    for mn, mx in ((0, 255), (0, 254), (3, 200), (17, 17), (0, 1), (250, 255)):
+        lut = S.host_u8_rescale_lut(mn, mx)
+        v = np.arange(mn, mx + 1, dtype=np.uint16)
+        assert np.array_equal(lut[v], oracle.scale_u16_to_u8(v))
+
+
+def test_clahe_cdfs_match_oracle_including_clip_and_empty_tiles():
+    rng = np.random.default_rng(7)
+    rows, cols = 1000, 777
+    th = np.zeros((64, 256), np.uint64)
+    tile_h, tile_w = -(-rows // 8), -(-cols // 8)
+    for t in range(64):
+        kind = t % 4
+        if kind == 0:
+            th[t] = rng.integers(0, 40, 256)
+        elif kind == 1:
+            th[t, rng.integers(0, 256, 5)] = rng.integers(500, 3000, 5)  # heavy clipping
+        elif kind == 2:
+            th[t, 0] = 11000                                             # one spike
+    cdfs = S.host_clahe_cdfs(th, rows, cols)
+    for ty in range(8):
+        for tx in range(8):
+            tr = min((ty + 1) * tile_h, rows) - ty * tile_h
+            tc = min((tx + 1) * tile_w, cols) - tx * tile_w
+            ref = oracle.clahe_tile_cdf(th[ty * 8 + tx].astype(np.uint32), tr, tc)
+            assert np.array_equal(cdfs[ty * 8 + tx], ref)
+
+
+def test_clahe_shape_rule_matches_oracle():
+    bad = [n for n in range(1, 80) if not S.host_clahe_shape_ok(n, 100)]
+    assert bad == [n for n in range(1, 80) if not oracle.clahe_shape_ok(n, 100)]
+    assert bad == [1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 17, 18, 19, 20, 25, 26, 27, 33, 34, 41]
+
+
+def test_stripe_plan_covers_rows_once():
+    for rows in (20000, 1001, 7, 64):
+        for n in (1, 2, 3, 4, 8):
+            r0, nr = S.host_stripe_plan(rows, n)
+            assert r0[0] == 0 and sum(nr) == rows
+            assert all(r0[k] + nr[k] == (r0[k + 1] if k + 1 < n else rows) for k in range(n))
+    assert S.host_stripe_plan(20000, 8)[1] == [2500] * 8  # = CLAHE tile rows of the 400 MP scene
