@@ -107,7 +107,8 @@ int sarpro_hip_autoscale_band_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_
                                   sarpro_hip_stats *stats_out);
 
 /* process_scalar_data_inplace (pipeline.rs:8-40): db = 10*log10(max(v,1e-10)) as f64,
- * mask = db > -50.  Either output may be NULL.  db is within 1 ulp(f64) of glibc's. */
+ * mask = db > -50 (exact).  Either output may be NULL.  db is within 2 ulp(f64) of glibc's
+ * value (so within 1 ulp when held as f32). */
 int sarpro_hip_db_mask_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols,
                            double *db_out, uint8_t *mask_out);
 
@@ -227,6 +228,18 @@ int sarpro_hip_host_clahe_shape_ok(size_t rows, size_t cols);
 /* Row-stripe plan: stripes aligned to CLAHE tile rows (tile_h = ceil(rows/8)).
  * row0_out / nrows_out hold nranks entries. */
 int sarpro_hip_host_stripe_plan(size_t rows, int nranks, size_t *row0_out, size_t *nrows_out);
+
+/* f32-input flavour: the per-pixel decisions as sorted f32 threshold tables (exact w.r.t. the
+ * reference's f64/libm evaluation; the device only compares).  thr[0] is unused;
+ * thr[k] = smallest valid f32 sample whose index/level is >= k (+inf if unreachable). */
+/* percentiles of compute_histogram_stats (autoscale.rs:81-159) from its 4096-bin histogram */
+int sarpro_hip_host_stats_from_bins4096(uint64_t valid_count, double min_db, double max_db, double mean_db,
+                                        double std_db, const uint64_t hist4096[4096], sarpro_hip_stats *out);
+float sarpro_hip_host_f32_valid_threshold(void); /* smallest f32 with 10*log10(v) > -50 (pipeline.rs:22) */
+int sarpro_hip_host_f32_bin4096_thresholds(double min_db, double max_db, float thr_out[4096]); /* autoscale.rs:113-115 */
+/* levels (autoscale.rs:440-442) under stats->low_clip/high_clip/gamma: 256 (U8) or 65536 (U16) entries */
+int sarpro_hip_host_f32_level_thresholds(const sarpro_hip_stats *stats, int bit_depth, float *thr_out);
+int sarpro_hip_host_f32_clahe_bin_thresholds(const sarpro_hip_stats *stats, float thr_out[256]); /* autoscale.rs:585-586,262-265 */
 
 /* ================= synthetic scene generator (bench / tests) ================= */
 /* counter-based (splitmix64) dual-pol GRD-like scene written

@@ -45,6 +45,8 @@ SYMBOLS = [
     "sarpro_hip_host_stats_from_dn_hist", "sarpro_hip_host_window", "sarpro_hip_host_level_lut_u16",
     "sarpro_hip_host_clahe_bin_lut_u16", "sarpro_hip_host_clahe_cdfs", "sarpro_hip_host_u8_rescale_lut",
     "sarpro_hip_host_synrgb_luts", "sarpro_hip_host_clahe_shape_ok", "sarpro_hip_host_stripe_plan",
+    "sarpro_hip_host_stats_from_bins4096", "sarpro_hip_host_f32_valid_threshold", "sarpro_hip_host_f32_bin4096_thresholds",
+    "sarpro_hip_host_f32_level_thresholds", "sarpro_hip_host_f32_clahe_bin_thresholds",
     "sarpro_hip_synth_scene_u16_dev",
 ]
 
@@ -106,3 +108,8 @@ _proto("sarpro_hip_host_synrgb_luts", _i, _i, _vp, _u64, _vp, C.POINTER(_i))
 _proto("sarpro_hip_host_clahe_shape_ok", _i, _sz, _sz)
 _proto("sarpro_hip_host_stripe_plan", _i, _sz, _i, _vp, _vp)
 _proto("sarpro_hip_synth_scene_u16_dev", _i, _vp, _u64, _i, _vp, _sz, _sz, _sz, _sz, _vp, _sz)
+_proto("sarpro_hip_host_f32_valid_threshold", C.c_float)
+_proto("sarpro_hip_host_f32_bin4096_thresholds", _i, C.c_double, C.c_double, _vp)
+_proto("sarpro_hip_host_f32_level_thresholds", _i, _S, _i, _vp)
+_proto("sarpro_hip_host_f32_clahe_bin_thresholds", _i, _S, _vp)
+_proto("sarpro_hip_host_stats_from_bins4096", _i, _u64, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _S)

@@ -356,3 +356,42 @@ def host_stripe_plan(rows: int, nranks: int):
     if rc:
         raise SarproHipError(rc, "host_stripe_plan")
     return [int(x) for x in r0], [int(x) for x in nr]
+
+
+def host_f32_valid_threshold() -> float:
+    return float(lib.sarpro_hip_host_f32_valid_threshold())
+
+
+def host_f32_bin4096_thresholds(min_db: float, max_db: float) -> np.ndarray:
+    thr = np.empty(4096, np.float32)
+    rc = lib.sarpro_hip_host_f32_bin4096_thresholds(min_db, max_db, _vp(thr))
+    if rc:
+        raise SarproHipError(rc, "host_f32_bin4096_thresholds")
+    return thr
+
+
+def host_f32_level_thresholds(st: Stats, bit_depth) -> np.ndarray:
+    thr = np.empty(256 if int(bit_depth) == 0 else 65536, np.float32)
+    rc = lib.sarpro_hip_host_f32_level_thresholds(C.byref(st), int(bit_depth), _vp(thr))
+    if rc:
+        raise SarproHipError(rc, "host_f32_level_thresholds")
+    return thr
+
+
+def host_f32_clahe_bin_thresholds(st: Stats) -> np.ndarray:
+    thr = np.empty(256, np.float32)
+    rc = lib.sarpro_hip_host_f32_clahe_bin_thresholds(C.byref(st), _vp(thr))
+    if rc:
+        raise SarproHipError(rc, "host_f32_clahe_bin_thresholds")
+    return thr
+
+
+def host_stats_from_bins4096(count: int, min_db: float, max_db: float, mean_db: float, std_db: float,
+                             hist4096: np.ndarray) -> Stats:
+    h = np.ascontiguousarray(hist4096, np.uint64)
+    assert h.size == 4096
+    st = Stats()
+    rc = lib.sarpro_hip_host_stats_from_bins4096(count, min_db, max_db, mean_db, std_db, _vp(h), C.byref(st))
+    if rc:
+        raise SarproHipError(rc, "host_stats_from_bins4096")
+    return st

@@ -178,9 +178,9 @@ static int upload_vec(sarpro_hip_ctx *ctx, DevBuf &d, const void *src, size_t by
     return SARPRO_HIP_OK;
 }
 
-int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, bool vec,
+int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,
              StripePlan **out) {
-    auto key = std::make_tuple(rows_total, cols, row0, rows_local, vec);
+    auto key = std::make_tuple(rows_total, cols, row0, rows_local, vecw);
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) { *out = it->second; return SARPRO_HIP_OK; }
     if (ctx->plans.size() > 16) { // bounded cache
@@ -193,9 +193,8 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
         ctx->plans.clear();
     }
     StripePlan *P = new StripePlan();
-    P->rows_total = rows_total; P->cols = cols; P->row0 = row0; P->rows_local = rows_local; P->vec = vec;
+    P->rows_total = rows_total; P->cols = cols; P->row0 = row0; P->rows_local = rows_local; P->vecw = vecw;
     build_clahe_geometry(rows_total, cols, &P->geom);
-    const int vecw = vec ? 8 : 1;
     const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
     const size_t target_items = 4096;
     const size_t chunk_rows = std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items);
@@ -290,7 +289,7 @@ static int job_init(U16Job &J) {
     J.vec = J.in_pitch % 8 == 0;
     for (int b = 0; b < J.nbands; ++b) J.vec = J.vec && ptr_aligned16(J.d_in[b]);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    return get_plan(ctx, J.rows_total, J.cols, J.row0, J.rows_local, J.vec, &J.plan);
+    return get_plan(ctx, J.rows_total, J.cols, J.row0, J.rows_local, J.vec ? 8 : 1, &J.plan);
 }
 
 // phase 1: local DN histograms -> ctx->ghist (u64 [nbands][65536]) on the device

@@ -42,7 +42,7 @@ struct PinnedBuf { // grow-only pinned host allocation
 // Work decomposition for one (scene shape, stripe) -- built once, cached on the context.
 struct StripePlan {
     size_t rows_total = 0, cols = 0, row0 = 0, rows_local = 0;
-    bool vec = false;
+    int vecw = 1;                       // pixels per lane of the kernels this plan feeds
     ClaheGeometry geom;                 // of the WHOLE scene (rows_total x cols)
     std::vector<Rect> hist_rects_tiled; // per-tile DN histogram items
     std::vector<Rect> hist_rects_flat;  // single-histogram items (non-CLAHE)
@@ -76,7 +76,7 @@ struct sarpro_hip_ctx {
     // pinned host mirrors
     sarpro::PinnedBuf h_ghist, h_small, h_upload;
 
-    std::map<std::tuple<size_t, size_t, size_t, size_t, bool>, sarpro::StripePlan *> plans;
+    std::map<std::tuple<size_t, size_t, size_t, size_t, int>, sarpro::StripePlan *> plans;
 
     // per-kernel timing of the last call
     bool timing = false;

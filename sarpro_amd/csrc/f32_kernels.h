@@ -1,0 +1,55 @@
+// f32_kernels.h -- launch interface of the f32-input kernels (f32_kernels.hip).
+#pragma once
+#include "kernels.h"
+
+namespace sarpro {
+
+struct F32Partial { // one per block of the pre-pass
+    unsigned long long count;
+    double sum, sumsq; // of dB over the valid samples
+    float minv, maxv;  // of the valid samples
+};
+
+struct F32LevelArgs {
+    const float *in;
+    void *out; // u8 or u16
+    size_t in_pitch, out_pitch;
+    uint32_t rows, cols;
+    float t_valid;
+    const float *thr;                // [256] (u8) or [65536] (u16); thr[0] unused
+    unsigned long long *level_hist;  // [256], u8 only
+};
+
+struct F32TileHistArgs {
+    const float *in;
+    size_t pitch;
+    const Rect *rects;
+    float t_valid;
+    const float *thr;                // [256]
+    unsigned long long *tile_bins;   // [64][256], zeroed by the caller
+};
+
+struct F32ClaheApplyArgs {
+    const float *in;
+    void *out;
+    size_t in_pitch, out_pitch;
+    const Rect *rects;
+    const double *cdfs;              // [64][256]
+    float t_valid;
+    const float *thr;                // [256]
+    const RowWeight *row_w, *col_w;
+    unsigned long long *level_hist;  // [256], u8 only
+    double max_val;
+};
+
+int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec);
+hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
+                              F32Partial *d_partials, int grid, hipStream_t s);
+hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
+                               const float *d_thr, unsigned long long *d_hist, hipStream_t s);
+hipError_t launch_f32_level(const F32LevelArgs &a, bool vec, bool out16, hipStream_t s);
+hipError_t launch_f32_tile_hist(const F32TileHistArgs &a, int nrects, bool vec, hipStream_t s);
+hipError_t launch_f32_clahe_apply(const F32ClaheApplyArgs &a, int nrects, bool vec, bool out16, hipStream_t s);
+hipError_t launch_db_mask_f32(const float *in, size_t n, float t_valid, double *db, uint8_t *mask, hipStream_t s);
+
+} // namespace sarpro

@@ -1,2 +1,326 @@
-// f32_kernels.hip -- kernels of the f32-input flavour (pending)
-#include "kernels.h"
+// f32_kernels.hip -- kernels of the f32-input flavour (pol-op results, resampled reads, any
+// Array2<f32> a caller hands to process_scalar_data_pipeline).
+//
+// Every decision the reference takes per pixel (valid?, 4096-bin index, CLAHE bin, output level)
+// is a monotone step function of the sample, so the host ships it as a sorted table of f32
+// thresholds (host_logic.cpp) and the device resolves it with a branch-free binary search in
+// LDS -- compares only, no device log10/pow in any integer result.  The only transcendental
+// evaluated here is log10 for the dB buffer itself (a1) and for mean/std, which tolerate ulps.
+#include "f32_kernels.h"
+
+#include <algorithm>
+
+namespace sarpro {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+
+__device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+
+// number of k in 1..N with v >= thr[k]  (thr sorted ascending, N = 2^m - 1, NaN compares false)
+template <int N>
+__device__ inline uint32_t step_search(const float *thr, float v) {
+    uint32_t idx = 0;
+#pragma unroll
+    for (uint32_t step = (N + 1) / 2; step; step >>= 1)
+        if (v >= thr[idx + step]) idx += step;
+    return idx;
+}
+
+template <int VEC> struct F32Vec;
+template <> struct F32Vec<4> {
+    float4 v;
+    __device__ static F32Vec load(const float *p) { F32Vec r; r.v = *reinterpret_cast<const float4 *>(p); return r; }
+    __device__ float get(int j) const { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+};
+template <> struct F32Vec<1> {
+    float v;
+    __device__ static F32Vec load(const float *p) { F32Vec r; r.v = *p; return r; }
+    __device__ float get(int) const { return v; }
+};
+
+// ------------------------------------------------------------------------------------
+// a. pre-pass: count / min / max of the valid samples and the dB moments (deterministic:
+//    per-block partials, reduced by the host in block order).
+// ------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict__ in, size_t pitch, uint32_t rows,
+                                                        uint32_t cols, float t_valid, F32Partial *__restrict__ out) {
+    const uint32_t vpr = (cols + VEC - 1) / VEC;
+    const uint64_t total = (uint64_t)rows * vpr;
+    unsigned long long cnt = 0;
+    double sum = 0.0, sumsq = 0.0;
+    float mn = INFINITY, mx = -INFINITY;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t r = (uint32_t)(idx / vpr);
+        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
+        const F32Vec<VEC> v = F32Vec<VEC>::load(in + (size_t)r * pitch + col);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float x = v.get(j);
+            if (col + j < cols && x >= t_valid) {
+                ++cnt;
+                mn = fminf(mn, x);
+                mx = fmaxf(mx, x);
+                const double db = 10.0 * log10((double)x);
+                sum += db;
+                sumsq += db * db;
+            }
+        }
+    }
+    __shared__ F32Partial part[kBlock];
+    part[threadIdx.x] = F32Partial{cnt, sum, sumsq, mn, mx};
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) { // fixed tree: deterministic
+        if ((int)threadIdx.x < s) {
+            F32Partial a = part[threadIdx.x], b = part[threadIdx.x + s];
+            a.count += b.count; a.sum += b.sum; a.sumsq += b.sumsq;
+            a.minv = fminf(a.minv, b.minv); a.maxv = fmaxf(a.maxv, b.maxv);
+            part[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
+// ------------------------------------------------------------------------------------
+// b. 4096-bin statistics histogram (autoscale.rs:108-117) by threshold search.
+// ------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict__ in, size_t pitch, uint32_t rows,
+                                                         uint32_t cols, float t_valid, const float *__restrict__ g_thr,
+                                                         unsigned long long *__restrict__ g_hist) {
+    __shared__ float thr[4096];
+    __shared__ uint32_t hist[4096];
+    for (int i = threadIdx.x; i < 4096; i += kBlock) { thr[i] = g_thr[i]; hist[i] = 0; }
+    __syncthreads();
+    const uint32_t vpr = (cols + VEC - 1) / VEC;
+    const uint64_t total = (uint64_t)rows * vpr;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t r = (uint32_t)(idx / vpr);
+        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
+        const F32Vec<VEC> v = F32Vec<VEC>::load(in + (size_t)r * pitch + col);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float x = v.get(j);
+            if (col + j < cols && x >= t_valid) atomicAdd(&hist[step_search<4095>(thr, x)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += kBlock)
+        if (hist[i]) atomicAdd(&g_hist[i], (unsigned long long)hist[i]);
+}
+
+// ------------------------------------------------------------------------------------
+// c. level map for the percentile strategies (autoscale.rs:437-447 / 647-655 / 731-741).
+//    u8: 255 thresholds in LDS + histogram of the levels; u16: 65535 thresholds gathered
+//    from global memory (256 KiB, L2-resident).
+// ------------------------------------------------------------------------------------
+template <int VEC, bool OUT16>
+__global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
+    __shared__ float thr[256];
+    __shared__ uint32_t hist[256];
+    if (!OUT16) { thr[threadIdx.x] = a.thr[threadIdx.x]; hist[threadIdx.x] = 0; }
+    __syncthreads();
+    const uint32_t vpr = (a.cols + VEC - 1) / VEC;
+    const uint64_t total = (uint64_t)a.rows * vpr;
+    uint32_t zeros = 0;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t r = (uint32_t)(idx / vpr);
+        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
+        const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.in_pitch + col);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (col + j >= a.cols) continue;
+            const float x = v.get(j);
+            uint32_t lv = 0;
+            if (x >= a.t_valid) lv = OUT16 ? step_search<65535>(a.thr, x) : step_search<255>(thr, x);
+            if (OUT16) {
+                reinterpret_cast<uint16_t *>(a.out)[(size_t)r * a.out_pitch + col + j] = (uint16_t)lv;
+            } else {
+                reinterpret_cast<uint8_t *>(a.out)[(size_t)r * a.out_pitch + col + j] = (uint8_t)lv;
+                if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u);
+            }
+        }
+    }
+    if (!OUT16) {
+        if (zeros) atomicAdd(&hist[0], zeros);
+        __syncthreads();
+        if (hist[threadIdx.x]) atomicAdd(&a.level_hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// d. CLAHE per-tile 256-bin histograms straight from the samples (autoscale.rs:247-269).
+// ------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
+    __shared__ float thr[256];
+    __shared__ uint32_t hist[256];
+    thr[threadIdx.x] = a.thr[threadIdx.x];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const Rect rc = a.rects[blockIdx.x];
+    const int col = rc.cstart + lane_id() * VEC;
+    if (col < rc.c1 && col + VEC > rc.c0) {
+        for (int r = rc.r0 + wave_id(); r < rc.r1; r += kWavesPerBlock) {
+            const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.pitch + col);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = col + j;
+                const float x = v.get(j);
+                if (c >= rc.c0 && c < rc.c1 && x >= a.t_valid) atomicAdd(&hist[step_search<255>(thr, x)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (hist[threadIdx.x])
+        atomicAdd(&a.tile_bins[(size_t)rc.id[0] * 256 + threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------
+// e. CLAHE apply for f32 samples: same blend as k_clahe_apply_u16 (kernels.hip), bin by
+//    threshold search.
+// ------------------------------------------------------------------------------------
+template <int VEC, bool OUT16>
+__global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a) {
+    __shared__ __align__(16) double cdf4[256 * 4];
+    __shared__ float thr[256];
+    __shared__ uint32_t hist[256];
+    const Rect rc = a.rects[blockIdx.x];
+    {
+        const int b = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cdf4[b * 4 + k] = a.cdfs[(size_t)rc.id[k] * 256 + b];
+        thr[b] = a.thr[b];
+        hist[b] = 0;
+    }
+    __syncthreads();
+    const int col = rc.cstart + lane_id() * VEC;
+    const bool lane_on = col < rc.c1 && col + VEC > rc.c0;
+    uint32_t zeros = 0;
+    double dx[VEC], omdx[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = col + j;
+        const RowWeight w = a.col_w[(c >= rc.c0 && c < rc.c1) ? c : rc.c0];
+        dx[j] = w.d;
+        omdx[j] = w.omd;
+    }
+    if (lane_on) {
+        for (int r = rc.r0 + wave_id(); r < rc.r1; r += kWavesPerBlock) {
+            const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.in_pitch + col);
+            const RowWeight rw = a.row_w[r];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = col + j;
+                if (c < rc.c0 || c >= rc.c1) continue;
+                const float x = v.get(j);
+                uint32_t lv = 0;
+                if (x >= a.t_valid) {
+                    const uint32_t bin = step_search<255>(thr, x);
+                    const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
+                    const double top = c4.x * omdx[j] + c4.y * dx[j];
+                    const double bottom = c4.z * omdx[j] + c4.w * dx[j];
+                    double o = top * rw.omd + bottom * rw.d;
+                    o = fmin(fmax(o, 0.0), 1.0);
+                    lv = (uint32_t)(o * a.max_val);
+                }
+                if (OUT16) {
+                    reinterpret_cast<uint16_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint16_t)lv;
+                } else {
+                    reinterpret_cast<uint8_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint8_t)lv;
+                    if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u);
+                }
+            }
+        }
+    }
+    if (!OUT16) {
+        if (zeros) atomicAdd(&hist[0], zeros);
+        __syncthreads();
+        if (hist[threadIdx.x]) atomicAdd(&a.level_hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// f. process_scalar_data_inplace (pipeline.rs:8-40): the dB buffer and the validity mask.
+//    mask is exact (threshold compare); db is the device's f64 log10 (<= 1 ulp from glibc's).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_db_mask_f32(const float *__restrict__ in, size_t n, float t_valid,
+                                                        double *__restrict__ db, uint8_t *__restrict__ mask) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const float x = in[i];
+        if (db) db[i] = 10.0 * log10(fmax((double)x, 1e-10));
+        if (mask) mask[i] = x >= t_valid ? 1 : 0;
+    }
+}
+
+inline int stream_grid(uint64_t items, int per_cu = 8) {
+    const uint64_t want = (items + kBlock - 1) / kBlock, cap = 256ull * per_cu;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+} // namespace
+
+int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec) {
+    const int V = vec ? 4 : 1;
+    return stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4);
+}
+
+hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
+                              F32Partial *d_partials, int grid, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL(k_f32_prepass<4>, dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+    else hipLaunchKernelGGL(k_f32_prepass<1>, dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
+                               const float *d_thr, unsigned long long *d_hist, hipStream_t s) {
+    const int V = vec ? 4 : 1;
+    dim3 grid(stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4));
+    if (vec) hipLaunchKernelGGL(k_f32_hist4096<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist);
+    else hipLaunchKernelGGL(k_f32_hist4096<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_level(const F32LevelArgs &a, bool vec, bool out16, hipStream_t s) {
+    const int V = vec ? 4 : 1;
+    dim3 grid(stream_grid((uint64_t)a.rows * ((a.cols + V - 1) / V)));
+    if (vec) {
+        if (out16) hipLaunchKernelGGL((k_f32_level<4, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_f32_level<4, false>), grid, dim3(kBlock), 0, s, a);
+    } else {
+        if (out16) hipLaunchKernelGGL((k_f32_level<1, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_f32_level<1, false>), grid, dim3(kBlock), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_tile_hist(const F32TileHistArgs &a, int nrects, bool vec, hipStream_t s) {
+    if (nrects <= 0) return hipSuccess;
+    if (vec) hipLaunchKernelGGL(k_f32_tile_hist<4>, dim3(nrects), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(k_f32_tile_hist<1>, dim3(nrects), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_clahe_apply(const F32ClaheApplyArgs &a, int nrects, bool vec, bool out16, hipStream_t s) {
+    if (nrects <= 0) return hipSuccess;
+    if (vec) {
+        if (out16) hipLaunchKernelGGL((k_f32_clahe_apply<4, true>), dim3(nrects), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_f32_clahe_apply<4, false>), dim3(nrects), dim3(kBlock), 0, s, a);
+    } else {
+        if (out16) hipLaunchKernelGGL((k_f32_clahe_apply<1, true>), dim3(nrects), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_f32_clahe_apply<1, false>), dim3(nrects), dim3(kBlock), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_db_mask_f32(const float *in, size_t n, float t_valid, double *db, uint8_t *mask, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_db_mask_f32, dim3(stream_grid(n)), dim3(kBlock), 0, s, in, n, t_valid, db, mask);
+    return hipGetLastError();
+}
+
+} // namespace sarpro

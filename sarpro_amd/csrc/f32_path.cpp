@@ -1,17 +1,375 @@
-// f32_path.cpp -- f32-input flavour (arbitrary float samples: pol-op results, resampled reads).
-// PENDING: entry points report an error until the threshold-table path lands.
+// f32_path.cpp -- orchestration of the f32-input flavour (arbitrary float samples: pol-op
+// results, resampled reads, user arrays).  Same pass structure as the u16 flavour, with the
+// per-DN tables replaced by f32 threshold tables (host_logic.cpp) resolved on the device by
+// binary search.  No CPU fallback: all rasters come from the kernels in f32_kernels.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "f32_kernels.h"
 #include "internal.h"
 
 using namespace sarpro;
 
-static int pending(sarpro_hip_ctx *ctx) {
-    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
-    ctx->err = "f32-input flavour not implemented yet";
-    return SARPRO_HIP_ERR_INVALID_ARG;
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+            return e__ == hipErrorOutOfMemory ? SARPRO_HIP_ERR_OOM : SARPRO_HIP_ERR_HIP;          \
+        }                                                                                         \
+    } while (0)
+#define RETCHK(expr)                                   \
+    do {                                               \
+        int rc__ = (expr);                             \
+        if (rc__ != SARPRO_HIP_OK) return rc__;        \
+    } while (0)
+
+static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+namespace {
+
+// device workspace layout (ctx->f32ws)
+constexpr size_t kOffPartials = 0;                                   // 2048 x 32 B
+constexpr size_t kOffThr4096 = 64 * 1024;                            // 16 KiB
+constexpr size_t kOffHist4096 = kOffThr4096 + 16 * 1024;             // 32 KiB
+constexpr size_t kOffThrLevel = kOffHist4096 + 32 * 1024;            // 256 KiB
+constexpr size_t kOffTileBins = kOffThrLevel + 256 * 1024;           // 128 KiB
+constexpr size_t kOffLevelHist = kOffTileBins + 128 * 1024;          // 2 KiB
+constexpr size_t kOffCdfs = kOffLevelHist + 4 * 1024;                // 128 KiB
+constexpr size_t kOffMap = kOffCdfs + 128 * 1024;                    // 256 B
+constexpr size_t kWsBytes = kOffMap + 4096;
+
+struct F32Band {
+    sarpro_hip_ctx *ctx = nullptr;
+    const float *d_in = nullptr;
+    size_t rows = 0, cols = 0, in_pitch = 0;
+    int strategy = 0, bit_depth = 0, tamed = 0;
+    void *d_out = nullptr;
+    size_t out_pitch = 0;
+    sarpro_hip_stats stats{};
+    uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
+};
+
+int rescale_in_place(F32Band &B, const uint64_t *level_hist) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    uint8_t resc[256];
+    bool identity = true;
+    if (B.tamed) {
+        for (int i = 0; i < 256; ++i) resc[i] = (uint8_t)i; // autoscale.rs:731-741 has no rescale
+    } else {
+        unsigned mn = 0, mx = 0;
+        bool any = false;
+        for (unsigned i = 0; i < 256; ++i)
+            if (level_hist[i]) { if (!any) mn = i; mx = i; any = true; }
+        u8_rescale_lut(mn, mx, resc); // autoscale.rs:348-364
+        for (unsigned i = 0; i < 256; ++i)
+            if (level_hist[i] && resc[i] != i) identity = false;
+    }
+    std::memset(B.final_hist, 0, sizeof(B.final_hist));
+    for (int i = 0; i < 256; ++i) B.final_hist[resc[i]] += level_hist[i];
+    if (!identity) {
+        uint8_t *stage = ctx->h_upload.as<uint8_t>();
+        std::memcpy(stage, resc, 256);
+        uint8_t *d_map = ctx->f32ws.as<uint8_t>() + kOffMap;
+        HIPCHK(ctx, hipMemcpyAsync(d_map, stage, 256, hipMemcpyHostToDevice, ctx->stream));
+        KernelTimer t(ctx, "remap_u8");
+        HIPCHK(ctx, launch_remap_u8(reinterpret_cast<uint8_t *>(B.d_out), B.out_pitch, (uint32_t)B.rows, (uint32_t)B.cols, d_map, ctx->stream));
+    }
+    return SARPRO_HIP_OK;
 }
 
-extern "C" int sarpro_hip_autoscale_band_f32(sarpro_hip_ctx *ctx, const float *, size_t, size_t, int, int, uint8_t *, uint16_t *, sarpro_hip_stats *) { return pending(ctx); }
-extern "C" int sarpro_hip_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, const float *, size_t, size_t, size_t, int, int, void *, size_t, sarpro_hip_stats *) { return pending(ctx); }
-extern "C" int sarpro_hip_db_mask_f32(sarpro_hip_ctx *ctx, const float *, size_t, size_t, double *, uint8_t *) { return pending(ctx); }
-extern "C" int sarpro_hip_tamed_synrgb_u8_f32(sarpro_hip_ctx *ctx, const float *, size_t, size_t, int, uint8_t *) { return pending(ctx); }
-extern "C" int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *, const float *, size_t, size_t, int, int, uint8_t *, uint8_t *, uint8_t *, sarpro_hip_stats *) { return pending(ctx); }
+int f32_band_run(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    const bool u8o = B.tamed || B.bit_depth == SARPRO_BITDEPTH_U8;
+    const bool clahe = B.strategy == SARPRO_STRATEGY_CLAHE && !B.tamed;
+    if (B.in_pitch < B.cols || B.out_pitch < B.cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    if (B.rows > 0x7FFFFFFFull || B.cols > 0x7FFFFFFFull) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "raster too large");
+    if (clahe && !clahe_shape_ok(B.rows, B.cols))
+        return fail(ctx, SARPRO_HIP_ERR_UNSUPPORTED_SHAPE,
+                    "CLAHE tile arithmetic underflows for this shape (reference panics: autoscale.rs:250,254)");
+    std::memset(&B.stats, 0, sizeof(B.stats));
+    std::memset(B.final_hist, 0, sizeof(B.final_hist));
+    if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->f32ws.reserve(kWsBytes));
+    HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
+    HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    const uint32_t rows = (uint32_t)B.rows, cols = (uint32_t)B.cols;
+    const bool vec = B.in_pitch % 4 == 0 && aligned16(B.d_in);
+    const float t_valid = valid_threshold_f32();
+    const size_t esz = u8o ? 1 : 2;
+
+    // ---- pass a: count / min / max / dB moments ----
+    const int pgrid = f32_prepass_grid(rows, cols, vec);
+    F32Partial *d_part = reinterpret_cast<F32Partial *>(ws + kOffPartials);
+    {
+        KernelTimer t(ctx, "f32_prepass");
+        HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, t_valid, vec, d_part, pgrid, ctx->stream));
+    }
+    F32Partial *h_part = ctx->h_small.as<F32Partial>();
+    HIPCHK(ctx, hipMemcpyAsync(h_part, d_part, sizeof(F32Partial) * (size_t)pgrid, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t count = 0;
+    double sum = 0.0, sumsq = 0.0;
+    float minv = INFINITY, maxv = -INFINITY;
+    for (int i = 0; i < pgrid; ++i) {
+        count += h_part[i].count; sum += h_part[i].sum; sumsq += h_part[i].sumsq;
+        minv = std::fmin(minv, h_part[i].minv); maxv = std::fmax(maxv, h_part[i].maxv);
+    }
+    if (count == 0) { // autoscale.rs:376-378 / 466-468 / 716-718: zero raster
+        HIPCHK(ctx, hipMemset2DAsync(B.d_out, B.out_pitch * esz, 0, B.cols * esz, B.rows, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        B.final_hist[0] = (uint64_t)B.rows * B.cols;
+        return SARPRO_HIP_OK;
+    }
+    if (std::isinf(maxv)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "non-finite (+inf) sample: the reference's statistics are undefined for it");
+    const double mean = sum / (double)count;
+    const double var = sumsq / (double)count - mean * mean;
+    const double std_db = count > 1 ? std::sqrt(std::fmax(var, 0.0)) : 0.0;
+    const double min_db = db_of_f32(minv), max_db = db_of_f32(maxv);
+
+    // ---- pass b: 4096-bin histogram -> percentiles (autoscale.rs:102-159) ----
+    uint64_t *h_hist = ctx->h_small.as<uint64_t>();
+    std::memset(h_hist, 0, sizeof(uint64_t) * 4096);
+    if (!(std::fabs(max_db - min_db) < 2.220446049250313e-16)) {
+        float *thr = ctx->h_upload.as<float>();
+        build_bin4096_thresholds(min_db, max_db, thr);
+        float *d_thr = reinterpret_cast<float *>(ws + kOffThr4096);
+        unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws + kOffHist4096);
+        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 4096, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * 4096, ctx->stream));
+        {
+            KernelTimer t(ctx, "f32_hist4096");
+            HIPCHK(ctx, launch_f32_hist4096(B.d_in, B.in_pitch, rows, cols, t_valid, vec, d_thr, d_hist, ctx->stream));
+        }
+        HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    RETCHK(stats_from_bins4096(count, min_db, max_db, mean, std_db, h_hist, &B.stats));
+    RETCHK(select_window(&B.stats, B.strategy, B.tamed));
+
+    unsigned long long *d_level_hist = reinterpret_cast<unsigned long long *>(ws + kOffLevelHist);
+    if (u8o) HIPCHK(ctx, hipMemsetAsync(d_level_hist, 0, sizeof(uint64_t) * 256, ctx->stream));
+
+    if (!clahe) {
+        // ---- pass c: level map by threshold search ----
+        const int nlevels = u8o ? 255 : 65535;
+        float *thr = ctx->h_upload.as<float>();
+        build_level_thresholds(B.stats, nlevels, thr);
+        float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
+        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * (size_t)(nlevels + 1), hipMemcpyHostToDevice, ctx->stream));
+        F32LevelArgs a{};
+        a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
+        a.rows = rows; a.cols = cols; a.t_valid = t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
+        KernelTimer t(ctx, "f32_level");
+        HIPCHK(ctx, launch_f32_level(a, vec, !u8o, ctx->stream));
+    } else {
+        // ---- pass d: CLAHE tile histograms -> CDFs; pass e: apply ----
+        StripePlan *plan = nullptr;
+        RETCHK(get_plan(ctx, B.rows, B.cols, 0, B.rows, vec ? 4 : 1, &plan));
+        float *thr = ctx->h_upload.as<float>();
+        build_clahe_bin_thresholds(B.stats, thr);
+        float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
+        unsigned long long *d_tile_bins = reinterpret_cast<unsigned long long *>(ws + kOffTileBins);
+        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_tile_bins, 0, sizeof(uint64_t) * 64 * 256, ctx->stream));
+        F32TileHistArgs ta{};
+        ta.in = B.d_in; ta.pitch = B.in_pitch; ta.rects = plan->d_hist_rects_tiled.as<Rect>();
+        ta.t_valid = t_valid; ta.thr = d_thr; ta.tile_bins = d_tile_bins;
+        {
+            KernelTimer t(ctx, "f32_tile_hist");
+            HIPCHK(ctx, launch_f32_tile_hist(ta, (int)plan->hist_rects_tiled.size(), vec, ctx->stream));
+        }
+        uint64_t *h_tb = ctx->h_small.as<uint64_t>();
+        HIPCHK(ctx, hipMemcpyAsync(h_tb, d_tile_bins, sizeof(uint64_t) * 64 * 256, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        double *h_cdfs = reinterpret_cast<double *>(ctx->h_upload.as<uint8_t>() + 4096);
+        RETCHK(clahe_cdfs(h_tb, B.rows, B.cols, h_cdfs));
+        double *d_cdfs = reinterpret_cast<double *>(ws + kOffCdfs);
+        HIPCHK(ctx, hipMemcpyAsync(d_cdfs, h_cdfs, sizeof(double) * 64 * 256, hipMemcpyHostToDevice, ctx->stream));
+        F32ClaheApplyArgs a{};
+        a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
+        a.rects = plan->d_apply_rects.as<Rect>(); a.cdfs = d_cdfs; a.t_valid = t_valid; a.thr = d_thr;
+        a.row_w = plan->d_row_w.as<RowWeight>(); a.col_w = plan->d_col_w.as<RowWeight>();
+        a.level_hist = d_level_hist; a.max_val = u8o ? 255.0 : 65535.0;
+        KernelTimer t(ctx, "f32_clahe_apply");
+        HIPCHK(ctx, launch_f32_clahe_apply(a, (int)plan->apply_rects.size(), vec, !u8o, ctx->stream));
+    }
+    if (u8o) {
+        uint64_t *h_lh = ctx->h_small.as<uint64_t>();
+        HIPCHK(ctx, hipMemcpyAsync(h_lh, d_level_hist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t lh[256];
+        std::memcpy(lh, h_lh, sizeof(lh));
+        RETCHK(rescale_in_place(B, lh));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------
+extern "C" int sarpro_hip_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, const float *d_in, size_t rows, size_t cols,
+                                                 size_t in_pitch, int strategy, int bit_depth, void *d_out,
+                                                 size_t out_pitch, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if ((!d_in || !d_out) && rows * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    timing_reset(ctx);
+    F32Band B;
+    B.ctx = ctx; B.d_in = d_in; B.rows = rows; B.cols = cols; B.in_pitch = in_pitch;
+    B.strategy = strategy; B.bit_depth = bit_depth; B.d_out = d_out; B.out_pitch = out_pitch;
+    int rc = f32_band_run(B);
+    if (rc == SARPRO_HIP_OK && stats_out) *stats_out = B.stats;
+    return rc;
+}
+
+static int host_band_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols, int strategy, int bit_depth,
+                         int tamed, uint8_t *out_u8, uint16_t *out_u16, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (!tamed && (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    const bool u8o = tamed || bit_depth == SARPRO_BITDEPTH_U8;
+    if (rows * cols && (!in || (u8o ? (void *)out_u8 : (void *)out_u16) == nullptr)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    timing_reset(ctx);
+    size_t pitch = 0;
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[0], in, rows, cols, 4, &pitch));
+    const size_t osz = u8o ? 1 : 2;
+    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max<size_t>(rows, 1) * pitch * osz));
+    F32Band B;
+    B.ctx = ctx; B.d_in = ctx->stage_in[0].as<float>(); B.rows = rows; B.cols = cols; B.in_pitch = pitch;
+    B.strategy = tamed ? SARPRO_STRATEGY_TAMED : strategy; B.bit_depth = u8o ? SARPRO_BITDEPTH_U8 : SARPRO_BITDEPTH_U16;
+    B.tamed = tamed; B.d_out = ctx->stage_out[0].p; B.out_pitch = pitch;
+    RETCHK(f32_band_run(B));
+    if (stats_out) *stats_out = B.stats;
+    return fetch_out_2d(ctx, u8o ? (void *)out_u8 : (void *)out_u16, ctx->stage_out[0].p, pitch * osz, cols * osz, rows);
+}
+
+extern "C" int sarpro_hip_autoscale_band_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols, int strategy,
+                                             int bit_depth, uint8_t *out_u8, uint16_t *out_u16, sarpro_hip_stats *stats_out) {
+    return host_band_f32(ctx, in, rows, cols, strategy, bit_depth, 0, out_u8, out_u16, stats_out);
+}
+
+extern "C" int sarpro_hip_tamed_synrgb_u8_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols, int is_copol,
+                                              uint8_t *out_u8) {
+    return host_band_f32(ctx, in, rows, cols, SARPRO_STRATEGY_TAMED, SARPRO_BITDEPTH_U8, is_copol ? kTamedCopol : kTamedCrosspol,
+                         out_u8, nullptr, nullptr);
+}
+
+extern "C" int sarpro_hip_db_mask_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols, double *db_out,
+                                      uint8_t *mask_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const size_t n = rows * cols;
+    if (n && !in) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (!n || (!db_out && !mask_out)) return SARPRO_HIP_OK;
+    timing_reset(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->stage_in[0].reserve(n * 4));
+    if (db_out) HIPCHK(ctx, ctx->stage_out[0].reserve(n * 8));
+    if (mask_out) HIPCHK(ctx, ctx->stage_out[1].reserve(n));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_in[0].p, in, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+        KernelTimer t(ctx, "db_mask_f32");
+        HIPCHK(ctx, launch_db_mask_f32(ctx->stage_in[0].as<float>(), n, valid_threshold_f32(),
+                                       db_out ? ctx->stage_out[0].as<double>() : nullptr,
+                                       mask_out ? ctx->stage_out[1].as<uint8_t>() : nullptr, ctx->stream));
+    }
+    if (db_out) HIPCHK(ctx, hipMemcpyAsync(db_out, ctx->stage_out[0].p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out) HIPCHK(ctx, hipMemcpyAsync(mask_out, ctx->stage_out[1].p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *band1, const float *band2, size_t rows,
+                                             size_t cols, int strategy, int mode, uint8_t *rgb_out, uint8_t *u8_band1,
+                                             uint8_t *u8_band2, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
+    if (rows * cols && (!band1 || !band2 || !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    timing_reset(ctx);
+    if (rows * cols == 0) return SARPRO_HIP_OK;
+    const float *bands[2] = {band1, band2};
+    size_t pitch = 0;
+    const size_t r1 = std::max<size_t>(rows, 1);
+    uint64_t combined[256];
+    std::memset(combined, 0, sizeof(combined));
+    for (int b = 0; b < 2; ++b) { // save.rs:320-351: pipeline(U8), Tamed -> band-specific tamed autoscale
+        RETCHK(stage_in_2d(ctx, ctx->stage_in[0], bands[b], rows, cols, 4, &pitch));
+        HIPCHK(ctx, ctx->levels[b].reserve(r1 * pitch));
+        F32Band B;
+        B.ctx = ctx; B.d_in = ctx->stage_in[0].as<float>(); B.rows = rows; B.cols = cols; B.in_pitch = pitch;
+        B.strategy = strategy; B.bit_depth = SARPRO_BITDEPTH_U8;
+        B.tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? kTamedCopol : kTamedCrosspol) : 0;
+        B.d_out = ctx->levels[b].p; B.out_pitch = pitch;
+        RETCHK(f32_band_run(B));
+        if (stats_out) stats_out[b] = B.stats;
+        for (int i = 0; i < 256; ++i) combined[i] += B.final_hist[i];
+    }
+    std::vector<uint8_t> luts(66048), tables(66048);
+    int fwc = -1;
+    if (strategy == SARPRO_STRATEGY_TAMED || strategy == SARPRO_STRATEGY_CLAHE) { // synthetic_rgb.rs:188-194
+        fwc = synrgb_floor_from_hist(combined, (uint64_t)rows * cols);
+        synrgb_luts_suppressed(fwc, luts.data());
+    } else {
+        synrgb_luts_default(luts.data());
+    }
+    uint8_t ident[256];
+    for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
+    fold_compose_tables(luts.data(), fwc, ident, ident, tables.data());
+    HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
+    uint8_t *tstage = ctx->h_upload.as<uint8_t>();
+    std::memcpy(tstage, tables.data(), 66048);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tstage, 66048, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * pitch * 3));
+    ComposeArgs c{};
+    c.b1 = ctx->levels[0].as<uint8_t>(); c.b2 = ctx->levels[1].as<uint8_t>(); c.in_pitch = pitch;
+    c.rgb = ctx->stage_out[0].as<uint8_t>(); c.rgb_pitch_px = pitch; c.rows = (uint32_t)rows; c.cols = (uint32_t)cols;
+    c.tables = ctx->tables.as<uint8_t>();
+    {
+        KernelTimer t(ctx, "compose_u8");
+        HIPCHK(ctx, launch_compose_u8(c, 16, ctx->stream));
+    }
+    RETCHK(fetch_out_2d(ctx, rgb_out, ctx->stage_out[0].p, pitch * 3, cols * 3, rows));
+    if (u8_band1) RETCHK(fetch_out_2d(ctx, u8_band1, ctx->levels[0].p, pitch, cols, rows));
+    if (u8_band2) RETCHK(fetch_out_2d(ctx, u8_band2, ctx->levels[1].p, pitch, cols, rows));
+    return SARPRO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host half of the f32 flavour (no GPU): exported for the CPU test-suite
+// ---------------------------------------------------------------------------------------
+extern "C" int sarpro_hip_host_stats_from_bins4096(uint64_t valid_count, double min_db, double max_db, double mean_db,
+                                                   double std_db, const uint64_t hist4096[4096], sarpro_hip_stats *out) {
+    if (!hist4096 || !out) return SARPRO_HIP_ERR_INVALID_ARG;
+    return stats_from_bins4096(valid_count, min_db, max_db, mean_db, std_db, hist4096, out);
+}
+
+extern "C" float sarpro_hip_host_f32_valid_threshold(void) { return valid_threshold_f32(); }
+
+extern "C" int sarpro_hip_host_f32_bin4096_thresholds(double min_db, double max_db, float thr_out[4096]) {
+    if (!thr_out || !(max_db > min_db)) return SARPRO_HIP_ERR_INVALID_ARG;
+    build_bin4096_thresholds(min_db, max_db, thr_out);
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_host_f32_level_thresholds(const sarpro_hip_stats *stats, int bit_depth, float *thr_out) {
+    if (!stats || !thr_out || (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16)) return SARPRO_HIP_ERR_INVALID_ARG;
+    build_level_thresholds(*stats, bit_depth == SARPRO_BITDEPTH_U8 ? 255 : 65535, thr_out);
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_host_f32_clahe_bin_thresholds(const sarpro_hip_stats *stats, float thr_out[256]) {
+    if (!stats || !thr_out) return SARPRO_HIP_ERR_INVALID_ARG;
+    build_clahe_bin_thresholds(*stats, thr_out);
+    return SARPRO_HIP_OK;
+}

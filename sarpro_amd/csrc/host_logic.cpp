@@ -531,3 +531,95 @@ int sarpro_hip_host_stripe_plan(size_t rows, int nranks, size_t *row0_out, size_
 }
 
 } // extern "C"
+
+// ======================= f32-input flavour: threshold tables =======================
+namespace sarpro {
+
+double db_of_f32(float v) { return 10.0 * std::log10(std::fmax((double)v, 1e-10)); }
+
+static inline float bits_to_f32(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
+static inline uint32_t f32_to_bits(float f) { uint32_t b; std::memcpy(&b, &f, 4); return b; }
+static const uint32_t kMaxFiniteBits = 0x7F7FFFFFu; // FLT_MAX
+
+// Smallest b in [lo, hi] with pred(b) (pred monotone false -> true over positive-float bit
+// patterns, which order like the floats); hi + 1 when none.  `guess` only speeds it up.
+template <typename P>
+static uint32_t find_first_bits(P pred, uint32_t lo, uint32_t hi, uint32_t guess) {
+    if (!pred(hi)) return hi + 1;
+    if (pred(lo)) return lo;
+    // invariant: !pred(lo) && pred(hi)
+    uint32_t g = std::min(std::max(guess, lo + 1), hi);
+    if (g != hi) {
+        if (pred(g)) { // gallop down
+            hi = g;
+            uint32_t step = 1;
+            while (hi - lo > step && pred(hi - step)) { hi -= step; step *= 2; }
+            if (hi - lo > step) lo = hi - step;
+        } else { // gallop up
+            lo = g;
+            uint32_t step = 1;
+            while (hi - lo > step && !pred(lo + step)) { lo += step; step *= 2; }
+            if (hi - lo > step) hi = lo + step;
+        }
+    }
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (pred(mid)) hi = mid; else lo = mid;
+    }
+    return hi;
+}
+
+float valid_threshold_f32() {
+    static float thr = [] {
+        uint32_t b = find_first_bits([](uint32_t x) { return db_of_f32(bits_to_f32(x)) > -50.0; }, 1u, kMaxFiniteBits,
+                                     f32_to_bits(1e-5f));
+        return bits_to_f32(b);
+    }();
+    return thr;
+}
+
+// Thresholds of a monotone integer-valued function `fn(db)` of the sample, for k = 1..n.
+// inv(k) gives an approximate dB value where fn first reaches k (initial guess only).
+template <typename F, typename G>
+static void step_thresholds(F fn, G inv_db, int n, float *thr) {
+    const uint32_t lo0 = f32_to_bits(valid_threshold_f32());
+    thr[0] = 0.0f;
+    const int64_t top = fn(db_of_f32(bits_to_f32(kMaxFiniteBits)));
+    uint32_t lo = lo0;
+    for (int k = 1; k <= n; ++k) {
+        if ((int64_t)k > top) { thr[k] = INFINITY; continue; }
+        double gdb = inv_db(k);
+        double gv = std::pow(10.0, gdb / 10.0);
+        uint32_t guess = (gv > 0.0 && gv < 3.0e38) ? f32_to_bits((float)gv) : lo;
+        uint32_t b = find_first_bits([&](uint32_t x) { return fn(db_of_f32(bits_to_f32(x))) >= (int64_t)k; }, lo,
+                                     kMaxFiniteBits, guess);
+        thr[k] = bits_to_f32(b);
+        lo = b; // thresholds are non-decreasing in k
+    }
+}
+
+void build_bin4096_thresholds(double min_db, double max_db, float *thr) {
+    const double span = max_db - min_db, inv_span = 1.0 / span; // autoscale.rs:105-106
+    auto idx = [=](double db) -> int64_t {
+        double t = clampd((db - min_db) * inv_span, 0.0, 1.0);
+        uint64_t i = as_u64(t * (double)kStatBins);
+        return (int64_t)(i >= (uint64_t)kStatBins ? kStatBins - 1 : i);
+    };
+    step_thresholds(idx, [=](int k) { return min_db + span * ((double)k / kStatBins); }, kStatBins - 1, thr);
+}
+
+void build_level_thresholds(const sarpro_hip_stats &s, int nlevels, float *thr) {
+    const double lo = s.low_clip, hi = s.high_clip, g = s.gamma, max_val = (double)nlevels;
+    const double range = std::fmax(hi - lo, 1.0);
+    auto lvl = [=](double db) -> int64_t { return (int64_t)level_of_db(db, lo, hi, g, max_val); };
+    step_thresholds(lvl, [=](int k) { return lo + range * std::pow((double)k / max_val, 1.0 / g); }, nlevels, thr);
+}
+
+void build_clahe_bin_thresholds(const sarpro_hip_stats &s, float *thr) {
+    const double lo = s.low_clip, hi = s.high_clip;
+    const double range = std::fmax(hi - lo, 1.0);
+    auto bin = [=](double db) -> int64_t { return (int64_t)clahe_bin_of_db(db, lo, hi); };
+    step_thresholds(bin, [=](int k) { return lo + range * (((double)k - 0.5) / 255.0); }, kClaheBins - 1, thr);
+}
+
+} // namespace sarpro

@@ -78,3 +78,21 @@ void fold_compose_tables(const uint8_t *luts, int floor_with_cushion /* -1: none
 int stripe_plan(size_t rows, int nranks, size_t *row0, size_t *nrows);
 
 } // namespace sarpro
+
+// ---------------------------------------------------------------------------------------
+// f32-input flavour: every per-pixel decision of the reference is a monotone step function of
+// the sample v (v -> max(v,1e-10) -> log10 -> affine -> clamp -> pow -> truncate), so each one
+// is captured EXACTLY by a sorted table of f32 thresholds found on the host with glibc's
+// log10/pow; the device only compares v against thresholds (no device libm in any decision).
+// ---------------------------------------------------------------------------------------
+namespace sarpro {
+double db_of_f32(float v);        // pipeline.rs:19-20
+float valid_threshold_f32();      // smallest f32 v with db_of_f32(v) > -50 (pipeline.rs:22)
+// thr[k], k = 1..4095: smallest valid f32 whose 4096-bin index (autoscale.rs:113-115) is >= k;
+// +inf when no f32 reaches k.  thr[0] is unused (set to 0).
+void build_bin4096_thresholds(double min_db, double max_db, float *thr4096);
+// thr[k], k = 1..nlevels: smallest valid f32 whose level (autoscale.rs:440-442) is >= k.
+void build_level_thresholds(const sarpro_hip_stats &s, int nlevels /*255 or 65535*/, float *thr);
+// thr[k], k = 1..255: smallest valid f32 whose CLAHE bin (autoscale.rs:585-586, 262-265) is >= k.
+void build_clahe_bin_thresholds(const sarpro_hip_stats &s, float *thr256);
+} // namespace sarpro

@@ -13,7 +13,7 @@ struct KernelTimer {
 };
 void timing_reset(sarpro_hip_ctx *ctx);
 size_t round_up(size_t x, size_t m);
-int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, bool vec,
+int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,
              StripePlan **out);
 int stage_in_2d(sarpro_hip_ctx *ctx, DevBuf &buf, const void *host, size_t rows, size_t cols, size_t esz,
                 size_t *pitch_elems);

@@ -110,3 +110,61 @@ def dualpol_synrgb(b1: np.ndarray, b2: np.ndarray, strategy: St, rows_total=None
         fl = S.host_synrgb_luts(strategy, hists[0] + hists[1], rows_total * b1.shape[1])[3]
         rgb[(u8[0] <= fl) & (u8[1] <= fl)] = 0
     return rgb, u8[0], u8[1]
+
+
+# ----------------------------------------------------------------------------- f32 flavour
+def _steps(thr: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """#{k >= 1 : v >= thr[k]} -- what the device's branch-free binary search returns."""
+    return np.searchsorted(thr[1:], v, side="right")
+
+
+def f32_levels(x: np.ndarray, strategy: St, u8: bool, tamed: int = 0):
+    """Levels of an f32 band through the product's threshold tables (numpy search = kernel)."""
+    import oracle  # only for the dB moments (mean/std), which the device computes with its own log10
+    x = np.ascontiguousarray(x, np.float32)
+    tv = np.float32(S.host_f32_valid_threshold())
+    valid = x >= tv  # NaN -> False
+    n = int(valid.sum())
+    if n == 0:
+        return np.zeros(x.shape, np.uint16), None
+    vmin, vmax = x[valid].min(), x[valid].max()
+    db_min = 10.0 * np.log10(np.float64(vmin))
+    db_max = 10.0 * np.log10(np.float64(vmax))
+    db_all, _ = oracle.db_mask(x)
+    dbv = db_all[valid]
+    assert db_min == dbv.min() and db_max == dbv.max()
+    mean, std = float(dbv.mean()), float(dbv.std())
+    hist = np.zeros(4096, np.uint64)
+    if not abs(db_max - db_min) < np.finfo(np.float64).eps:
+        thr = S.host_f32_bin4096_thresholds(float(db_min), float(db_max))
+        hist = np.bincount(_steps(thr, x[valid]), minlength=4096).astype(np.uint64)
+    st = S.host_stats_from_bins4096(n, float(db_min), float(db_max), mean, std, hist)
+    S.host_window(st, strategy, tamed)
+    if strategy == St.Clahe and not tamed:
+        bins = _steps(S.host_f32_clahe_bin_thresholds(st), x).astype(np.int64)
+        dn_like = np.where(valid, 1, 0).astype(np.uint16)  # validity carrier for the shared helpers
+        rows, cols = x.shape
+        th_, tw_ = -(-rows // 8), -(-cols // 8)
+        tile = np.zeros((64, 256), np.uint64)
+        for ty in range(8):
+            for tx in range(8):
+                sl = (slice(ty * th_, min((ty + 1) * th_, rows)), slice(tx * tw_, min((tx + 1) * tw_, cols)))
+                tile[ty * 8 + tx] = np.bincount(bins[sl][valid[sl]].ravel(), minlength=256)
+        cdfs = S.host_clahe_cdfs(tile, rows, cols)
+        # reuse the u16 blend helper: feed it "bins" through an identity-like table
+        lut = np.arange(65536, dtype=np.int64) % 256
+        fake = np.where(valid, bins, 0).astype(np.uint16)
+        lv = clahe_apply(np.where(valid, fake + 256 * 1, 0).astype(np.uint16), lut.astype(np.uint8), cdfs, rows, cols,
+                         255.0 if u8 else 65535.0)
+        return np.where(valid, lv, 0).astype(np.uint16), st
+    thr = S.host_f32_level_thresholds(st, Bd.U8 if (u8 or tamed) else Bd.U16)
+    lv = _steps(thr, x)
+    return np.where(valid, lv, 0).astype(np.uint16), st
+
+
+def f32_pipeline(x: np.ndarray, bit_depth: Bd, strategy: St):
+    lv, st = f32_levels(x, strategy, bit_depth == Bd.U8)
+    if bit_depth == Bd.U16:
+        return lv, st
+    resc = S.host_u8_rescale_lut(int(lv.min()), int(lv.max()))
+    return resc[lv], st

@@ -1,0 +1,99 @@
+"""GPU parity, f32-input flavour (arbitrary float samples), through the C ABI vs the oracle.
+Bit-exact for every u8/u16 raster; the f64 dB buffer within 1 ulp (tolerance written below)."""
+import numpy as np
+import pytest
+
+import f32data
+import oracle
+from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, SarproHipError, synth
+from sarpro_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("ratio", lambda: f32data.ratio_scene(257, 300)),
+         ("resampled", lambda: f32data.resampled_scene(128, 203)),
+         ("nasty", lambda: f32data.nasty_scene(190, 331)),
+         ("integral", lambda: synth.scene_u16(100, 264, 0).astype(np.float32))]
+
+
+@pytest.mark.parametrize("name,make", CASES)
+@pytest.mark.parametrize("strategy", list(St))
+@pytest.mark.parametrize("bit_depth", list(Bd))
+def test_pipeline_f32_matches_oracle(ctx, name, make, strategy, bit_depth):
+    x = make()
+    u8, u16, st = ctx.process_scalar_data_pipeline(x, bit_depth, strategy, want_stats=True)
+    rc, ref, so = oracle.pipeline(x, int(bit_depth), int(strategy), want_stats=True)
+    assert rc == 0
+    got = u8 if bit_depth == Bd.U8 else u16
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} px differ"
+    for k in ("valid_count", "min_db", "max_db", "median_db", "p01", "p02", "p05", "p10", "p25", "p75", "p90",
+              "p95", "p98", "p99", "low_clip", "high_clip", "gamma"):
+        assert getattr(st, k) == getattr(so, k), k
+    # mean/std: device log10 + tree sums vs Welford: informational statistics, 1e-9 relative
+    assert abs(st.mean_db - so.mean_db) <= 1e-9 * max(1.0, abs(so.mean_db))
+    assert abs(st.std_db - so.std_db) <= 1e-9 * max(1.0, abs(so.std_db))
+
+
+def test_integral_f32_equals_u16_flavour(ctx):
+    dn = synth.scene_u16(200, 328, 1)
+    for strategy in (St.Clahe, St.Standard, St.Adaptive):
+        for bd in Bd:
+            a = ctx.process_scalar_data_pipeline(dn, bd, strategy)
+            b = ctx.process_scalar_data_pipeline(dn.astype(np.float32), bd, strategy)
+            k = 0 if bd == Bd.U8 else 1
+            assert np.array_equal(a[k], b[k])
+
+
+def test_db_mask_f32(ctx):
+    x = f32data.nasty_scene(120, 200, seed=3)
+    x.ravel()[:4] = [1.0, 65535.0, 0.0, 2.0]
+    db, mask = ctx.process_scalar_data_inplace(x)
+    rdb, rmask = oracle.db_mask(x)
+    assert np.array_equal(mask, rmask.astype(bool))          # exact
+    # tolerance: 2 ulp(f64) -- the device's f64 log10 and glibc's are each within ~1 ulp of the true
+    # value; the north-star bar (1 ulp on an f32 dB buffer) is checked on the f32-rounded values below
+    ulp = np.spacing(np.abs(rdb))
+    assert np.all(np.abs(db - rdb) <= 2 * ulp), float(np.max(np.abs(db - rdb) / ulp))
+    assert db.ravel()[0] == 0.0 and db.ravel()[2] == -100.0  # SURVEY 8c known answers
+    assert abs(db.ravel()[1] - 48.164733037652496) <= np.spacing(48.164733037652496)
+    # as an f32 buffer the two agree to 1 ulp(f32)
+    assert np.all(np.abs(db.astype(np.float32) - rdb.astype(np.float32)) <= np.spacing(np.abs(rdb.astype(np.float32))))
+
+
+@pytest.mark.parametrize("is_copol", [True, False])
+def test_tamed_synrgb_u8_f32(ctx, is_copol):
+    x = f32data.resampled_scene(150, 170, 0 if is_copol else 1)
+    assert np.array_equal(ctx.autoscale_db_image_tamed_synrgb_u8(x, is_copol), oracle.tamed_synrgb_u8(x, is_copol))
+
+
+@pytest.mark.parametrize("strategy", list(St))
+def test_dualpol_synrgb_f32_matches_oracle(ctx, strategy):
+    b1, b2 = f32data.resampled_scene(140, 230, 0), f32data.resampled_scene(140, 230, 1)
+    rgb, u1, u2 = ctx.dualpol_synrgb(b1, b2, strategy, want_u8=True)
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1, b2, int(strategy))
+    assert rc == 0
+    assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb)
+
+
+def test_polop_then_clahe_u16(ctx):
+    # BASELINE config 3(ii): ratio_arrays(VV, VH) -> CLAHE, U16
+    a = synth.scene_u16(256, 320, 0).astype(np.float32)
+    b = synth.scene_u16(256, 320, 1).astype(np.float32)
+    ratio = ctx.log_ratio_arrays(a, b)
+    assert np.array_equal(ratio, oracle.polop(4, a, b))
+    _, u16 = ctx.process_scalar_data_pipeline(ratio, Bd.U16, St.Clahe)
+    rc, ref = oracle.pipeline(ratio, 1, int(St.Clahe))
+    assert rc == 0 and np.array_equal(u16, ref)
+
+
+def test_f32_degenerate_and_errors(ctx):
+    for x in (np.zeros((40, 50), np.float32), np.full((40, 50), -3.0, np.float32), np.full((40, 50), np.nan, np.float32),
+              np.full((40, 50), 7.25, np.float32)):
+        for strategy in (St.Standard, St.Clahe, St.Tamed):
+            for bd in Bd:
+                u8, u16 = ctx.process_scalar_data_pipeline(x, bd, strategy)
+                rc, ref = oracle.pipeline(x, int(bd), int(strategy))
+                assert rc == 0 and np.array_equal(u8 if bd == Bd.U8 else u16, ref)
+    with pytest.raises(SarproHipError) as ei:
+        ctx.process_scalar_data_pipeline(np.ones((9, 64), np.float32), Bd.U8, St.Clahe)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED_SHAPE
