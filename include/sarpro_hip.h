@@ -172,7 +172,8 @@ int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **names_out, fl
 /* One scene split into row stripes, one per rank.  Each phase
  * ends in a small integer reduction that the caller merges across ranks (RCCL
  * all-reduce(sum) on the returned DEVICE buffers, or sarpro_hip_comm_* below), so the
- * N-rank result is bit-identical to the 1-rank result. */
+ * N-rank result is bit-identical to the 1-rank result.  A phase returns with its buffer
+ * complete; the caller's reduction must be complete before it calls the next phase. */
 typedef struct sarpro_hip_stripe sarpro_hip_stripe;
 /* rows_total x cols scene; this rank owns rows [row0, row0+rows_local).  d_band1/2 are the
  * local stripe (rows_local x cols, pitch in elements). */

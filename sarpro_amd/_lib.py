@@ -55,6 +55,29 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' "
         "or make -C sarpro_amd/csrc). sarpro_amd has no fallback implementation.")
 
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so / libhsa-runtime64.so.  Two HIP runtimes in
+    one process cannot both own the GPU ("No HIP GPUs are available" from whichever initialises
+    second), so when torch is installed we load ITS runtime first: libsarpro_hip.so's NEEDED
+    libamdhip64.so.7 then binds to the copy torch will use too.  Standalone users (the Rust / C
+    callers of the C ABI) get the system ROCm runtime.  SARPRO_HIP_RUNTIME=system skips this."""
+    if os.environ.get("SARPRO_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+_share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 
 _vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64

@@ -854,6 +854,7 @@ extern "C" int sarpro_hip_stripe_begin_u16(sarpro_hip_ctx *ctx, const uint16_t *
 extern "C" int sarpro_hip_stripe_phase1(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *count) {
     if (!s || !d_buf || !count || s->phase != 0) return SARPRO_HIP_ERR_INVALID_ARG;
     RETCHK(job_phase1(s->job));
+    HIPCHK(s->job.ctx, hipStreamSynchronize(s->job.ctx->stream)); // the buffer is complete when we return
     *d_buf = s->job.ctx->ghist.as<uint64_t>();
     *count = 65536 * 2;
     s->phase = 1;
@@ -864,6 +865,7 @@ extern "C" int sarpro_hip_stripe_phase2(sarpro_hip_stripe *s, uint64_t **d_buf, 
     if (!s || !d_buf || !count || s->phase != 1) return SARPRO_HIP_ERR_INVALID_ARG;
     RETCHK(job_after_phase1(s->job));
     RETCHK(job_phase2(s->job));
+    HIPCHK(s->job.ctx, hipStreamSynchronize(s->job.ctx->stream));
     if (s->job.clahe()) { *d_buf = s->job.ctx->tile_bins.as<uint64_t>(); *count = 64 * 256 * 2; }
     else { *d_buf = nullptr; *count = 0; }
     s->phase = 2;
@@ -874,6 +876,7 @@ extern "C" int sarpro_hip_stripe_phase3(sarpro_hip_stripe *s, uint64_t **d_buf, 
     if (!s || !d_buf || !count || s->phase != 2) return SARPRO_HIP_ERR_INVALID_ARG;
     void *outs[kMaxBands] = {nullptr, nullptr};
     RETCHK(job_phase3(s->job, outs, 0));
+    HIPCHK(s->job.ctx, hipStreamSynchronize(s->job.ctx->stream));
     if (s->job.clahe()) { *d_buf = s->job.ctx->level_hist.as<uint64_t>(); *count = 256 * 2; }
     else { *d_buf = nullptr; *count = 0; } // percentile strategies: level histogram follows from the reduced DN histogram
     s->phase = 3;
