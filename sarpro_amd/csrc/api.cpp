@@ -3,7 +3,9 @@
 // entry point replaces.  No CPU fallback exists anywhere in this file: every raster result is
 // produced by the kernels in kernels.hip.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -41,6 +43,7 @@ namespace sarpro {
 
 void timing_reset(sarpro_hip_ctx *ctx) {
     ctx->times.clear();
+    ctx->host_times.clear();
     ctx->events_used = 0;
 }
 
@@ -66,6 +69,17 @@ KernelTimer::~KernelTimer() {
 }
 
 size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+HostTimer::HostTimer(sarpro_hip_ctx *c, const char *n) : ctx(c), name(n) {
+    if (ctx->timing) t0 = std::chrono::steady_clock::now().time_since_epoch().count();
+}
+HostTimer::~HostTimer() {
+    if (!ctx->timing) return;
+    const long long t1 = std::chrono::steady_clock::now().time_since_epoch().count();
+    const double ms = (double)(t1 - t0) * (double)std::chrono::steady_clock::period::num /
+                      (double)std::chrono::steady_clock::period::den * 1e3;
+    ctx->host_times.push_back({name, (float)ms});
+}
 
 } // namespace sarpro
 
@@ -107,10 +121,8 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     sarpro_hip_comm_destroy(ctx);
     for (auto &kv : ctx->plans) {
-        StripePlan *p = kv.second;
-        p->d_hist_rects_tiled.release(); p->d_hist_rects_flat.release(); p->d_apply_rects.release();
-        p->d_row_w.release(); p->d_col_w.release();
-        delete p;
+        kv.second->release_all();
+        delete kv.second;
     }
     for (int b = 0; b < kMaxBands; ++b) { ctx->tile_hist[b].release(); ctx->levels[b].release(); ctx->stage_in[b].release(); }
     for (auto &b : ctx->stage_out) b.release();
@@ -143,6 +155,12 @@ extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **na
         if (ms) ms[n] = v;
         ++n;
     }
+    for (const auto &h : ctx->host_times) { // host segments (wall clock), names start with "host:"
+        if (n >= max_entries) break;
+        if (names) names[n] = h.first;
+        if (ms) ms[n] = h.second;
+        ++n;
+    }
     return n;
 }
 
@@ -151,9 +169,8 @@ extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **na
 // ---------------------------------------------------------------------------------------
 namespace sarpro {
 
-static void add_rects(std::vector<Rect> &out, const StripePlan &P, size_t gr0, size_t gr1, size_t c0, size_t c1,
-                      const int ids[4], size_t chunk_rows, int vecw) {
-    const size_t lo = std::max(gr0, P.row0), hi = std::min(gr1, P.row0 + P.rows_local);
+static void push_strips(std::vector<Rect> &out, const StripePlan &P, size_t lo, size_t hi, size_t c0, size_t c1,
+                        const int ids[4], size_t chunk_rows, int vecw) {
     if (lo >= hi || c0 >= c1) return;
     const size_t strip = 64 * (size_t)vecw;
     for (size_t cs = c0 / vecw * vecw; cs < c1; cs += strip) {
@@ -167,6 +184,23 @@ static void add_rects(std::vector<Rect> &out, const StripePlan &P, size_t gr0, s
             r.r1 = (int32_t)(std::min(rr + chunk_rows, hi) - P.row0);
             out.push_back(r);
         }
+    }
+}
+
+// Global rows [gr0, gr1) x columns [c0, c1) clipped to the local stripe -> work items.  With
+// `sliver` given (vecw == 8) the aligned interior goes to `out`, the edge leftovers to `sliver`.
+static void add_rects(std::vector<Rect> &out, std::vector<Rect> *sliver, const StripePlan &P, size_t gr0, size_t gr1,
+                      size_t c0, size_t c1, const int ids[4], size_t chunk_rows, int vecw) {
+    const size_t lo = std::max(gr0, P.row0), hi = std::min(gr1, P.row0 + P.rows_local);
+    if (lo >= hi || c0 >= c1) return;
+    if (!sliver) { push_strips(out, P, lo, hi, c0, c1, ids, chunk_rows, vecw); return; }
+    const size_t a = (c0 + vecw - 1) / vecw * vecw, b = c1 / vecw * vecw; // aligned interior [a, b)
+    if (a < b) {
+        push_strips(out, P, lo, hi, a, b, ids, chunk_rows, vecw);
+        push_strips(*sliver, P, lo, hi, c0, a, ids, chunk_rows * 4, 1);
+        push_strips(*sliver, P, lo, hi, b, c1, ids, chunk_rows * 4, 1);
+    } else {
+        push_strips(*sliver, P, lo, hi, c0, c1, ids, chunk_rows * 4, 1);
     }
 }
 
@@ -184,12 +218,7 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) { *out = it->second; return SARPRO_HIP_OK; }
     if (ctx->plans.size() > 16) { // bounded cache
-        for (auto &kv : ctx->plans) {
-            StripePlan *p = kv.second;
-            p->d_hist_rects_tiled.release(); p->d_hist_rects_flat.release(); p->d_apply_rects.release();
-            p->d_row_w.release(); p->d_col_w.release();
-            delete p;
-        }
+        for (auto &kv : ctx->plans) { kv.second->release_all(); delete kv.second; }
         ctx->plans.clear();
     }
     StripePlan *P = new StripePlan();
@@ -199,17 +228,18 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     const size_t target_items = 4096;
     const size_t chunk_rows = std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items);
     const ClaheGeometry &g = P->geom;
+    const bool split = false; // edge lanes are masked inside the vector kernels; no separate sliver items
     for (size_t ty = 0; ty < (size_t)kTiles; ++ty) {
         const size_t r0 = std::min(ty * g.tile_h, rows_total), r1 = std::min((ty + 1) * g.tile_h, rows_total);
         for (size_t tx = 0; tx < (size_t)kTiles; ++tx) {
             const size_t c0 = std::min(tx * g.tile_w, cols), c1 = std::min((tx + 1) * g.tile_w, cols);
             const int ids[4] = {(int)(ty * kTiles + tx), 0, 0, 0};
-            add_rects(P->hist_rects_tiled, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
+            add_rects(P->hist_rects_tiled, split ? &P->hist_sliver_tiled : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
         }
     }
     {
         const int ids[4] = {0, 0, 0, 0};
-        add_rects(P->hist_rects_flat, *P, 0, rows_total, 0, cols, ids, chunk_rows, vecw);
+        add_rects(P->hist_rects_flat, split ? &P->hist_sliver_flat : nullptr, *P, 0, rows_total, 0, cols, ids, chunk_rows, vecw);
     }
     for (size_t ri = 0; ri + 1 < g.row_cell_start.size(); ++ri) {
         const size_t r0 = g.row_cell_start[ri], r1 = g.row_cell_start[ri + 1];
@@ -219,17 +249,19 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
             const RowWeight &cw = g.col_w[c0];
             const int ids[4] = {rw.t0 * kTiles + cw.t0, rw.t0 * kTiles + cw.t1, rw.t1 * kTiles + cw.t0,
                                 rw.t1 * kTiles + cw.t1};
-            add_rects(P->apply_rects, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
+            add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
         }
     }
     int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_tiled, P->hist_sliver_tiled.data(), P->hist_sliver_tiled.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_flat, P->hist_sliver_flat.data(), P->hist_sliver_flat.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_apply_sliver, P->apply_sliver.data(), P->apply_sliver.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_row_w, g.row_w.data(), g.row_w.size() * sizeof(RowWeight));
     if (!rc) rc = upload_vec(ctx, P->d_col_w, g.col_w.data(), g.col_w.size() * sizeof(RowWeight));
     if (rc) {
-        P->d_hist_rects_tiled.release(); P->d_hist_rects_flat.release(); P->d_apply_rects.release();
-        P->d_row_w.release(); P->d_col_w.release();
+        P->release_all();
         delete P;
         return rc;
     }
@@ -311,7 +343,15 @@ static int job_phase1(U16Job &J) {
     const int nrects = (int)(tiled ? J.plan->hist_rects_tiled.size() : J.plan->hist_rects_flat.size());
     {
         KernelTimer t(ctx, "dn_hist_u16");
-        HIPCHK(ctx, launch_dn_hist_u16(a, nrects, J.nbands, J.vec, ctx->stream));
+        if (J.vec) HIPCHK(ctx, launch_dn_hist_u16_interior(a, nrects, J.nbands, ctx->stream));
+        else HIPCHK(ctx, launch_dn_hist_u16(a, nrects, J.nbands, false, ctx->stream));
+    }
+    if (J.vec) { // < 8-column leftovers at tile edges: scalar kernel
+        const int ns = (int)(tiled ? J.plan->hist_sliver_tiled.size() : J.plan->hist_sliver_flat.size());
+        a.rects = (tiled ? J.plan->d_hist_sliver_tiled : J.plan->d_hist_sliver_flat).as<Rect>();
+        a.lds_bins = 2048;
+        KernelTimer t(ctx, "dn_hist_u16_sliver");
+        HIPCHK(ctx, launch_dn_hist_u16(a, ns, J.nbands, false, ctx->stream));
     }
     for (int b = 0; b < J.nbands; ++b) {
         KernelTimer t(ctx, "sum_tile_hists");
@@ -331,7 +371,12 @@ static int job_after_phase1(U16Job &J) {
     HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
     HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
     for (int b = 0; b < J.nbands; ++b) {
-        const uint64_t *h = ctx->h_ghist.as<uint64_t>() + (size_t)b * 65536;
+        uint64_t *h = ctx->h_ghist.as<uint64_t>() + (size_t)b * 65536;
+        { // the interior kernel does not count DN = 0: it is what is left of the scene
+            uint64_t others = 0;
+            for (uint32_t dn = 1; dn < 65536; ++dn) others += h[dn];
+            h[0] = (uint64_t)J.rows_total * J.cols - others;
+        }
         RETCHK(stats_from_dn_hist(h, &J.stats[b]));
         RETCHK(select_window(&J.stats[b], J.strategy, J.tamed_kind(b)));
         if (J.clahe()) build_clahe_bin_lut_u16(J.stats[b], &J.lut[b]);
@@ -432,11 +477,22 @@ static int job_phase3(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch)
         a.col_w = J.plan->d_col_w.as<RowWeight>();
         a.row_off = (int32_t)J.row0;
         a.max_val = u8o ? 255.0 : 65535.0;
+        if (const char *e = getenv("SARPRO_HIP_ABLATE")) a.ablate = (uint32_t)atoi(e); // timing experiments only
         if (u8o) HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
         const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out[0]) && (J.nbands < 2 || ptr_aligned16(a.out[1]));
         if (vec != J.vec) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
-        KernelTimer t(ctx, "clahe_apply_u16");
-        HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, J.vec, !u8o, ctx->stream));
+        {
+            KernelTimer t(ctx, "clahe_apply_u16");
+            if (J.vec && u8o && !(a.ablate & 8) && clahe_apply_spec_ok(a, J.nbands))
+                HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
+            else
+                HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, J.vec, !u8o, ctx->stream));
+        }
+        if (J.vec && !J.plan->apply_sliver.empty()) { // < 8-column leftovers at cell edges: scalar exact kernel
+            a.rects = J.plan->d_apply_sliver.as<Rect>();
+            KernelTimer t(ctx, "clahe_apply_sliver");
+            HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_sliver.size(), J.nbands, false, !u8o, ctx->stream));
+        }
         return SARPRO_HIP_OK;
     }
     // percentile strategies: the level histogram is known on the host already; publish it on the
@@ -462,7 +518,14 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
         uint64_t *h = ctx->h_small.as<uint64_t>() + 64 * 256 * kMaxBands;
         HIPCHK(ctx, hipMemcpyAsync(h, ctx->level_hist.p, sizeof(uint64_t) * 256 * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int b = 0; b < J.nbands; ++b) std::memcpy(J.level_hist_h[b], h + (size_t)b * 256, sizeof(uint64_t) * 256);
+        for (int b = 0; b < J.nbands; ++b) {
+            std::memcpy(J.level_hist_h[b], h + (size_t)b * 256, sizeof(uint64_t) * 256);
+            if (J.clahe()) { // the speculative kernel does not count level 0: it is what is left of the scene
+                uint64_t others = 0;
+                for (int i = 1; i < 256; ++i) others += J.level_hist_h[b][i];
+                J.level_hist_h[b][0] = (uint64_t)J.rows_total * J.cols - others;
+            }
+        }
     }
     if (u8o) for (int b = 0; b < J.nbands; ++b) job_rescale_from_level_hist(J, b);
 
@@ -571,11 +634,11 @@ static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch
         if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out) * (size_t)J.nbands);
         return SARPRO_HIP_OK;
     }
-    RETCHK(job_phase1(J));
-    RETCHK(job_after_phase1(J));
-    RETCHK(job_phase2(J));
-    RETCHK(job_phase3(J, d_out, out_pitch));
-    RETCHK(job_phase4(J, d_out, out_pitch, d_rgb, rgb_pitch_px, false));
+    { HostTimer t(J.ctx, "host:phase1_launch"); RETCHK(job_phase1(J)); }
+    { HostTimer t(J.ctx, "host:after_phase1(sync+stats+tables)"); RETCHK(job_after_phase1(J)); }
+    { HostTimer t(J.ctx, "host:phase2_launch"); RETCHK(job_phase2(J)); }
+    { HostTimer t(J.ctx, "host:phase3(sync+cdfs+launch)"); RETCHK(job_phase3(J, d_out, out_pitch)); }
+    { HostTimer t(J.ctx, "host:phase4(sync+tables+launch+sync)"); RETCHK(job_phase4(J, d_out, out_pitch, d_rgb, rgb_pitch_px, false)); }
     if (stats_out) for (int b = 0; b < J.nbands; ++b) stats_out[b] = J.stats[b];
     return SARPRO_HIP_OK;
 }

@@ -44,10 +44,19 @@ struct StripePlan {
     size_t rows_total = 0, cols = 0, row0 = 0, rows_local = 0;
     int vecw = 1;                       // pixels per lane of the kernels this plan feeds
     ClaheGeometry geom;                 // of the WHOLE scene (rows_total x cols)
-    std::vector<Rect> hist_rects_tiled; // per-tile DN histogram items
-    std::vector<Rect> hist_rects_flat;  // single-histogram items (non-CLAHE)
-    std::vector<Rect> apply_rects;      // interpolation-cell items
+    // For vecw == 8 the items are split: INTERIOR items have c0, c1 multiples of 8 (every lane owns
+    // 8 valid pixels: the branch-free kernels), SLIVER items hold the < 8 leftover columns at each
+    // tile / cell edge and run the scalar kernels.  Other widths keep everything in the first list.
+    std::vector<Rect> hist_rects_tiled, hist_sliver_tiled; // per-tile DN histogram items
+    std::vector<Rect> hist_rects_flat, hist_sliver_flat;   // single-histogram items (non-CLAHE)
+    std::vector<Rect> apply_rects, apply_sliver;           // interpolation-cell items
     DevBuf d_hist_rects_tiled, d_hist_rects_flat, d_apply_rects, d_row_w, d_col_w;
+    DevBuf d_hist_sliver_tiled, d_hist_sliver_flat, d_apply_sliver;
+    void release_all() {
+        d_hist_rects_tiled.release(); d_hist_rects_flat.release(); d_apply_rects.release();
+        d_hist_sliver_tiled.release(); d_hist_sliver_flat.release(); d_apply_sliver.release();
+        d_row_w.release(); d_col_w.release();
+    }
 };
 
 struct KernelTime { const char *name; hipEvent_t start, stop; };
@@ -81,6 +90,7 @@ struct sarpro_hip_ctx {
     // per-kernel timing of the last call
     bool timing = false;
     std::vector<sarpro::KernelTime> times;
+    std::vector<std::pair<const char *, float>> host_times;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
 

@@ -11,6 +11,14 @@ struct KernelTimer {
     KernelTimer(sarpro_hip_ctx *c, const char *name);
     ~KernelTimer();
 };
+// Wall-clock time of a host segment (reported with the kernel times, names start with "host:").
+struct HostTimer {
+    sarpro_hip_ctx *ctx;
+    const char *name;
+    long long t0 = 0;
+    HostTimer(sarpro_hip_ctx *c, const char *n);
+    ~HostTimer();
+};
 void timing_reset(sarpro_hip_ctx *ctx);
 size_t round_up(size_t x, size_t m);
 int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,

@@ -46,6 +46,7 @@ struct ClaheApplyArgs {
     unsigned long long *level_hist[kMaxBands]; // [256] histogram of u8 levels, or null
     int32_t row_off;
     double max_val;                         // 255.0 or 65535.0
+    uint32_t ablate;                        // timing experiments only (SARPRO_HIP_ABLATE): 1 no hist, 2 no LUT, 4 no CDF gather
 };
 
 struct LutApplyArgs {
@@ -67,12 +68,15 @@ struct ComposeArgs {
 };
 
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);
+hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nbands, hipStream_t s);
 hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned long long *out,
                                  hipStream_t s);
 hipError_t launch_tile_bin_hist(const uint32_t *tile_hist, int ntiles, const uint8_t *binlut,
                                 unsigned long long *out, hipStream_t s);
 hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,
                                   hipStream_t s);
+bool clahe_apply_spec_ok(const ClaheApplyArgs &a, int nbands);
+hipError_t launch_clahe_apply_u8_spec(const ClaheApplyArgs &a, int nrects, int nbands, hipStream_t s);
 hipError_t launch_lut_apply_u16(const LutApplyArgs &a, bool vec, bool out16, hipStream_t s);
 hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s);
 hipError_t launch_polop_f32(int op, const float *a, const float *b, size_t n, float *out, hipStream_t s);

@@ -35,6 +35,20 @@ template <> struct U16Vec<1> {
     __device__ uint32_t get(int) const { return v; }
 };
 
+// Per-lane keep-mask for an 8-sample vector whose columns [col, col+8) may straddle [c0, c1).
+struct EdgeMask {
+    uint32_t m[4];
+    __device__ EdgeMask(int col, int c0, int c1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ca = col + 2 * k, cb = ca + 1;
+            m[k] = ((ca >= c0 && ca < c1) ? 0x0000FFFFu : 0u) | ((cb >= c0 && cb < c1) ? 0xFFFF0000u : 0u);
+        }
+    }
+    __device__ void apply(U16Vec<8> &v) const { v.v.x &= m[0]; v.v.y &= m[1]; v.v.z &= m[2]; v.v.w &= m[3]; }
+    __device__ bool keep(int j) const { return (m[j >> 1] >> (16 * (j & 1))) & 1u; }
+};
+
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
@@ -89,6 +103,78 @@ __global__ __launch_bounds__(kBlock) void k_dn_hist_u16(DnHistArgs a) {
     if (zeros) atomicAdd(&lds_hist[0], zeros); // slot 0 is otherwise unused (d == 0 never lands in LDS)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < W; i += kBlock) {
+        const uint32_t n = lds_hist[i];
+        if (n) atomicAdd(&gh[i], n);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 1b. The same histogram for 16-byte-vector rasters, the form the 400 MP scene runs.  No per-pixel branches: each pixel does ONE
+//     unconditional ds_add_u32 -- DN in [1, lds_bins) to its bin, everything else (DN = 0 and the
+//     bright tail) to a per-lane dummy word, so the no-data wedge neither serialises on one LDS
+//     word nor costs an exec-mask round trip.  Bright-tail pixels are flagged in a bitmask and
+//     added to the tile's global histogram by a rarely taken branch per row.  The DN = 0 count is
+//     not accumulated at all: it is (pixels of the tile) - (sum of the other bins), restored on
+//     the host.  Loads are software-pipelined: the next two rows are in flight while two rows are
+//     consumed (4 KiB per wave).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_dn_hist_u16_interior(DnHistArgs a) {
+    constexpr int VEC = 8;
+    extern __shared__ uint32_t lds_hist[];
+    const Rect rc = a.rects[blockIdx.x];
+    const int band = blockIdx.y;
+    const uint16_t *__restrict__ in = a.in[band];
+    uint32_t *__restrict__ gh = a.tile_hist[band] + (size_t)rc.id[0] * 65536u;
+    const uint32_t W = a.lds_bins;
+
+    for (uint32_t i = threadIdx.x; i < W + kWave; i += kBlock) lds_hist[i] = 0;
+    __syncthreads();
+
+    const int col = rc.cstart + lane_id() * VEC;
+    const uint32_t dummy = (W + (uint32_t)lane_id()) * 4u; // byte offset of this lane's dummy word
+    unsigned char *lds_bytes = reinterpret_cast<unsigned char *>(lds_hist);
+    // lanes that straddle the item's edge zero their out-of-range samples at load (4 ANDs per row):
+    // DN = 0 lands in the dummy word and is never counted
+    const EdgeMask em(col, rc.c0, rc.c1);
+
+    auto consume = [&](const U16Vec<VEC> &v) {
+        uint32_t big = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t d = v.get(j);
+            const bool in_lds = d - 1u < W - 1u; // 1 <= d < W
+            big |= (d >= W ? 1u : 0u) << j;
+            const uint32_t off = in_lds ? d * 4u : dummy;
+            atomicAdd(reinterpret_cast<uint32_t *>(lds_bytes + off), 1u);
+        }
+        if (big) { // bright tail: rare
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if ((big >> j) & 1u) atomicAdd(&gh[v.get(j)], 1u);
+        }
+    };
+
+    if (col < rc.c1 && col + VEC > rc.c0) {
+        const int step = kWavesPerBlock;
+        const uint16_t *p = in + col;
+        int r = rc.r0 + wave_id();
+        U16Vec<VEC> a0{}, a1{};
+        if (r < rc.r1) a0 = U16Vec<VEC>::load(p + (size_t)r * a.pitch);
+        if (r + step < rc.r1) a1 = U16Vec<VEC>::load(p + (size_t)(r + step) * a.pitch);
+        for (; r < rc.r1; r += 2 * step) {
+            U16Vec<VEC> b0{}, b1{};
+            if (r + 2 * step < rc.r1) b0 = U16Vec<VEC>::load(p + (size_t)(r + 2 * step) * a.pitch);
+            if (r + 3 * step < rc.r1) b1 = U16Vec<VEC>::load(p + (size_t)(r + 3 * step) * a.pitch);
+            em.apply(a0);
+            em.apply(a1);
+            consume(a0);
+            if (r + step < rc.r1) consume(a1);
+            a0 = b0;
+            a1 = b1;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x + 1; i < W; i += kBlock) { // bin 0 is restored on the host
         const uint32_t n = lds_hist[i];
         if (n) atomicAdd(&gh[i], n);
     }
@@ -183,8 +269,9 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
         for (int j = 0; j < VEC; ++j) {
             const uint32_t d = v.get(j);
             const uint32_t dc = min(max(d, win_lo), win_hi);
-            const uint32_t bin = lut_lds ? (uint32_t)lds_lut[dc - win_lo] : (uint32_t)glut[dc];
-            const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
+            uint32_t bin = (a.ablate & 2) ? (d & 255u) : (lut_lds ? (uint32_t)lds_lut[dc - win_lo] : (uint32_t)glut[dc]);
+            const double4 c4 = (a.ablate & 4) ? make_double4(0.25 * bin, 0.5, 0.75, 1.0)
+                                              : *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
             const double top = c4.x * omdx[j] + c4.y * dx[j];
             const double bottom = c4.z * omdx[j] + c4.w * dx[j];
             double o = top * omdy + bottom * dy;
@@ -192,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
             const uint32_t level = (uint32_t)(o * a.max_val); // truncation, o*max_val in [0, max_val]
             lv[j] = d ? level : 0u;                           // invalid (DN = 0) -> 0
         }
-        if (!OUT16 && ghist) {
+        if (!OUT16 && ghist && !(a.ablate & 1)) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int c = col + j;
@@ -246,6 +333,157 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
         __syncthreads();
         const uint32_t n = lds_hist[threadIdx.x];
         if (n) atomicAdd(&ghist[threadIdx.x], (unsigned long long)n);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 4b. CLAHE apply, u8 output, speculative form (the headline kernel).
+//     PMC profiling of kernel 4 showed it bound by VALU issue and LDS latency (38 VALU + 13 SALU
+//     instructions and 32 B of conflicting LDS gathers per pixel, waves waiting 50 % of the time),
+//     not by HBM.  This form does per pixel:
+//       DN -> min(DN, win_hi) -> u16 table in LDS that holds the BYTE OFFSET of the pixel's CDF
+//       entry (entry 256 is all-zero and is where DN = 0 points, so invalid pixels need no
+//       branch) -> one 16-B gather of the four CDFs as f32 -> 6 f32 FMAs -> floor.
+//     The f32 result decides the level unless o*255 lies within kSpecDelta of an integer; those
+//     pixels (~0.8 %) are recomputed with the reference's exact f64 sequence (CDFs and column
+//     weights as f64 in LDS), so the raster is bit-identical to kernel 4's.
+//     Error bound (u = 2^-24; |dx|,|dy| <= 1, weight pairs sum to <= 2, CDFs in [0,1]): inputs
+//     rounded once (u), each product <= 3u, each sum adds u of a magnitude <= 2, the 255 factor is
+//     folded into the row weights (+u):  |y32 - y| <= 255*34u + u*|y| < 6e-4 with y = o*255.
+//     kSpecDelta = 1/256 = 3.9e-3 leaves > 6x margin.  y32 == 0 exactly happens only when every
+//     product is exactly zero in f64 too (f32 rounding never flushes these operands to zero), so
+//     an exact zero is decided (level 0) without the f64 path.
+//     Level 0 goes to a per-lane dummy histogram word (bin 0 = pixels - other bins, on the host).
+// ------------------------------------------------------------------------------------
+constexpr float kSpecDelta = 1.0f / 256.0f;
+constexpr uint32_t kSpecLutMaxEntries = 16384; // u16 offsets: 32 KiB of LDS at most
+
+struct SpecLds { // byte offsets into dynamic LDS
+    static constexpr uint32_t cdf64 = 0;                      // [257][4] double
+    static constexpr uint32_t cdf32 = 257 * 32;               // [257] float4
+    static constexpr uint32_t colw = cdf32 + 257 * 16 + 16;   // [512][2] double (16-B aligned)
+    static constexpr uint32_t hist = colw + 512 * 16;         // [256 + 64] u32
+    static constexpr uint32_t lut = hist + (256 + 64) * 4;    // [win_hi + 1] u16
+};
+
+__global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a) {
+    constexpr int VEC = 8;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const Rect rc = a.rects[blockIdx.x];
+    const int band = blockIdx.y;
+    const uint16_t *__restrict__ in = a.in[band];
+    const double *__restrict__ cdfs = a.cdfs[band];
+    const uint8_t *__restrict__ glut = a.binlut[band];
+    const uint32_t win_hi = a.win_hi[band];
+    unsigned long long *ghist = a.level_hist[band];
+    const int col = rc.cstart + lane_id() * VEC;
+    const bool full = col >= rc.c0 && col + VEC <= rc.c1;
+    const EdgeMask em(col, rc.c0, rc.c1); // edge lanes: out-of-range samples become DN = 0 (level 0, uncounted, unstored)
+    {
+        const int b = threadIdx.x;
+        double c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = cdfs[(size_t)rc.id[k] * 256 + b];
+        *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + b * 32) = make_double4(c[0], c[1], c[2], c[3]);
+        *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + b * 16) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
+        if (b == 0) {
+            *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + 256 * 32) = make_double4(0.0, 0.0, 0.0, 0.0);
+            *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + 256 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
+        for (int i = b; i < 512; i += kBlock) { // exact column weights of this strip, for the f64 path
+            const int c2 = rc.cstart + i;
+            const RowWeight w = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0];
+            *reinterpret_cast<double2 *>(lds + SpecLds::colw + i * 16) = make_double2(w.d, w.omd);
+        }
+        uint16_t *lut = reinterpret_cast<uint16_t *>(lds + SpecLds::lut);
+        for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(i ? (uint32_t)glut[i] * 16u : 256u * 16u);
+    }
+    __syncthreads();
+
+    float dxf[VEC], omdxf[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const double2 w = *reinterpret_cast<const double2 *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 16);
+        dxf[j] = (float)w.x;
+        omdxf[j] = (float)w.y;
+    }
+    const uint32_t dummy = SpecLds::hist + (256u + (uint32_t)lane_id()) * 4u;
+
+    auto process_row = [&](int r, const U16Vec<VEC> &v) {
+        const RowWeight rw = a.row_w[a.row_off + r]; // wave-uniform
+        const float dy255 = (float)rw.d * 255.0f, omdy255 = (float)rw.omd * 255.0f;
+        uint32_t lv[VEC], off[VEC];
+        uint32_t pend = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t i = min(v.get(j), win_hi);
+            off[j] = *reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(lds + SpecLds::cdf32 + off[j]);
+            const float top = fmaf(c4.y, dxf[j], c4.x * omdxf[j]);
+            const float bottom = fmaf(c4.w, dxf[j], c4.z * omdxf[j]);
+            const float y = fmaf(bottom, dy255, top * omdy255);
+            const float fl = floorf(y);
+            lv[j] = (uint32_t)min(max((int)fl, 0), 255);
+            const bool near = fabsf((y - fl) - 0.5f) > 0.5f - kSpecDelta && y != 0.0f;
+            pend |= (near ? 1u : 0u) << j;
+        }
+        while (pend) { // exact recomputation (reference op order, autoscale.rs:327-329, 602)
+            const int j = __ffs(pend) - 1;
+            pend &= pend - 1;
+            uint32_t o8 = off[0];
+#pragma unroll
+            for (int jj = 1; jj < VEC; ++jj) o8 = (jj == j) ? off[jj] : o8;
+            const double4 c4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + o8 * 2u);
+            const double2 cw = *reinterpret_cast<const double2 *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 16);
+            const double top = c4.x * cw.y + c4.y * cw.x;
+            const double bottom = c4.z * cw.y + c4.w * cw.x;
+            double o = top * rw.omd + bottom * rw.d;
+            o = fmin(fmax(o, 0.0), 1.0);
+            const uint32_t level = (uint32_t)(o * 255.0);
+#pragma unroll
+            for (int jj = 0; jj < VEC; ++jj) lv[jj] = (jj == j) ? level : lv[jj];
+        }
+        if (ghist) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const uint32_t h = lv[j] ? SpecLds::hist + lv[j] * 4u : dummy;
+                atomicAdd(reinterpret_cast<uint32_t *>(lds + h), 1u);
+            }
+        }
+        uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out[band]) + (size_t)r * a.out_pitch + col;
+        if (full) {
+            uint2 pk;
+            pk.x = lv[0] | (lv[1] << 8) | (lv[2] << 16) | (lv[3] << 24);
+            pk.y = lv[4] | (lv[5] << 8) | (lv[6] << 16) | (lv[7] << 24);
+            *reinterpret_cast<uint2 *>(o8) = pk;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (em.keep(j)) o8[j] = (uint8_t)lv[j];
+        }
+    };
+
+    if (col < rc.c1 && col + VEC > rc.c0) {
+        const int step = kWavesPerBlock;
+        const uint16_t *p = in + col;
+        int r = rc.r0 + wave_id();
+        U16Vec<VEC> cur{}, nxt{};
+        if (r < rc.r1) cur = U16Vec<VEC>::load(p + (size_t)r * a.in_pitch);
+        for (; r < rc.r1; r += step) {
+            if (r + step < rc.r1) nxt = U16Vec<VEC>::load(p + (size_t)(r + step) * a.in_pitch);
+            em.apply(cur);
+            process_row(r, cur);
+            cur = nxt;
+        }
+    }
+    if (ghist) {
+        __syncthreads();
+        const uint32_t n = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[threadIdx.x];
+        if (n && threadIdx.x) atomicAdd(&ghist[threadIdx.x], (unsigned long long)n); // bin 0 restored on the host
     }
 }
 
@@ -478,6 +716,13 @@ hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool 
     return hipGetLastError();
 }
 
+hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nbands, hipStream_t s) {
+    if (nrects <= 0) return hipSuccess;
+    const size_t lds = ((size_t)a.lds_bins + kWave) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_dn_hist_u16_interior, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned long long *out, hipStream_t s) {
     hipLaunchKernelGGL(k_sum_tile_hists, dim3(65536 / kBlock), dim3(kBlock), 0, s, tile_hist, ntiles, out);
     return hipGetLastError();
@@ -494,6 +739,21 @@ size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands) {
     if (a.lut_in_lds)
         for (int b = 0; b < nbands; ++b) win = std::max<size_t>(win, a.win_hi[b] - a.win_lo[b] + 1);
     return 256 * 4 * 8 + 256 * 4 + ((win + 15) & ~(size_t)15);
+}
+
+bool clahe_apply_spec_ok(const ClaheApplyArgs &a, int nbands) {
+    for (int b = 0; b < nbands; ++b)
+        if (a.win_hi[b] + 1 > kSpecLutMaxEntries) return false;
+    return true;
+}
+
+hipError_t launch_clahe_apply_u8_spec(const ClaheApplyArgs &a, int nrects, int nbands, hipStream_t s) {
+    if (nrects <= 0) return hipSuccess;
+    uint32_t hi = 0;
+    for (int b = 0; b < nbands; ++b) hi = std::max(hi, a.win_hi[b]);
+    const size_t lds = SpecLds::lut + (((size_t)hi + 1) * 2 + 15 & ~(size_t)15);
+    hipLaunchKernelGGL(k_clahe_apply_u8_spec, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,
