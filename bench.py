@@ -147,7 +147,8 @@ def main():
             bytes_launch = alg_bpp.get(dom, 0.0) * local_px
             achieved = bytes_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": pmc_traffic_gb(dom, rows_local * cols),
                         "ms_per_launch": round(per_launch[dom], 4),
                         "kernels_ms_per_step": {k: round(total_ms[k], 4) for k in sorted(total_ms)}}
         out = {
@@ -169,6 +170,21 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def pmc_traffic_gb(kernel, local_px):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r1_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied), scaled
+    to this run's pixel count.  None when the kernel has no committed measurement."""
+    names = {"clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_u16_interior",
+             "compose_u8": "k_compose_u8", "lut_apply_u16": "k_lut_apply_u16"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            t = json.load(f)
+        gb = t[names[kernel]]["total"] * (local_px / 4.0e8)
+        return {"value": round(gb, 3), "unit": "GB", "source": "profiles/r1_traffic.json (rocprofv3 PMC, separate passes)"}
+    except Exception:
+        return None
 
 
 def cpu_baseline(ctx, q, side, strategy, torch, dev):
