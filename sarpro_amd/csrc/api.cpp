@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 
+#include "chain_kernels.h"
 #include "context.h"
 #include "internal.h"
 
@@ -128,6 +129,7 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     for (auto &b : ctx->stage_out) b.release();
     ctx->ghist.release(); ctx->tile_bins.release(); ctx->cdfs.release(); ctx->luts.release();
     ctx->level_hist.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
+    ctx->chain_consts.release(); ctx->chain_state.release();
     ctx->h_ghist.release(); ctx->h_small.release(); ctx->h_upload.release();
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -626,6 +628,139 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
     return SARPRO_HIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Device-resident chain: CLAHE, u8 output, vector layout, whole scene on this GPU.  The host only
+// enqueues: statistics, CLAHE bins, CDFs, rescale and compose tables are computed by small kernels
+// (chain_kernels.hip), so there is ONE stream synchronisation per scene, at the end.
+// ---------------------------------------------------------------------------------------
+constexpr size_t kChainOffDb = 0, kChainOffSupp = 65536 * 8, kChainOffBlue = kChainOffSupp + 21504;
+constexpr size_t kChainConstBytes = kChainOffBlue + 65536;
+constexpr size_t kStateOffResc = 2 * sizeof(ChainBandState), kStateOffIdent = kStateOffResc + 512,
+                 kStateOffFloor = kStateOffIdent + 16, kStateBytes = kStateOffFloor + 16;
+
+static int chain_prepare(sarpro_hip_ctx *ctx) {
+    if (ctx->chain_ready) return SARPRO_HIP_OK;
+    HIPCHK(ctx, ctx->chain_consts.reserve(kChainConstBytes));
+    HIPCHK(ctx, ctx->chain_state.reserve(kStateBytes));
+    uint8_t *d = ctx->chain_consts.as<uint8_t>();
+    HIPCHK(ctx, hipMemcpyAsync(d + kChainOffDb, db_table_u16(), 65536 * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d + kChainOffSupp, synrgb_supp_rg_tables(), 41 * 512, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d + kChainOffBlue, synrgb_blue_pair_supp(), 65536, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->chain_ready = true;
+    return SARPRO_HIP_OK;
+}
+
+static bool chain_eligible(const U16Job &J) {
+    if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
+    return J.clahe() && J.u8_out() && J.vec && !J.tamed_force && J.row0 == 0 && J.rows_local == J.rows_total;
+}
+
+static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
+                         sarpro_hip_stats *stats_out) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    RETCHK(chain_prepare(ctx));
+    const uint32_t rows = (uint32_t)J.rows_local, cols = (uint32_t)J.cols;
+    HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
+    HIPCHK(ctx, ctx->tile_bins.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands));
+    HIPCHK(ctx, ctx->cdfs.reserve(sizeof(double) * 64 * 256 * kMaxBands));
+    HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
+    HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
+    HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
+    uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
+    ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
+
+    RETCHK(job_phase1(J)); // per-tile DN histograms -> ctx->ghist
+    {
+        ChainStatsArgs sa{};
+        sa.ghist = ctx->ghist.as<unsigned long long>();
+        sa.db = reinterpret_cast<const double *>(consts + kChainOffDb);
+        sa.state = d_state;
+        sa.binlut = ctx->luts.as<uint8_t>();
+        sa.binlut_stride = 131072;
+        KernelTimer t(ctx, "chain_stats");
+        HIPCHK(ctx, launch_chain_stats(sa, J.nbands, ctx->stream));
+    }
+    for (int b = 0; b < J.nbands; ++b) {
+        KernelTimer t(ctx, "tile_bin_hist");
+        HIPCHK(ctx, launch_tile_bin_hist(ctx->tile_hist[b].as<uint32_t>(), kTiles * kTiles, ctx->luts.as<uint8_t>() + (size_t)b * 131072,
+                                         ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256, ctx->stream));
+    }
+    {
+        KernelTimer t(ctx, "chain_cdfs");
+        HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
+                                      J.nbands, ctx->stream));
+    }
+    // apply: levels into the internal rasters (dual-pol) or straight into the caller's raster (single band)
+    const bool direct = !J.synrgb;
+    if (!direct) RETCHK(ensure_levels(J));
+    ClaheApplyArgs a{};
+    for (int b = 0; b < J.nbands; ++b) {
+        a.in[b] = J.d_in[b];
+        a.out[b] = direct ? d_out[b] : (void *)J.d_levels[b];
+        a.cdfs[b] = ctx->cdfs.as<double>() + (size_t)b * 64 * 256;
+        a.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+        a.level_hist[b] = ctx->level_hist.as<unsigned long long>() + (size_t)b * 256;
+    }
+    a.in_pitch = J.in_pitch;
+    a.out_pitch = direct ? out_pitch : J.lvl_pitch;
+    a.rects = J.plan->d_apply_rects.as<Rect>();
+    a.row_w = J.plan->d_row_w.as<RowWeight>();
+    a.col_w = J.plan->d_col_w.as<RowWeight>();
+    a.row_off = 0;
+    a.max_val = 255.0;
+    a.dev_state = d_state;
+    if (a.out_pitch % 8 != 0 || !ptr_aligned16(a.out[0]) || (J.nbands > 1 && !ptr_aligned16(a.out[1])))
+        return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
+    HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
+    {
+        KernelTimer t(ctx, "clahe_apply_u16");
+        HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
+    }
+    {
+        ChainFinishArgs fa{};
+        fa.level_hist = ctx->level_hist.as<unsigned long long>();
+        fa.total_px = (unsigned long long)J.rows_total * J.cols;
+        fa.nbands = J.nbands;
+        fa.resc_out = state + kStateOffResc;
+        fa.identity_out = state + kStateOffIdent;
+        fa.tables = J.synrgb ? ctx->tables.as<uint8_t>() : nullptr;
+        fa.supp_rg = consts + kChainOffSupp;
+        fa.blue_pair_supp = consts + kChainOffBlue;
+        fa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        KernelTimer t(ctx, "chain_finish");
+        HIPCHK(ctx, launch_chain_finish(fa, ctx->stream));
+    }
+    if (J.synrgb) {
+        ComposeArgs c{};
+        c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch;
+        c.rgb = d_rgb; c.rgb_pitch_px = rgb_pitch_px; c.rows = rows; c.cols = cols;
+        c.tables = ctx->tables.as<uint8_t>();
+        const int cvec = (c.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(c.b1) && ptr_aligned16(c.b2) && ptr_aligned16(d_rgb)) ? 16 : 1;
+        {
+            KernelTimer t(ctx, "compose_u8");
+            HIPCHK(ctx, launch_compose_u8(c, cvec, ctx->stream));
+        }
+        for (int b = 0; b < 2; ++b) // optional per-band u8 rasters: levels through the band's rescale
+            if (d_out[b])
+                HIPCHK(ctx, launch_chain_remap(J.d_levels[b], J.lvl_pitch, reinterpret_cast<uint8_t *>(d_out[b]), out_pitch, rows, cols,
+                                               state + kStateOffResc + (size_t)b * 256, nullptr, ctx->stream));
+    } else {
+        // single band: the apply pass wrote levels into the caller's raster; rescale in place unless it is the identity
+        HIPCHK(ctx, launch_chain_remap(reinterpret_cast<uint8_t *>(d_out[0]), out_pitch, reinterpret_cast<uint8_t *>(d_out[0]), out_pitch, rows,
+                                       cols, state + kStateOffResc, state + kStateOffIdent, ctx->stream));
+    }
+    ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
+    HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
+    for (int b = 0; b < J.nbands; ++b) {
+        J.stats[b] = h_state[b].stats;
+        if (stats_out) stats_out[b] = J.stats[b];
+    }
+    return SARPRO_HIP_OK;
+}
+
 static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
                        sarpro_hip_stats *stats_out) {
     timing_reset(J.ctx);
@@ -633,6 +768,10 @@ static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch
     if (J.rows_local == 0 || J.cols == 0) {
         if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out) * (size_t)J.nbands);
         return SARPRO_HIP_OK;
+    }
+    if (chain_eligible(J)) {
+        HostTimer t(J.ctx, "host:chain(enqueue+final sync)");
+        return job_run_chain(J, d_out, out_pitch, d_rgb, rgb_pitch_px, stats_out);
     }
     { HostTimer t(J.ctx, "host:phase1_launch"); RETCHK(job_phase1(J)); }
     { HostTimer t(J.ctx, "host:after_phase1(sync+stats+tables)"); RETCHK(job_after_phase1(J)); }

@@ -1,0 +1,327 @@
+// chain_kernels.hip -- the host half of the CLAHE u8 path, moved onto the device so the headline
+// chain (histogram -> statistics -> CLAHE bins -> CDFs -> apply -> rescale / synRGB tables ->
+// compose) runs with NO host synchronisation between kernels.
+//
+// Everything here is +, -, *, /, sqrt, floor, round and integer<->float conversion in IEEE f64/f32
+// (built with -ffp-contract=off, correctly rounded division): the results are bit-identical to
+// host_logic.cpp, which remains the implementation for the other strategies, the f32 flavour and
+// the row-stripe protocol.  Transcendentals never run here: the dB value of every DN, the powf
+// tables of the suppressed synRGB LUTs (one per possible floor) and the blue pair tables are
+// constant tables built once on the host with glibc and uploaded at context creation.
+#include "chain_kernels.h"
+
+#include <cfloat>
+
+namespace sarpro {
+namespace {
+
+constexpr int kStatsBlock = 1024;
+
+__device__ inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// deterministic block reductions over kStatsBlock threads (fixed tree)
+template <typename T, typename Op>
+__device__ T block_reduce(T v, T *scratch /*[kStatsBlock]*/, Op op) {
+    scratch[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = kStatsBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) scratch[threadIdx.x] = op(scratch[threadIdx.x], scratch[threadIdx.x + s]);
+        __syncthreads();
+    }
+    T r = scratch[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
+// compute_histogram_stats (autoscale.rs:35-160) over the DN histogram + the CLAHE window
+// (autoscale.rs:544-548, 564) + the DN -> bin table (autoscale.rs:583-591, 262-265).
+// One block per band.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
+    __shared__ unsigned long long hist[kStatBins];
+    __shared__ unsigned long long scr_u64[kStatsBlock];
+    __shared__ double scr_f64[kStatsBlock];
+    __shared__ uint32_t scr_u32[kStatsBlock];
+    __shared__ double pct[11];
+
+    const int band = blockIdx.x;
+    const unsigned long long *__restrict__ h = a.ghist + (size_t)band * 65536;
+    const double *__restrict__ db = a.db;
+    ChainBandState *out = a.state + band;
+    uint8_t *binlut = a.binlut + (size_t)band * a.binlut_stride;
+    const int t = threadIdx.x;
+
+    // ---- count / min / max DN over valid samples (DN >= 1) ----
+    unsigned long long cnt = 0;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) {
+        const unsigned long long n = dn ? h[dn] : 0ull;
+        if (n) { cnt += n; mn = min(mn, dn); mx = max(mx, dn); }
+    }
+    const unsigned long long count = block_reduce(cnt, scr_u64, [](unsigned long long x, unsigned long long y) { return x + y; });
+    const uint32_t min_dn = block_reduce(mn, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+    const uint32_t max_dn = block_reduce(mx, scr_u32, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+
+    sarpro_hip_stats st;
+    st.valid_count = count;
+    st.min_db = st.max_db = st.mean_db = st.std_db = st.median_db = 0.0;
+    st.p01 = st.p02 = st.p05 = st.p10 = st.p25 = st.p75 = st.p90 = st.p95 = st.p98 = st.p99 = 0.0;
+    st.low_clip = st.high_clip = 0.0;
+    st.gamma = 1.0;
+    st.skew_factor = st.tail_heaviness = 0.0;
+
+    if (count == 0) { // no valid pixel: every DN is invalid, the bin table is irrelevant (autoscale.rs:466-468)
+        for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) binlut[dn] = 0;
+        if (t == 0) { out->stats = st; out->win_hi = 1; }
+        return;
+    }
+    const double min_db = db[min_dn], max_db = db[max_dn];
+
+    // ---- mean / std (per-DN sums; informational) ----
+    double s1 = 0.0;
+    for (uint32_t dn = t + 1; dn < 65536u; dn += kStatsBlock) s1 += (double)h[dn] * db[dn];
+    const double mean = block_reduce(s1, scr_f64, [](double x, double y) { return x + y; }) / (double)count;
+    double s2 = 0.0;
+    for (uint32_t dn = t + 1; dn < 65536u; dn += kStatsBlock) { const double d = db[dn] - mean; s2 += (double)h[dn] * d * d; }
+    const double m2 = block_reduce(s2, scr_f64, [](double x, double y) { return x + y; });
+    st.min_db = min_db; st.max_db = max_db; st.mean_db = mean;
+    st.std_db = count > 1 ? sqrt(m2 / (double)count) : 0.0;
+
+    if (fabs(max_db - min_db) < DBL_EPSILON) { // autoscale.rs:81-100
+        st.median_db = st.p01 = st.p02 = st.p05 = st.p10 = st.p25 = min_db;
+        st.p75 = st.p90 = st.p95 = st.p98 = st.p99 = max_db;
+    } else {
+        // ---- 4096-bin histogram over [min, max] (autoscale.rs:103-117) ----
+        for (int i = t; i < kStatBins; i += kStatsBlock) hist[i] = 0;
+        __syncthreads();
+        const double span = max_db - min_db, inv_span = 1.0 / span;
+        for (uint32_t dn = t + 1; dn < 65536u; dn += kStatsBlock) {
+            const unsigned long long n = h[dn];
+            if (!n) continue;
+            const double tt = clampd((db[dn] - min_db) * inv_span, 0.0, 1.0);
+            unsigned long long idx = (unsigned long long)(tt * (double)kStatBins);
+            if (idx >= (unsigned long long)kStatBins) idx = kStatBins - 1;
+            atomicAdd(&hist[idx], n);
+        }
+        __syncthreads();
+        // ---- exclusive prefix over the bins: thread t owns bins 4t .. 4t+3 ----
+        unsigned long long own[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { own[k] = hist[4 * t + k]; tot += own[k]; }
+        scr_u64[t] = tot;
+        __syncthreads();
+        for (int off = 1; off < kStatsBlock; off <<= 1) { // Hillis-Steele inclusive scan (integers: order-free)
+            const unsigned long long v = t >= off ? scr_u64[t - off] : 0ull;
+            __syncthreads();
+            scr_u64[t] += v;
+            __syncthreads();
+        }
+        unsigned long long excl = scr_u64[t] - tot;
+        __syncthreads();
+        // ---- percentile inversion (autoscale.rs:120-140) ----
+        const double ps[11] = {0.5, 0.01, 0.02, 0.05, 0.10, 0.25, 0.75, 0.90, 0.95, 0.98, 0.99};
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            unsigned long long target = (unsigned long long)floor(ps[q] * (double)count);
+            if (target >= count) target = count - 1;
+            unsigned long long e = excl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (own[k] && target >= e && target < e + own[k]) {
+                    const double frac = (double)(target - e) / (double)own[k];
+                    const double bin_width = span / (double)kStatBins;
+                    const double bin_start = min_db + (double)(4 * t + k) * bin_width;
+                    pct[q] = bin_start + frac * bin_width;
+                }
+                e += own[k];
+            }
+        }
+        __syncthreads();
+        st.median_db = pct[0]; st.p01 = pct[1]; st.p02 = pct[2]; st.p05 = pct[3]; st.p10 = pct[4]; st.p25 = pct[5];
+        st.p75 = pct[6]; st.p90 = pct[7]; st.p95 = pct[8]; st.p98 = pct[9]; st.p99 = pct[10];
+    }
+    // ---- CLAHE window + DN -> bin table ----
+    const double low = st.p01, high = st.p99;
+    st.low_clip = low; st.high_clip = high; st.gamma = 1.0;
+    const double range = fmax(high - low, 1.0);
+    uint32_t first_hi = 65535u; // first DN >= 1 whose dB value reached the high clip: the table is constant from there
+    for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) {
+        uint8_t bin = 0;
+        if (dn) {
+            const double d = db[dn];
+            const double clipped = fmin(fmax(d, low), high);
+            const double v = clampd((clipped - low) / range, 0.0, 1.0);
+            long long b = (long long)round(v * 255.0);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            bin = (uint8_t)b;
+            if (d >= high) first_hi = min(first_hi, dn);
+        }
+        binlut[dn] = bin;
+    }
+    const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+    if (t == 0) { out->stats = st; out->win_hi = win_hi; }
+}
+
+// ------------------------------------------------------------------------------------
+// clip / redistribute / CDF of every tile (autoscale.rs:271-302).  One block per (tile, band).
+// The clip threshold is a multiple of 2^-7 and the counts are integers < 2^32, so every f64 sum
+// below is exact and order-free.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chain_cdfs(const unsigned long long *__restrict__ tile_bins,
+                                                    double *__restrict__ cdfs, uint32_t rows, uint32_t cols) {
+    __shared__ double scr[256];
+    __shared__ unsigned long long cum[256];
+    const int tile = blockIdx.x, band = blockIdx.y, b = threadIdx.x;
+    const uint32_t tile_h = (rows + kTiles - 1) / kTiles, tile_w = (cols + kTiles - 1) / kTiles;
+    const uint32_t ty = tile / kTiles, tx = tile % kTiles;
+    const uint32_t r0 = min(ty * tile_h, rows), r1 = min((ty + 1) * tile_h, rows);
+    const uint32_t c0 = min(tx * tile_w, cols), c1 = min((tx + 1) * tile_w, cols);
+    const size_t base = ((size_t)band * kTiles * kTiles + tile) * 256;
+    unsigned long long hv = tile_bins[base + b];
+
+    const double avg = (double)((unsigned long long)(r1 - r0) * (unsigned long long)(c1 - c0)) / 256.0;
+    const double thr = fmax(kClipLimit * avg, 1.0);
+    double ex = 0.0;
+    if ((double)hv > thr) { ex = (double)hv - thr; hv = (unsigned long long)(uint32_t)thr; } // `as u32` truncates (thr < 2^32 here)
+    scr[b] = ex;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (b < s) scr[b] += scr[b + s]; __syncthreads(); }
+    const double excess = scr[0];
+    __syncthreads();
+    const double add = floor(excess / 256.0);
+    const unsigned long long remainder = (unsigned long long)round(excess - add * 256.0);
+    double hd = (double)hv + add;
+    unsigned long long hn = hd >= 4294967295.0 ? 4294967295ull : (unsigned long long)hd; // `as u32` saturates
+    hn += remainder / 256 + ((unsigned long long)b < remainder % 256 ? 1 : 0);         // round-robin from bin 0
+    cum[b] = hn;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long v = b >= off ? cum[b - off] : 0ull;
+        __syncthreads();
+        cum[b] += v;
+        __syncthreads();
+    }
+    const double total = fmax((double)cum[255], 1.0);
+    cdfs[base + b] = clampd((double)cum[b] / total, 0.0, 1.0);
+}
+
+// ------------------------------------------------------------------------------------
+// After the apply pass: u8 rescale of each band (autoscale.rs:348-364), suppressed-synRGB floor
+// from the combined histogram of the FINAL u8 bands (synthetic_rgb.rs:92-113) and the compose
+// tables with both folded in (host_logic.cpp: fold_compose_tables).  One block.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a) {
+    __shared__ unsigned long long lh[2][256];
+    __shared__ uint8_t resc[2][256];
+    __shared__ unsigned long long combined[256];
+    __shared__ int s_fwc;
+    const int t = threadIdx.x;
+    for (int i = t; i < 512; i += kStatsBlock) {
+        const int b = i >> 8, k = i & 255;
+        lh[b][k] = (b < a.nbands) ? a.level_hist[(size_t)b * 256 + k] : 0ull;
+    }
+    if (t < 256) combined[t] = 0;
+    __syncthreads();
+    if (t < a.nbands) { // level 0 is not counted by the apply kernel: it is what is left of the scene
+        unsigned long long others = 0;
+        for (int k = 1; k < 256; ++k) others += lh[t][k];
+        lh[t][0] = a.total_px - others;
+    }
+    __syncthreads();
+    if (t < a.nbands) {
+        unsigned mn = 0, mx = 0;
+        bool any = false;
+        for (unsigned k = 0; k < 256; ++k)
+            if (lh[t][k]) { if (!any) mn = k; mx = k; any = true; }
+        const float fmn = (float)mn, fmx = (float)mx;
+        const float scale = fmx > fmn ? 255.0f / (fmx - fmn) : 1.0f;
+        for (unsigned x = 0; x < 256; ++x) {
+            float val = roundf(((float)x - fmn) * scale);
+            val = val < 0.0f ? 0.0f : (val > 255.0f ? 255.0f : val);
+            resc[t][x] = (uint8_t)val;
+        }
+    }
+    __syncthreads();
+    if (t < 256) for (int b = 0; b < a.nbands; ++b) atomicAdd(&combined[resc[b][t]], lh[b][t]);
+    if (t < 512 && a.resc_out) a.resc_out[t] = (t >> 8) < a.nbands ? resc[t >> 8][t & 255] : (uint8_t)(t & 255);
+    if (t < a.nbands && a.identity_out) {
+        bool ident = true;
+        for (int k = 0; k < 256; ++k) if (lh[t][k] && resc[t][k] != k) ident = false;
+        a.identity_out[t] = ident ? 1 : 0;
+    }
+    __syncthreads();
+    if (a.nbands < 2 || !a.tables) return;
+    if (t == 0) { // synthetic_rgb.rs:99-113 with the reference's saturating u32 counters
+        const uint32_t total = (uint32_t)(a.total_px + a.total_px);
+        const double tc = round((double)total * 0.05);
+        const uint32_t target = tc >= 4294967295.0 ? 4294967295u : (uint32_t)tc;
+        uint32_t cumulative = 0;
+        int floor_value = 0;
+        for (int i = 0; i < 256; ++i) {
+            const unsigned long long hi = combined[i] > 4294967295ull ? 4294967295ull : combined[i];
+            const unsigned long long c = (unsigned long long)cumulative + hi;
+            cumulative = c > 4294967295ull ? 4294967295u : (uint32_t)c;
+            if (cumulative >= target) { floor_value = i; break; }
+        }
+        const int fwc = floor_value + 3 < 40 ? floor_value + 3 : 40;
+        s_fwc = fwc;
+        if (a.floor_out) *a.floor_out = fwc;
+    }
+    __syncthreads();
+    const int fwc = s_fwc;
+    const uint8_t *lut_r = a.supp_rg + (size_t)fwc * 512, *lut_g = lut_r + 256; // powf tables per floor (host-built)
+    uint8_t *R2 = a.tables, *G2 = a.tables + 256, *B2 = a.tables + 512;
+    if (t < 256) {
+        const int r1 = resc[0][t], r2 = resc[1][t];
+        R2[t] = r1 <= fwc ? 0 : lut_r[r1];
+        G2[t] = r2 <= fwc ? 0 : lut_g[r2];
+    }
+    for (int i = t; i < 65536; i += kStatsBlock) {
+        const int v1 = i >> 8, v2 = i & 255;
+        const int r1 = resc[0][v1], r2 = resc[1][v2];
+        const bool water = r1 <= fwc && r2 <= fwc;
+        B2[i] = water ? 0 : a.blue_pair_supp[((size_t)lut_r[r1] << 8) | lut_g[r2]];
+    }
+}
+
+// In-place u8 remap with the map in device memory (per-band u8 outputs of the chain).
+__global__ __launch_bounds__(256) void k_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst,
+                                                     size_t dst_pitch, uint32_t rows, uint32_t cols,
+                                                     const uint8_t *__restrict__ map, const uint8_t *__restrict__ skip) {
+    if (skip && *skip && src == dst) return; // identity map, in place: nothing to do
+    __shared__ uint8_t m[256];
+    m[threadIdx.x] = map[threadIdx.x];
+    __syncthreads();
+    const uint64_t total = (uint64_t)rows * cols;
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+        const uint32_t r = (uint32_t)(idx / cols), c = (uint32_t)(idx - (uint64_t)r * cols);
+        dst[(size_t)r * dst_pitch + c] = m[src[(size_t)r * src_pitch + c]];
+    }
+}
+
+} // namespace
+
+hipError_t launch_chain_stats(const ChainStatsArgs &a, int nbands, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_stats, dim3(nbands), dim3(kStatsBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_chain_cdfs(const unsigned long long *tile_bins, double *cdfs, uint32_t rows, uint32_t cols, int nbands,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_cdfs, dim3(kTiles * kTiles, nbands), dim3(256), 0, s, tile_bins, cdfs, rows, cols);
+    return hipGetLastError();
+}
+hipError_t launch_chain_finish(const ChainFinishArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_finish, dim3(1), dim3(kStatsBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, uint32_t rows,
+                              uint32_t cols, const uint8_t *d_map, const uint8_t *d_skip_flag, hipStream_t s) {
+    if (!rows || !cols) return hipSuccess;
+    const uint64_t want = ((uint64_t)rows * cols + 255) / 256;
+    hipLaunchKernelGGL(k_chain_remap, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, src, src_pitch, dst,
+                       dst_pitch, rows, cols, d_map, d_skip_flag);
+    return hipGetLastError();
+}
+
+} // namespace sarpro

@@ -427,6 +427,21 @@ void synrgb_luts_suppressed(int fwc, uint8_t *luts) {
     blue_lut(lut_r, lut_g, false, lut_b);
 }
 
+const uint8_t *synrgb_blue_pair_supp() { return blue_pair_table(false); }
+
+const uint8_t *synrgb_supp_rg_tables() {
+    static uint8_t tab[41][512];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<uint8_t> luts(66048);
+        for (int fwc = 0; fwc <= 40; ++fwc) {
+            synrgb_luts_suppressed(fwc, luts.data());
+            std::memcpy(tab[fwc], luts.data(), 512);
+        }
+    });
+    return &tab[0][0];
+}
+
 void fold_compose_tables(const uint8_t *luts, int fwc, const uint8_t *resc1, const uint8_t *resc2,
                          uint8_t *tables) {
     const uint8_t *lut_r = luts, *lut_g = luts + 256, *lut_b = luts + 512;

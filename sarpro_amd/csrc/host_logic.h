@@ -77,6 +77,10 @@ void fold_compose_tables(const uint8_t *luts, int floor_with_cushion /* -1: none
 
 int stripe_plan(size_t rows, int nranks, size_t *row0, size_t *nrows);
 
+// constant tables the device-resident chain uploads once (chain_kernels.hip)
+const uint8_t *synrgb_supp_rg_tables(); // [41][512]: suppressed lut_r | lut_g for floor_with_cushion = 0..40
+const uint8_t *synrgb_blue_pair_supp(); // [256][256]: blue of the suppressed variant per (r, g) pair
+
 } // namespace sarpro
 
 // ---------------------------------------------------------------------------------------

@@ -46,6 +46,8 @@ struct ClaheApplyArgs {
     unsigned long long *level_hist[kMaxBands]; // [256] histogram of u8 levels, or null
     int32_t row_off;
     double max_val;                         // 255.0 or 65535.0
+    const struct ChainBandState *dev_state;  // chain mode: win_hi is read from device memory (null: use win_hi[])
+    uint32_t lut_cap;                       // speculative kernel: LDS capacity of the offset table (entries)
     uint32_t ablate;                        // timing experiments only (SARPRO_HIP_ABLATE): 1 no hist, 2 no LUT, 4 no CDF gather
 };
 
@@ -76,7 +78,8 @@ hipError_t launch_tile_bin_hist(const uint32_t *tile_hist, int ntiles, const uin
 hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,
                                   hipStream_t s);
 bool clahe_apply_spec_ok(const ClaheApplyArgs &a, int nbands);
-hipError_t launch_clahe_apply_u8_spec(const ClaheApplyArgs &a, int nrects, int nbands, hipStream_t s);
+hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, hipStream_t s);
+constexpr uint32_t kChainLutEntries = 8192; // LDS offset-table capacity when the window is only known on the device
 hipError_t launch_lut_apply_u16(const LutApplyArgs &a, bool vec, bool out16, hipStream_t s);
 hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s);
 hipError_t launch_polop_f32(int op, const float *a, const float *b, size_t n, float *out, hipStream_t s);

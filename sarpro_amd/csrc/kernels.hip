@@ -8,6 +8,7 @@
 // Built with -ffp-contract=off: the CLAHE blend must round like the reference's separate
 // f64 multiplies and adds (autoscale.rs:327-329), never as FMAs.
 #include "kernels.h"
+#include "chain_kernels.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -374,7 +375,9 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
     const uint16_t *__restrict__ in = a.in[band];
     const double *__restrict__ cdfs = a.cdfs[band];
     const uint8_t *__restrict__ glut = a.binlut[band];
-    const uint32_t win_hi = a.win_hi[band];
+    // the table is constant from win_hi on; beyond the LDS capacity it is gathered from global memory
+    const uint32_t win_hi = a.dev_state ? a.dev_state[band].win_hi : a.win_hi[band];
+    const bool lut_lds = win_hi < a.lut_cap;
     unsigned long long *ghist = a.level_hist[band];
     const int col = rc.cstart + lane_id() * VEC;
     const bool full = col >= rc.c0 && col + VEC <= rc.c1;
@@ -397,7 +400,8 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             *reinterpret_cast<double2 *>(lds + SpecLds::colw + i * 16) = make_double2(w.d, w.omd);
         }
         uint16_t *lut = reinterpret_cast<uint16_t *>(lds + SpecLds::lut);
-        for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(i ? (uint32_t)glut[i] * 16u : 256u * 16u);
+        if (lut_lds)
+            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(i ? (uint32_t)glut[i] * 16u : 256u * 16u);
     }
     __syncthreads();
 
@@ -418,7 +422,8 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const uint32_t i = min(v.get(j), win_hi);
-            off[j] = *reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u);
+            off[j] = lut_lds ? (uint32_t)*reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u)
+                             : (i ? (uint32_t)glut[i] * 16u : 256u * 16u);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -741,17 +746,18 @@ size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands) {
     return 256 * 4 * 8 + 256 * 4 + ((win + 15) & ~(size_t)15);
 }
 
-bool clahe_apply_spec_ok(const ClaheApplyArgs &a, int nbands) {
-    for (int b = 0; b < nbands; ++b)
-        if (a.win_hi[b] + 1 > kSpecLutMaxEntries) return false;
-    return true;
-}
+bool clahe_apply_spec_ok(const ClaheApplyArgs &, int) { return true; }
 
-hipError_t launch_clahe_apply_u8_spec(const ClaheApplyArgs &a, int nrects, int nbands, hipStream_t s) {
+hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, hipStream_t s) {
     if (nrects <= 0) return hipSuccess;
-    uint32_t hi = 0;
-    for (int b = 0; b < nbands; ++b) hi = std::max(hi, a.win_hi[b]);
-    const size_t lds = SpecLds::lut + (((size_t)hi + 1) * 2 + 15 & ~(size_t)15);
+    if (a.dev_state) {
+        a.lut_cap = kChainLutEntries; // window only known on the device: fixed LDS capacity, global gather beyond it
+    } else {
+        uint32_t hi = 0;
+        for (int b = 0; b < nbands; ++b) hi = std::max(hi, a.win_hi[b]);
+        a.lut_cap = std::min<uint32_t>(hi + 1, kSpecLutMaxEntries);
+    }
+    const size_t lds = SpecLds::lut + (((size_t)a.lut_cap) * 2 + 15 & ~(size_t)15);
     hipLaunchKernelGGL(k_clahe_apply_u8_spec, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }

@@ -163,3 +163,35 @@ def test_synrgb_matches_oracle(ctx, strategy, n):
     got = ctx.create_synthetic_rgb_by_mode_and_strategy(Mode.Default, strategy, b1, b2)
     ref = oracle.synrgb(0, int(strategy), b1, b2)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(257, 300), (512, 640), (43, 1000)])
+def test_device_chain_equals_host_orchestrated_path(ctx, shape, monkeypatch):
+    """CLAHE u8 runs as a device-resident chain (statistics, bins, CDFs, tables computed by kernels);
+    SARPRO_HIP_NO_CHAIN=1 forces the host-orchestrated phases.  Both must give the oracle's raster."""
+    rows, cols = shape
+    b1, b2 = scene(rows, cols, 0), scene(rows, cols, 1)
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1.astype(np.float32), b2.astype(np.float32), int(St.Clahe))
+    for no_chain in ("0", "1"):
+        monkeypatch.setenv("SARPRO_HIP_NO_CHAIN", no_chain)
+        rgb, u1, u2, st = ctx.dualpol_synrgb(b1, b2, St.Clahe, want_u8=True, want_stats=True)
+        assert np.array_equal(rgb, rrgb) and np.array_equal(u1, r1) and np.array_equal(u2, r2)
+        u8, _, s1 = ctx.process_scalar_data_pipeline(b1, Bd.U8, St.Clahe, want_stats=True)
+        assert np.array_equal(u8, r1)
+        rc1, _, so = oracle.pipeline(b1.astype(np.float32), 0, int(St.Clahe), want_stats=True)
+        for k in ("valid_count", "min_db", "max_db", "median_db", "p01", "p10", "p25", "p75", "p99", "low_clip", "high_clip"):
+            assert getattr(s1, k) == getattr(so, k) == getattr(st[0], k), (k, no_chain)
+
+
+def test_device_chain_non_identity_rescale(ctx):
+    # a band whose CLAHE levels do not span 0..255 (no invalid pixel, narrow data): the chain must
+    # apply scale_u16_to_u8 (autoscale.rs:348-364) through its device-built map
+    rng = np.random.default_rng(2)
+    dn = rng.integers(900, 1100, size=(96, 128)).astype(np.uint16)
+    dn2 = rng.integers(300, 5000, size=(96, 128)).astype(np.uint16)
+    u8, _ = ctx.process_scalar_data_pipeline(dn, Bd.U8, St.Clahe)
+    rc, ref = oracle.pipeline(dn.astype(np.float32), 0, int(St.Clahe))
+    assert rc == 0 and np.array_equal(u8, ref)
+    rgb, u1, u2 = ctx.dualpol_synrgb(dn, dn2, St.Clahe, want_u8=True)
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(dn.astype(np.float32), dn2.astype(np.float32), int(St.Clahe))
+    assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb)
