@@ -348,7 +348,7 @@ static int job_phase1(U16Job &J) {
         if (J.vec) HIPCHK(ctx, launch_dn_hist_u16_interior(a, nrects, J.nbands, ctx->stream));
         else HIPCHK(ctx, launch_dn_hist_u16(a, nrects, J.nbands, false, ctx->stream));
     }
-    if (J.vec) { // < 8-column leftovers at tile edges: scalar kernel
+    if (J.vec && !(tiled ? J.plan->hist_sliver_tiled : J.plan->hist_sliver_flat).empty()) { // unused unless the planner splits slivers
         const int ns = (int)(tiled ? J.plan->hist_sliver_tiled.size() : J.plan->hist_sliver_flat.size());
         a.rects = (tiled ? J.plan->d_hist_sliver_tiled : J.plan->d_hist_sliver_flat).as<Rect>();
         a.lds_bins = 2048;
@@ -416,15 +416,17 @@ static int job_phase2(U16Job &J) {
     sarpro_hip_ctx *ctx = J.ctx;
     if (!J.clahe()) return SARPRO_HIP_OK;
     HIPCHK(ctx, ctx->tile_bins.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands));
+    TileBinHistArgs ta{};
     for (int b = 0; b < J.nbands; ++b) {
         uint8_t *stage = ctx->h_upload.as<uint8_t>() + (size_t)b * 65536;
         for (int i = 0; i < 65536; ++i) stage[i] = (uint8_t)J.lut[b].full[i];
         HIPCHK(ctx, hipMemcpyAsync(ctx->luts.as<uint8_t>() + (size_t)b * 131072, stage, 65536, hipMemcpyHostToDevice, ctx->stream));
-        KernelTimer t(ctx, "tile_bin_hist");
-        HIPCHK(ctx, launch_tile_bin_hist(ctx->tile_hist[b].as<uint32_t>(), kTiles * kTiles,
-                                         ctx->luts.as<uint8_t>() + (size_t)b * 131072,
-                                         ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256, ctx->stream));
+        ta.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+        ta.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+        ta.out[b] = ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256;
     }
+    KernelTimer t(ctx, "tile_bin_hist");
+    HIPCHK(ctx, launch_tile_bin_hist(ta, kTiles * kTiles, J.nbands, ctx->stream));
     return SARPRO_HIP_OK;
 }
 
@@ -682,10 +684,15 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         KernelTimer t(ctx, "chain_stats");
         HIPCHK(ctx, launch_chain_stats(sa, J.nbands, ctx->stream));
     }
-    for (int b = 0; b < J.nbands; ++b) {
+    {
+        TileBinHistArgs ta{};
+        for (int b = 0; b < J.nbands; ++b) {
+            ta.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+            ta.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+            ta.out[b] = ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256;
+        }
         KernelTimer t(ctx, "tile_bin_hist");
-        HIPCHK(ctx, launch_tile_bin_hist(ctx->tile_hist[b].as<uint32_t>(), kTiles * kTiles, ctx->luts.as<uint8_t>() + (size_t)b * 131072,
-                                         ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256, ctx->stream));
+        HIPCHK(ctx, launch_tile_bin_hist(ta, kTiles * kTiles, J.nbands, ctx->stream));
     }
     {
         KernelTimer t(ctx, "chain_cdfs");
@@ -711,6 +718,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     a.row_off = 0;
     a.max_val = 255.0;
     a.dev_state = d_state;
+    a.lut_cap = ctx->chain_lut_cap;
     if (a.out_pitch % 8 != 0 || !ptr_aligned16(a.out[0]) || (J.nbands > 1 && !ptr_aligned16(a.out[1])))
         return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
     HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
@@ -754,10 +762,17 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
     HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
+    uint32_t hi = 0;
     for (int b = 0; b < J.nbands; ++b) {
         J.stats[b] = h_state[b].stats;
         if (stats_out) stats_out[b] = J.stats[b];
+        hi = std::max(hi, h_state[b].win_hi);
     }
+    // size the LDS offset table of the NEXT scene from this scene's window (speed only: a window larger
+    // than the capacity is gathered from global memory, with identical results)
+    uint32_t cap = 2048;
+    while (cap < hi + 1 && cap < 16384) cap *= 2;
+    ctx->chain_lut_cap = cap;
     return SARPRO_HIP_OK;
 }
 

@@ -19,18 +19,36 @@ constexpr int kStatsBlock = 1024;
 
 __device__ inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// deterministic block reductions over kStatsBlock threads (fixed tree)
+// deterministic block reduction over kStatsBlock threads: butterfly inside each wave (shuffles, no
+// barrier), then the 16 wave results through LDS in a fixed order
 template <typename T, typename Op>
-__device__ T block_reduce(T v, T *scratch /*[kStatsBlock]*/, Op op) {
-    scratch[threadIdx.x] = v;
+__device__ T block_reduce(T v, T *scratch /*[>= 16]*/, Op op) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
+    __syncthreads(); // scratch may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int s = kStatsBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) scratch[threadIdx.x] = op(scratch[threadIdx.x], scratch[threadIdx.x + s]);
-        __syncthreads();
-    }
     T r = scratch[0];
-    __syncthreads();
+#pragma unroll
+    for (int w = 1; w < kStatsBlock / 64; ++w) r = op(r, scratch[w]);
     return r;
+}
+
+// exclusive prefix sum of one u64 per thread over the block (integers: order-free)
+__device__ unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long *scratch /*[>= 16]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w = 0; w < wave; ++w) base += scratch[w];
+    return base + incl - v;
 }
 
 // ------------------------------------------------------------------------------------
@@ -52,16 +70,32 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     uint8_t *binlut = a.binlut + (size_t)band * a.binlut_stride;
     const int t = threadIdx.x;
 
-    // ---- count / min / max DN over valid samples (DN >= 1) ----
+    // ---- one sweep: count / min / max DN over valid samples (DN >= 1) and the dB moments.
+    //      Each thread owns 64 DNs; loads are issued 8 at a time so they overlap. ----
     unsigned long long cnt = 0;
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
-    for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) {
-        const unsigned long long n = dn ? h[dn] : 0ull;
-        if (n) { cnt += n; mn = min(mn, dn); mx = max(mx, dn); }
+    double s1 = 0.0, s2 = 0.0;
+    for (uint32_t base = 0; base < 65536u; base += 8 * kStatsBlock) {
+        unsigned long long hv[8];
+        double dv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint32_t dn = base + k * kStatsBlock + t; hv[k] = h[dn]; dv[k] = db[dn]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t dn = base + k * kStatsBlock + t;
+            if (dn && hv[k]) {
+                cnt += hv[k]; mn = min(mn, dn); mx = max(mx, dn);
+                const double w = (double)hv[k];
+                s1 += w * dv[k];
+                s2 += w * dv[k] * dv[k];
+            }
+        }
     }
     const unsigned long long count = block_reduce(cnt, scr_u64, [](unsigned long long x, unsigned long long y) { return x + y; });
     const uint32_t min_dn = block_reduce(mn, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
     const uint32_t max_dn = block_reduce(mx, scr_u32, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+    const double sum1 = block_reduce(s1, scr_f64, [](double x, double y) { return x + y; });
+    const double sum2 = block_reduce(s2, scr_f64, [](double x, double y) { return x + y; });
 
     sarpro_hip_stats st;
     st.valid_count = count;
@@ -78,15 +112,10 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     }
     const double min_db = db[min_dn], max_db = db[max_dn];
 
-    // ---- mean / std (per-DN sums; informational) ----
-    double s1 = 0.0;
-    for (uint32_t dn = t + 1; dn < 65536u; dn += kStatsBlock) s1 += (double)h[dn] * db[dn];
-    const double mean = block_reduce(s1, scr_f64, [](double x, double y) { return x + y; }) / (double)count;
-    double s2 = 0.0;
-    for (uint32_t dn = t + 1; dn < 65536u; dn += kStatsBlock) { const double d = db[dn] - mean; s2 += (double)h[dn] * d * d; }
-    const double m2 = block_reduce(s2, scr_f64, [](double x, double y) { return x + y; });
+    // ---- mean / std (informational): var = E[x^2] - mean^2 ----
+    const double mean = sum1 / (double)count;
     st.min_db = min_db; st.max_db = max_db; st.mean_db = mean;
-    st.std_db = count > 1 ? sqrt(m2 / (double)count) : 0.0;
+    st.std_db = count > 1 ? sqrt(fmax(sum2 / (double)count - mean * mean, 0.0)) : 0.0;
 
     if (fabs(max_db - min_db) < DBL_EPSILON) { // autoscale.rs:81-100
         st.median_db = st.p01 = st.p02 = st.p05 = st.p10 = st.p25 = min_db;
@@ -96,29 +125,36 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         for (int i = t; i < kStatBins; i += kStatsBlock) hist[i] = 0;
         __syncthreads();
         const double span = max_db - min_db, inv_span = 1.0 / span;
-        for (uint32_t dn = t + 1; dn < 65536u; dn += kStatsBlock) {
-            const unsigned long long n = h[dn];
-            if (!n) continue;
-            const double tt = clampd((db[dn] - min_db) * inv_span, 0.0, 1.0);
-            unsigned long long idx = (unsigned long long)(tt * (double)kStatBins);
-            if (idx >= (unsigned long long)kStatBins) idx = kStatBins - 1;
-            atomicAdd(&hist[idx], n);
+        // thread t owns the 64 consecutive DNs [64t, 64t+64): the bin index is monotone in DN, so equal
+        // indices form runs that are summed in a register and flushed with ONE LDS atomic per run
+        // (bright DNs crowd into the top bins: per-DN atomics from 64 lanes would all hit one word)
+        unsigned long long run = 0, run_idx = ~0ull;
+        for (uint32_t base = 64u * t; base < 64u * t + 64u; base += 8) {
+            unsigned long long hv[8];
+            double dv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { hv[k] = h[base + k]; dv[k] = db[base + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!(base + k) || !hv[k]) continue;
+                const double tt = clampd((dv[k] - min_db) * inv_span, 0.0, 1.0);
+                unsigned long long idx = (unsigned long long)(tt * (double)kStatBins);
+                if (idx >= (unsigned long long)kStatBins) idx = kStatBins - 1;
+                if (idx != run_idx) {
+                    if (run) atomicAdd(&hist[run_idx], run);
+                    run = 0;
+                    run_idx = idx;
+                }
+                run += hv[k];
+            }
         }
+        if (run) atomicAdd(&hist[run_idx], run);
         __syncthreads();
         // ---- exclusive prefix over the bins: thread t owns bins 4t .. 4t+3 ----
         unsigned long long own[4], tot = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { own[k] = hist[4 * t + k]; tot += own[k]; }
-        scr_u64[t] = tot;
-        __syncthreads();
-        for (int off = 1; off < kStatsBlock; off <<= 1) { // Hillis-Steele inclusive scan (integers: order-free)
-            const unsigned long long v = t >= off ? scr_u64[t - off] : 0ull;
-            __syncthreads();
-            scr_u64[t] += v;
-            __syncthreads();
-        }
-        unsigned long long excl = scr_u64[t] - tot;
-        __syncthreads();
+        const unsigned long long excl = block_exclusive_scan(tot, scr_u64);
         // ---- percentile inversion (autoscale.rs:120-140) ----
         const double ps[11] = {0.5, 0.01, 0.02, 0.05, 0.10, 0.25, 0.75, 0.90, 0.95, 0.98, 0.99};
 #pragma unroll
@@ -209,7 +245,8 @@ __global__ __launch_bounds__(256) void k_chain_cdfs(const unsigned long long *__
 // ------------------------------------------------------------------------------------
 // After the apply pass: u8 rescale of each band (autoscale.rs:348-364), suppressed-synRGB floor
 // from the combined histogram of the FINAL u8 bands (synthetic_rgb.rs:92-113) and the compose
-// tables with both folded in (host_logic.cpp: fold_compose_tables).  One block.
+// tables with both folded in (host_logic.cpp: fold_compose_tables).  Every block recomputes the
+// (tiny) maps and builds its slice of the 65536-entry blue table; block 0 also publishes the maps.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a) {
     __shared__ unsigned long long lh[2][256];
@@ -244,8 +281,9 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
     }
     __syncthreads();
     if (t < 256) for (int b = 0; b < a.nbands; ++b) atomicAdd(&combined[resc[b][t]], lh[b][t]);
-    if (t < 512 && a.resc_out) a.resc_out[t] = (t >> 8) < a.nbands ? resc[t >> 8][t & 255] : (uint8_t)(t & 255);
-    if (t < a.nbands && a.identity_out) {
+    const bool lead = blockIdx.x == 0;
+    if (lead && t < 512 && a.resc_out) a.resc_out[t] = (t >> 8) < a.nbands ? resc[t >> 8][t & 255] : (uint8_t)(t & 255);
+    if (lead && t < a.nbands && a.identity_out) {
         bool ident = true;
         for (int k = 0; k < 256; ++k) if (lh[t][k] && resc[t][k] != k) ident = false;
         a.identity_out[t] = ident ? 1 : 0;
@@ -266,18 +304,18 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
         }
         const int fwc = floor_value + 3 < 40 ? floor_value + 3 : 40;
         s_fwc = fwc;
-        if (a.floor_out) *a.floor_out = fwc;
+        if (lead && a.floor_out) *a.floor_out = fwc;
     }
     __syncthreads();
     const int fwc = s_fwc;
     const uint8_t *lut_r = a.supp_rg + (size_t)fwc * 512, *lut_g = lut_r + 256; // powf tables per floor (host-built)
     uint8_t *R2 = a.tables, *G2 = a.tables + 256, *B2 = a.tables + 512;
-    if (t < 256) {
+    if (lead && t < 256) {
         const int r1 = resc[0][t], r2 = resc[1][t];
         R2[t] = r1 <= fwc ? 0 : lut_r[r1];
         G2[t] = r2 <= fwc ? 0 : lut_g[r2];
     }
-    for (int i = t; i < 65536; i += kStatsBlock) {
+    for (int i = blockIdx.x * kStatsBlock + t; i < 65536; i += gridDim.x * kStatsBlock) {
         const int v1 = i >> 8, v2 = i & 255;
         const int r1 = resc[0][v1], r2 = resc[1][v2];
         const bool water = r1 <= fwc && r2 <= fwc;
@@ -312,7 +350,7 @@ hipError_t launch_chain_cdfs(const unsigned long long *tile_bins, double *cdfs, 
     return hipGetLastError();
 }
 hipError_t launch_chain_finish(const ChainFinishArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_chain_finish, dim3(1), dim3(kStatsBlock), 0, s, a);
+    hipLaunchKernelGGL(k_chain_finish, dim3(a.nbands == 2 && a.tables ? 64 : 1), dim3(kStatsBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, uint32_t rows,

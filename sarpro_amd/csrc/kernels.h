@@ -73,8 +73,12 @@ hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool 
 hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nbands, hipStream_t s);
 hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned long long *out,
                                  hipStream_t s);
-hipError_t launch_tile_bin_hist(const uint32_t *tile_hist, int ntiles, const uint8_t *binlut,
-                                unsigned long long *out, hipStream_t s);
+struct TileBinHistArgs {
+    const uint32_t *tile_hist[kMaxBands]; // [ntiles][65536]
+    const uint8_t *binlut[kMaxBands];     // [65536]
+    unsigned long long *out[kMaxBands];   // [ntiles][256]
+};
+hipError_t launch_tile_bin_hist(const TileBinHistArgs &a, int ntiles, int nbands, hipStream_t s);
 hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,
                                   hipStream_t s);
 bool clahe_apply_spec_ok(const ClaheApplyArgs &a, int nbands);

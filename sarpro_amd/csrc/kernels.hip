@@ -196,19 +196,25 @@ __global__ __launch_bounds__(kBlock) void k_sum_tile_hists(const uint32_t *__res
 // 3. Per-tile 256-bin CLAHE histogram from the per-tile DN histogram and the DN -> bin table
 //    (autoscale.rs:259-268 without touching the pixels again).  One block per tile.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_tile_bin_hist(const uint32_t *__restrict__ th,
-                                                          const uint8_t *__restrict__ binlut,
-                                                          unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_tile_bin_hist(TileBinHistArgs a) {
     __shared__ unsigned long long h[256];
-    const uint32_t *__restrict__ t = th + (size_t)blockIdx.x * 65536u;
+    const int band = blockIdx.y;
+    const uint32_t *__restrict__ t = a.tile_hist[band] + (size_t)blockIdx.x * 65536u;
+    const uint8_t *__restrict__ binlut = a.binlut[band];
     h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t dn = threadIdx.x; dn < 65536u; dn += kBlock) {
-        const uint32_t n = t[dn];
-        if (n && dn) atomicAdd(&h[binlut[dn]], (unsigned long long)n); // DN = 0 is invalid: not counted
+    for (uint32_t base = 0; base < 65536u; base += 8 * kBlock) { // 8 independent loads in flight per thread
+        uint32_t n[8], bin[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint32_t dn = base + k * kBlock + threadIdx.x; n[k] = t[dn]; bin[k] = binlut[dn]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t dn = base + k * kBlock + threadIdx.x;
+            if (n[k] && dn) atomicAdd(&h[bin[k]], (unsigned long long)n[k]); // DN = 0 is invalid: not counted
+        }
     }
     __syncthreads();
-    out[(size_t)blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
+    a.out[band][(size_t)blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------
@@ -733,9 +739,8 @@ hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned
     return hipGetLastError();
 }
 
-hipError_t launch_tile_bin_hist(const uint32_t *tile_hist, int ntiles, const uint8_t *binlut,
-                                unsigned long long *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_tile_bin_hist, dim3(ntiles), dim3(kBlock), 0, s, tile_hist, binlut, out);
+hipError_t launch_tile_bin_hist(const TileBinHistArgs &a, int ntiles, int nbands, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_bin_hist, dim3(ntiles, nbands), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -751,7 +756,8 @@ bool clahe_apply_spec_ok(const ClaheApplyArgs &, int) { return true; }
 hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, hipStream_t s) {
     if (nrects <= 0) return hipSuccess;
     if (a.dev_state) {
-        a.lut_cap = kChainLutEntries; // window only known on the device: fixed LDS capacity, global gather beyond it
+        // window only known on the device: capacity chosen by the caller (from the previous scene), global gather beyond it
+        if (a.lut_cap < 256 || a.lut_cap > kSpecLutMaxEntries) a.lut_cap = kChainLutEntries;
     } else {
         uint32_t hi = 0;
         for (int b = 0; b < nbands; ++b) hi = std::max(hi, a.win_hi[b]);
