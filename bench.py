@@ -138,7 +138,8 @@ def main():
         per_launch = {k: float(np.mean(v)) for k, v in ktimes.items()}
         launches = {k: len(v) / args.steps for k, v in ktimes.items()}
         total_ms = {k: per_launch[k] * launches[k] for k in per_launch}
-        dom = max(total_ms, key=total_ms.get) if total_ms else None
+        kern = {k: v for k, v in total_ms.items() if not k.startswith("host:")}  # host:* entries are wall-clock segments
+        dom = max(kern, key=kern.get) if kern else None
         # algorithmic bytes per pixel PER LAUNCH (both bands), DESIGN.md section 4
         alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0}
         roofline = None
