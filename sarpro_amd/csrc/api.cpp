@@ -228,7 +228,7 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     build_clahe_geometry(rows_total, cols, &P->geom);
     const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
     const size_t target_items = 4096;
-    const size_t chunk_rows = std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items);
+    const size_t chunk_rows = std::min<size_t>(256, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 256: the apply kernel stages one item's row weights in LDS
     const ClaheGeometry &g = P->geom;
     const bool split = false; // edge lanes are masked inside the vector kernels; no separate sliver items
     for (size_t ty = 0; ty < (size_t)kTiles; ++ty) {
@@ -253,6 +253,19 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
                                 rw.t1 * kTiles + cw.t1};
             add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
         }
+    }
+    // launch order = sweep order: consecutive work items cover adjacent column strips of the same row
+    // chunk, so the workgroups resident at any moment read neighbouring 1-KiB segments of the same
+    // image rows (DRAM page locality) instead of strips megabytes apart
+    auto sweep_order = [](std::vector<Rect> &v) {
+        std::stable_sort(v.begin(), v.end(), [](const Rect &x, const Rect &y) {
+            return x.r0 != y.r0 ? x.r0 < y.r0 : x.cstart < y.cstart;
+        });
+    };
+    if (!getenv("SARPRO_HIP_NO_SWEEP_ORDER")) {
+        sweep_order(P->hist_rects_tiled);
+        sweep_order(P->hist_rects_flat);
+        sweep_order(P->apply_rects);
     }
     int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
@@ -481,13 +494,12 @@ static int job_phase3(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch)
         a.col_w = J.plan->d_col_w.as<RowWeight>();
         a.row_off = (int32_t)J.row0;
         a.max_val = u8o ? 255.0 : 65535.0;
-        if (const char *e = getenv("SARPRO_HIP_ABLATE")) a.ablate = (uint32_t)atoi(e); // timing experiments only
         if (u8o) HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
         const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out[0]) && (J.nbands < 2 || ptr_aligned16(a.out[1]));
         if (vec != J.vec) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
         {
             KernelTimer t(ctx, "clahe_apply_u16");
-            if (J.vec && u8o && !(a.ablate & 8) && clahe_apply_spec_ok(a, J.nbands))
+            if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands))
                 HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
             else
                 HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, J.vec, !u8o, ctx->stream));

@@ -48,7 +48,6 @@ struct ClaheApplyArgs {
     double max_val;                         // 255.0 or 65535.0
     const struct ChainBandState *dev_state;  // chain mode: win_hi is read from device memory (null: use win_hi[])
     uint32_t lut_cap;                       // speculative kernel: LDS capacity of the offset table (entries)
-    uint32_t ablate;                        // timing experiments only (SARPRO_HIP_ABLATE): 1 no hist, 2 no LUT, 4 no CDF gather
 };
 
 struct LutApplyArgs {

@@ -276,9 +276,8 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
         for (int j = 0; j < VEC; ++j) {
             const uint32_t d = v.get(j);
             const uint32_t dc = min(max(d, win_lo), win_hi);
-            uint32_t bin = (a.ablate & 2) ? (d & 255u) : (lut_lds ? (uint32_t)lds_lut[dc - win_lo] : (uint32_t)glut[dc]);
-            const double4 c4 = (a.ablate & 4) ? make_double4(0.25 * bin, 0.5, 0.75, 1.0)
-                                              : *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
+            const uint32_t bin = lut_lds ? (uint32_t)lds_lut[dc - win_lo] : (uint32_t)glut[dc];
+            const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
             const double top = c4.x * omdx[j] + c4.y * dx[j];
             const double bottom = c4.z * omdx[j] + c4.w * dx[j];
             double o = top * omdy + bottom * dy;
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
             const uint32_t level = (uint32_t)(o * a.max_val); // truncation, o*max_val in [0, max_val]
             lv[j] = d ? level : 0u;                           // invalid (DN = 0) -> 0
         }
-        if (!OUT16 && ghist && !(a.ablate & 1)) {
+        if (!OUT16 && ghist) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int c = col + j;
@@ -356,90 +355,69 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     weights as f64 in LDS), so the raster is bit-identical to kernel 4's.
 //     Error bound (u = 2^-24; |dx|,|dy| <= 1, weight pairs sum to <= 2, CDFs in [0,1]): inputs
 //     rounded once (u), each product <= 3u, each sum adds u of a magnitude <= 2, the 255 factor is
-//     folded into the row weights (+u):  |y32 - y| <= 255*34u + u*|y| < 6e-4 with y = o*255.
+//     folded into the row weights (+u), the final add rounds once more (+u):  |y32 - y| <= 255*34u + u*|y| < 6e-4 with y = o*255.
 //     kSpecDelta = 1/256 = 3.9e-3 leaves > 6x margin.  y32 == 0 exactly happens only when every
 //     product is exactly zero in f64 too (f32 rounding never flushes these operands to zero), so
 //     an exact zero is decided (level 0) without the f64 path.
 //     Level 0 goes to a per-lane dummy histogram word (bin 0 = pixels - other bins, on the host).
 // ------------------------------------------------------------------------------------
 constexpr float kSpecDelta = 1.0f / 256.0f;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr uint32_t kSpecLutMaxEntries = 16384; // u16 offsets: 32 KiB of LDS at most
 
 struct SpecLds { // byte offsets into dynamic LDS
     static constexpr uint32_t cdf64 = 0;                      // [257][4] double
     static constexpr uint32_t cdf32 = 257 * 32;               // [257] float4
-    static constexpr uint32_t colw = cdf32 + 257 * 16 + 16;   // [512][2] double (16-B aligned)
-    static constexpr uint32_t hist = colw + 512 * 16;         // [256 + 64] u32
-    static constexpr uint32_t lut = hist + (256 + 64) * 4;    // [win_hi + 1] u16
+    static constexpr uint32_t colw = cdf32 + 257 * 16 + 16;   // [512] double: exact dx of the strip's columns
+    static constexpr uint32_t hist = colw + 512 * 8;          // [256 + 64] u32
+    static constexpr uint32_t roww = hist + (256 + 64) * 4;   // [256] double: exact dy of the item's rows
+    static constexpr uint32_t lut = roww + 256 * 8;           // [lut_cap] u16
 };
+// (1 - dx) and (1 - dy) are recomputed as 1.0 - d: the reference's own expression (autoscale.rs:327-329)
 
-__global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a) {
+template <bool LUT_LDS>
+__device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const Rect &rc, int band, unsigned char *lds,
+                                                uint32_t win_hi) {
     constexpr int VEC = 8;
-    extern __shared__ __align__(16) unsigned char lds[];
-    const Rect rc = a.rects[blockIdx.x];
-    const int band = blockIdx.y;
     const uint16_t *__restrict__ in = a.in[band];
-    const double *__restrict__ cdfs = a.cdfs[band];
     const uint8_t *__restrict__ glut = a.binlut[band];
-    // the table is constant from win_hi on; beyond the LDS capacity it is gathered from global memory
-    const uint32_t win_hi = a.dev_state ? a.dev_state[band].win_hi : a.win_hi[band];
-    const bool lut_lds = win_hi < a.lut_cap;
-    unsigned long long *ghist = a.level_hist[band];
+    const bool count_levels = a.level_hist[band] != nullptr;
     const int col = rc.cstart + lane_id() * VEC;
     const bool full = col >= rc.c0 && col + VEC <= rc.c1;
     const EdgeMask em(col, rc.c0, rc.c1); // edge lanes: out-of-range samples become DN = 0 (level 0, uncounted, unstored)
-    {
-        const int b = threadIdx.x;
-        double c[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c[k] = cdfs[(size_t)rc.id[k] * 256 + b];
-        *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + b * 32) = make_double4(c[0], c[1], c[2], c[3]);
-        *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + b * 16) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
-        if (b == 0) {
-            *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + 256 * 32) = make_double4(0.0, 0.0, 0.0, 0.0);
-            *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + 256 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
-        for (int i = b; i < 512; i += kBlock) { // exact column weights of this strip, for the f64 path
-            const int c2 = rc.cstart + i;
-            const RowWeight w = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0];
-            *reinterpret_cast<double2 *>(lds + SpecLds::colw + i * 16) = make_double2(w.d, w.omd);
-        }
-        uint16_t *lut = reinterpret_cast<uint16_t *>(lds + SpecLds::lut);
-        if (lut_lds)
-            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(i ? (uint32_t)glut[i] * 16u : 256u * 16u);
-    }
-    __syncthreads();
 
     float dxf[VEC], omdxf[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const double2 w = *reinterpret_cast<const double2 *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 16);
-        dxf[j] = (float)w.x;
-        omdxf[j] = (float)w.y;
+        const double d = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
+        dxf[j] = (float)d;
+        omdxf[j] = (float)(1.0 - d);
     }
     const uint32_t dummy = SpecLds::hist + (256u + (uint32_t)lane_id()) * 4u;
 
     auto process_row = [&](int r, const U16Vec<VEC> &v) {
-        const RowWeight rw = a.row_w[a.row_off + r]; // wave-uniform
-        const float dy255 = (float)rw.d * 255.0f, omdy255 = (float)rw.omd * 255.0f;
+        const double dy = *reinterpret_cast<const double *>(lds + SpecLds::roww + (r - rc.r0) * 8); // wave-uniform
+        const double omdy = 1.0 - dy;
+        const v2f wy = {(float)omdy * 255.0f, (float)dy * 255.0f};
         uint32_t lv[VEC], off[VEC];
         uint32_t pend = 0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const uint32_t i = min(v.get(j), win_hi);
-            off[j] = lut_lds ? (uint32_t)*reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u)
+            off[j] = LUT_LDS ? (uint32_t)*reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u)
                              : (i ? (uint32_t)glut[i] * 16u : 256u * 16u);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(lds + SpecLds::cdf32 + off[j]);
-            const float top = fmaf(c4.y, dxf[j], c4.x * omdxf[j]);
-            const float bottom = fmaf(c4.w, dxf[j], c4.z * omdxf[j]);
-            const float y = fmaf(bottom, dy255, top * omdy255);
-            const float fl = floorf(y);
-            lv[j] = (uint32_t)min(max((int)fl, 0), 255);
-            const bool near = fabsf((y - fl) - 0.5f) > 0.5f - kSpecDelta && y != 0.0f;
+            const v4f c4 = *reinterpret_cast<const v4f *>(lds + SpecLds::cdf32 + off[j]);
+            const v2f a0 = {c4.x, c4.y}, a1 = {c4.z, c4.w};
+            const v2f tb = __builtin_elementwise_fma(a1, v2f{dxf[j], dxf[j]}, a0 * v2f{omdxf[j], omdxf[j]}); // (top, bottom)
+            const v2f p = tb * wy;
+            const float y = p.x + p.y;
+            const float fr = __builtin_amdgcn_fractf(y);           // y - floor(y)
+            lv[j] = (uint32_t)min(max((int)floorf(y), 0), 255);
+            const bool near = fabsf(fr - 0.5f) > 0.5f - kSpecDelta && y != 0.0f;
             pend |= (near ? 1u : 0u) << j;
         }
         while (pend) { // exact recomputation (reference op order, autoscale.rs:327-329, 602)
@@ -449,16 +427,16 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
 #pragma unroll
             for (int jj = 1; jj < VEC; ++jj) o8 = (jj == j) ? off[jj] : o8;
             const double4 c4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + o8 * 2u);
-            const double2 cw = *reinterpret_cast<const double2 *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 16);
-            const double top = c4.x * cw.y + c4.y * cw.x;
-            const double bottom = c4.z * cw.y + c4.w * cw.x;
-            double o = top * rw.omd + bottom * rw.d;
+            const double dx = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
+            const double top = c4.x * (1.0 - dx) + c4.y * dx;
+            const double bottom = c4.z * (1.0 - dx) + c4.w * dx;
+            double o = top * omdy + bottom * dy;
             o = fmin(fmax(o, 0.0), 1.0);
             const uint32_t level = (uint32_t)(o * 255.0);
 #pragma unroll
             for (int jj = 0; jj < VEC; ++jj) lv[jj] = (jj == j) ? level : lv[jj];
         }
-        if (ghist) {
+        if (count_levels) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const uint32_t h = lv[j] ? SpecLds::hist + lv[j] * 4u : dummy;
@@ -491,6 +469,44 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             cur = nxt;
         }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const Rect rc = a.rects[blockIdx.x];
+    const int band = blockIdx.y;
+    const double *__restrict__ cdfs = a.cdfs[band];
+    const uint8_t *__restrict__ glut = a.binlut[band];
+    // the table is constant from win_hi on; beyond the LDS capacity it is gathered from global memory
+    const uint32_t win_hi = a.dev_state ? a.dev_state[band].win_hi : a.win_hi[band];
+    const bool lut_lds = win_hi < a.lut_cap;
+    unsigned long long *ghist = a.level_hist[band];
+    {
+        const int b = threadIdx.x;
+        double c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = cdfs[(size_t)rc.id[k] * 256 + b];
+        *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + b * 32) = make_double4(c[0], c[1], c[2], c[3]);
+        // f32 copy laid out (c00, c10 | c01, c11): (top, bottom) = (x,y)*(1-dx) + (z,w)*dx are two packed-f32 ops
+        *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + b * 16) = make_float4((float)c[0], (float)c[2], (float)c[1], (float)c[3]);
+        if (b == 0) {
+            *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + 256 * 32) = make_double4(0.0, 0.0, 0.0, 0.0);
+            *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + 256 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
+        for (int i = b; i < rc.r1 - rc.r0; i += kBlock) // exact dy of this item's rows (<= 256 rows per item)
+            *reinterpret_cast<double *>(lds + SpecLds::roww + i * 8) = a.row_w[a.row_off + rc.r0 + i].d;
+        for (int i = b; i < 512; i += kBlock) { // exact column weights of this strip, for the f64 path
+            const int c2 = rc.cstart + i;
+            *reinterpret_cast<double *>(lds + SpecLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
+        }
+        uint16_t *lut = reinterpret_cast<uint16_t *>(lds + SpecLds::lut);
+        if (lut_lds)
+            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(i ? (uint32_t)glut[i] * 16u : 256u * 16u);
+    }
+    __syncthreads();
+    if (lut_lds) clahe_spec_rows<true>(a, rc, band, lds, win_hi);
+    else clahe_spec_rows<false>(a, rc, band, lds, win_hi);
     if (ghist) {
         __syncthreads();
         const uint32_t n = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[threadIdx.x];

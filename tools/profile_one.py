@@ -1,5 +1,7 @@
+"""A few headline passes with nothing else in the process: the target of rocprofv3 runs
+(rocprofv3 --kernel-trace --stats | --pmc ... -- python3 tools/profile_one.py <passes> <strategy>)."""
 import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sarpro_amd as S
 from sarpro_amd import synth

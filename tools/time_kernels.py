@@ -1,5 +1,6 @@
+"""Per-kernel HIP-event times and host segments of the headline pass (400 MP dual-pol CLAHE + synRGB)."""
 import os, sys, time, json
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import sarpro_amd as S
 from sarpro_amd import synth
@@ -18,7 +19,6 @@ def run(n=6):
             for k,v in ctx.last_kernel_times(): acc.setdefault(k,[]).append(v)
             acc.setdefault("TOTAL",[]).append(dt)
     return {k: round(float(np.mean(v)),3) for k,v in acc.items()}
-for abl in (0,8):
-    os.environ["SARPRO_HIP_ABLATE"]=str(abl)
-    r=run()
-    print("ablate",abl, {k:v for k,v in r.items() if k in ("clahe_apply_u16","TOTAL")} if abl else r)
+r = run()
+for k, v in r.items():
+    print(f"{k:45s} {v:8.3f} ms")
