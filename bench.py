@@ -38,14 +38,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["batch", "stripe"], default="batch")
     ap.add_argument("--rows", type=int, default=20000)
     ap.add_argument("--cols", type=int, default=20000)
     ap.add_argument("--strategy", default="clahe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=7000, help="side of the square CPU-baseline sample scene")
+    ap.add_argument("--cpu-sample", type=int, default=12000, help="side of the square CPU-baseline sample scene")
     args = ap.parse_args()
 
     import torch
