@@ -143,6 +143,34 @@ int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *band1, const
                                   uint8_t *rgb_out, uint8_t *u8_band1, uint8_t *u8_band2,
                                   sarpro_hip_stats *stats_out);
 
+/* ================= resize + pad (first "next" row) ================= */
+/* Bookkeeping the reference returns next to the raster (resize.rs:98-108). */
+typedef struct {
+    size_t final_cols, final_rows;
+    double scale_x, scale_y;
+    size_t pad_left, pad_top;
+} sarpro_hip_resize_meta;
+/* Output shape of resize_image_data_with_meta for (cols, rows, target_size (0 = None), pad):
+ * calculate_resize_dimensions (resize.rs:6-30) + add_padding_to_square (padding.rs:12). */
+int sarpro_hip_resize_output_dims(size_t cols, size_t rows, size_t target_size, int pad, size_t *final_cols,
+                                  size_t *final_rows);
+/* resize_image_data_with_meta (resize.rs:91-236): Lanczos3 resample to target_size on the long side
+ * (skipped when already there), then optional centre zero-pad to a square.  bit_depth selects u8 / u16
+ * elements.  `out` holds final_rows * final_cols elements.  Dimension and padding rules are exact; the
+ * Lanczos3 arithmetic restates the fast_image_resize crate's convolution and its parity with the crate
+ * is unpinned (crate source absent, version not locked). */
+int sarpro_hip_resize_image_data(sarpro_hip_ctx *ctx, const void *data, size_t cols, size_t rows, size_t target_size,
+                                 int bit_depth, int pad, void *out, sarpro_hip_resize_meta *meta);
+int sarpro_hip_resize_image_data_dev(sarpro_hip_ctx *ctx, const void *d_data, size_t cols, size_t rows, size_t pitch,
+                                     size_t target_size, int bit_depth, int pad, void *d_out, size_t out_pitch,
+                                     sarpro_hip_resize_meta *meta);
+/* The JPEG/multiband branch with its resize and pad steps (save.rs:317-367): per-band u8 autoscale at
+ * native resolution -> resize -> pad -> synRGB, all on the device; only the final RGB
+ * (final_rows * final_cols * 3 bytes, see sarpro_hip_resize_output_dims) crosses PCIe. */
+int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *band1, const uint16_t *band2, size_t rows,
+                                          size_t cols, int strategy, int mode, size_t target_size, int pad,
+                                          uint8_t *rgb_out, sarpro_hip_resize_meta *meta);
+
 /* ================= device-pointer entry points ================= */
 /* Same operations on rasters already resident in HBM.  pitch = row stride in elements
  * (>= cols).  The vectorised kernels need base pointers aligned to 16 bytes and

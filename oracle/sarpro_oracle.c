@@ -750,4 +750,158 @@ int sarpro_oracle_dualpol_synrgb_f32(const float *band1, const float *band2, siz
     return rc;
 }
 
+
+/* ====================================================================== */
+/* resize.rs:32-89  resize_u8_image / resize_u16_image                     */
+/* The arithmetic is the third-party crate fast_image_resize (Cargo.toml:33 */
+/* `^5.2.1`, NOT pinned: no Cargo.lock; source absent from the reference).  */
+/* PARITY UNPINNED for this function: what follows restates the crate's     */
+/* published convolution algorithm as of 5.x -- ResizeAlg::Convolution(     */
+/* Lanczos3), adaptive kernel size, coefficients normalised per output      */
+/* pixel, fixed-point i16 (u8) / i32 (u16) weights with the largest         */
+/* precision that keeps the largest weight in range, horizontal pass into   */
+/* an integer intermediate, then vertical pass -- and is anchored only on   */
+/* the reference's call sites (resize.rs:39-52, 62-81).                     */
+/* ====================================================================== */
+static double oracle_sinc(double x) { if (x == 0.0) return 1.0; x *= 3.14159265358979323846; return sin(x) / x; }
+static double oracle_lanczos3(double x) { return (x >= -3.0 && x < 3.0) ? oracle_sinc(x) * oracle_sinc(x / 3.0) : 0.0; }
+
+typedef struct { size_t window; uint32_t *start, *size; double *w; } oracle_coeffs;
+
+static int oracle_precompute(size_t in_size, size_t out_size, oracle_coeffs *c) {
+    double scale = (double)in_size / (double)out_size;
+    double filter_scale = scale > 1.0 ? scale : 1.0;
+    double radius = 3.0 * filter_scale;
+    c->window = (size_t)ceil(radius) * 2 + 1;
+    double recip = 1.0 / filter_scale;
+    c->start = (uint32_t *)malloc(out_size * sizeof(uint32_t));
+    c->size = (uint32_t *)malloc(out_size * sizeof(uint32_t));
+    c->w = (double *)calloc(out_size * c->window, sizeof(double));
+    if (!c->start || !c->size || !c->w) return ORACLE_ERR_OOM;
+    for (size_t ox = 0; ox < out_size; ++ox) {
+        double in_center = ((double)ox + 0.5) * scale;
+        uint32_t x_min = f64_as_u32(fmax(floor(in_center - radius), 0.0));
+        uint32_t x_max = f64_as_u32(fmin(ceil(in_center + radius), (double)in_size));
+        double center = in_center - 0.5, ww = 0.0;
+        double *w = c->w + ox * c->window;
+        for (uint32_t x = x_min; x < x_max; ++x) { w[x - x_min] = oracle_lanczos3(((double)x - center) * recip); ww += w[x - x_min]; }
+        if (ww != 0.0) for (uint32_t x = x_min; x < x_max; ++x) w[x - x_min] /= ww;
+        c->start[ox] = x_min;
+        c->size[ox] = x_max - x_min;
+    }
+    return ORACLE_OK;
+}
+static void oracle_coeffs_free(oracle_coeffs *c) { free(c->start); free(c->size); free(c->w); }
+
+static int oracle_precision(const oracle_coeffs *c, size_t out_size, int limit_bits, int max_precision) {
+    double max_w = 0.0;
+    for (size_t i = 0; i < out_size * c->window; ++i) if (c->w[i] > max_w) max_w = c->w[i];
+    int precision = 0;
+    for (int cur = 0; cur < max_precision; ++cur) {
+        precision = cur;
+        double next = round(max_w * (double)(1ll << (cur + 1)));
+        if (next >= (double)(1ll << limit_bits)) break;
+    }
+    return precision;
+}
+
+/* one pass along x: src (rows x in_cols) -> dst (rows x out_cols); elem 1 = u8 / i16 weights, 2 = u16 / i32 weights */
+static int oracle_convolve_x(const void *src, size_t rows, size_t in_cols, void *dst, size_t out_cols, int elem) {
+    oracle_coeffs c;
+    int rc = oracle_precompute(in_cols, out_cols, &c);
+    if (rc) return rc;
+    int precision = elem == 1 ? oracle_precision(&c, out_cols, 15, 22) : oracle_precision(&c, out_cols, 31, 45);
+    double scale = (double)(1ll << precision);
+    int64_t *k = (int64_t *)malloc(out_cols * c.window * sizeof(int64_t));
+    if (!k) { oracle_coeffs_free(&c); return ORACLE_ERR_OOM; }
+    for (size_t i = 0; i < out_cols * c.window; ++i) k[i] = (int64_t)round(c.w[i] * scale);
+    int64_t initial = precision > 0 ? (1ll << (precision - 1)) : 0;
+    int64_t maxv = elem == 1 ? 255 : 65535;
+    for (size_t r = 0; r < rows; ++r) {
+        for (size_t ox = 0; ox < out_cols; ++ox) {
+            int64_t ss = initial;
+            const int64_t *kk = k + ox * c.window;
+            for (uint32_t t = 0; t < c.size[ox]; ++t) {
+                size_t x = c.start[ox] + t;
+                int64_t v = elem == 1 ? ((const uint8_t *)src)[r * in_cols + x] : ((const uint16_t *)src)[r * in_cols + x];
+                ss += v * kk[t];
+            }
+            int64_t o = ss >> precision;
+            o = o < 0 ? 0 : (o > maxv ? maxv : o);
+            if (elem == 1) ((uint8_t *)dst)[r * out_cols + ox] = (uint8_t)o; else ((uint16_t *)dst)[r * out_cols + ox] = (uint16_t)o;
+        }
+    }
+    free(k);
+    oracle_coeffs_free(&c);
+    return ORACLE_OK;
+}
+
+static void oracle_transpose(const void *src, size_t rows, size_t cols, void *dst, int elem) {
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) {
+            if (elem == 1) ((uint8_t *)dst)[c * rows + r] = ((const uint8_t *)src)[r * cols + c];
+            else ((uint16_t *)dst)[c * rows + r] = ((const uint16_t *)src)[r * cols + c];
+        }
+}
+
+/* elem_size 1 (u8) or 2 (u16); dst holds dst_rows*dst_cols elements */
+int sarpro_oracle_resize_lanczos3(const void *src, size_t cols, size_t rows, size_t dst_cols, size_t dst_rows,
+                                  size_t elem_size, void *dst) {
+    if (elem_size != 1 && elem_size != 2) return ORACLE_ERR_INVALID_ARG;
+    if (!cols || !rows || !dst_cols || !dst_rows) return ORACLE_ERR_INVALID_ARG;
+    int elem = (int)elem_size;
+    void *h = malloc(rows * dst_cols * elem_size);           /* horizontal pass */
+    void *ht = malloc(rows * dst_cols * elem_size);          /* transposed: (dst_cols x rows) */
+    void *vt = malloc(dst_rows * dst_cols * elem_size);      /* vertical pass on the transposed image */
+    int rc = ORACLE_ERR_OOM;
+    if (h && ht && vt) {
+        rc = oracle_convolve_x(src, rows, cols, h, dst_cols, elem);
+        if (rc == ORACLE_OK) {
+            oracle_transpose(h, rows, dst_cols, ht, elem);
+            rc = oracle_convolve_x(ht, dst_cols, rows, vt, dst_rows, elem);
+        }
+        if (rc == ORACLE_OK) oracle_transpose(vt, dst_cols, dst_rows, dst, elem);
+    }
+    free(h); free(ht); free(vt);
+    return rc;
+}
+
+/* resize.rs:91-236  resize_image_data_with_meta.  target_size 0 = None.  out must hold
+   max(final dims)^2 elements when pad, else new_cols*new_rows.  meta_out[6] =
+   final_cols, final_rows, scale_x, scale_y, pad_left, pad_top (as doubles). */
+int sarpro_oracle_resize_image_data_with_meta(const void *data, size_t original_cols, size_t original_rows,
+                                              size_t target_size, size_t elem_size, int pad, void *out,
+                                              double *meta_out) {
+    size_t cols = original_cols, rows = original_rows;
+    double scale_x = 1.0, scale_y = 1.0;
+    const void *cur = data;
+    void *resized = NULL;
+    if (target_size) {
+        size_t current_long = original_cols > original_rows ? original_cols : original_rows;
+        if (current_long != target_size) { /* :112-145 early-out when already at the requested long side */
+            size_t nc, nr;
+            sarpro_oracle_resize_dims(original_cols, original_rows, target_size, &nc, &nr);
+            resized = malloc((nc != 0 && nr != 0 ? nc * nr : 1) * elem_size);
+            if (!resized) return ORACLE_ERR_OOM;
+            int rc = sarpro_oracle_resize_lanczos3(data, original_cols, original_rows, nc, nr, elem_size, resized);
+            if (rc) { free(resized); return rc; }
+            scale_x = (double)nc / (double)original_cols; /* :168-169 */
+            scale_y = (double)nr / (double)original_rows;
+            cols = nc; rows = nr; cur = resized;
+        }
+    }
+    size_t pad_left = 0, pad_top = 0, fc = cols, fr = rows;
+    if (pad) {
+        size_t m = cols > rows ? cols : rows;
+        sarpro_oracle_pad_to_square(cur, cols, rows, elem_size, out);
+        pad_left = (m - cols) / 2; pad_top = (m - rows) / 2; fc = fr = m;
+    } else {
+        memcpy(out, cur, cols * rows * elem_size);
+    }
+    free(resized);
+    if (meta_out) { meta_out[0] = (double)fc; meta_out[1] = (double)fr; meta_out[2] = scale_x; meta_out[3] = scale_y;
+                    meta_out[4] = (double)pad_left; meta_out[5] = (double)pad_top; }
+    return ORACLE_OK;
+}
+
 const char *sarpro_oracle_version(void) { return "sarpro-oracle 1 (restates bogwi/sarpro v0.3.0 src/core/processing)"; }

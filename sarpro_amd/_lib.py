@@ -28,6 +28,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class ResizeMeta(C.Structure):
+    _fields_ = [("final_cols", C.c_size_t), ("final_rows", C.c_size_t), ("scale_x", C.c_double), ("scale_y", C.c_double),
+                ("pad_left", C.c_size_t), ("pad_top", C.c_size_t)]
+
+
 # every symbol include/sarpro_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "sarpro_hip_ctx_create", "sarpro_hip_ctx_destroy", "sarpro_hip_last_error", "sarpro_hip_version",
@@ -47,6 +52,8 @@ SYMBOLS = [
     "sarpro_hip_host_synrgb_luts", "sarpro_hip_host_clahe_shape_ok", "sarpro_hip_host_stripe_plan",
     "sarpro_hip_host_stats_from_bins4096", "sarpro_hip_host_f32_valid_threshold", "sarpro_hip_host_f32_bin4096_thresholds",
     "sarpro_hip_host_f32_level_thresholds", "sarpro_hip_host_f32_clahe_bin_thresholds",
+    "sarpro_hip_resize_output_dims", "sarpro_hip_resize_image_data", "sarpro_hip_resize_image_data_dev",
+    "sarpro_hip_dualpol_synrgb_resized_u16",
     "sarpro_hip_synth_scene_u16_dev",
 ]
 
@@ -136,3 +143,8 @@ _proto("sarpro_hip_host_f32_bin4096_thresholds", _i, C.c_double, C.c_double, _vp
 _proto("sarpro_hip_host_f32_level_thresholds", _i, _S, _i, _vp)
 _proto("sarpro_hip_host_f32_clahe_bin_thresholds", _i, _S, _vp)
 _proto("sarpro_hip_host_stats_from_bins4096", _i, _u64, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _S)
+_M = C.POINTER(ResizeMeta)
+_proto("sarpro_hip_resize_output_dims", _i, _sz, _sz, _sz, _i, C.POINTER(_sz), C.POINTER(_sz))
+_proto("sarpro_hip_resize_image_data", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _M)
+_proto("sarpro_hip_resize_image_data_dev", _i, _vp, _vp, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _M)
+_proto("sarpro_hip_dualpol_synrgb_resized_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)

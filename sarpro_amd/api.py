@@ -191,6 +191,35 @@ class Context:
             out += ([st[0], st[1]],)
         return out if len(out) > 1 else rgb
 
+    # ------------------------------------------------------------------ resize.rs:91 / save.rs:317-367
+    def resize_image_data_with_meta(self, data: np.ndarray, target_size: int | None, pad: bool):
+        """Returns (final raster, ResizeMeta): Lanczos3 to `target_size` on the long side, optional square pad."""
+        from ._lib import ResizeMeta
+        if data.dtype not in (np.uint8, np.uint16) or data.ndim != 2:
+            raise ValueError("data must be a 2-D uint8 or uint16 raster")
+        rows, cols = data.shape
+        fc, fr = resize_output_dims(cols, rows, target_size, pad)
+        out = np.empty((fr, fc), data.dtype)
+        m = ResizeMeta()
+        x = np.ascontiguousarray(data)
+        self._chk(lib.sarpro_hip_resize_image_data(self._h, _vp(x), cols, rows, target_size or 0,
+                                                   0 if data.dtype == np.uint8 else 1, int(pad), _vp(out), C.byref(m)))
+        return out, m
+
+    def dualpol_synrgb_resized(self, band1: np.ndarray, band2: np.ndarray, strategy: AutoscaleStrategy,
+                               target_size: int | None, pad: bool, mode: SyntheticRgbMode = SyntheticRgbMode.Default):
+        """save.rs:317-367 with its resize / pad steps: u16 bands in, (final_rows, final_cols, 3) RGB out."""
+        from ._lib import ResizeMeta
+        rows, cols = band1.shape
+        fc, fr = resize_output_dims(cols, rows, target_size, pad)
+        rgb = np.empty((fr, fc, 3), np.uint8)
+        m = ResizeMeta()
+        b1 = np.ascontiguousarray(band1, np.uint16)
+        b2 = np.ascontiguousarray(band2, np.uint16)
+        self._chk(lib.sarpro_hip_dualpol_synrgb_resized_u16(self._h, _vp(b1), _vp(b2), rows, cols, int(strategy), int(mode),
+                                                            target_size or 0, int(pad), _vp(rgb), C.byref(m)))
+        return rgb, m
+
     # ------------------------------------------------------------------ device-pointer variants
     def dev_autoscale_band_u16(self, d_in: int, rows: int, cols: int, in_pitch: int, strategy, bit_depth,
                                d_out: int, out_pitch: int) -> Stats:
@@ -395,3 +424,11 @@ def host_stats_from_bins4096(count: int, min_db: float, max_db: float, mean_db: 
     if rc:
         raise SarproHipError(rc, "host_stats_from_bins4096")
     return st
+
+
+def resize_output_dims(cols: int, rows: int, target_size: int | None, pad: bool):
+    fc, fr = C.c_size_t(), C.c_size_t()
+    rc = lib.sarpro_hip_resize_output_dims(cols, rows, target_size or 0, int(pad), C.byref(fc), C.byref(fr))
+    if rc:
+        raise SarproHipError(rc, "resize_output_dims")
+    return fc.value, fr.value

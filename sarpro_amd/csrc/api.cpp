@@ -130,6 +130,7 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     ctx->ghist.release(); ctx->tile_bins.release(); ctx->cdfs.release(); ctx->luts.release();
     ctx->level_hist.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
     ctx->chain_consts.release(); ctx->chain_state.release();
+    ctx->resize_tmp.release(); ctx->resize_coef[0].release(); ctx->resize_coef[1].release(); ctx->resized[0].release(); ctx->resized[1].release();
     ctx->h_ghist.release(); ctx->h_small.release(); ctx->h_upload.release();
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -827,6 +828,18 @@ extern "C" int sarpro_hip_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, const uint
     void *outs[kMaxBands] = {d_out, nullptr};
     return job_run_all(J, outs, out_pitch, nullptr, 0, stats_out);
 }
+
+namespace sarpro {
+int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
+                uint8_t *d_out, size_t out_pitch) {
+    U16Job J;
+    J.ctx = ctx; J.nbands = 1; J.d_in[0] = d_in;
+    J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = in_pitch;
+    J.strategy = tamed ? SARPRO_STRATEGY_TAMED : strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.tamed_force = tamed;
+    void *outs[kMaxBands] = {d_out, nullptr};
+    return job_run_all(J, outs, out_pitch, nullptr, 0, nullptr);
+}
+} // namespace sarpro
 
 extern "C" int sarpro_hip_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2,
                                                  size_t rows, size_t cols, size_t in_pitch, int strategy, int mode,

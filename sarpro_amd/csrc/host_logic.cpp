@@ -638,3 +638,58 @@ void build_clahe_bin_thresholds(const sarpro_hip_stats &s, float *thr) {
 }
 
 } // namespace sarpro
+
+// ======================= resize =======================
+namespace sarpro {
+
+static double sinc_pi(double x) { if (x == 0.0) return 1.0; x *= 3.14159265358979323846; return std::sin(x) / x; }
+static double lanczos3(double x) { return (x >= -3.0 && x < 3.0) ? sinc_pi(x) * sinc_pi(x / 3.0) : 0.0; }
+
+void build_resize_coeffs(uint32_t in_size, uint32_t out_size, int elem_size, ResizeCoeffs *c) {
+    c->in_size = in_size; c->out_size = out_size;
+    const double scale = (double)in_size / (double)out_size;
+    const double filter_scale = scale > 1.0 ? scale : 1.0; // adaptive kernel size
+    const double radius = 3.0 * filter_scale;
+    c->window = (uint32_t)std::ceil(radius) * 2 + 1;
+    const double recip = 1.0 / filter_scale;
+    c->start.assign(out_size, 0);
+    c->size.assign(out_size, 0);
+    std::vector<double> w((size_t)out_size * c->window, 0.0);
+    double max_w = 0.0;
+    for (uint32_t ox = 0; ox < out_size; ++ox) {
+        const double in_center = ((double)ox + 0.5) * scale;
+        const uint32_t x_min = as_u32(std::fmax(std::floor(in_center - radius), 0.0));
+        const uint32_t x_max = as_u32(std::fmin(std::ceil(in_center + radius), (double)in_size));
+        const double center = in_center - 0.5;
+        double ww = 0.0;
+        double *row = w.data() + (size_t)ox * c->window;
+        for (uint32_t x = x_min; x < x_max; ++x) { row[x - x_min] = lanczos3(((double)x - center) * recip); ww += row[x - x_min]; }
+        if (ww != 0.0) for (uint32_t x = x_min; x < x_max; ++x) row[x - x_min] /= ww;
+        c->start[ox] = x_min;
+        c->size[ox] = x_max - x_min;
+    }
+    for (double v : w) max_w = std::max(max_w, v);
+    const int limit_bits = elem_size == 1 ? 15 : 31, max_precision = elem_size == 1 ? 22 : 45;
+    int precision = 0;
+    for (int cur = 0; cur < max_precision; ++cur) { // largest precision that keeps the largest weight in range
+        precision = cur;
+        if (std::round(max_w * (double)(1ll << (cur + 1))) >= (double)(1ll << limit_bits)) break;
+    }
+    c->precision = precision;
+    const double fx = (double)(1ll << precision);
+    c->k.assign((size_t)out_size * c->window, 0);
+    for (uint32_t ox = 0; ox < out_size; ++ox)
+        for (uint32_t t = 0; t < c->window; ++t)
+            c->k[(size_t)t * out_size + ox] = (int32_t)std::round(w[(size_t)ox * c->window + t] * fx);
+}
+
+void resize_dimensions(size_t original_cols, size_t original_rows, size_t target_size, size_t *new_cols, size_t *new_rows) {
+    const size_t short_side = std::min(original_rows, original_cols), long_side = std::max(original_rows, original_cols);
+    if (target_size > long_side) { *new_cols = original_cols; *new_rows = original_rows; return; } // resize.rs:14-20
+    const double scale_factor = (double)target_size / (double)long_side;
+    const size_t new_short = (size_t)as_u64(std::round((double)short_side * scale_factor));
+    if (original_cols > original_rows) { *new_cols = target_size; *new_rows = new_short; }
+    else { *new_cols = new_short; *new_rows = target_size; }
+}
+
+} // namespace sarpro

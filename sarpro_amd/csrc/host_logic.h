@@ -100,3 +100,18 @@ void build_level_thresholds(const sarpro_hip_stats &s, int nlevels /*255 or 6553
 // thr[k], k = 1..255: smallest valid f32 whose CLAHE bin (autoscale.rs:585-586, 262-265) is >= k.
 void build_clahe_bin_thresholds(const sarpro_hip_stats &s, float *thr256);
 } // namespace sarpro
+
+// ---------------------------------------------------------------------------------------
+// Lanczos3 resize (resize.rs:32-89 -> fast_image_resize `Convolution(Lanczos3)`; parity with the
+// crate is UNPINNED) -- fixed-point coefficient tables for one axis.
+// ---------------------------------------------------------------------------------------
+namespace sarpro {
+struct ResizeCoeffs {
+    uint32_t in_size = 0, out_size = 0, window = 0;
+    int precision = 0;                 // result = clamp((sum + (1 << (precision-1))) >> precision)
+    std::vector<uint32_t> start, size; // [out_size] first input index / tap count
+    std::vector<int32_t> k;            // [window][out_size] (tap-major so lanes over outputs coalesce)
+};
+void build_resize_coeffs(uint32_t in_size, uint32_t out_size, int elem_size /*1: i16 range, 2: i32 range*/, ResizeCoeffs *out);
+void resize_dimensions(size_t original_cols, size_t original_rows, size_t target_size, size_t *new_cols, size_t *new_rows); // resize.rs:6-30
+} // namespace sarpro

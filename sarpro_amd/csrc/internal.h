@@ -27,4 +27,10 @@ int stage_in_2d(sarpro_hip_ctx *ctx, DevBuf &buf, const void *host, size_t rows,
                 size_t *pitch_elems);
 int fetch_out_2d(sarpro_hip_ctx *ctx, void *host, const void *dev, size_t pitch_bytes, size_t row_bytes, size_t rows);
 
+// one band -> final u8 raster on the device (pipeline.rs:42 at U8; tamed: 1 copol / 2 crosspol -> autoscale.rs:710)
+int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
+                uint8_t *d_out, size_t out_pitch);
+int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t rows, size_t in_pitch, size_t target_size,
+                   int elem_size, int pad, void *d_out, size_t out_pitch, sarpro_hip_resize_meta *meta);
+
 } // namespace sarpro

@@ -1,0 +1,23 @@
+// resize_kernels.h -- launch interface of the Lanczos3 resample passes (resize_kernels.hip).
+#pragma once
+#include "kernels.h"
+
+namespace sarpro {
+
+struct ResizePassArgs {
+    const void *src;
+    void *dst;
+    size_t src_pitch, dst_pitch; // elements
+    uint32_t in_size, out_size;  // along the resampled axis
+    uint32_t width;              // vertical pass: number of columns
+    int precision;
+    uint32_t max_val;            // 255 or 65535
+    const uint32_t *start, *size; // [out_size]
+    const int32_t *k;             // [window][out_size]
+};
+
+hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s);
+hipError_t launch_resize_v(const ResizePassArgs &a, int elem_size, hipStream_t s);
+constexpr size_t kResizeRowLdsMax = 64 * 1024; // one source row must fit in (default-limit) dynamic LDS
+
+} // namespace sarpro

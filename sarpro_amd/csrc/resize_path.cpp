@@ -1,0 +1,189 @@
+// resize_path.cpp -- resize_image_data_with_meta (resize.rs:91-236) and the resized dual-pol
+// composition (save.rs:317-367 with target_size / pad) on the device: the 400 MP level rasters never
+// leave HBM, only the small RGB does.  Lanczos3 arithmetic: see resize_kernels.hip (parity with the
+// third-party crate is unpinned); dimension rules and centre padding are exact restatements
+// (resize.rs:6-30, padding.rs:5-49).
+#include <algorithm>
+#include <cstring>
+
+#include "internal.h"
+#include "resize_kernels.h"
+
+using namespace sarpro;
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+            return e__ == hipErrorOutOfMemory ? SARPRO_HIP_ERR_OOM : SARPRO_HIP_ERR_HIP;          \
+        }                                                                                         \
+    } while (0)
+#define RETCHK(expr)                                   \
+    do {                                               \
+        int rc__ = (expr);                             \
+        if (rc__ != SARPRO_HIP_OK) return rc__;        \
+    } while (0)
+
+static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" int sarpro_hip_resize_output_dims(size_t cols, size_t rows, size_t target_size, int pad, size_t *final_cols,
+                                             size_t *final_rows) {
+    if (!final_cols || !final_rows) return SARPRO_HIP_ERR_INVALID_ARG;
+    size_t c = cols, r = rows;
+    if (target_size && std::max(cols, rows) != target_size) resize_dimensions(cols, rows, target_size, &c, &r);
+    if (pad) c = r = std::max(c, r);
+    *final_cols = c; *final_rows = r;
+    return SARPRO_HIP_OK;
+}
+
+namespace {
+
+int upload_coeffs(sarpro_hip_ctx *ctx, const ResizeCoeffs &c, DevBuf &buf, ResizePassArgs *a) {
+    const size_t n = c.out_size, kb = c.k.size() * sizeof(int32_t);
+    const size_t bytes = n * 8 + kb;
+    HIPCHK(ctx, buf.reserve(bytes));
+    HIPCHK(ctx, ctx->h_upload.reserve(std::max<size_t>(bytes, 2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024)));
+    uint8_t *h = ctx->h_upload.as<uint8_t>();
+    std::memcpy(h, c.start.data(), n * 4);
+    std::memcpy(h + n * 4, c.size.data(), n * 4);
+    std::memcpy(h + n * 8, c.k.data(), kb);
+    HIPCHK(ctx, hipMemcpyAsync(buf.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the pinned stage is reused by the next table
+    a->start = buf.as<uint32_t>();
+    a->size = buf.as<uint32_t>() + n;
+    a->k = reinterpret_cast<const int32_t *>(buf.as<uint8_t>() + n * 8);
+    a->in_size = c.in_size; a->out_size = c.out_size; a->precision = c.precision;
+    return SARPRO_HIP_OK;
+}
+
+} // namespace
+
+namespace sarpro {
+
+// d_out must hold final_rows x out_pitch elements (see sarpro_hip_resize_output_dims)
+int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t rows, size_t in_pitch, size_t target_size,
+                   int elem_size, int pad, void *d_out, size_t out_pitch, sarpro_hip_resize_meta *meta) {
+    if (elem_size != 1 && elem_size != 2) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad element size");
+    if (in_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t nc = cols, nr = rows;
+    double sx = 1.0, sy = 1.0;
+    const bool do_resize = target_size && std::max(cols, rows) != target_size && cols && rows; // resize.rs:110-145
+    if (do_resize) resize_dimensions(cols, rows, target_size, &nc, &nr);
+    size_t fc = nc, fr = nr, pad_left = 0, pad_top = 0;
+    if (pad) { fc = fr = std::max(nc, nr); pad_left = (fc - nc) / 2; pad_top = (fr - nr) / 2; } // padding.rs:12-14
+    if (out_pitch < fc) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "out_pitch < final columns");
+    if (meta) { meta->final_cols = fc; meta->final_rows = fr; meta->scale_x = sx; meta->scale_y = sy; meta->pad_left = pad_left; meta->pad_top = pad_top; }
+    if (!fc || !fr) return SARPRO_HIP_OK;
+    uint8_t *out = reinterpret_cast<uint8_t *>(d_out);
+    if (pad) HIPCHK(ctx, hipMemset2DAsync(out, out_pitch * elem_size, 0, fc * elem_size, fr, ctx->stream));
+    uint8_t *dst = out + (pad_top * out_pitch + pad_left) * elem_size;
+    if (!do_resize) {
+        if (nc && nr)
+            HIPCHK(ctx, hipMemcpy2DAsync(dst, out_pitch * elem_size, d_in, in_pitch * elem_size, nc * elem_size, nr, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return SARPRO_HIP_OK;
+    }
+    if (!nc || !nr) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "target size collapses a dimension to zero");
+    if (cols * elem_size > kResizeRowLdsMax) return fail(ctx, SARPRO_HIP_ERR_UNSUPPORTED_SHAPE, "source row too long for the LDS-staged horizontal pass");
+    sx = (double)nc / (double)cols; sy = (double)nr / (double)rows; // resize.rs:168-169
+    if (meta) { meta->scale_x = sx; meta->scale_y = sy; }
+    // horizontal pass -> intermediate (rows x nc), vertical pass -> destination window
+    const size_t tmp_pitch = round_up(nc, 64);
+    HIPCHK(ctx, ctx->resize_tmp.reserve(rows * tmp_pitch * elem_size));
+    ResizeCoeffs ch, cv;
+    build_resize_coeffs((uint32_t)cols, (uint32_t)nc, elem_size, &ch);
+    build_resize_coeffs((uint32_t)rows, (uint32_t)nr, elem_size, &cv);
+    ResizePassArgs ah{}, av{};
+    RETCHK(upload_coeffs(ctx, ch, ctx->resize_coef[0], &ah));
+    RETCHK(upload_coeffs(ctx, cv, ctx->resize_coef[1], &av));
+    ah.src = d_in; ah.src_pitch = in_pitch; ah.dst = ctx->resize_tmp.p; ah.dst_pitch = tmp_pitch;
+    ah.max_val = elem_size == 1 ? 255u : 65535u;
+    av.src = ctx->resize_tmp.p; av.src_pitch = tmp_pitch; av.dst = dst; av.dst_pitch = out_pitch;
+    av.width = (uint32_t)nc; av.max_val = ah.max_val;
+    {
+        KernelTimer t(ctx, "resize_h");
+        HIPCHK(ctx, launch_resize_h(ah, (uint32_t)rows, elem_size, ctx->stream));
+    }
+    {
+        KernelTimer t(ctx, "resize_v");
+        HIPCHK(ctx, launch_resize_v(av, elem_size, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+} // namespace sarpro
+
+extern "C" int sarpro_hip_resize_image_data_dev(sarpro_hip_ctx *ctx, const void *d_data, size_t cols, size_t rows, size_t pitch,
+                                                size_t target_size, int bit_depth, int pad, void *d_out, size_t out_pitch,
+                                                sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if ((!d_data || !d_out) && cols * rows) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    timing_reset(ctx);
+    return resize_pad_dev(ctx, d_data, cols, rows, pitch, target_size, bit_depth == SARPRO_BITDEPTH_U8 ? 1 : 2, pad, d_out, out_pitch, meta);
+}
+
+extern "C" int sarpro_hip_resize_image_data(sarpro_hip_ctx *ctx, const void *data, size_t cols, size_t rows, size_t target_size,
+                                            int bit_depth, int pad, void *out, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if ((!data || !out) && cols * rows) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    timing_reset(ctx);
+    const size_t esz = bit_depth == SARPRO_BITDEPTH_U8 ? 1 : 2;
+    size_t pitch = 0, fc = 0, fr = 0;
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[0], data, rows, cols, esz, &pitch));
+    RETCHK(sarpro_hip_resize_output_dims(cols, rows, target_size, pad, &fc, &fr));
+    const size_t opitch = round_up(std::max<size_t>(fc, 1), 64);
+    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max<size_t>(fr, 1) * opitch * esz));
+    sarpro_hip_resize_meta m{};
+    RETCHK(resize_pad_dev(ctx, ctx->stage_in[0].p, cols, rows, pitch, target_size, (int)esz, pad, ctx->stage_out[0].p, opitch, &m));
+    if (meta) *meta = m;
+    return fetch_out_2d(ctx, out, ctx->stage_out[0].p, opitch * esz, fc * esz, fr);
+}
+
+// save.rs:317-367 including the resize / pad steps between the per-band autoscale and the composition
+// (the reference's order: autoscale -> resize -> pad -> synRGB; the suppressed floor therefore sees
+// the zero padding, synthetic_rgb.rs:92-99).  Host u16 bands in, final_rows x final_cols RGB out.
+extern "C" int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *band1, const uint16_t *band2, size_t rows,
+                                                     size_t cols, int strategy, int mode, size_t target_size, int pad,
+                                                     uint8_t *rgb_out, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (rows * cols && (!band1 || !band2 || !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
+    const uint16_t *bands[2] = {band1, band2};
+    size_t fc = 0, fr = 0;
+    RETCHK(sarpro_hip_resize_output_dims(cols, rows, target_size, pad, &fc, &fr));
+    const size_t r1 = std::max<size_t>(rows, 1);
+    const size_t opitch = round_up(std::max<size_t>(fc, 1), 64);
+    sarpro_hip_resize_meta m{};
+    for (int b = 0; b < 2; ++b) {
+        size_t pitch = 0;
+        RETCHK(stage_in_2d(ctx, ctx->stage_in[0], bands[b], rows, cols, 2, &pitch));
+        HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * pitch));
+        // per-band u8 at native resolution (pipeline.rs:42; Tamed: autoscale.rs:710 with the band's polarisation)
+        const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0;
+        RETCHK(band_u8_dev(ctx, ctx->stage_in[0].as<uint16_t>(), rows, cols, pitch, strategy, tamed, ctx->stage_out[0].as<uint8_t>(), pitch));
+        HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch));
+        RETCHK(resize_pad_dev(ctx, ctx->stage_out[0].p, cols, rows, pitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m));
+    }
+    if (meta) *meta = m;
+    if (!fc || !fr) return SARPRO_HIP_OK;
+    // composition on the resized, padded bands: compact them (pitch == cols) so the flat entry point applies
+    HIPCHK(ctx, ctx->stage_out[1].reserve(fc * fr));
+    HIPCHK(ctx, ctx->stage_out[2].reserve(fc * fr));
+    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max(fc * fr * 3, r1 * round_up(std::max<size_t>(cols, 1), 64))));
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[1].p, fc, ctx->resized[0].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[2].p, fc, ctx->resized[1].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
+    RETCHK(sarpro_hip_synrgb_u8_dev(ctx, mode, strategy, ctx->stage_out[1].as<uint8_t>(), ctx->stage_out[2].as<uint8_t>(), fc * fr,
+                                    ctx->stage_out[0].as<uint8_t>()));
+    HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->stage_out[0].p, fc * fr * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}

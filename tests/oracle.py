@@ -186,3 +186,21 @@ def resize_dims(cols: int, rows: int, target: int):
     nc, nr = C.c_size_t(), C.c_size_t()
     lib().sarpro_oracle_resize_dims(C.c_size_t(cols), C.c_size_t(rows), C.c_size_t(target), C.byref(nc), C.byref(nr))
     return nc.value, nr.value
+
+
+def resize_image_data_with_meta(a: np.ndarray, target_size, pad: bool):
+    """resize.rs:91-236 -> (raster, meta dict)"""
+    a = np.ascontiguousarray(a)
+    rows, cols = a.shape
+    nc, nr = (cols, rows)
+    if target_size and max(cols, rows) != target_size:
+        nc, nr = resize_dims(cols, rows, target_size)
+    fc, fr = (max(nc, nr),) * 2 if pad else (nc, nr)
+    out = np.empty((fr, fc), a.dtype)
+    meta = np.zeros(6, np.float64)
+    rc = lib().sarpro_oracle_resize_image_data_with_meta(_p(a), C.c_size_t(cols), C.c_size_t(rows), C.c_size_t(target_size or 0),
+                                                         C.c_size_t(a.itemsize), int(pad), _p(out), _p(meta))
+    assert rc == OK, rc
+    assert (int(meta[0]), int(meta[1])) == (fc, fr)
+    return out, dict(final_cols=int(meta[0]), final_rows=int(meta[1]), scale_x=meta[2], scale_y=meta[3],
+                     pad_left=int(meta[4]), pad_top=int(meta[5]))
