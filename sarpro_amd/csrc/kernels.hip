@@ -351,17 +351,23 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //       entry (entry 256 is all-zero and is where DN = 0 points, so invalid pixels need no
 //       branch) -> one 16-B gather of the four CDFs as f32 -> 6 f32 FMAs -> floor.
 //     The f32 result decides the level unless o*255 lies within kSpecDelta of an integer; those
-//     pixels (~0.8 %) are recomputed with the reference's exact f64 sequence (CDFs and column
+//     pixels (~0.4 %) are recomputed with the reference's exact f64 sequence (CDFs and column
 //     weights as f64 in LDS), so the raster is bit-identical to kernel 4's.
-//     Error bound (u = 2^-24; |dx|,|dy| <= 1, weight pairs sum to <= 2, CDFs in [0,1]): inputs
-//     rounded once (u), each product <= 3u, each sum adds u of a magnitude <= 2, the 255 factor is
-//     folded into the row weights (+u), the final add rounds once more (+u):  |y32 - y| <= 255*34u + u*|y| < 6e-4 with y = o*255.
-//     kSpecDelta = 1/256 = 3.9e-3 leaves > 6x margin.  y32 == 0 exactly happens only when every
-//     product is exactly zero in f64 too (f32 rounding never flushes these operands to zero), so
-//     an exact zero is decided (level 0) without the f64 path.
+//     Error bound of the f32 value y32 against the reference's y = o*255 (u = 2^-24):
+//       inputs are the f64 CDFs / weights rounded once to f32 (1+e, |e| <= u); with
+//       S = |c00 (1-dx)| + |c01 dx| <= 2 (dx in [-0.5, 1): the first half tile extrapolates),
+//       top32 = fma(c01, dx, c00*(1-dx)) carries <= 3u per product + u for the sum:  |dtop| <= 4uS <= 8u,
+//       the same for bottom, and |top|, |bottom| <= 2;  the row weights hold the 255 factor
+//       (2 roundings), p = (top, bottom) * wy adds one more, the final add one more:
+//       |y32 - y| <= 255 (|1-dy| + |dy|) (8u + 3u*2) + u |y|  <=  255*2*14u + 1020u  =  4.9e-4.
+//     kSpecDelta = 1/512 = 1.95e-3 leaves a 4x margin on that worst case (interior cells, where
+//     the weights are in [0,1], are 4x tighter still): outside it floor(y32) = floor(y), inside
+//     it the exact path decides.  The reference's own f64 rounding (1e-13) is far below it.
+//     y32 == 0 exactly happens only when every product is exactly zero in f64 too (f32 rounding
+//     never flushes these operands to zero), so an exact zero is decided (level 0) directly.
 //     Level 0 goes to a per-lane dummy histogram word (bin 0 = pixels - other bins, on the host).
 // ------------------------------------------------------------------------------------
-constexpr float kSpecDelta = 1.0f / 256.0f;
+constexpr float kSpecDelta = 1.0f / 512.0f;
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr uint32_t kSpecLutMaxEntries = 16384; // u16 offsets: 32 KiB of LDS at most

@@ -42,8 +42,22 @@ extern "C" int sarpro_hip_resize_output_dims(size_t cols, size_t rows, size_t ta
 
 namespace {
 
-int upload_coeffs(sarpro_hip_ctx *ctx, const ResizeCoeffs &c, DevBuf &buf, ResizePassArgs *a) {
-    const size_t n = c.out_size, kb = c.k.size() * sizeof(int32_t);
+// Coefficient tables of one axis on the device, cached on the context by (in, out, element size): the
+// two bands of a scene (and every scene of a batch with the same shape) reuse them.
+int get_coeffs(sarpro_hip_ctx *ctx, int slot, uint32_t in_size, uint32_t out_size, int elem_size, ResizePassArgs *a) {
+    auto &key = ctx->resize_key[slot];
+    DevBuf &buf = ctx->resize_coef[slot];
+    const size_t n = out_size;
+    if (key[0] == in_size && key[1] == out_size && key[2] == (uint32_t)elem_size && buf.p) {
+        a->start = buf.as<uint32_t>();
+        a->size = buf.as<uint32_t>() + n;
+        a->k = reinterpret_cast<const int32_t *>(buf.as<uint8_t>() + n * 8);
+        a->in_size = in_size; a->out_size = out_size; a->precision = (int)key[3];
+        return SARPRO_HIP_OK;
+    }
+    ResizeCoeffs c;
+    build_resize_coeffs(in_size, out_size, elem_size, &c);
+    const size_t kb = c.k.size() * sizeof(int32_t);
     const size_t bytes = n * 8 + kb;
     HIPCHK(ctx, buf.reserve(bytes));
     HIPCHK(ctx, ctx->h_upload.reserve(std::max<size_t>(bytes, 2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024)));
@@ -57,6 +71,7 @@ int upload_coeffs(sarpro_hip_ctx *ctx, const ResizeCoeffs &c, DevBuf &buf, Resiz
     a->size = buf.as<uint32_t>() + n;
     a->k = reinterpret_cast<const int32_t *>(buf.as<uint8_t>() + n * 8);
     a->in_size = c.in_size; a->out_size = c.out_size; a->precision = c.precision;
+    key[0] = in_size; key[1] = out_size; key[2] = (uint32_t)elem_size; key[3] = (uint32_t)c.precision;
     return SARPRO_HIP_OK;
 }
 
@@ -95,12 +110,9 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     // horizontal pass -> intermediate (rows x nc), vertical pass -> destination window
     const size_t tmp_pitch = round_up(nc, 64);
     HIPCHK(ctx, ctx->resize_tmp.reserve(rows * tmp_pitch * elem_size));
-    ResizeCoeffs ch, cv;
-    build_resize_coeffs((uint32_t)cols, (uint32_t)nc, elem_size, &ch);
-    build_resize_coeffs((uint32_t)rows, (uint32_t)nr, elem_size, &cv);
     ResizePassArgs ah{}, av{};
-    RETCHK(upload_coeffs(ctx, ch, ctx->resize_coef[0], &ah));
-    RETCHK(upload_coeffs(ctx, cv, ctx->resize_coef[1], &av));
+    RETCHK(get_coeffs(ctx, 0, (uint32_t)cols, (uint32_t)nc, elem_size, &ah));
+    RETCHK(get_coeffs(ctx, 1, (uint32_t)rows, (uint32_t)nr, elem_size, &av));
     ah.src = d_in; ah.src_pitch = in_pitch; ah.dst = ctx->resize_tmp.p; ah.dst_pitch = tmp_pitch;
     ah.max_val = elem_size == 1 ? 255u : 65535u;
     av.src = ctx->resize_tmp.p; av.src_pitch = tmp_pitch; av.dst = dst; av.dst_pitch = out_pitch;
