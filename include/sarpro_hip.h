@@ -171,6 +171,31 @@ int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *b
                                           size_t cols, int strategy, int mode, size_t target_size, int pad,
                                           uint8_t *rgb_out, sarpro_hip_resize_meta *meta);
 
+/* save_processed_image (save.rs:23-170) up to the raster its writer receives: pipeline at native
+ * resolution -> resize -> pad, on the device.  `out` holds final_rows * final_cols u8 / u16 elements.
+ * The multiband TIFF branch (save.rs:200-316) is this call once per band. */
+int sarpro_hip_process_band_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols, int strategy,
+                                        int bit_depth, size_t target_size, int pad, void *out,
+                                        sarpro_hip_resize_meta *meta);
+int sarpro_hip_process_band_resized_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols, int strategy,
+                                        int bit_depth, size_t target_size, int pad, void *out,
+                                        sarpro_hip_resize_meta *meta);
+
+/* Batch mode (api/mod.rs:474-536 process_directory_to_path; BatchReport :453-458) for scenes already
+ * decoded into host memory: one worker thread + context per listed device (a device may be listed
+ * more than once), scenes dealt dynamically, no collective.  continue_on_error = 0 stops handing out
+ * scenes after the first failure (the rest count as skipped) and returns that failure's status. */
+typedef struct {
+    const uint16_t *band1, *band2; /* rows x cols each */
+    size_t rows, cols;
+    uint8_t *rgb_out;              /* final_rows * final_cols * 3 (sarpro_hip_resize_output_dims) */
+    int *status_out;               /* optional per-scene status */
+} sarpro_hip_batch_scene;
+typedef struct { size_t processed, skipped, errors; } sarpro_hip_batch_report;
+int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, const sarpro_hip_batch_scene *scenes,
+                                                size_t nscenes, int strategy, int mode, size_t target_size, int pad,
+                                                int continue_on_error, sarpro_hip_batch_report *report);
+
 /* ================= device-pointer entry points ================= */
 /* Same operations on rasters already resident in HBM.  pitch = row stride in elements
  * (>= cols).  The vectorised kernels need base pointers aligned to 16 bytes and

@@ -33,6 +33,15 @@ class ResizeMeta(C.Structure):
                 ("pad_left", C.c_size_t), ("pad_top", C.c_size_t)]
 
 
+class BatchScene(C.Structure):
+    _fields_ = [("band1", C.c_void_p), ("band2", C.c_void_p), ("rows", C.c_size_t), ("cols", C.c_size_t),
+                ("rgb_out", C.c_void_p), ("status_out", C.POINTER(C.c_int))]
+
+
+class BatchReport(C.Structure):  # api/mod.rs:453-458
+    _fields_ = [("processed", C.c_size_t), ("skipped", C.c_size_t), ("errors", C.c_size_t)]
+
+
 # every symbol include/sarpro_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "sarpro_hip_ctx_create", "sarpro_hip_ctx_destroy", "sarpro_hip_last_error", "sarpro_hip_version",
@@ -53,7 +62,8 @@ SYMBOLS = [
     "sarpro_hip_host_stats_from_bins4096", "sarpro_hip_host_f32_valid_threshold", "sarpro_hip_host_f32_bin4096_thresholds",
     "sarpro_hip_host_f32_level_thresholds", "sarpro_hip_host_f32_clahe_bin_thresholds",
     "sarpro_hip_resize_output_dims", "sarpro_hip_resize_image_data", "sarpro_hip_resize_image_data_dev",
-    "sarpro_hip_dualpol_synrgb_resized_u16",
+    "sarpro_hip_dualpol_synrgb_resized_u16", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
+    "sarpro_hip_batch_dualpol_synrgb_resized_u16",
     "sarpro_hip_synth_scene_u16_dev",
 ]
 
@@ -148,3 +158,7 @@ _proto("sarpro_hip_resize_output_dims", _i, _sz, _sz, _sz, _i, C.POINTER(_sz), C
 _proto("sarpro_hip_resize_image_data", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _M)
 _proto("sarpro_hip_resize_image_data_dev", _i, _vp, _vp, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _M)
 _proto("sarpro_hip_dualpol_synrgb_resized_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
+_proto("sarpro_hip_process_band_resized_u16", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
+_proto("sarpro_hip_process_band_resized_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
+_proto("sarpro_hip_batch_dualpol_synrgb_resized_u16", _i, C.POINTER(_i), _i, C.POINTER(BatchScene), _sz, _i, _i, _sz, _i, _i,
+       C.POINTER(BatchReport))

@@ -220,6 +220,21 @@ class Context:
                                                             target_size or 0, int(pad), _vp(rgb), C.byref(m)))
         return rgb, m
 
+    def save_processed_image_raster(self, processed: np.ndarray, bit_depth: BitDepth, strategy: AutoscaleStrategy,
+                                    target_size: int | None, pad: bool):
+        """save_processed_image (save.rs:23-170) up to the raster its writer receives -> (raster, ResizeMeta)."""
+        from ._lib import ResizeMeta
+        rows, cols = processed.shape
+        fc, fr = resize_output_dims(cols, rows, target_size, pad)
+        out = np.empty((fr, fc), np.uint8 if bit_depth == BitDepth.U8 else np.uint16)
+        m = ResizeMeta()
+        if processed.dtype == np.uint16:
+            x, fn = np.ascontiguousarray(processed), lib.sarpro_hip_process_band_resized_u16
+        else:
+            x, fn = np.ascontiguousarray(processed, np.float32), lib.sarpro_hip_process_band_resized_f32
+        self._chk(fn(self._h, _vp(x), rows, cols, int(strategy), int(bit_depth), target_size or 0, int(pad), _vp(out), C.byref(m)))
+        return out, m
+
     # ------------------------------------------------------------------ device-pointer variants
     def dev_autoscale_band_u16(self, d_in: int, rows: int, cols: int, in_pitch: int, strategy, bit_depth,
                                d_out: int, out_pitch: int) -> Stats:
@@ -432,3 +447,29 @@ def resize_output_dims(cols: int, rows: int, target_size: int | None, pad: bool)
     if rc:
         raise SarproHipError(rc, "resize_output_dims")
     return fc.value, fr.value
+
+
+def batch_dualpol_synrgb_resized(devices, scenes, strategy, target_size, pad, mode=SyntheticRgbMode.Default,
+                                 continue_on_error: bool = True):
+    """process_directory_to_path semantics (api/mod.rs:474-536) for in-memory scenes.
+    scenes: list of (band1_u16, band2_u16).  Returns (list of RGB arrays or None, BatchReport, statuses)."""
+    from ._lib import BatchReport, BatchScene
+    n = len(scenes)
+    arr = (BatchScene * max(n, 1))()
+    keep, outs, stats = [], [], (C.c_int * max(n, 1))()
+    for i, (b1, b2) in enumerate(scenes):
+        b1 = np.ascontiguousarray(b1, np.uint16)
+        b2 = np.ascontiguousarray(b2, np.uint16)
+        rows, cols = b1.shape
+        fc, fr = resize_output_dims(cols, rows, target_size, pad)
+        rgb = np.empty((fr, fc, 3), np.uint8)
+        keep.append((b1, b2))
+        outs.append(rgb)
+        arr[i] = BatchScene(b1.ctypes.data, b2.ctypes.data if b2.shape == b1.shape else None, rows, cols, rgb.ctypes.data,
+                            C.cast(C.byref(stats, i * C.sizeof(C.c_int)), C.POINTER(C.c_int)))
+    dev = (C.c_int * len(devices))(*devices)
+    rep = BatchReport()
+    rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_u16(dev, len(devices), arr, n, int(strategy), int(mode), target_size or 0,
+                                                         int(pad), int(continue_on_error), C.byref(rep))
+    st = [stats[i] for i in range(n)]
+    return [o if s == 0 else None for o, s in zip(outs, st)], rep, st, rc

@@ -1,0 +1,123 @@
+// batch.cpp -- save.rs orchestration without the writers, and the batch driver.
+//   * sarpro_hip_process_band_resized_*: save_processed_image (save.rs:23-170) up to the raster the
+//     writer receives: pipeline -> resize -> pad, device-resident.
+//   * sarpro_hip_batch_dualpol_synrgb_resized_u16: process_directory_to_path semantics
+//     (api/mod.rs:474-536; cli/runner.rs:277-345) for in-memory scenes: scenes are dealt to one worker
+//     thread per GPU (no collective: scenes are independent), failures are counted and -- with
+//     continue_on_error -- do not stop the batch (BatchReport, api/mod.rs:453-458).
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "internal.h"
+
+using namespace sarpro;
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+            return e__ == hipErrorOutOfMemory ? SARPRO_HIP_ERR_OOM : SARPRO_HIP_ERR_HIP;          \
+        }                                                                                         \
+    } while (0)
+#define RETCHK(expr)                                   \
+    do {                                               \
+        int rc__ = (expr);                             \
+        if (rc__ != SARPRO_HIP_OK) return rc__;        \
+    } while (0)
+
+static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static int process_band_resized(sarpro_hip_ctx *ctx, const void *in, bool is_f32, size_t rows, size_t cols, int strategy,
+                                int bit_depth, size_t target_size, int pad, void *out, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if (rows * cols && (!in || !out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    const size_t esz = bit_depth == SARPRO_BITDEPTH_U8 ? 1 : 2;
+    size_t pitch = 0, fc = 0, fr = 0;
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[0], in, rows, cols, is_f32 ? 4 : 2, &pitch));
+    HIPCHK(ctx, ctx->stage_out[1].reserve(std::max<size_t>(rows, 1) * pitch * esz));
+    // process_scalar_data_pipeline at native resolution (save.rs:52)
+    if (is_f32)
+        RETCHK(sarpro_hip_autoscale_band_f32_dev(ctx, ctx->stage_in[0].as<float>(), rows, cols, pitch, strategy, bit_depth,
+                                                 ctx->stage_out[1].p, pitch, nullptr));
+    else
+        RETCHK(sarpro_hip_autoscale_band_u16_dev(ctx, ctx->stage_in[0].as<uint16_t>(), rows, cols, pitch, strategy, bit_depth,
+                                                 ctx->stage_out[1].p, pitch, nullptr));
+    // resize_image_data_with_meta (save.rs:54-63)
+    RETCHK(sarpro_hip_resize_output_dims(cols, rows, target_size, pad, &fc, &fr));
+    const size_t opitch = round_up(std::max<size_t>(fc, 1), 64);
+    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max<size_t>(fr, 1) * opitch * esz));
+    sarpro_hip_resize_meta m{};
+    RETCHK(resize_pad_dev(ctx, ctx->stage_out[1].p, cols, rows, pitch, target_size, (int)esz, pad, ctx->stage_out[0].p, opitch, &m));
+    if (meta) *meta = m;
+    return fetch_out_2d(ctx, out, ctx->stage_out[0].p, opitch * esz, fc * esz, fr);
+}
+
+extern "C" int sarpro_hip_process_band_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols, int strategy,
+                                                   int bit_depth, size_t target_size, int pad, void *out,
+                                                   sarpro_hip_resize_meta *meta) {
+    return process_band_resized(ctx, in, false, rows, cols, strategy, bit_depth, target_size, pad, out, meta);
+}
+
+extern "C" int sarpro_hip_process_band_resized_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols, int strategy,
+                                                   int bit_depth, size_t target_size, int pad, void *out,
+                                                   sarpro_hip_resize_meta *meta) {
+    return process_band_resized(ctx, in, true, rows, cols, strategy, bit_depth, target_size, pad, out, meta);
+}
+
+extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, const sarpro_hip_batch_scene *scenes,
+                                                           size_t nscenes, int strategy, int mode, size_t target_size, int pad,
+                                                           int continue_on_error, sarpro_hip_batch_report *report) {
+    if (!devices || ndevices <= 0 || (!scenes && nscenes) || !report) return SARPRO_HIP_ERR_INVALID_ARG;
+    std::memset(report, 0, sizeof(*report));
+    std::atomic<size_t> next{0}, processed{0}, errors{0};
+    std::atomic<bool> stop{false};
+    std::atomic<int> first_error{SARPRO_HIP_OK};
+    std::vector<int> status(nscenes, SARPRO_HIP_OK);
+    auto worker = [&](int dev) {
+        sarpro_hip_ctx *ctx = nullptr;
+        int rc = sarpro_hip_ctx_create(dev, 0, &ctx);
+        if (rc != SARPRO_HIP_OK) { // this worker cannot run; the others take its share
+            int expected = SARPRO_HIP_OK;
+            first_error.compare_exchange_strong(expected, rc);
+            return;
+        }
+        for (;;) {
+            if (stop.load()) break;
+            const size_t i = next.fetch_add(1);
+            if (i >= nscenes) break;
+            const sarpro_hip_batch_scene &sc = scenes[i];
+            rc = sarpro_hip_dualpol_synrgb_resized_u16(ctx, sc.band1, sc.band2, sc.rows, sc.cols, strategy, mode, target_size, pad,
+                                                       sc.rgb_out, nullptr);
+            status[i] = rc;
+            if (rc == SARPRO_HIP_OK) {
+                processed.fetch_add(1);
+            } else {
+                errors.fetch_add(1);
+                int expected = SARPRO_HIP_OK;
+                first_error.compare_exchange_strong(expected, rc);
+                if (!continue_on_error) stop.store(true); // api/mod.rs:518-526
+            }
+        }
+        sarpro_hip_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> pool;
+    for (int d = 0; d < ndevices; ++d) pool.emplace_back(worker, devices[d]);
+    for (auto &t : pool) t.join();
+    report->processed = processed.load();
+    report->errors = errors.load();
+    report->skipped = nscenes - report->processed - report->errors; // not attempted after a fatal error
+    for (size_t i = 0; i < nscenes && scenes; ++i)
+        if (scenes[i].status_out) *scenes[i].status_out = status[i];
+    if (report->errors && !continue_on_error) return first_error.load();
+    if (report->processed + report->errors == 0 && nscenes) return first_error.load() ? first_error.load() : SARPRO_HIP_ERR_NO_DEVICE;
+    return SARPRO_HIP_OK;
+}

@@ -67,3 +67,39 @@ def test_dualpol_resized_flow_matches_oracle(ctx, strategy, target, pad):
         u8.append(oracle.resize_image_data_with_meta(u, target, pad)[0])
     ref = oracle.synrgb(0, int(strategy), u8[0], u8[1])
     assert rgb.shape == ref.shape and np.array_equal(rgb, ref)
+
+
+@pytest.mark.parametrize("strategy", [St.Standard, St.Clahe])
+@pytest.mark.parametrize("bit_depth", [0, 1])
+@pytest.mark.parametrize("kind", ["u16", "f32"])
+def test_save_processed_image_raster(ctx, strategy, bit_depth, kind):
+    """save_processed_image (save.rs:23-170) minus the writer: pipeline -> resize -> pad."""
+    import f32data
+    from sarpro_amd import BitDepth
+    x = synth.scene_u16(300, 410, 0) if kind == "u16" else f32data.resampled_scene(300, 410)
+    got, m = ctx.save_processed_image_raster(x, BitDepth(bit_depth), strategy, 128, True)
+    rc, full = oracle.pipeline(x.astype(np.float32), bit_depth, int(strategy))
+    ref, mo = oracle.resize_image_data_with_meta(full, 128, True)
+    assert rc == 0 and np.array_equal(got, ref)
+    assert (m.pad_left, m.pad_top, m.scale_x, m.scale_y) == (mo["pad_left"], mo["pad_top"], mo["scale_x"], mo["scale_y"])
+
+
+def test_batch_driver_counts_and_continues_on_error(ctx):
+    """Batch semantics of api/mod.rs:474-536: independent scenes over worker contexts, failures counted."""
+    import sarpro_amd as S
+    scenes = []
+    for k in range(5):
+        scenes.append((synth.scene_u16(200, 260, 0, seed=synth.SEED_SCENE_A + k), synth.scene_u16(200, 260, 1, seed=synth.SEED_SCENE_A + k)))
+    bad = (synth.scene_u16(9, 64, 0), synth.scene_u16(9, 64, 1))  # CLAHE tile underflow: the reference panics on it
+    scenes.insert(2, bad)
+    outs, rep, st, rc = S.batch_dualpol_synrgb_resized([0, 0], scenes, St.Clahe, 96, True, continue_on_error=True)
+    assert rc == 0 and (rep.processed, rep.errors, rep.skipped) == (5, 1, 0)
+    assert st[2] == S._lib.ERR_UNSUPPORTED_SHAPE and outs[2] is None
+    for i, (b1, b2) in enumerate(scenes):
+        if i == 2:
+            continue
+        u8 = [oracle.resize_image_data_with_meta(oracle.pipeline(b.astype(np.float32), 0, int(St.Clahe))[1], 96, True)[0] for b in (b1, b2)]
+        assert np.array_equal(outs[i], oracle.synrgb(0, int(St.Clahe), u8[0], u8[1])), i
+    # stop-on-error: one worker, the failing scene first -> nothing else is attempted
+    outs, rep, st, rc = S.batch_dualpol_synrgb_resized([0], [bad] + scenes[:2], St.Clahe, 96, True, continue_on_error=False)
+    assert rc == S._lib.ERR_UNSUPPORTED_SHAPE and (rep.processed, rep.errors, rep.skipped) == (0, 1, 2)
