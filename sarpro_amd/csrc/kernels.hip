@@ -586,6 +586,7 @@ __global__ __launch_bounds__(kBlock) void k_lut_apply_u16(LutApplyArgs a) {
 // ------------------------------------------------------------------------------------
 constexpr int kComposeBlock = 1024; // 66 KiB of tables per block -> 2 blocks (32 waves) per CU
 constexpr int kComposeTableBytes = 512 + 65536;
+constexpr int kComposeStageBytes = (kComposeBlock / kWave) * 3072; // per-wave 3 KiB transpose stage (VEC = 16)
 
 template <int VEC>
 __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
@@ -597,37 +598,70 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
     }
     __syncthreads();
     const uint8_t *R2 = lds_raw, *G2 = lds_raw + 256, *B2 = lds_raw + 512;
+    // per-wave stage: a lane's 48 output bytes are interleaved RGB of ITS 16 pixels; written straight
+    // to memory each of the three 16-B stores of a wave would touch 64 separate 48-B-strided pieces.
+    // Staging them in LDS and reading back lane-linear makes every store instruction 1 KiB contiguous.
+    uint4 *stage = reinterpret_cast<uint4 *>(lds_raw + kComposeTableBytes + (threadIdx.x >> 6) * 3072);
+    const int lane = threadIdx.x & 63;
     const uint32_t vpr = (a.cols + VEC - 1) / VEC;
     const uint64_t total = (uint64_t)a.rows * vpr;
-    for (uint64_t idx = (uint64_t)blockIdx.x * kComposeBlock + threadIdx.x; idx < total;
-         idx += (uint64_t)gridDim.x * kComposeBlock) {
-        const uint32_t r = (uint32_t)(idx / vpr);
-        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
-        const uint8_t *p1 = a.b1 + (size_t)r * a.in_pitch + col;
-        const uint8_t *p2 = a.b2 + (size_t)r * a.in_pitch + col;
-        uint8_t *po = a.rgb + ((size_t)r * a.rgb_pitch_px + col) * 3;
-        if (VEC == 16 && col + VEC <= a.cols) {
-            const uint4 q1 = *reinterpret_cast<const uint4 *>(p1);
-            const uint4 q2 = *reinterpret_cast<const uint4 *>(p2);
-            const uint32_t w1[4] = {q1.x, q1.y, q1.z, q1.w}, w2[4] = {q2.x, q2.y, q2.z, q2.w};
+    const uint64_t nwaves = (uint64_t)gridDim.x * (kComposeBlock / kWave);
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (kComposeBlock / kWave) + (threadIdx.x >> 6);
+    if (VEC == 16) {
+        // a wave owns 64 consecutive vectors of one row (1024 px); rows are walked wave-wide so the
+        // transposed stores stay inside one row
+        const uint32_t wpr = (vpr + 63) / 64; // wave-chunks per row
+        const uint64_t chunks = (uint64_t)a.rows * wpr;
+        for (uint64_t ch = wave0; ch < chunks; ch += nwaves) {
+            const uint32_t r = (uint32_t)(ch / wpr);
+            const uint32_t v0 = (uint32_t)(ch - (uint64_t)r * wpr) * 64;
+            const uint32_t v = v0 + lane;
+            const uint32_t col = v * 16;
+            const bool fullv = col + 16 <= a.cols;
+            const uint32_t nfull = (a.cols / 16 > v0) ? min(64u, a.cols / 16 - v0) : 0u; // full vectors in this chunk (prefix)
             uint32_t o[12];
+            if (fullv) {
+                const uint4 q1 = *reinterpret_cast<const uint4 *>(a.b1 + (size_t)r * a.in_pitch + col);
+                const uint4 q2 = *reinterpret_cast<const uint4 *>(a.b2 + (size_t)r * a.in_pitch + col);
+                const uint32_t w1[4] = {q1.x, q1.y, q1.z, q1.w}, w2[4] = {q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { // 4 px -> 12 bytes -> 3 dwords
-                uint32_t px[4][3];
+                for (int g = 0; g < 4; ++g) { // 4 px -> 12 bytes -> 3 dwords
+                    uint32_t px[4][3];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t v1 = (w1[g] >> (8 * j)) & 0xFF, v2 = (w2[g] >> (8 * j)) & 0xFF;
-                    px[j][0] = R2[v1]; px[j][1] = G2[v2]; px[j][2] = B2[(v1 << 8) | v2];
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t v1 = (w1[g] >> (8 * j)) & 0xFF, v2 = (w2[g] >> (8 * j)) & 0xFF;
+                        px[j][0] = R2[v1]; px[j][1] = G2[v2]; px[j][2] = B2[(v1 << 8) | v2];
+                    }
+                    o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
+                    o[3 * g + 1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
+                    o[3 * g + 2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
                 }
-                o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
-                o[3 * g + 1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
-                o[3 * g + 2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+                stage[lane * 3 + 0] = make_uint4(o[0], o[1], o[2], o[3]);
+                stage[lane * 3 + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+                stage[lane * 3 + 2] = make_uint4(o[8], o[9], o[10], o[11]);
             }
-            uint4 *d = reinterpret_cast<uint4 *>(po);
-            d[0] = make_uint4(o[0], o[1], o[2], o[3]);
-            d[1] = make_uint4(o[4], o[5], o[6], o[7]);
-            d[2] = make_uint4(o[8], o[9], o[10], o[11]);
-        } else {
+            // (same wave wrote and reads the stage: program order inside a wave, no barrier needed)
+            uint8_t *rowp = a.rgb + ((size_t)r * a.rgb_pitch_px + (size_t)v0 * 16) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t slot = k * 64 + lane; // 16-B slot of the chunk's 3 * nfull slots
+                if (slot < nfull * 3) reinterpret_cast<uint4 *>(rowp)[slot] = stage[slot];
+            }
+            if (!fullv && col < a.cols) { // ragged tail of the row: scalar
+                const uint8_t *p1 = a.b1 + (size_t)r * a.in_pitch + col, *p2 = a.b2 + (size_t)r * a.in_pitch + col;
+                uint8_t *po = a.rgb + ((size_t)r * a.rgb_pitch_px + col) * 3;
+                for (uint32_t j = 0; col + j < a.cols; ++j) {
+                    const uint32_t v1 = p1[j], v2 = p2[j];
+                    po[3 * j + 0] = R2[v1]; po[3 * j + 1] = G2[v2]; po[3 * j + 2] = B2[(v1 << 8) | v2];
+                }
+            }
+        }
+    } else {
+        for (uint64_t idx = (uint64_t)blockIdx.x * kComposeBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kComposeBlock) {
+            const uint32_t r = (uint32_t)(idx / vpr);
+            const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
+            const uint8_t *p1 = a.b1 + (size_t)r * a.in_pitch + col, *p2 = a.b2 + (size_t)r * a.in_pitch + col;
+            uint8_t *po = a.rgb + ((size_t)r * a.rgb_pitch_px + col) * 3;
             for (int j = 0; j < VEC && col + j < a.cols; ++j) {
                 const uint32_t v1 = p1[j], v2 = p2[j];
                 po[3 * j + 0] = R2[v1]; po[3 * j + 1] = G2[v2]; po[3 * j + 2] = B2[(v1 << 8) | v2];
@@ -826,8 +860,8 @@ hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s) {
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
     const uint64_t items = (uint64_t)a.rows * ((a.cols + vec - 1) / vec);
     dim3 grid(stream_grid(items, kComposeBlock, 2));
-    if (vec == 16) hipLaunchKernelGGL(k_compose_u8<16>, grid, dim3(kComposeBlock), kComposeTableBytes, s, a);
-    else hipLaunchKernelGGL(k_compose_u8<1>, grid, dim3(kComposeBlock), kComposeTableBytes, s, a);
+    if (vec == 16) hipLaunchKernelGGL(k_compose_u8<16>, grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
+    else hipLaunchKernelGGL(k_compose_u8<1>, grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
     return hipGetLastError();
 }
 
