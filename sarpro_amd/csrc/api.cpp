@@ -173,7 +173,7 @@ extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **na
 namespace sarpro {
 
 static void push_strips(std::vector<Rect> &out, const StripePlan &P, size_t lo, size_t hi, size_t c0, size_t c1,
-                        const int ids[4], size_t chunk_rows, int vecw) {
+                        const int ids[4], size_t chunk_rows, int vecw, int flags = 0) {
     if (lo >= hi || c0 >= c1) return;
     const size_t strip = 64 * (size_t)vecw;
     for (size_t cs = c0 / vecw * vecw; cs < c1; cs += strip) {
@@ -182,6 +182,7 @@ static void push_strips(std::vector<Rect> &out, const StripePlan &P, size_t lo, 
         r.c1 = (int32_t)std::min(c1, cs + strip);
         r.cstart = (int32_t)cs;
         for (int k = 0; k < 4; ++k) r.id[k] = ids[k];
+        r.pad[0] = flags;
         for (size_t rr = lo; rr < hi; rr += chunk_rows) {
             r.r0 = (int32_t)(rr - P.row0);
             r.r1 = (int32_t)(std::min(rr + chunk_rows, hi) - P.row0);
@@ -193,10 +194,10 @@ static void push_strips(std::vector<Rect> &out, const StripePlan &P, size_t lo, 
 // Global rows [gr0, gr1) x columns [c0, c1) clipped to the local stripe -> work items.  With
 // `sliver` given (vecw == 8) the aligned interior goes to `out`, the edge leftovers to `sliver`.
 static void add_rects(std::vector<Rect> &out, std::vector<Rect> *sliver, const StripePlan &P, size_t gr0, size_t gr1,
-                      size_t c0, size_t c1, const int ids[4], size_t chunk_rows, int vecw) {
+                      size_t c0, size_t c1, const int ids[4], size_t chunk_rows, int vecw, int flags = 0) {
     const size_t lo = std::max(gr0, P.row0), hi = std::min(gr1, P.row0 + P.rows_local);
     if (lo >= hi || c0 >= c1) return;
-    if (!sliver) { push_strips(out, P, lo, hi, c0, c1, ids, chunk_rows, vecw); return; }
+    if (!sliver) { push_strips(out, P, lo, hi, c0, c1, ids, chunk_rows, vecw, flags); return; }
     const size_t a = (c0 + vecw - 1) / vecw * vecw, b = c1 / vecw * vecw; // aligned interior [a, b)
     if (a < b) {
         push_strips(out, P, lo, hi, a, b, ids, chunk_rows, vecw);
@@ -252,7 +253,12 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
             const RowWeight &cw = g.col_w[c0];
             const int ids[4] = {rw.t0 * kTiles + cw.t0, rw.t0 * kTiles + cw.t1, rw.t1 * kTiles + cw.t0,
                                 rw.t1 * kTiles + cw.t1};
-            add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw);
+            // bit 0: the cell holds negative blend weights (dy < 0 or dx < 0: the first half tile extrapolates,
+            // autoscale.rs:308-313) -- the speculative apply kernel widens its f32 error margin there
+            bool neg = false;
+            for (size_t r = r0; r < r1 && !neg; ++r) neg = g.row_w[r].d < 0.0;
+            for (size_t c = c0; c < c1 && !neg; ++c) neg = g.col_w[c].d < 0.0;
+            add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw, neg ? 1 : 0);
         }
     }
     // launch order = sweep order: consecutive work items cover adjacent column strips of the same row

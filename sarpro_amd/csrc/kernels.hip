@@ -159,19 +159,22 @@ __global__ __launch_bounds__(kBlock) void k_dn_hist_u16_interior(DnHistArgs a) {
         const int step = kWavesPerBlock;
         const uint16_t *p = in + col;
         int r = rc.r0 + wave_id();
-        U16Vec<VEC> a0{}, a1{};
-        if (r < rc.r1) a0 = U16Vec<VEC>::load(p + (size_t)r * a.pitch);
-        if (r + step < rc.r1) a1 = U16Vec<VEC>::load(p + (size_t)(r + step) * a.pitch);
-        for (; r < rc.r1; r += 2 * step) {
-            U16Vec<VEC> b0{}, b1{};
-            if (r + 2 * step < rc.r1) b0 = U16Vec<VEC>::load(p + (size_t)(r + 2 * step) * a.pitch);
-            if (r + 3 * step < rc.r1) b1 = U16Vec<VEC>::load(p + (size_t)(r + 3 * step) * a.pitch);
-            em.apply(a0);
-            em.apply(a1);
-            consume(a0);
-            if (r + step < rc.r1) consume(a1);
-            a0 = b0;
-            a1 = b1;
+        // loads are unconditional (row index clamped to the item's last row) so the compiler can keep two
+        // rows in flight behind a counted vmcnt; rows past the end are loaded redundantly but not consumed
+        if (r < rc.r1) {
+            const int last = rc.r1 - 1;
+            U16Vec<VEC> a0 = U16Vec<VEC>::load(p + (size_t)r * a.pitch);
+            U16Vec<VEC> a1 = U16Vec<VEC>::load(p + (size_t)min(r + step, last) * a.pitch);
+            for (; r < rc.r1; r += 2 * step) {
+                const U16Vec<VEC> b0 = U16Vec<VEC>::load(p + (size_t)min(r + 2 * step, last) * a.pitch);
+                const U16Vec<VEC> b1 = U16Vec<VEC>::load(p + (size_t)min(r + 3 * step, last) * a.pitch);
+                em.apply(a0);
+                em.apply(a1);
+                consume(a0);
+                if (r + step < rc.r1) consume(a1);
+                a0 = b0;
+                a1 = b1;
+            }
         }
     }
     __syncthreads();
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //       entry (entry 256 is all-zero and is where DN = 0 points, so invalid pixels need no
 //       branch) -> one 16-B gather of the four CDFs as f32 -> 6 f32 FMAs -> floor.
 //     The f32 result decides the level unless o*255 lies within kSpecDelta of an integer; those
-//     pixels (~0.4 %) are recomputed with the reference's exact f64 sequence (CDFs and column
+//     pixels (~0.1 % in interior cells) are recomputed with the reference's exact f64 sequence (CDFs and column
 //     weights as f64 in LDS), so the raster is bit-identical to kernel 4's.
 //     Error bound of the f32 value y32 against the reference's y = o*255 (u = 2^-24):
 //       inputs are the f64 CDFs / weights rounded once to f32 (1+e, |e| <= u); with
@@ -360,14 +363,17 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //       the same for bottom, and |top|, |bottom| <= 2;  the row weights hold the 255 factor
 //       (2 roundings), p = (top, bottom) * wy adds one more, the final add one more:
 //       |y32 - y| <= 255 (|1-dy| + |dy|) (8u + 3u*2) + u |y|  <=  255*2*14u + 1020u  =  4.9e-4.
-//     kSpecDelta = 1/512 = 1.95e-3 leaves a 4x margin on that worst case (interior cells, where
-//     the weights are in [0,1], are 4x tighter still): outside it floor(y32) = floor(y), inside
-//     it the exact path decides.  The reference's own f64 rounding (1e-13) is far below it.
-//     y32 == 0 exactly happens only when every product is exactly zero in f64 too (f32 rounding
-//     never flushes these operands to zero), so an exact zero is decided (level 0) directly.
+//     In interior cells (every weight in [0,1], S <= 1, weight pairs sum to 1) the same steps give
+//       |dtop| <= 4u, |y32 - y| <= 255 (4u + 3u) + 255u = 255*8u = 1.2e-4.
+//     The margin is therefore chosen per work item: kSpecDeltaEdge = 1/512 = 1.95e-3 where the cell
+//     extrapolates (first half tile row / column), kSpecDeltaInner = 1/2048 = 4.9e-4 elsewhere --
+//     4x the respective worst case.  Outside the margin floor(y32) = floor(y), inside it the exact
+//     path decides.  The reference's own f64 rounding (1e-13) is far below it.
+//     All-zero and all-one CDF entries, whose exact results are known, get biased f32 entries that land
+//     mid-interval (see the staging code), so they never reach the exact path.
 //     Level 0 goes to a per-lane dummy histogram word (bin 0 = pixels - other bins, on the host).
 // ------------------------------------------------------------------------------------
-constexpr float kSpecDelta = 1.0f / 512.0f;
+constexpr float kSpecDeltaEdge = 1.0f / 512.0f, kSpecDeltaInner = 1.0f / 2048.0f;
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr uint32_t kSpecLutMaxEntries = 16384; // u16 offsets: 32 KiB of LDS at most
@@ -401,64 +407,64 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         omdxf[j] = (float)(1.0 - d);
     }
     const uint32_t dummy = SpecLds::hist + (256u + (uint32_t)lane_id()) * 4u;
+    const float near_thr = 0.5f - ((rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner); // pad[0] bit 0: extrapolating cell
 
     auto process_row = [&](int r, const U16Vec<VEC> &v) {
         const double dy = *reinterpret_cast<const double *>(lds + SpecLds::roww + (r - rc.r0) * 8); // wave-uniform
         const double omdy = 1.0 - dy;
-        const v2f wy = {(float)omdy * 255.0f, (float)dy * 255.0f};
-        uint32_t lv[VEC], off[VEC];
-        uint32_t pend = 0;
+        const float wy1 = (float)omdy * 255.0f, wy2 = (float)dy * 255.0f;
+        uint32_t off[VEC];
+        float fr[VEC];
+        uint32_t pk[2] = {0u, 0u}; // the 8 levels, packed as they will be stored
+        float worst = 0.0f;        // max |frac - 0.5| over the lane's pixels: one compare decides "all certain"
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const uint32_t i = min(v.get(j), win_hi);
             off[j] = LUT_LDS ? (uint32_t)*reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u)
-                             : (i ? (uint32_t)glut[i] * 16u : 256u * 16u);
+                             : SpecLds::cdf32 + (i ? (uint32_t)glut[i] * 16u : 256u * 16u);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const v4f c4 = *reinterpret_cast<const v4f *>(lds + SpecLds::cdf32 + off[j]);
-            const v2f a0 = {c4.x, c4.y}, a1 = {c4.z, c4.w};
-            const v2f tb = __builtin_elementwise_fma(a1, v2f{dxf[j], dxf[j]}, a0 * v2f{omdxf[j], omdxf[j]}); // (top, bottom)
-            const v2f p = tb * wy;
-            const float y = p.x + p.y;
-            const float fr = __builtin_amdgcn_fractf(y);           // y - floor(y)
-            lv[j] = (uint32_t)min(max((int)floorf(y), 0), 255);
-            const bool near = fabsf(fr - 0.5f) > 0.5f - kSpecDelta && y != 0.0f;
-            pend |= (near ? 1u : 0u) << j;
+            const float4 c4 = *reinterpret_cast<const float4 *>(lds + off[j]); // (c00, c10, c01, c11)
+            const float top = fmaf(c4.z, dxf[j], c4.x * omdxf[j]);
+            const float bottom = fmaf(c4.w, dxf[j], c4.y * omdxf[j]);
+            const float y = fmaf(bottom, wy2, top * wy1);
+            const float f = __builtin_amdgcn_fractf(y); // y - floor(y)
+            fr[j] = f;
+            pk[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(y - f, j & 3, pk[j >> 2]); // floor(y) saturated to 0..255
+            worst = fmaxf(worst, fabsf(f - 0.5f));
         }
-        while (pend) { // exact recomputation (reference op order, autoscale.rs:327-329, 602)
-            const int j = __ffs(pend) - 1;
-            pend &= pend - 1;
-            uint32_t o8 = off[0];
+        if (worst > near_thr) { // rare: some pixel of this lane lies within the margin of an integer -> exact path
 #pragma unroll
-            for (int jj = 1; jj < VEC; ++jj) o8 = (jj == j) ? off[jj] : o8;
-            const double4 c4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + o8 * 2u);
-            const double dx = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
-            const double top = c4.x * (1.0 - dx) + c4.y * dx;
-            const double bottom = c4.z * (1.0 - dx) + c4.w * dx;
-            double o = top * omdy + bottom * dy;
-            o = fmin(fmax(o, 0.0), 1.0);
-            const uint32_t level = (uint32_t)(o * 255.0);
-#pragma unroll
-            for (int jj = 0; jj < VEC; ++jj) lv[jj] = (jj == j) ? level : lv[jj];
+            for (int j = 0; j < VEC; ++j) {
+                if (fabsf(fr[j] - 0.5f) > near_thr) { // reference op order (autoscale.rs:327-329, 602)
+                    const double4 c4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + (off[j] - SpecLds::cdf32) * 2u);
+                    const double dx = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
+                    const double top = c4.x * (1.0 - dx) + c4.y * dx;
+                    const double bottom = c4.z * (1.0 - dx) + c4.w * dx;
+                    double o = top * omdy + bottom * dy;
+                    o = fmin(fmax(o, 0.0), 1.0);
+                    const uint32_t level = (uint32_t)(o * 255.0);
+                    const uint32_t sh = 8 * (j & 3);
+                    pk[j >> 2] = (pk[j >> 2] & ~(0xFFu << sh)) | (level << sh);
+                }
+            }
         }
         if (count_levels) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const uint32_t h = lv[j] ? SpecLds::hist + lv[j] * 4u : dummy;
+                const uint32_t lv = (pk[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const uint32_t h = lv ? SpecLds::hist + lv * 4u : dummy;
                 atomicAdd(reinterpret_cast<uint32_t *>(lds + h), 1u);
             }
         }
         uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out[band]) + (size_t)r * a.out_pitch + col;
         if (full) {
-            uint2 pk;
-            pk.x = lv[0] | (lv[1] << 8) | (lv[2] << 16) | (lv[3] << 24);
-            pk.y = lv[4] | (lv[5] << 8) | (lv[6] << 16) | (lv[7] << 24);
-            *reinterpret_cast<uint2 *>(o8) = pk;
+            *reinterpret_cast<uint2 *>(o8) = make_uint2(pk[0], pk[1]);
         } else {
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                if (em.keep(j)) o8[j] = (uint8_t)lv[j];
+                if (em.keep(j)) o8[j] = (uint8_t)(pk[j >> 2] >> (8 * (j & 3)));
         }
     };
 
@@ -466,13 +472,17 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         const int step = kWavesPerBlock;
         const uint16_t *p = in + col;
         int r = rc.r0 + wave_id();
-        U16Vec<VEC> cur{}, nxt{};
-        if (r < rc.r1) cur = U16Vec<VEC>::load(p + (size_t)r * a.in_pitch);
-        for (; r < rc.r1; r += step) {
-            if (r + step < rc.r1) nxt = U16Vec<VEC>::load(p + (size_t)(r + step) * a.in_pitch);
-            em.apply(cur);
-            process_row(r, cur);
-            cur = nxt;
+        // the next row is always loaded (clamped to the item's last row: at worst one redundant load), so the
+        // load is unconditional and the compiler can wait with vmcnt(1) -- a conditional prefetch made it wait
+        // vmcnt(0) right after issuing it, i.e. no overlap at all inside a wave
+        if (r < rc.r1) {
+            U16Vec<VEC> cur = U16Vec<VEC>::load(p + (size_t)r * a.in_pitch);
+            for (; r < rc.r1; r += step) {
+                const U16Vec<VEC> nxt = U16Vec<VEC>::load(p + (size_t)min(r + step, rc.r1 - 1) * a.in_pitch);
+                em.apply(cur);
+                process_row(r, cur);
+                cur = nxt;
+            }
         }
     }
 }
@@ -493,11 +503,26 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = cdfs[(size_t)rc.id[k] * 256 + b];
         *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + b * 32) = make_double4(c[0], c[1], c[2], c[3]);
-        // f32 copy laid out (c00, c10 | c01, c11): (top, bottom) = (x,y)*(1-dx) + (z,w)*dx are two packed-f32 ops
-        *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + b * 16) = make_float4((float)c[0], (float)c[2], (float)c[1], (float)c[3]);
+        // f32 copy laid out (c00, c10 | c01, c11): (top, bottom) = (x,y)*(1-dx) + (z,w)*dx are two packed-f32 ops.
+        // Saturated bins (all four CDFs exactly 1.0: at least the top bin, i.e. every pixel above p99) blend
+        // to y = 255 +- rounding, which the margin test would send to the exact path for ~1 % of all pixels.
+        // In an interior cell their exact result is known: with dx in [0,1), fl(fl(1-dx) + dx) = 1.0 exactly
+        // (the error of fl(1-dx) is at most half an ulp of the result and ties round to even), likewise
+        // for dy, so o = 1.0 and the level is 255.  Their f32 entry is therefore biased to 1.001: y32 = 255.25
+        // floors (and clamps) to 255 and is never "near".  Extrapolating cells keep the exact path.
+        const bool saturated = c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0 && !(rc.pad[0] & 1);
+        // Bins whose four CDFs are all exactly 0 (and entry 256, where invalid pixels point) have the exact
+        // result 0 whatever the weights; their f32 entry is k = 0.5/255 so that y32 = 0.5 (weights sum to 1):
+        // level 0, never "near" -- no separate zero test per pixel.
+        const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
+        const float kz = 0.5f / 255.0f;
+        *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + b * 16) =
+            saturated ? make_float4(1.001f, 1.001f, 1.001f, 1.001f)
+            : zero    ? make_float4(kz, kz, kz, kz)
+                      : make_float4((float)c[0], (float)c[2], (float)c[1], (float)c[3]);
         if (b == 0) {
             *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + 256 * 32) = make_double4(0.0, 0.0, 0.0, 0.0);
-            *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + 256 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + 256 * 16) = make_float4(kz, kz, kz, kz);
         }
         for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
         for (int i = b; i < rc.r1 - rc.r0; i += kBlock) // exact dy of this item's rows (<= 256 rows per item)
@@ -508,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
         }
         uint16_t *lut = reinterpret_cast<uint16_t *>(lds + SpecLds::lut);
         if (lut_lds)
-            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(i ? (uint32_t)glut[i] * 16u : 256u * 16u);
+            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(SpecLds::cdf32 + (i ? (uint32_t)glut[i] * 16u : 256u * 16u));
     }
     __syncthreads();
     if (lut_lds) clahe_spec_rows<true>(a, rc, band, lds, win_hi);
