@@ -34,6 +34,29 @@ pub struct sarpro_hip_stats {
     pub skew_factor: f64, pub tail_heaviness: f64,
 }
 
+/// Bookkeeping of `resize_image_data_with_meta` (resize.rs:98-108).
+#[repr(C)]
+#[derive(Debug, Default, Clone, Copy)]
+pub struct sarpro_hip_resize_meta {
+    pub final_cols: usize, pub final_rows: usize,
+    pub scale_x: f64, pub scale_y: f64,
+    pub pad_left: usize, pub pad_top: usize,
+}
+
+/// One scene of a batch (`process_directory_to_path`, api/mod.rs:474-536).
+#[repr(C)]
+pub struct sarpro_hip_batch_scene {
+    pub band1: *const u16, pub band2: *const u16,
+    pub rows: usize, pub cols: usize,
+    pub rgb_out: *mut u8,
+    pub status_out: *mut c_int,
+}
+
+/// `BatchReport` (api/mod.rs:453-458).
+#[repr(C)]
+#[derive(Debug, Default, Clone, Copy)]
+pub struct sarpro_hip_batch_report { pub processed: usize, pub skipped: usize, pub errors: usize }
+
 pub const SARPRO_HIP_OK: c_int = 0;
 pub const SARPRO_HIP_ERR_UNSUPPORTED_SHAPE: c_int = -3;
 
@@ -59,6 +82,19 @@ extern "C" {
     pub fn sarpro_hip_dualpol_synrgb_u16(ctx: *mut sarpro_hip_ctx, band1: *const u16, band2: *const u16, rows: usize,
         cols: usize, strategy: c_int, mode: c_int, rgb_out: *mut u8, u8_band1: *mut u8, u8_band2: *mut u8,
         stats_out: *mut sarpro_hip_stats) -> c_int;
+    pub fn sarpro_hip_resize_output_dims(cols: usize, rows: usize, target_size: usize, pad: c_int,
+        final_cols: *mut usize, final_rows: *mut usize) -> c_int;
+    pub fn sarpro_hip_resize_image_data(ctx: *mut sarpro_hip_ctx, data: *const c_void, cols: usize, rows: usize,
+        target_size: usize, bit_depth: c_int, pad: c_int, out: *mut c_void, meta: *mut sarpro_hip_resize_meta) -> c_int;
+    pub fn sarpro_hip_process_band_resized_f32(ctx: *mut sarpro_hip_ctx, input: *const f32, rows: usize, cols: usize,
+        strategy: c_int, bit_depth: c_int, target_size: usize, pad: c_int, out: *mut c_void,
+        meta: *mut sarpro_hip_resize_meta) -> c_int;
+    pub fn sarpro_hip_dualpol_synrgb_resized_u16(ctx: *mut sarpro_hip_ctx, band1: *const u16, band2: *const u16,
+        rows: usize, cols: usize, strategy: c_int, mode: c_int, target_size: usize, pad: c_int, rgb_out: *mut u8,
+        meta: *mut sarpro_hip_resize_meta) -> c_int;
+    pub fn sarpro_hip_batch_dualpol_synrgb_resized_u16(devices: *const c_int, ndevices: c_int,
+        scenes: *const sarpro_hip_batch_scene, nscenes: usize, strategy: c_int, mode: c_int, target_size: usize,
+        pad: c_int, continue_on_error: c_int, report: *mut sarpro_hip_batch_report) -> c_int;
     // device-pointer, stripe, comm and host-half entry points: see include/sarpro_hip.h
     pub fn sarpro_hip_ctx_stream(ctx: *mut sarpro_hip_ctx) -> *mut c_void;
 }
@@ -145,6 +181,35 @@ impl RasterCore {
         self.chk(unsafe { sarpro_hip_dualpol_synrgb_f32(self.ctx, b1.as_ptr(), b2.as_ptr(), rows, cols, strategy, mode,
             rgb.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut()) })?;
         Ok(rgb)
+    }
+}
+
+impl RasterCore {
+    /// `resize_image_data_with_meta` (resize.rs:91) for a u8 raster: returns (final_cols, final_rows, data, meta).
+    pub fn resize_image_data_u8(&self, data: &[u8], cols: usize, rows: usize, target_size: Option<usize>, pad: bool)
+        -> Result<(usize, usize, Vec<u8>, sarpro_hip_resize_meta), HipError> {
+        let (mut fc, mut fr) = (0usize, 0usize);
+        self.chk(unsafe { sarpro_hip_resize_output_dims(cols, rows, target_size.unwrap_or(0), pad as c_int, &mut fc, &mut fr) })?;
+        let mut out = vec![0u8; fc * fr];
+        let mut meta = sarpro_hip_resize_meta::default();
+        self.chk(unsafe { sarpro_hip_resize_image_data(self.ctx, data.as_ptr() as *const c_void, cols, rows,
+            target_size.unwrap_or(0), 0, pad as c_int, out.as_mut_ptr() as *mut c_void, &mut meta) })?;
+        Ok((fc, fr, out, meta))
+    }
+
+    /// The whole JPEG branch of `save_processed_multiband_image_sequential` (save.rs:317-367) for u16 GRD bands:
+    /// autoscale -> resize -> pad -> synRGB on the device; returns (final_cols, final_rows, rgb, meta).
+    pub fn dualpol_synrgb_resized_u16(&self, band1: &[u16], band2: &[u16], rows: usize, cols: usize, strategy: i32,
+        mode: i32, target_size: Option<usize>, pad: bool) -> Result<(usize, usize, Vec<u8>, sarpro_hip_resize_meta), HipError> {
+        assert_eq!(band1.len(), rows * cols);
+        assert_eq!(band2.len(), rows * cols);
+        let (mut fc, mut fr) = (0usize, 0usize);
+        self.chk(unsafe { sarpro_hip_resize_output_dims(cols, rows, target_size.unwrap_or(0), pad as c_int, &mut fc, &mut fr) })?;
+        let mut rgb = vec![0u8; fc * fr * 3];
+        let mut meta = sarpro_hip_resize_meta::default();
+        self.chk(unsafe { sarpro_hip_dualpol_synrgb_resized_u16(self.ctx, band1.as_ptr(), band2.as_ptr(), rows, cols, strategy,
+            mode, target_size.unwrap_or(0), pad as c_int, rgb.as_mut_ptr(), &mut meta) })?;
+        Ok((fc, fr, rgb, meta))
     }
 }
 

@@ -74,3 +74,40 @@ def test_oracle_matches_committed_golden_vectors():
     # the synthetic scene exercises all four Standard arms across the fixtures
     gammas = {float(g[f"stats_{n}_s0_b0"][18]) for n in ins}
     assert {1.0, 0.9} <= gammas
+
+
+def test_oracle_resize_is_lanczos3_within_fixed_point_error():
+    # smooth image (no clipping in the intermediate): the integer pipeline stays within 1 LSB of float Lanczos3
+    y, x = np.mgrid[0:240, 0:360]
+    a = (127.5 + 100 * np.sin(x / 17.0) * np.cos(y / 23.0)).astype(np.uint8)
+    out, _ = oracle.resize_image_data_with_meta(a, 90, False)
+
+    def coef(n_in, n_out):
+        scale = n_in / n_out; fs = max(scale, 1.0); rad = 3 * fs
+        res = []
+        for ox in range(n_out):
+            c = (ox + 0.5) * scale
+            x0, x1 = int(max(np.floor(c - rad), 0)), int(min(np.ceil(c + rad), n_in))
+            t = (np.arange(x0, x1) - (c - 0.5)) / fs
+            w = np.where((t >= -3) & (t < 3), np.sinc(t) * np.sinc(t / 3), 0.0)
+            res.append((x0, w / w.sum()))
+        return res
+    H, V = coef(360, 90), coef(240, 60)
+    tmp = np.stack([(a[:, x0:x0 + len(w)] * w).sum(1) for x0, w in H], 1)
+    ref = np.stack([(tmp[x0:x0 + len(w)] * w[:, None]).sum(0) for x0, w in V], 0)
+    assert out.shape == (60, 90)
+    assert np.abs(out.astype(np.float64) - ref).max() <= 1.0
+
+
+def test_resize_dimension_and_padding_rules():
+    # resize.rs:6-30 / padding.rs:5-49 / resize.rs:110-145 (already at the requested long side -> no resample)
+    a = np.arange(12 * 20, dtype=np.uint8).reshape(12, 20)
+    out, m = oracle.resize_image_data_with_meta(a, 20, True)
+    assert out.shape == (20, 20) and m["pad_top"] == 4 and m["pad_left"] == 0 and m["scale_x"] == 1.0
+    assert np.array_equal(out[4:16], a) and not out[:4].any() and not out[16:].any()
+    out, m = oracle.resize_image_data_with_meta(a, None, False)
+    assert np.array_equal(out, a) and (m["final_cols"], m["final_rows"]) == (20, 12)
+    out, m = oracle.resize_image_data_with_meta(a, 10, False)
+    assert out.shape == (6, 10) and m["scale_x"] == 0.5 and m["scale_y"] == 0.5
+    out, m = oracle.resize_image_data_with_meta(a, 100, False)   # target larger than the image: dimensions kept
+    assert out.shape == (12, 20)
