@@ -141,7 +141,7 @@ def main():
         kern = {k: v for k, v in total_ms.items() if not k.startswith("host:")}  # host:* entries are wall-clock segments
         dom = max(kern, key=kern.get) if kern else None
         # algorithmic bytes per pixel PER LAUNCH (both bands), DESIGN.md section 4
-        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0}
+        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0}
         roofline = None
         if dom:
             local_px = rows_local * cols
@@ -177,7 +177,7 @@ def pmc_traffic_gb(kernel, local_px):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r1_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied), scaled
     to this run's pixel count.  None when the kernel has no committed measurement."""
-    names = {"clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_u16_interior",
+    names = {"clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_u16_interior",
              "compose_u8": "k_compose_u8", "lut_apply_u16": "k_lut_apply_u16"}
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:

@@ -504,12 +504,12 @@ static int job_phase3(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch)
         if (u8o) HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
         const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out[0]) && (J.nbands < 2 || ptr_aligned16(a.out[1]));
         if (vec != J.vec) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
-        {
+        if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands)) {
+            KernelTimer t(ctx, "clahe_apply_u8_spec");
+            HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
+        } else {
             KernelTimer t(ctx, "clahe_apply_u16");
-            if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands))
-                HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
-            else
-                HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, J.vec, !u8o, ctx->stream));
+            HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, J.vec, !u8o, ctx->stream));
         }
         if (J.vec && !J.plan->apply_sliver.empty()) { // < 8-column leftovers at cell edges: scalar exact kernel
             a.rects = J.plan->d_apply_sliver.as<Rect>();
@@ -742,7 +742,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
     HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
     {
-        KernelTimer t(ctx, "clahe_apply_u16");
+        KernelTimer t(ctx, "clahe_apply_u8_spec");
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
     }
     {
