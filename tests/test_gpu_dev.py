@@ -207,3 +207,24 @@ def test_full_size_400mp_parity_by_decomposition(ctx):
         exp = torch.stack([R[a], G[b], B[a * 256 + b]], dim=-1)
         exp[water] = 0
         assert torch.equal(img[r0:r0 + 2500], exp)
+
+
+def test_library_rccl_communicator_single_rank():
+    """The library-owned RCCL communicator (dlopen'ed librccl, ncclAllReduce(sum, u64) on the context's
+    stream) driving the stripe protocol; one rank is all a 1-GPU box offers, the N-rank arithmetic is
+    covered by test_row_stripes_are_bit_identical_to_one_piece and the gloo test."""
+    rows, cols = 300, 392
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    rc, rrgb, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(St.Clahe))
+    with S.Context(0) as c:
+        c.comm_init(1, 0, S.comm_unique_id())
+        pitch = 448
+        d = [dev_u16(x, pitch) for x in b]
+        rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+        s = c.stripe_begin_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, 0, rows, pitch, St.Clahe, Mode.Default)
+        c.comm_allreduce_sum_u64(*s.phase1())
+        c.comm_allreduce_sum_u64(*s.phase2())
+        c.comm_allreduce_sum_u64(*s.phase3())
+        s.phase4(rgb.data_ptr(), pitch)
+        s.end()
+        assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb)
