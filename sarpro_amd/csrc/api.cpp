@@ -789,9 +789,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     }
     // size the LDS offset table of the NEXT scene from this scene's window (speed only: a window larger
     // than the capacity is gathered from global memory, with identical results)
-    uint32_t cap = 2048;
-    while (cap < hi + 1 && cap < 16384) cap *= 2;
-    ctx->chain_lut_cap = cap;
+    ctx->chain_lut_cap = std::min<uint32_t>(16384, std::max<uint32_t>(1024, (hi + 1 + 255) / 256 * 256));
     return SARPRO_HIP_OK;
 }
 

@@ -379,10 +379,27 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr uint32_t kSpecLutMaxEntries = 16384; // u16 offsets: 32 KiB of LDS at most
 
+// The f32 CDF table is stored kCdfCopies times, interleaved so that copy c only occupies the 16-B slot
+// classes {c, c+R, ...} of each 256-B LDS row; lane l reads copy l % R.  A ds_read_b128 services 16 lanes
+// per cycle group and every such group holds exactly 16/R lanes of each residue, so lanes of different
+// copies can never collide and the random per-pixel bins only conflict among 16/R lanes instead of 16.
+// Measured on MI355X (400 MP scene): R = 2 costs 4 KiB of LDS per workgroup, which drops residency from
+// 6 to 5 workgroups per CU, and the kernel gets SLOWER (0.78 -> 0.82 ms): it is more sensitive to resident
+// waves than to gather conflicts.  Kept as a tunable; 1 = a single copy.
+constexpr uint32_t kCdfCopies = 1;
+constexpr uint32_t kCdfPerRow = 16 / kCdfCopies;                         // entries per 256-B row
+constexpr uint32_t kCdf32Bytes = ((257 + kCdfPerRow - 1) / kCdfPerRow) * 256;
+__host__ __device__ constexpr uint32_t cdf32_offset(uint32_t entry) {    // byte offset of copy 0 of `entry`
+    return (entry / kCdfPerRow) * 256u + (entry % kCdfPerRow) * kCdfCopies * 16u;
+}
+__host__ __device__ constexpr uint32_t cdf32_entry(uint32_t offset) {    // inverse of cdf32_offset
+    return (offset / 256u) * kCdfPerRow + (offset % 256u) / (kCdfCopies * 16u);
+}
+
 struct SpecLds { // byte offsets into dynamic LDS
     static constexpr uint32_t cdf64 = 0;                      // [257][4] double
-    static constexpr uint32_t cdf32 = 257 * 32;               // [257] float4
-    static constexpr uint32_t colw = cdf32 + 257 * 16 + 16;   // [512] double: exact dx of the strip's columns
+    static constexpr uint32_t cdf32 = 257 * 32 + 224;         // kCdfCopies interleaved copies of [257] float4 (256-B aligned)
+    static constexpr uint32_t colw = cdf32 + kCdf32Bytes;     // [512] double: exact dx of the strip's columns
     static constexpr uint32_t hist = colw + 512 * 8;          // [256 + 64] u32
     static constexpr uint32_t roww = hist + (256 + 64) * 4;   // [256] double: exact dy of the item's rows
     static constexpr uint32_t lut = roww + 256 * 8;           // [lut_cap] u16
@@ -408,6 +425,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         omdxf[j] = (float)(1.0 - d);
     }
     const uint32_t dummy = SpecLds::hist + (256u + (uint32_t)lane_id()) * 4u;
+    const uint32_t copy_off = ((uint32_t)lane_id() & (kCdfCopies - 1)) * 16u; // this lane's copy of the f32 CDF table
     const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner; // pad[0] bit 0: extrapolating cell
 
     auto process_row = [&](int r, const U16Vec<VEC> &v) {
@@ -422,11 +440,11 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         for (int j = 0; j < VEC; ++j) {
             const uint32_t i = min(v.get(j), win_hi);
             off[j] = LUT_LDS ? (uint32_t)*reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u)
-                             : SpecLds::cdf32 + (i ? (uint32_t)glut[i] * 16u : 256u * 16u);
+                             : SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(lds + off[j]); // (c00, c10, c01, c11)
+            const float4 c4 = *reinterpret_cast<const float4 *>(lds + off[j] + copy_off); // (c00, c10, c01, c11)
             const float top = fmaf(c4.z, dxf[j], c4.x * omdxf[j]);
             const float bottom = fmaf(c4.w, dxf[j], c4.y * omdxf[j]);
             // ym = y - 0.5: v_cvt_pk_u8_f32 rounds to nearest-even and saturates, so cvt(ym) = floor(y) clamped to
@@ -441,7 +459,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 if (fr[j] < near_delta) { // reference op order (autoscale.rs:327-329, 602)
-                    const double4 c4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + (off[j] - SpecLds::cdf32) * 2u);
+                    const double4 c4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + cdf32_entry(off[j] - SpecLds::cdf32) * 32u);
                     const double dx = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
                     const double top = c4.x * (1.0 - dx) + c4.y * dx;
                     const double bottom = c4.z * (1.0 - dx) + c4.w * dx;
@@ -519,13 +537,17 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
         // level 0, never "near" -- no separate zero test per pixel.
         const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
         const float kz = 0.5f / 255.0f;
-        *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + b * 16) =
-            saturated ? make_float4(1.001f, 1.001f, 1.001f, 1.001f)
-            : zero    ? make_float4(kz, kz, kz, kz)
-                      : make_float4((float)c[0], (float)c[2], (float)c[1], (float)c[3]);
+        const float4 e32 = saturated ? make_float4(1.001f, 1.001f, 1.001f, 1.001f)
+                           : zero    ? make_float4(kz, kz, kz, kz)
+                                     : make_float4((float)c[0], (float)c[2], (float)c[1], (float)c[3]);
+#pragma unroll
+        for (uint32_t cc = 0; cc < kCdfCopies; ++cc)
+            *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + cdf32_offset(b) + cc * 16) = e32;
         if (b == 0) {
             *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + 256 * 32) = make_double4(0.0, 0.0, 0.0, 0.0);
-            *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + 256 * 16) = make_float4(kz, kz, kz, kz);
+#pragma unroll
+            for (uint32_t cc = 0; cc < kCdfCopies; ++cc)
+                *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + cdf32_offset(256) + cc * 16) = make_float4(kz, kz, kz, kz);
         }
         for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
         for (int i = b; i < rc.r1 - rc.r0; i += kBlock) // exact dy of this item's rows (<= 256 rows per item)
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
         }
         uint16_t *lut = reinterpret_cast<uint16_t *>(lds + SpecLds::lut);
         if (lut_lds)
-            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(SpecLds::cdf32 + (i ? (uint32_t)glut[i] * 16u : 256u * 16u));
+            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u));
     }
     __syncthreads();
     if (lut_lds) clahe_spec_rows<true>(a, rc, band, lds, win_hi);
