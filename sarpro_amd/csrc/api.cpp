@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <string>
 
 #include "chain_kernels.h"
@@ -392,7 +393,8 @@ static int job_after_phase1(U16Job &J) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
     HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
-    for (int b = 0; b < J.nbands; ++b) {
+    // the bands are independent: band 1 is worked on by a helper thread while this thread does band 0
+    auto band_work = [&J, ctx](int b) -> int {
         uint64_t *h = ctx->h_ghist.as<uint64_t>() + (size_t)b * 65536;
         { // the interior kernel does not count DN = 0: it is what is left of the scene
             uint64_t others = 0;
@@ -403,13 +405,21 @@ static int job_after_phase1(U16Job &J) {
         RETCHK(select_window(&J.stats[b], J.strategy, J.tamed_kind(b)));
         if (J.clahe()) build_clahe_bin_lut_u16(J.stats[b], &J.lut[b]);
         else build_level_lut_u16(J.stats[b], J.u8_out() ? SARPRO_BITDEPTH_U8 : SARPRO_BITDEPTH_U16, J.tamed_kind(b), &J.lut[b]);
-
         if (!J.clahe() && J.u8_out()) {
             // levels are a function of DN: their histogram, min and max follow from the DN histogram
             std::memset(J.level_hist_h[b], 0, sizeof(J.level_hist_h[b]));
             for (uint32_t dn = 0; dn < 65536; ++dn)
                 if (h[dn]) J.level_hist_h[b][dn ? J.lut[b].full[dn] : 0] += h[dn];
         }
+        return SARPRO_HIP_OK;
+    };
+    if (J.nbands == 2) {
+        std::future<int> other = std::async(std::launch::async, band_work, 1);
+        const int rc0 = band_work(0), rc1 = other.get();
+        if (rc0) return rc0;
+        if (rc1) return rc1;
+    } else {
+        RETCHK(band_work(0));
     }
     return SARPRO_HIP_OK;
 }
@@ -553,9 +563,18 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
     if (u8o) for (int b = 0; b < J.nbands; ++b) job_rescale_from_level_hist(J, b);
 
     uint8_t *up = ctx->h_upload.as<uint8_t>();
+    // dual-pol percentile strategies without per-band outputs: ONE fused pass DN,DN -> RGB (7 B/px), no
+    // intermediate u8 rasters
+    bool fused = false;
+    if (!J.clahe() && J.synrgb && !d_out[0] && !d_out[1] && J.vec && J.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 &&
+        ptr_aligned16(d_rgb) && !getenv("SARPRO_HIP_NO_FUSED")) {
+        LutComposeArgs probe{};
+        probe.win_hi[0] = J.lut[0].win_hi; probe.win_hi[1] = J.lut[1].win_hi;
+        fused = lut_compose_fits(probe);
+    }
     if (!J.clahe()) {
         // table apply: final = resc[level[DN]] (u8) or level[DN] (u16)
-        const bool need_levels = J.synrgb && (d_out[0] == nullptr || d_out[1] == nullptr);
+        const bool need_levels = !fused && J.synrgb && (d_out[0] == nullptr || d_out[1] == nullptr);
         if (need_levels) RETCHK(ensure_levels(J));
         for (int b = 0; b < J.nbands; ++b) {
             LutApplyArgs a{};
@@ -574,6 +593,7 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
             void *d_lut = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
             HIPCHK(ctx, hipMemcpyAsync(d_lut, stage, 65536 * esz, hipMemcpyHostToDevice, ctx->stream));
             a.lut = d_lut;
+            if (fused) continue; // the tables are consumed by the fused pass below
             const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out);
             KernelTimer t(ctx, "lut_apply_u16");
             HIPCHK(ctx, launch_lut_apply_u16(a, vec, !u8o, ctx->stream));
@@ -617,6 +637,22 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
     std::memcpy(tstage, tables.data(), 66048);
     HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tstage, 66048, hipMemcpyHostToDevice, ctx->stream));
 
+    if (fused) {
+        LutComposeArgs f{};
+        for (int b = 0; b < 2; ++b) {
+            f.in[b] = J.d_in[b];
+            f.lut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+            f.win_hi[b] = J.lut[b].win_hi;
+        }
+        f.rgb = d_rgb; f.in_pitch = J.in_pitch; f.rgb_pitch_px = rgb_pitch_px; f.rows = rows; f.cols = cols;
+        f.tables = ctx->tables.as<uint8_t>();
+        {
+            KernelTimer t(ctx, "lut_compose_u16");
+            HIPCHK(ctx, launch_lut_compose_u16(f, ctx->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return SARPRO_HIP_OK;
+    }
     ComposeArgs c{};
     if (J.clahe()) { c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch; }
     else if (d_out[0] && d_out[1]) { c.b1 = (const uint8_t *)d_out[0]; c.b2 = (const uint8_t *)d_out[1]; c.in_pitch = out_pitch; }

@@ -85,6 +85,17 @@ hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, 
 constexpr uint32_t kChainLutEntries = 8192; // LDS offset-table capacity when the window is only known on the device
 hipError_t launch_lut_apply_u16(const LutApplyArgs &a, bool vec, bool out16, hipStream_t s);
 hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s);
+struct LutComposeArgs {
+    const uint16_t *in[kMaxBands];
+    uint8_t *rgb;
+    size_t in_pitch, rgb_pitch_px;   // elements / pixels; multiples of 16, 16-byte aligned bases
+    uint32_t rows, cols;
+    const uint8_t *lut[kMaxBands];   // full 65536-entry DN -> final u8 tables (entry 0 = invalid pixels)
+    uint32_t win_hi[kMaxBands];      // the tables are constant from win_hi on
+    const uint8_t *tables;           // R2[256] | G2[256] | B2[65536]
+};
+bool lut_compose_fits(const LutComposeArgs &a);
+hipError_t launch_lut_compose_u16(const LutComposeArgs &a, hipStream_t s);
 hipError_t launch_polop_f32(int op, const float *a, const float *b, size_t n, float *out, hipStream_t s);
 hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q /*[4][65536]*/,
                                   size_t rows_total, size_t cols, size_t row0, size_t rows_local,

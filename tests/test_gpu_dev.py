@@ -228,3 +228,25 @@ def test_library_rccl_communicator_single_rank():
         s.phase4(rgb.data_ptr(), pitch)
         s.end()
         assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb)
+
+
+@pytest.mark.parametrize("strategy", [St.Standard, St.Robust, St.Adaptive, St.Equalized, St.Tamed, St.Default])
+@pytest.mark.parametrize("shape", [(200, 320), (150, 273)])
+def test_fused_lut_compose_pass_equals_unfused(ctx, strategy, shape, monkeypatch):
+    """Percentile strategies, dual-pol, no per-band outputs: one fused DN,DN -> RGB kernel (7 B/px).
+    It must equal the oracle and the unfused path (SARPRO_HIP_NO_FUSED=1), incl. ragged row tails."""
+    rows, cols = shape
+    pitch = (cols + 63) // 64 * 64
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    rc, rrgb, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(strategy))
+    d = [dev_u16(x, pitch) for x in b]
+    for no_fused in ("0", "1"):
+        monkeypatch.setenv("SARPRO_HIP_NO_FUSED", no_fused)
+        if no_fused == "0":
+            monkeypatch.delenv("SARPRO_HIP_NO_FUSED")
+        rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+        with S.Context(0, timing=True) as c:
+            c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, Mode.Default, rgb.data_ptr(), pitch)
+            names = [n for n, _ in c.last_kernel_times()]
+        assert ("lut_compose_u16" in names) == (no_fused == "0")
+        assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb), (strategy, no_fused)
