@@ -141,7 +141,7 @@ def main():
         kern = {k: v for k, v in total_ms.items() if not k.startswith("host:")}  # host:* entries are wall-clock segments
         dom = max(kern, key=kern.get) if kern else None
         # algorithmic bytes per pixel PER LAUNCH (both bands), DESIGN.md section 4
-        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0}
+        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0, "lut_compose_u16": 7.0}
         roofline = None
         if dom:
             local_px = rows_local * cols
@@ -159,7 +159,7 @@ def main():
             "scaling": "strong" if (args.mode == "stripe" and world > 1) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"dual-pol u16 {rows}x{cols} scene resident in HBM -> dB + {strategy.name} autoscale u8 x2 "
-                                   f"-> synRGB (suppressed) interleaved u8, native resolution (save.rs:317-367)",
+                                   f"-> synRGB ({'suppressed' if strategy.name in ('Clahe', 'Tamed') else 'default'} variant) interleaved u8, native resolution (save.rs:317-367)",
                        "mode": args.mode if world > 1 else "single", "rows": rows, "cols": cols,
                        "scenes_per_step": scenes_per_step},
             "roofline": roofline,
@@ -178,7 +178,7 @@ def pmc_traffic_gb(kernel, local_px):
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied), scaled
     to this run's pixel count.  None when the kernel has no committed measurement."""
     names = {"clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_u16_interior",
-             "compose_u8": "k_compose_u8", "lut_apply_u16": "k_lut_apply_u16"}
+             "compose_u8": "k_compose_u8", "lut_apply_u16": "k_lut_apply_u16", "lut_compose_u16": "k_lut_compose_u16"}
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
             t = json.load(f)
