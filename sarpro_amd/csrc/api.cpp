@@ -376,10 +376,14 @@ static int job_phase1(U16Job &J) {
         KernelTimer t(ctx, "dn_hist_u16_sliver");
         HIPCHK(ctx, launch_dn_hist_u16(a, ns, J.nbands, false, ctx->stream));
     }
-    for (int b = 0; b < J.nbands; ++b) {
+    {
+        SumTileHistArgs sa{};
+        for (int b = 0; b < J.nbands; ++b) {
+            sa.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+            sa.out[b] = ctx->ghist.as<unsigned long long>() + (size_t)b * 65536;
+        }
         KernelTimer t(ctx, "sum_tile_hists");
-        HIPCHK(ctx, launch_sum_tile_hists(ctx->tile_hist[b].as<uint32_t>(), ntiles,
-                                          ctx->ghist.as<unsigned long long>() + (size_t)b * 65536, ctx->stream));
+        HIPCHK(ctx, launch_sum_tile_hists(sa, ntiles, J.nbands, ctx->stream));
     }
     return SARPRO_HIP_OK;
 }

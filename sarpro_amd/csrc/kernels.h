@@ -70,8 +70,11 @@ struct ComposeArgs {
 
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);
 hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nbands, hipStream_t s);
-hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned long long *out,
-                                 hipStream_t s);
+struct SumTileHistArgs {
+    const uint32_t *tile_hist[kMaxBands]; // [ntiles][65536]
+    unsigned long long *out[kMaxBands];   // [65536]
+};
+hipError_t launch_sum_tile_hists(const SumTileHistArgs &a, int ntiles, int nbands, hipStream_t s);
 struct TileBinHistArgs {
     const uint32_t *tile_hist[kMaxBands]; // [ntiles][65536]
     const uint8_t *binlut[kMaxBands];     // [65536]

@@ -187,12 +187,12 @@ __global__ __launch_bounds__(kBlock) void k_dn_hist_u16_interior(DnHistArgs a) {
 // ------------------------------------------------------------------------------------
 // 2. Sum the per-tile histograms into the band's global 65536-bin histogram (u64).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_sum_tile_hists(const uint32_t *__restrict__ th, int ntiles,
-                                                           unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_sum_tile_hists(SumTileHistArgs a, int ntiles) {
+    const uint32_t *__restrict__ th = a.tile_hist[blockIdx.y];
     const uint32_t dn = blockIdx.x * kBlock + threadIdx.x;
     unsigned long long s = 0;
     for (int t = 0; t < ntiles; ++t) s += th[(size_t)t * 65536u + dn];
-    out[dn] = s;
+    a.out[blockIdx.y][dn] = s;
 }
 
 // ------------------------------------------------------------------------------------
@@ -914,8 +914,8 @@ hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nban
     return hipGetLastError();
 }
 
-hipError_t launch_sum_tile_hists(const uint32_t *tile_hist, int ntiles, unsigned long long *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_tile_hists, dim3(65536 / kBlock), dim3(kBlock), 0, s, tile_hist, ntiles, out);
+hipError_t launch_sum_tile_hists(const SumTileHistArgs &a, int ntiles, int nbands, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_tile_hists, dim3(65536 / kBlock, nbands), dim3(kBlock), 0, s, a, ntiles);
     return hipGetLastError();
 }
 
