@@ -696,7 +696,8 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
 // (chain_kernels.hip), so there is ONE stream synchronisation per scene, at the end.
 // ---------------------------------------------------------------------------------------
 constexpr size_t kChainOffDb = 0, kChainOffSupp = 65536 * 8, kChainOffBlue = kChainOffSupp + 21504;
-constexpr size_t kChainConstBytes = kChainOffBlue + 65536;
+constexpr size_t kChainOffBlueDef = kChainOffBlue + 65536, kChainOffDefRg = kChainOffBlueDef + 65536;
+constexpr size_t kChainOffGamma = kChainOffDefRg + 512, kChainConstBytes = kChainOffGamma + 3 * 256 * 8;
 constexpr size_t kStateOffResc = 2 * sizeof(ChainBandState), kStateOffIdent = kStateOffResc + 512,
                  kStateOffFloor = kStateOffIdent + 16, kStateBytes = kStateOffFloor + 16;
 
@@ -708,6 +709,11 @@ static int chain_prepare(sarpro_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemcpyAsync(d + kChainOffDb, db_table_u16(), 65536 * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d + kChainOffSupp, synrgb_supp_rg_tables(), 41 * 512, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d + kChainOffBlue, synrgb_blue_pair_supp(), 65536, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d + kChainOffBlueDef, synrgb_blue_pair_default(), 65536, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint8_t> dflt(66048);
+    synrgb_luts_default(dflt.data());
+    HIPCHK(ctx, hipMemcpyAsync(d + kChainOffDefRg, dflt.data(), 512, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d + kChainOffGamma, gamma_level_thresholds_u8(), 3 * 256 * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->chain_ready = true;
     return SARPRO_HIP_OK;
@@ -796,6 +802,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         fa.supp_rg = consts + kChainOffSupp;
         fa.blue_pair_supp = consts + kChainOffBlue;
         fa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        fa.suppressed = 1; // CLAHE always composes with the suppressed variant (synthetic_rgb.rs:188-194)
         KernelTimer t(ctx, "chain_finish");
         HIPCHK(ctx, launch_chain_finish(fa, ctx->stream));
     }
@@ -833,6 +840,90 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     return SARPRO_HIP_OK;
 }
 
+// Device-resident chain for the percentile strategies, dual-pol, RGB only: histogram -> statistics + window +
+// u8 level of every DN + level histogram (k_chain_stats, levels mode) -> rescale / floor / tables and DN -> final
+// u8 tables (k_chain_finish) -> ONE fused pass DN,DN -> RGB (k_lut_compose_u16).  No host synchronisation in
+// between; gamma != 1 is resolved against host-built thresholds, so no pow runs on the device.
+static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands], const uint8_t *d_rgb, size_t rgb_pitch_px) {
+    if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
+    return !J.clahe() && J.synrgb && J.nbands == 2 && !d_out[0] && !d_out[1] && J.vec && J.in_pitch % 16 == 0 &&
+           rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb) && J.row0 == 0 && J.rows_local == J.rows_total;
+}
+
+static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    RETCHK(chain_prepare(ctx));
+    HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
+    HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
+    HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
+    HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
+    uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
+    ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
+    const bool suppressed = J.strategy == SARPRO_STRATEGY_TAMED; // CLAHE is not handled here
+
+    RETCHK(job_phase1(J)); // DN histograms -> ctx->ghist
+    {
+        ChainStatsArgs sa{};
+        sa.ghist = ctx->ghist.as<unsigned long long>();
+        sa.db = reinterpret_cast<const double *>(consts + kChainOffDb);
+        sa.state = d_state;
+        sa.binlut = ctx->luts.as<uint8_t>();
+        sa.binlut_stride = 131072;
+        sa.levels_mode = 1;
+        sa.strategy = J.strategy;
+        for (int b = 0; b < 2; ++b) sa.tamed_kind[b] = J.tamed_kind(b);
+        sa.total_px = (unsigned long long)J.rows_total * J.cols;
+        sa.level_hist = ctx->level_hist.as<unsigned long long>();
+        sa.gamma_thr = reinterpret_cast<const double *>(consts + kChainOffGamma);
+        KernelTimer t(ctx, "chain_stats");
+        HIPCHK(ctx, launch_chain_stats(sa, 2, ctx->stream));
+    }
+    {
+        ChainFinishArgs fa{};
+        fa.level_hist = ctx->level_hist.as<unsigned long long>();
+        fa.total_px = (unsigned long long)J.rows_total * J.cols;
+        fa.nbands = 2;
+        fa.resc_out = state + kStateOffResc;
+        fa.identity_out = state + kStateOffIdent;
+        fa.tables = ctx->tables.as<uint8_t>();
+        fa.supp_rg = consts + kChainOffSupp;
+        fa.blue_pair_supp = consts + kChainOffBlue;
+        fa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        fa.levels_mode = 1;
+        for (int b = 0; b < 2; ++b) fa.no_rescale[b] = J.tamed_kind(b) != kNotTamedSynrgb;
+        fa.suppressed = suppressed ? 1 : 0;
+        fa.dn_tables = ctx->luts.as<uint8_t>();
+        fa.dn_table_stride = 131072;
+        fa.default_rg = consts + kChainOffDefRg;
+        fa.blue_pair_default = consts + kChainOffBlueDef;
+        KernelTimer t(ctx, "chain_finish");
+        HIPCHK(ctx, launch_chain_finish(fa, ctx->stream));
+    }
+    {
+        LutComposeArgs f{};
+        for (int b = 0; b < 2; ++b) { f.in[b] = J.d_in[b]; f.lut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072; }
+        f.rgb = d_rgb; f.in_pitch = J.in_pitch; f.rgb_pitch_px = rgb_pitch_px;
+        f.rows = (uint32_t)J.rows_local; f.cols = (uint32_t)J.cols;
+        f.tables = ctx->tables.as<uint8_t>();
+        f.dev_state = d_state;
+        f.lut_cap = ctx->chain_levels_cap;
+        KernelTimer t(ctx, "lut_compose_u16");
+        HIPCHK(ctx, launch_lut_compose_u16(f, ctx->stream));
+    }
+    ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
+    HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
+    uint32_t hi = 0;
+    for (int b = 0; b < 2; ++b) {
+        J.stats[b] = h_state[b].stats;
+        if (stats_out) stats_out[b] = J.stats[b];
+        hi = std::max(hi, h_state[b].win_hi);
+    }
+    // LDS capacity (bytes per band) of the NEXT scene's DN tables (speed only)
+    ctx->chain_levels_cap = std::min<uint32_t>(16384, std::max<uint32_t>(2048, (hi + 1 + 1023) / 1024 * 1024));
+    return SARPRO_HIP_OK;
+}
+
 static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
                        sarpro_hip_stats *stats_out) {
     timing_reset(J.ctx);
@@ -844,6 +935,10 @@ static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch
     if (chain_eligible(J)) {
         HostTimer t(J.ctx, "host:chain(enqueue+final sync)");
         return job_run_chain(J, d_out, out_pitch, d_rgb, rgb_pitch_px, stats_out);
+    }
+    if (chain_levels_eligible(J, d_out, d_rgb, rgb_pitch_px)) {
+        HostTimer t(J.ctx, "host:chain(enqueue+final sync)");
+        return job_run_chain_levels(J, d_rgb, rgb_pitch_px, stats_out);
     }
     { HostTimer t(J.ctx, "host:phase1_launch"); RETCHK(job_phase1(J)); }
     { HostTimer t(J.ctx, "host:after_phase1(sync+stats+tables)"); RETCHK(job_after_phase1(J)); }

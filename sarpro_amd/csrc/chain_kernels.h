@@ -14,8 +14,15 @@ struct ChainStatsArgs {
     const unsigned long long *ghist; // [nbands][65536]
     const double *db;                // [65536] dB value of every DN (host-built, glibc)
     ChainBandState *state;           // [nbands]
-    uint8_t *binlut;                 // per band, binlut_stride bytes apart
+    uint8_t *binlut;                 // per band, binlut_stride bytes apart: CLAHE bin or u8 level of every DN
     size_t binlut_stride;
+    // percentile strategies (levels mode): window by strategy, u8 level of every DN, level histogram
+    int levels_mode;                 // 0: CLAHE bins (window p01..p99); 1: u8 levels of `strategy`
+    int strategy;
+    int tamed_kind[kMaxBands];       // 0 / 1 copol / 2 crosspol (autoscale.rs:721-727)
+    unsigned long long total_px;     // pixels per band (level 0 also counts the invalid ones)
+    unsigned long long *level_hist;  // [nbands][256], levels mode only
+    const double *gamma_thr;         // [3][256]: x-thresholds of trunc(pow(x, g) * 255) for g = 0.8, 0.9, 1.1 (host-built)
 };
 
 struct ChainFinishArgs {
@@ -28,6 +35,15 @@ struct ChainFinishArgs {
     const uint8_t *supp_rg;               // [41][512] suppressed lut_r|lut_g for every floor value
     const uint8_t *blue_pair_supp;        // [256][256]
     int *floor_out;                       // optional
+    // levels mode (percentile strategies): bin 0 of level_hist is exact, the DN -> level tables become
+    // DN -> FINAL u8 tables (rescale applied) and the compose tables are built without folding it again
+    int levels_mode;
+    int no_rescale[2];                    // tamed-synrgb bands have no u8 rescale (autoscale.rs:731-741)
+    int suppressed;                       // 1: suppressed synRGB variant (Tamed / Clahe), 0: default variant
+    uint8_t *dn_tables;                   // [2] x dn_table_stride: in: level of every DN, out: final u8 of every DN
+    size_t dn_table_stride;
+    const uint8_t *default_rg;            // [512] default lut_r | lut_g (synthetic_rgb.rs:22-29)
+    const uint8_t *blue_pair_default;     // [256][256]
 };
 
 hipError_t launch_chain_stats(const ChainStatsArgs &a, int nbands, hipStream_t s);

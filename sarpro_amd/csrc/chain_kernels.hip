@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
 
     if (count == 0) { // no valid pixel: every DN is invalid, the bin table is irrelevant (autoscale.rs:466-468)
         for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) binlut[dn] = 0;
+        if (a.levels_mode && t < 256) a.level_hist[(size_t)band * 256 + t] = t == 0 ? a.total_px : 0ull;
         if (t == 0) { out->stats = st; out->win_hi = 1; }
         return;
     }
@@ -177,26 +178,119 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         st.median_db = pct[0]; st.p01 = pct[1]; st.p02 = pct[2]; st.p05 = pct[3]; st.p10 = pct[4]; st.p25 = pct[5];
         st.p75 = pct[6]; st.p90 = pct[7]; st.p95 = pct[8]; st.p98 = pct[9]; st.p99 = pct[10];
     }
-    // ---- CLAHE window + DN -> bin table ----
-    const double low = st.p01, high = st.p99;
-    st.low_clip = low; st.high_clip = high; st.gamma = 1.0;
-    const double range = fmax(high - low, 1.0);
-    uint32_t first_hi = 65535u; // first DN >= 1 whose dB value reached the high clip: the table is constant from there
-    for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) {
-        uint8_t bin = 0;
-        if (dn) {
-            const double d = db[dn];
-            const double clipped = fmin(fmax(d, low), high);
-            const double v = clampd((clipped - low) / range, 0.0, 1.0);
-            long long b = (long long)round(v * 255.0);
-            b = b < 0 ? 0 : (b > 255 ? 255 : b);
-            bin = (uint8_t)b;
-            if (d >= high) first_hi = min(first_hi, dn);
+    if (!a.levels_mode) {
+        // ---- CLAHE window + DN -> bin table ----
+        const double low = st.p01, high = st.p99;
+        st.low_clip = low; st.high_clip = high; st.gamma = 1.0;
+        const double range = fmax(high - low, 1.0);
+        uint32_t first_hi = 65535u; // first DN >= 1 whose dB value reached the high clip: the table is constant from there
+        for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) {
+            uint8_t bin = 0;
+            if (dn) {
+                const double d = db[dn];
+                const double clipped = fmin(fmax(d, low), high);
+                const double v = clampd((clipped - low) / range, 0.0, 1.0);
+                long long b = (long long)round(v * 255.0);
+                b = b < 0 ? 0 : (b > 255 ? 255 : b);
+                bin = (uint8_t)b;
+                if (d >= high) first_hi = min(first_hi, dn);
+            }
+            binlut[dn] = bin;
         }
-        binlut[dn] = bin;
+        const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+        if (t == 0) { out->stats = st; out->win_hi = win_hi; }
+        return;
     }
-    const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
-    if (t == 0) { out->stats = st; out->win_hi = win_hi; }
+    // ---- percentile strategies: window (autoscale.rs:404-429, 491-564, 721-729) ----
+    {
+        const double dynamic_range = st.max_db - st.min_db, iqr = st.p75 - st.p25;
+        double low, high, gamma = 1.0;
+        const int tamed = a.tamed_kind[band];
+        if (tamed) {
+            low = tamed == 1 ? fmin(st.p02, st.p05) : st.p05; high = st.p99;
+        } else switch (a.strategy) {
+        case SARPRO_STRATEGY_STANDARD:
+            if (dynamic_range < 15.0) {
+                const double range = fmax(20.0, dynamic_range * 0.8);
+                low = st.median_db - range / 2.0; high = st.median_db + range / 2.0; gamma = 1.1;
+            } else if (iqr < 5.0) {
+                low = st.p25 - 2.5 * iqr; high = st.p75 + 2.5 * iqr;
+            } else if (dynamic_range > 40.0) {
+                low = fmax(st.p02, st.min_db + 0.02 * dynamic_range);
+                high = fmin(st.p98, st.max_db - 0.02 * dynamic_range);
+                gamma = 0.9;
+            } else { low = st.p02; high = st.p98; }
+            low = fmax(low, st.min_db);
+            high = fmin(high, st.max_db);
+            break;
+        case SARPRO_STRATEGY_ROBUST: {
+            const double thr = 2.5 * iqr;
+            low = fmax(fmax(st.p25 - thr, st.p01), st.min_db);
+            high = fmin(fmin(st.p75 + thr, st.p99), st.max_db);
+            break;
+        }
+        case SARPRO_STRATEGY_ADAPTIVE: {
+            const double skew = (st.mean_db - st.median_db) / fmax(fabs(st.std_db), 1.0);
+            const double tail = (st.p99 - st.p95) / fmax(st.p95 - st.p75, 1.0);
+            st.skew_factor = skew; st.tail_heaviness = tail;
+            if (fabs(skew) > 0.5) {
+                if (skew > 0.0) { low = st.p02; high = st.p98; gamma = 0.9; }
+                else { low = st.p05; high = st.p95; gamma = 1.1; }
+            } else if (tail > 2.0) { low = st.p10; high = st.p90; gamma = 0.8; }
+            else { low = st.p05; high = st.p95; }
+            break;
+        }
+        case SARPRO_STRATEGY_EQUALIZED: low = st.p01; high = st.p99; break;
+        case SARPRO_STRATEGY_TAMED: low = st.p25; high = st.p99; break;
+        default: low = st.p05; high = st.p95; break; // Default (Standard never reaches the advanced arm)
+        }
+        st.low_clip = low; st.high_clip = high; st.gamma = gamma;
+    }
+    // ---- u8 level of every DN (autoscale.rs:440-442 / 649-651 / 734-736) + the level histogram.
+    //      gamma != 1: trunc(pow(x, g) * 255) is resolved against host-built thresholds of x (glibc pow),
+    //      so no pow runs here and the level is exactly the reference's. ----
+    {
+        const double low = st.low_clip, high = st.high_clip, gamma = st.gamma;
+        const double range = fmax(high - low, 1.0);
+        const double *gthr = gamma == 0.8 ? a.gamma_thr : (gamma == 0.9 ? a.gamma_thr + 256 : (gamma == 1.1 ? a.gamma_thr + 512 : nullptr));
+        unsigned long long *lh = hist; // reuse the 4096-bin LDS array: first 256 words
+        __syncthreads();
+        for (int i = t; i < 256; i += kStatsBlock) lh[i] = 0;
+        __syncthreads();
+        uint32_t first_hi = 65535u;
+        unsigned long long run = 0;
+        uint32_t run_level = 0xFFFFFFFFu;
+        for (uint32_t dn = 64u * t; dn < 64u * t + 64u; ++dn) { // contiguous DNs per thread: levels form runs
+            uint32_t level = 0;
+            if (dn) {
+                const double d = db[dn];
+                const double clipped = fmin(fmax(d, low), high);
+                const double x = (clipped - low) / range;
+                if (gthr) {
+                    uint32_t idx = 0; // number of k in 1..255 with x >= thr[k]  (NaN / negative x -> 0)
+#pragma unroll
+                    for (uint32_t step = 128; step; step >>= 1)
+                        if (x >= gthr[idx + step]) idx += step;
+                    level = idx;
+                } else {
+                    const double y = clampd(x * 255.0, 0.0, 255.0);
+                    level = (y == y) ? (uint32_t)y : 0u;
+                }
+                if (d >= high) first_hi = min(first_hi, dn);
+            }
+            binlut[dn] = (uint8_t)level;
+            const unsigned long long n = dn ? h[dn] : (a.total_px - count); // DN = 0: every invalid pixel is level 0
+            if (n) {
+                if (level != run_level) { if (run) atomicAdd(&lh[run_level], run); run = 0; run_level = level; }
+                run += n;
+            }
+        }
+        if (run) atomicAdd(&lh[run_level], run);
+        const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+        __syncthreads();
+        if (t < 256) a.level_hist[(size_t)band * 256 + t] = lh[t];
+        if (t == 0) { out->stats = st; out->win_hi = win_hi; }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -260,7 +354,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
     }
     if (t < 256) combined[t] = 0;
     __syncthreads();
-    if (t < a.nbands) { // level 0 is not counted by the apply kernel: it is what is left of the scene
+    if (t < a.nbands && !a.levels_mode) { // level 0 is not counted by the apply kernel: it is what is left of the scene
         unsigned long long others = 0;
         for (int k = 1; k < 256; ++k) others += lh[t][k];
         lh[t][0] = a.total_px - others;
@@ -276,7 +370,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
         for (unsigned x = 0; x < 256; ++x) {
             float val = roundf(((float)x - fmn) * scale);
             val = val < 0.0f ? 0.0f : (val > 255.0f ? 255.0f : val);
-            resc[t][x] = (uint8_t)val;
+            resc[t][x] = a.no_rescale[t] ? (uint8_t)x : (uint8_t)val;
         }
     }
     __syncthreads();
@@ -289,8 +383,13 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
         a.identity_out[t] = ident ? 1 : 0;
     }
     __syncthreads();
+    if (a.levels_mode) // DN -> level tables become DN -> final u8 tables; the compose tables then take final values
+        for (int i = blockIdx.x * kStatsBlock + t; i < 2 * 65536; i += gridDim.x * kStatsBlock) {
+            const int b = i >> 16;
+            if (b < a.nbands) { uint8_t *p = a.dn_tables + (size_t)b * a.dn_table_stride + (i & 65535); *p = resc[b][*p]; }
+        }
     if (a.nbands < 2 || !a.tables) return;
-    if (t == 0) { // synthetic_rgb.rs:99-113 with the reference's saturating u32 counters
+    if (t == 0 && a.suppressed) { // synthetic_rgb.rs:99-113 with the reference's saturating u32 counters
         const uint32_t total = (uint32_t)(a.total_px + a.total_px);
         const double tc = round((double)total * 0.05);
         const uint32_t target = tc >= 4294967295.0 ? 4294967295u : (uint32_t)tc;
@@ -307,19 +406,22 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
         if (lead && a.floor_out) *a.floor_out = fwc;
     }
     __syncthreads();
-    const int fwc = s_fwc;
-    const uint8_t *lut_r = a.supp_rg + (size_t)fwc * 512, *lut_g = lut_r + 256; // powf tables per floor (host-built)
+    const int fwc = a.suppressed ? s_fwc : -1;
+    const uint8_t *lut_r = a.suppressed ? a.supp_rg + (size_t)fwc * 512 : a.default_rg, *lut_g = lut_r + 256; // host-built powf tables
+    const uint8_t *pair = a.suppressed ? a.blue_pair_supp : a.blue_pair_default;
     uint8_t *R2 = a.tables, *G2 = a.tables + 256, *B2 = a.tables + 512;
+    const bool fold = !a.levels_mode; // levels mode: the values that reach the compose tables are already final
     if (lead && t < 256) {
-        const int r1 = resc[0][t], r2 = resc[1][t];
+        const int r1 = fold ? resc[0][t] : t, r2 = fold ? resc[1][t] : t;
         R2[t] = r1 <= fwc ? 0 : lut_r[r1];
         G2[t] = r2 <= fwc ? 0 : lut_g[r2];
     }
     for (int i = blockIdx.x * kStatsBlock + t; i < 65536; i += gridDim.x * kStatsBlock) {
         const int v1 = i >> 8, v2 = i & 255;
-        const int r1 = resc[0][v1], r2 = resc[1][v2];
-        const bool water = r1 <= fwc && r2 <= fwc;
-        B2[i] = water ? 0 : a.blue_pair_supp[((size_t)lut_r[r1] << 8) | lut_g[r2]];
+        const int r1 = fold ? resc[0][v1] : v1, r2 = fold ? resc[1][v2] : v2;
+        const bool water = r1 <= fwc && r2 <= fwc;                 // suppressed only (fwc = -1 otherwise)
+        const bool b2zero = !a.suppressed && r2 == 0;             // default variant: `if b2 == 0 { blue = 0 }` (synthetic_rgb.rs:38-40)
+        B2[i] = (water || b2zero) ? 0 : pair[((size_t)lut_r[r1] << 8) | lut_g[r2]];
     }
 }
 
@@ -350,7 +452,7 @@ hipError_t launch_chain_cdfs(const unsigned long long *tile_bins, double *cdfs, 
     return hipGetLastError();
 }
 hipError_t launch_chain_finish(const ChainFinishArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_chain_finish, dim3(a.nbands == 2 && a.tables ? 64 : 1), dim3(kStatsBlock), 0, s, a);
+    hipLaunchKernelGGL(k_chain_finish, dim3((a.nbands == 2 && a.tables) || a.levels_mode ? 64 : 1), dim3(kStatsBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, uint32_t rows,

@@ -87,6 +87,7 @@ struct sarpro_hip_ctx {
     sarpro::DevBuf chain_consts;                 // device-resident chain: dB table | suppressed lut_r/g per floor | blue pairs
     sarpro::DevBuf chain_state;                  // ChainBandState[2] | resc[2][256] | identity[2] | floor
     bool chain_ready = false;
+    uint32_t chain_levels_cap = 4096;            // LDS bytes per band of the fused pass's DN tables (percentile chain)
     uint32_t chain_lut_cap = 4096;               // LDS capacity (entries) of the apply kernel's offset table
     // pinned host mirrors
     sarpro::PinnedBuf h_ghist, h_small, h_upload;

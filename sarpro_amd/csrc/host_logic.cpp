@@ -428,6 +428,35 @@ void synrgb_luts_suppressed(int fwc, uint8_t *luts) {
 }
 
 const uint8_t *synrgb_blue_pair_supp() { return blue_pair_table(false); }
+const uint8_t *synrgb_blue_pair_default() { return blue_pair_table(true); }
+
+const double *gamma_level_thresholds_u8() {
+    static double tab[3][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const double gammas[3] = {0.8, 0.9, 1.1};
+        for (int g = 0; g < 3; ++g) {
+            auto level = [&](double x) { return (int)as_u16(clampd(std::pow(x, gammas[g]) * 255.0, 0.0, 255.0)); };
+            tab[g][0] = 0.0;
+            uint64_t lo_bits = 0; // bit patterns of non-negative doubles order like the doubles
+            for (int k = 1; k < 256; ++k) {
+                uint64_t lo = lo_bits, hi;
+                const double one = 1.0;
+                std::memcpy(&hi, &one, 8);
+                // invariant: level(lo) < k <= level(hi)   (level(0) = 0, level(1) = 255)
+                while (hi - lo > 1) {
+                    const uint64_t mid = lo + (hi - lo) / 2;
+                    double xm;
+                    std::memcpy(&xm, &mid, 8);
+                    if (level(xm) >= k) hi = mid; else lo = mid;
+                }
+                std::memcpy(&tab[g][k], &hi, 8);
+                lo_bits = lo;
+            }
+        }
+    });
+    return &tab[0][0];
+}
 
 const uint8_t *synrgb_supp_rg_tables() {
     static uint8_t tab[41][512];

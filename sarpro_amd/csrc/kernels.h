@@ -96,6 +96,8 @@ struct LutComposeArgs {
     const uint8_t *lut[kMaxBands];   // full 65536-entry DN -> final u8 tables (entry 0 = invalid pixels)
     uint32_t win_hi[kMaxBands];      // the tables are constant from win_hi on
     const uint8_t *tables;           // R2[256] | G2[256] | B2[65536]
+    const struct ChainBandState *dev_state; // chain mode: win_hi is read from device memory; lut_cap = LDS capacity per band
+    uint32_t lut_cap;
 };
 bool lut_compose_fits(const LutComposeArgs &a);
 hipError_t launch_lut_compose_u16(const LutComposeArgs &a, hipStream_t s);

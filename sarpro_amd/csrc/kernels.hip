@@ -727,22 +727,15 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
 //     the table is constant), then the synRGB tables of kernel 6.  No intermediate raster exists.
 //     Algorithmic traffic = actual traffic: 4 B/px read + 3 B/px written = 7 B/px.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kComposeBlock) void k_lut_compose_u16(LutComposeArgs a) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-        for (int i = threadIdx.x; i < kComposeTableBytes / 16; i += kComposeBlock) dst[i] = src[i];
-    }
-    uint8_t *lut1 = lds_raw + kComposeTableBytes + kComposeStageBytes;
-    uint8_t *lut2 = lut1 + ((a.win_hi[0] + 16) & ~15u);
-    for (uint32_t i = threadIdx.x; i <= a.win_hi[0]; i += kComposeBlock) lut1[i] = a.lut[0][i];
-    for (uint32_t i = threadIdx.x; i <= a.win_hi[1]; i += kComposeBlock) lut2[i] = a.lut[1][i];
-    __syncthreads();
+template <bool GLOBAL_LUT>
+__device__ __forceinline__ void lut_compose_rows(const LutComposeArgs &a, unsigned char *lds_raw, uint32_t hi1, uint32_t hi2,
+                                                 uint32_t lut2_off) {
     const uint8_t *R2 = lds_raw, *G2 = lds_raw + 256, *B2 = lds_raw + 512;
+    const uint8_t *lut1 = lds_raw + kComposeTableBytes + kComposeStageBytes, *lut2 = lut1 + lut2_off;
+    auto look1 = [&](uint32_t d) -> uint32_t { return GLOBAL_LUT ? a.lut[0][min(d, hi1)] : lut1[min(d, hi1)]; };
+    auto look2 = [&](uint32_t d) -> uint32_t { return GLOBAL_LUT ? a.lut[1][min(d, hi2)] : lut2[min(d, hi2)]; };
     uint4 *stage = reinterpret_cast<uint4 *>(lds_raw + kComposeTableBytes + (threadIdx.x >> 6) * 3072);
     const int lane = threadIdx.x & 63;
-    const uint32_t hi1 = a.win_hi[0], hi2 = a.win_hi[1];
     const uint32_t vpr = (a.cols + 15) / 16, wpr = (vpr + 63) / 64;
     const uint64_t chunks = (uint64_t)a.rows * wpr;
     const uint64_t nwaves = (uint64_t)gridDim.x * (kComposeBlock / kWave);
@@ -767,7 +760,7 @@ __global__ __launch_bounds__(kComposeBlock) void k_lut_compose_u16(LutComposeArg
                     const int k = g * 4 + j;
                     const uint32_t d1 = (k & 1) ? (w1[k >> 1] >> 16) : (w1[k >> 1] & 0xFFFFu);
                     const uint32_t d2 = (k & 1) ? (w2[k >> 1] >> 16) : (w2[k >> 1] & 0xFFFFu);
-                    const uint32_t v1 = lut1[min(d1, hi1)], v2 = lut2[min(d2, hi2)];
+                    const uint32_t v1 = look1(d1), v2 = look2(d2);
                     px[j][0] = R2[v1]; px[j][1] = G2[v2]; px[j][2] = B2[(v1 << 8) | v2];
                 }
                 o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
@@ -787,11 +780,34 @@ __global__ __launch_bounds__(kComposeBlock) void k_lut_compose_u16(LutComposeArg
         if (!fullv && col < a.cols) { // ragged tail of the row: scalar
             uint8_t *po = a.rgb + ((size_t)r * a.rgb_pitch_px + col) * 3;
             for (uint32_t j = 0; col + j < a.cols; ++j) {
-                const uint32_t v1 = lut1[min((uint32_t)p1[j], hi1)], v2 = lut2[min((uint32_t)p2[j], hi2)];
+                const uint32_t v1 = look1(p1[j]), v2 = look2(p2[j]);
                 po[3 * j + 0] = R2[v1]; po[3 * j + 1] = G2[v2]; po[3 * j + 2] = B2[(v1 << 8) | v2];
             }
         }
     }
+}
+
+__global__ __launch_bounds__(kComposeBlock) void k_lut_compose_u16(LutComposeArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < kComposeTableBytes / 16; i += kComposeBlock) dst[i] = src[i];
+    }
+    // window edges: from the host (host-orchestrated path) or from device memory (chain).  When a window exceeds
+    // the LDS capacity chosen at launch both tables are gathered from global memory instead (same results).
+    const uint32_t wh1 = a.dev_state ? a.dev_state[0].win_hi : a.win_hi[0], wh2 = a.dev_state ? a.dev_state[1].win_hi : a.win_hi[1];
+    const uint32_t cap = a.dev_state ? a.lut_cap : 65536u;
+    const bool global_lut = wh1 >= cap || wh2 >= cap;
+    const uint32_t lut2_off = a.dev_state ? cap : ((wh1 + 16) & ~15u);
+    if (!global_lut) {
+        uint8_t *lut1 = lds_raw + kComposeTableBytes + kComposeStageBytes, *lut2 = lut1 + lut2_off;
+        for (uint32_t i = threadIdx.x; i <= wh1; i += kComposeBlock) lut1[i] = a.lut[0][i];
+        for (uint32_t i = threadIdx.x; i <= wh2; i += kComposeBlock) lut2[i] = a.lut[1][i];
+    }
+    __syncthreads();
+    if (global_lut) lut_compose_rows<true>(a, lds_raw, wh1, wh2, lut2_off);
+    else lut_compose_rows<false>(a, lds_raw, wh1, wh2, lut2_off);
 }
 
 // ------------------------------------------------------------------------------------
@@ -990,12 +1006,14 @@ hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s) {
 }
 
 bool lut_compose_fits(const LutComposeArgs &a) {
+    if (a.dev_state) return true; // capacity-limited inside the kernel
     return (size_t)kComposeTableBytes + kComposeStageBytes + ((a.win_hi[0] + 16) & ~15u) + ((a.win_hi[1] + 16) & ~15u) <= 160 * 1024;
 }
 
 hipError_t launch_lut_compose_u16(const LutComposeArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
-    const size_t lds = (size_t)kComposeTableBytes + kComposeStageBytes + ((a.win_hi[0] + 16) & ~15u) + ((a.win_hi[1] + 16) & ~15u);
+    const size_t lds = a.dev_state ? (size_t)kComposeTableBytes + kComposeStageBytes + 2 * (size_t)a.lut_cap
+                                   : (size_t)kComposeTableBytes + kComposeStageBytes + ((a.win_hi[0] + 16) & ~15u) + ((a.win_hi[1] + 16) & ~15u);
     static bool attr_set = false;
     if (!attr_set) { // more than the default 64 KiB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lut_compose_u16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -240,13 +240,21 @@ def test_fused_lut_compose_pass_equals_unfused(ctx, strategy, shape, monkeypatch
     b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
     rc, rrgb, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(strategy))
     d = [dev_u16(x, pitch) for x in b]
-    for no_fused in ("0", "1"):
+    # three routes to the same raster: device-resident chain (default), host-orchestrated fused pass, unfused passes
+    for no_chain, no_fused in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("SARPRO_HIP_NO_CHAIN", no_chain)
         monkeypatch.setenv("SARPRO_HIP_NO_FUSED", no_fused)
         if no_fused == "0":
             monkeypatch.delenv("SARPRO_HIP_NO_FUSED")
         rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
         with S.Context(0, timing=True) as c:
-            c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, Mode.Default, rgb.data_ptr(), pitch)
+            st = c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, Mode.Default, rgb.data_ptr(), pitch)
             names = [n for n, _ in c.last_kernel_times()]
         assert ("lut_compose_u16" in names) == (no_fused == "0")
-        assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb), (strategy, no_fused)
+        assert ("chain_stats" in names) == (no_chain == "0")
+        assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb), (strategy, no_chain, no_fused)
+        for k in (0, 1):  # statistics and the chosen window are the reference's on every route
+            so = oracle.pipeline(b[k].astype(np.float32), 0, int(strategy), want_stats=True)[2] if strategy != St.Tamed else None
+            if so is not None:
+                for f in ("valid_count", "min_db", "max_db", "median_db", "p01", "p25", "p75", "p99", "low_clip", "high_clip", "gamma"):
+                    assert getattr(st[k], f) == getattr(so, f), (strategy, no_chain, f)
