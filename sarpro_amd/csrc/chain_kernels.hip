@@ -260,30 +260,44 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         uint32_t first_hi = 65535u;
         unsigned long long run = 0;
         uint32_t run_level = 0xFFFFFFFFu;
-        for (uint32_t dn = 64u * t; dn < 64u * t + 64u; ++dn) { // contiguous DNs per thread: levels form runs
-            uint32_t level = 0;
-            if (dn) {
-                const double d = db[dn];
-                const double clipped = fmin(fmax(d, low), high);
-                const double x = (clipped - low) / range;
-                if (gthr) {
-                    uint32_t idx = 0; // number of k in 1..255 with x >= thr[k]  (NaN / negative x -> 0)
+        for (uint32_t base = 64u * t; base < 64u * t + 64u; base += 8) { // contiguous DNs per thread: levels form runs
+            unsigned long long hv[8];
+            double dv[8];
 #pragma unroll
-                    for (uint32_t step = 128; step; step >>= 1)
-                        if (x >= gthr[idx + step]) idx += step;
-                    level = idx;
-                } else {
-                    const double y = clampd(x * 255.0, 0.0, 255.0);
-                    level = (y == y) ? (uint32_t)y : 0u;
+            for (int k = 0; k < 8; ++k) { hv[k] = h[base + k]; dv[k] = db[base + k]; } // 16 independent loads in flight
+            uint32_t lvl8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t dn = base + k;
+                uint32_t level = 0;
+                if (dn) {
+                    const double d = dv[k];
+                    const double clipped = fmin(fmax(d, low), high);
+                    const double x = (clipped - low) / range;
+                    if (gthr) {
+                        uint32_t idx = 0; // number of k in 1..255 with x >= thr[k]  (NaN / negative x -> 0)
+#pragma unroll
+                        for (uint32_t step = 128; step; step >>= 1)
+                            if (x >= gthr[idx + step]) idx += step;
+                        level = idx;
+                    } else {
+                        const double y = clampd(x * 255.0, 0.0, 255.0);
+                        level = (y == y) ? (uint32_t)y : 0u;
+                    }
+                    if (d >= high) first_hi = min(first_hi, dn);
                 }
-                if (d >= high) first_hi = min(first_hi, dn);
+                lvl8[k] = level;
+                const unsigned long long n = dn ? hv[k] : (a.total_px - count); // DN = 0: every invalid pixel is level 0
+                if (n) {
+                    if (level != run_level) { if (run) atomicAdd(&lh[run_level], run); run = 0; run_level = level; }
+                    run += n;
+                }
             }
-            binlut[dn] = (uint8_t)level;
-            const unsigned long long n = dn ? h[dn] : (a.total_px - count); // DN = 0: every invalid pixel is level 0
-            if (n) {
-                if (level != run_level) { if (run) atomicAdd(&lh[run_level], run); run = 0; run_level = level; }
-                run += n;
-            }
+            // 8 consecutive table bytes in one store
+            uint2 pk;
+            pk.x = lvl8[0] | (lvl8[1] << 8) | (lvl8[2] << 16) | (lvl8[3] << 24);
+            pk.y = lvl8[4] | (lvl8[5] << 8) | (lvl8[6] << 16) | (lvl8[7] << 24);
+            *reinterpret_cast<uint2 *>(binlut + base) = pk;
         }
         if (run) atomicAdd(&lh[run_level], run);
         const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
