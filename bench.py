@@ -90,20 +90,11 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
 
-    def allreduce(ptr, count):
-        ctx.comm_allreduce_sum_u64(ptr, count)  # RCCL all-reduce(sum, u64) on the library's stream
-
     def step():
         if args.mode == "stripe" and world > 1:
-            s = ctx.stripe_begin_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, row0, rows_local, pitch,
-                                     strategy, SyntheticRgbMode.Default)
-            try:
-                allreduce(*s.phase1())
-                allreduce(*s.phase2())
-                allreduce(*s.phase3())
-                s.phase4(rgb.data_ptr(), pitch)
-            finally:
-                s.end()
+            # one call: device-resident chain with its RCCL all-reduces enqueued on the library's stream
+            ctx.stripe_run_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, row0, rows_local, pitch, strategy,
+                               SyntheticRgbMode.Default, rgb.data_ptr(), pitch)
         else:
             ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, strategy,
                                        SyntheticRgbMode.Default, rgb.data_ptr(), pitch)

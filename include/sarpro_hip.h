@@ -244,6 +244,14 @@ int sarpro_hip_stripe_phase4(sarpro_hip_stripe *s, uint8_t *d_rgb, size_t rgb_pi
                              sarpro_hip_stats *stats_out);
 void sarpro_hip_stripe_end(sarpro_hip_stripe *s);
 
+/* The same stripe in ONE call per rank, reductions over the library's communicator (sarpro_hip_comm_init
+ * must have been called): the device-resident chains with their small all-reduces enqueued on the stream,
+ * no host synchronisation until the stripe's RGB (rows_local x cols x 3) is complete.  Every rank of the
+ * communicator must make the call (a rank may hold an empty stripe). */
+int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total,
+                              size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
+                              uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out);
+
 /* RCCL communicator owned by the library (optional: callers may reduce the phase buffers
  * with their own communicator, e.g. torch.distributed's).  uid is the 128-byte
  * ncclUniqueId produced by sarpro_hip_comm_unique_id on rank 0 and shipped to all ranks. */

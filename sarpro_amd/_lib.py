@@ -53,7 +53,7 @@ SYMBOLS = [
     "sarpro_hip_dualpol_synrgb_u16_dev", "sarpro_hip_polop_f32_dev", "sarpro_hip_synrgb_u8_dev",
     "sarpro_hip_last_kernel_times",
     "sarpro_hip_stripe_begin_u16", "sarpro_hip_stripe_phase1", "sarpro_hip_stripe_phase2",
-    "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end",
+    "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end", "sarpro_hip_stripe_run_u16",
     "sarpro_hip_comm_unique_id", "sarpro_hip_comm_init", "sarpro_hip_comm_allreduce_sum_u64",
     "sarpro_hip_comm_destroy",
     "sarpro_hip_host_stats_from_dn_hist", "sarpro_hip_host_window", "sarpro_hip_host_level_lut_u16",
@@ -162,3 +162,4 @@ _proto("sarpro_hip_process_band_resized_u16", _i, _vp, _vp, _sz, _sz, _i, _i, _s
 _proto("sarpro_hip_process_band_resized_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_batch_dualpol_synrgb_resized_u16", _i, C.POINTER(_i), _i, C.POINTER(BatchScene), _sz, _i, _i, _sz, _i, _i,
        C.POINTER(BatchReport))
+_proto("sarpro_hip_stripe_run_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)

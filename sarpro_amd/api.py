@@ -280,6 +280,14 @@ class Context:
                                                   in_pitch, int(strategy), int(mode), C.byref(h)))
         return Stripe(self, h)
 
+    def stripe_run_u16(self, d_b1: int, d_b2: int, rows_total: int, cols: int, row0: int, rows_local: int, in_pitch: int,
+                       strategy, mode, d_rgb: int, rgb_pitch_px: int):
+        """One row stripe, reductions over the library's RCCL communicator, everything on the stream."""
+        st = (Stats * 2)()
+        self._chk(lib.sarpro_hip_stripe_run_u16(self._h, _vp(d_b1), _vp(d_b2), rows_total, cols, row0, rows_local, in_pitch,
+                                                int(strategy), int(mode), _vp(d_rgb), rgb_pitch_px, st))
+        return [st[0], st[1]]
+
     def comm_init(self, nranks: int, rank: int, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._chk(lib.sarpro_hip_comm_init(self._h, nranks, rank, buf))

@@ -306,6 +306,7 @@ struct U16Job {
     bool synrgb = false; // dual-pol JPEG branch (save.rs:317-367): always U8, Tamed uses tamed_synrgb
     int tamed_force = 0; // single band tamed_synrgb entry point: 1 copol, 2 crosspol
     bool vec = false;
+    bool reduce = false; // row stripe of a multi-rank scene: histograms are all-reduced over ctx->comm, on the stream
     StripePlan *plan = nullptr;
     // host-side state between phases
     sarpro_hip_stats stats[kMaxBands];
@@ -721,7 +722,14 @@ static int chain_prepare(sarpro_hip_ctx *ctx) {
 
 static bool chain_eligible(const U16Job &J) {
     if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
-    return J.clahe() && J.u8_out() && J.vec && !J.tamed_force && J.row0 == 0 && J.rows_local == J.rows_total;
+    return J.clahe() && J.u8_out() && J.vec && !J.tamed_force && (J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total));
+}
+
+// row-stripe mode: merge a small integer buffer across ranks without leaving the stream
+static int chain_reduce(U16Job &J, void *d_buf, size_t count_u64, const char *what) {
+    if (!J.reduce) return SARPRO_HIP_OK;
+    KernelTimer t(J.ctx, what);
+    return comm_allreduce_sum_u64_async(J.ctx, reinterpret_cast<uint64_t *>(d_buf), count_u64);
 }
 
 static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
@@ -739,6 +747,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
 
     RETCHK(job_phase1(J)); // per-tile DN histograms -> ctx->ghist
+    RETCHK(chain_reduce(J, ctx->ghist.p, 65536 * (size_t)J.nbands, "allreduce_dn_hist"));
     {
         ChainStatsArgs sa{};
         sa.ghist = ctx->ghist.as<unsigned long long>();
@@ -759,6 +768,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         KernelTimer t(ctx, "tile_bin_hist");
         HIPCHK(ctx, launch_tile_bin_hist(ta, kTiles * kTiles, J.nbands, ctx->stream));
     }
+    RETCHK(chain_reduce(J, ctx->tile_bins.p, 64 * 256 * (size_t)J.nbands, "allreduce_tile_hists"));
     {
         KernelTimer t(ctx, "chain_cdfs");
         HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
@@ -780,7 +790,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     a.rects = J.plan->d_apply_rects.as<Rect>();
     a.row_w = J.plan->d_row_w.as<RowWeight>();
     a.col_w = J.plan->d_col_w.as<RowWeight>();
-    a.row_off = 0;
+    a.row_off = (int32_t)J.row0;
     a.max_val = 255.0;
     a.dev_state = d_state;
     a.lut_cap = ctx->chain_lut_cap;
@@ -791,6 +801,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         KernelTimer t(ctx, "clahe_apply_u8_spec");
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
     }
+    RETCHK(chain_reduce(J, ctx->level_hist.p, 256 * kMaxBands, "allreduce_level_hist"));
     {
         ChainFinishArgs fa{};
         fa.level_hist = ctx->level_hist.as<unsigned long long>();
@@ -847,7 +858,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
 static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands], const uint8_t *d_rgb, size_t rgb_pitch_px) {
     if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
     return !J.clahe() && J.synrgb && J.nbands == 2 && !d_out[0] && !d_out[1] && J.vec && J.in_pitch % 16 == 0 &&
-           rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb) && J.row0 == 0 && J.rows_local == J.rows_total;
+           rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb) && (J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total));
 }
 
 static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
@@ -862,6 +873,7 @@ static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, 
     const bool suppressed = J.strategy == SARPRO_STRATEGY_TAMED; // CLAHE is not handled here
 
     RETCHK(job_phase1(J)); // DN histograms -> ctx->ghist
+    RETCHK(chain_reduce(J, ctx->ghist.p, 65536 * 2, "allreduce_dn_hist"));
     {
         ChainStatsArgs sa{};
         sa.ghist = ctx->ghist.as<unsigned long long>();
@@ -928,7 +940,7 @@ static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch
                        sarpro_hip_stats *stats_out) {
     timing_reset(J.ctx);
     RETCHK(job_init(J));
-    if (J.rows_local == 0 || J.cols == 0) {
+    if ((J.rows_local == 0 && !J.reduce) || J.cols == 0) { // a rank with an empty stripe still joins the reductions
         if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out) * (size_t)J.nbands);
         return SARPRO_HIP_OK;
     }
@@ -941,9 +953,13 @@ static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch
         return job_run_chain_levels(J, d_rgb, rgb_pitch_px, stats_out);
     }
     { HostTimer t(J.ctx, "host:phase1_launch"); RETCHK(job_phase1(J)); }
+    // (row-stripe mode without the device chain: the same phases with a synchronous all-reduce after each)
+    if (J.reduce) RETCHK(sarpro_hip_comm_allreduce_sum_u64(J.ctx, J.ctx->ghist.as<uint64_t>(), 65536 * (size_t)J.nbands));
     { HostTimer t(J.ctx, "host:after_phase1(sync+stats+tables)"); RETCHK(job_after_phase1(J)); }
     { HostTimer t(J.ctx, "host:phase2_launch"); RETCHK(job_phase2(J)); }
+    if (J.reduce && J.clahe()) RETCHK(sarpro_hip_comm_allreduce_sum_u64(J.ctx, J.ctx->tile_bins.as<uint64_t>(), 64 * 256 * (size_t)J.nbands));
     { HostTimer t(J.ctx, "host:phase3(sync+cdfs+launch)"); RETCHK(job_phase3(J, d_out, out_pitch)); }
+    if (J.reduce && J.clahe() && J.u8_out()) RETCHK(sarpro_hip_comm_allreduce_sum_u64(J.ctx, J.ctx->level_hist.as<uint64_t>(), 256 * kMaxBands));
     { HostTimer t(J.ctx, "host:phase4(sync+tables+launch+sync)"); RETCHK(job_phase4(J, d_out, out_pitch, d_rgb, rgb_pitch_px, false)); }
     if (stats_out) for (int b = 0; b < J.nbands; ++b) stats_out[b] = J.stats[b];
     return SARPRO_HIP_OK;
@@ -1276,3 +1292,22 @@ extern "C" int sarpro_hip_stripe_phase4(sarpro_hip_stripe *s, uint8_t *d_rgb, si
 }
 
 extern "C" void sarpro_hip_stripe_end(sarpro_hip_stripe *s) { delete s; }
+
+// One call per rank for one row stripe of a scene, reductions over the library's RCCL communicator
+// (sarpro_hip_comm_init): the device-resident chains run unchanged with three (CLAHE) or one (percentile
+// strategies) small all-reduces enqueued on the stream between their kernels -- no host synchronisation
+// until the stripe's RGB is complete.
+extern "C" int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total,
+                                         size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
+                                         uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (!ctx->comm) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "sarpro_hip_comm_init has not been called on this context");
+    if ((!d_band1 || !d_band2 || !d_rgb) && rows_local * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (rgb_pitch_px < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "rgb_pitch_px < cols");
+    U16Job J;
+    J.ctx = ctx; J.nbands = 2; J.d_in[0] = d_band1; J.d_in[1] = d_band2;
+    J.rows_total = rows_total; J.cols = cols; J.row0 = row0; J.rows_local = rows_local; J.in_pitch = in_pitch;
+    J.strategy = strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.mode = mode; J.synrgb = true; J.reduce = true;
+    void *outs[kMaxBands] = {nullptr, nullptr};
+    return job_run_all(J, outs, 0, d_rgb, rgb_pitch_px, stats_out);
+}

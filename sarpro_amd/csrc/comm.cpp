@@ -78,8 +78,10 @@ extern "C" int sarpro_hip_comm_init(sarpro_hip_ctx *ctx, int nranks, int rank, c
     return SARPRO_HIP_OK;
 }
 
-extern "C" int sarpro_hip_comm_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count) {
-    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+namespace sarpro {
+// all-reduce(sum, u64) enqueued on the context's stream, no host synchronisation (the stripe chain keeps
+// running on the stream behind it)
+int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count) {
     if (!ctx->comm) { ctx->err = "communicator not initialised"; return SARPRO_HIP_ERR_INVALID_ARG; }
     if (!count) return SARPRO_HIP_OK;
     if (!d_buf) return SARPRO_HIP_ERR_INVALID_ARG;
@@ -90,6 +92,14 @@ extern "C" int sarpro_hip_comm_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *
         ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
         return SARPRO_HIP_ERR_RCCL;
     }
+    return SARPRO_HIP_OK;
+}
+} // namespace sarpro
+
+extern "C" int sarpro_hip_comm_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    int rc = sarpro::comm_allreduce_sum_u64_async(ctx, d_buf, count);
+    if (rc) return rc;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "stream sync after all-reduce failed"; return SARPRO_HIP_ERR_HIP; }
     return SARPRO_HIP_OK;
 }

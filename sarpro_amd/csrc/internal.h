@@ -30,6 +30,7 @@ int fetch_out_2d(sarpro_hip_ctx *ctx, void *host, const void *dev, size_t pitch_
 // one band -> final u8 raster on the device (pipeline.rs:42 at U8; tamed: 1 copol / 2 crosspol -> autoscale.rs:710)
 int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
                 uint8_t *d_out, size_t out_pitch);
+int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);
 int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t rows, size_t in_pitch, size_t target_size,
                    int elem_size, int pad, void *d_out, size_t out_pitch, sarpro_hip_resize_meta *meta);
 
