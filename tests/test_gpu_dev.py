@@ -277,3 +277,13 @@ def test_stripe_run_single_call_over_library_communicator(strategy):
             assert ("allreduce_dn_hist" in names) == (pitch == 448)   # chain route only with vector-friendly pitches
             assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb), (strategy, pitch)
             assert st[0].valid_count == int((b[0] > 0).sum())
+
+
+def test_stripe_run_empty_stripe_still_joins_the_reductions():
+    rows, cols = 256, 448
+    with S.Context(0) as c:
+        c.comm_init(1, 0, S.comm_unique_id())
+        rgb = torch.zeros((1, cols * 3), dtype=torch.uint8, device="cuda")
+        for strategy in (St.Clahe, St.Robust):
+            st = c.stripe_run_u16(0, 0, rows, cols, rows, 0, cols, strategy, Mode.Default, rgb.data_ptr(), cols)
+            assert st[0].valid_count == 0
