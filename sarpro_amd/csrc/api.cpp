@@ -129,7 +129,7 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     for (int b = 0; b < kMaxBands; ++b) { ctx->tile_hist[b].release(); ctx->levels[b].release(); ctx->stage_in[b].release(); }
     for (auto &b : ctx->stage_out) b.release();
     ctx->ghist.release(); ctx->tile_bins.release(); ctx->cdfs.release(); ctx->luts.release();
-    ctx->level_hist.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
+    ctx->level_hist.release(); ctx->hist_flags.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
     ctx->chain_consts.release(); ctx->chain_state.release();
     ctx->resize_tmp.release(); ctx->resize_coef[0].release(); ctx->resize_coef[1].release(); ctx->resized[0].release(); ctx->resized[1].release();
     ctx->h_ghist.release(); ctx->h_small.release(); ctx->h_upload.release();
@@ -797,9 +797,22 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     if (a.out_pitch % 8 != 0 || !ptr_aligned16(a.out[0]) || (J.nbands > 1 && !ptr_aligned16(a.out[1])))
         return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
     HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
+    // whole scene on this device: levels >= 64 are only counted in bulk (chain_kernels.hip k_level_hist_guard); a row
+    // stripe keeps the full histogram, which is what the ranks sum
+    a.partial_hist = (!J.reduce && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;
     {
         KernelTimer t(ctx, "clahe_apply_u8_spec");
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
+    }
+    if (a.partial_hist) {
+        KernelTimer t(ctx, "level_hist_guard");
+        HIPCHK(ctx, ctx->hist_flags.reserve(sizeof(uint32_t) * kMaxBands));
+        HIPCHK(ctx, launch_level_hist_guard(ctx->level_hist.as<unsigned long long>(), (unsigned long long)J.rows_total * J.cols, J.nbands,
+                                            ctx->hist_flags.as<uint32_t>(), ctx->stream));
+        for (int b = 0; b < J.nbands; ++b)
+            HIPCHK(ctx, launch_level_hist_if_flagged(reinterpret_cast<const uint8_t *>(a.out[b]), a.out_pitch, (uint32_t)J.rows_local, cols,
+                                                     ctx->level_hist.as<unsigned long long>() + (size_t)b * 256,
+                                                     ctx->hist_flags.as<uint32_t>() + b, ctx->stream));
     }
     RETCHK(chain_reduce(J, ctx->level_hist.p, 256 * kMaxBands, "allreduce_level_hist"));
     {

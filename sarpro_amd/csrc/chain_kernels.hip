@@ -454,6 +454,61 @@ __global__ __launch_bounds__(256) void k_chain_remap(const uint8_t *src, size_t 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Partial level histogram of the speculative apply kernel (kernels.hip, PARTIAL_HIST): bins 1..63 are exact, the
+// pixels at levels >= 64 were added in bulk to SOME bins >= 64 such that their total and the highest occupied level
+// are those of the true histogram.  What k_chain_finish derives from the histogram is unchanged by that:
+//   * bin 0 = pixels - sum(other bins): the sum is preserved;
+//   * the u8 rescale range (autoscale.rs:348-364) is the lowest and the highest occupied level: the highest is
+//     preserved; the lowest is read from the exact bins PROVIDED some level <= kGuardMinLevel (27) is occupied;
+//   * the synRGB floor (synthetic_rgb.rs:99-113) is the first final level f whose cumulative count reaches 5 %, and
+//     only matters below 37 (floor + 3 is capped at 40).  The rescale maps level x >= 64 to round((x - lo) * 255 /
+//     (hi - lo)) >= 64 - lo >= 37 when lo <= 27, so every final level below 37 only collects exact bins: the search
+//     either stops at the same f < 37, or runs past 36 in both histograms, where the cap makes the result 40;
+//   * "the rescale is the identity on the occupied levels" <=> lo = 0 and hi = 255 (or a single level 0): lo, hi only.
+// This guard checks the proviso; when no level <= 27 is occupied (never on natural data: CLAHE output starts at the
+// CDF's foot) it clears the histogram and raises the flag that makes k_level_hist_if_flagged recount the level raster.
+// ------------------------------------------------------------------------------------
+constexpr int kGuardMinLevel = 27;
+__global__ __launch_bounds__(256) void k_level_hist_guard(unsigned long long *level_hist, unsigned long long total_px,
+                                                          uint32_t *flags) {
+    __shared__ unsigned long long part[256];
+    __shared__ int low_occupied;
+    unsigned long long *lh = level_hist + (size_t)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    const unsigned long long v = t ? lh[t] : 0ull;
+    part[t] = v;
+    if (t == 0) low_occupied = 0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) part[t] += part[t + s];
+        __syncthreads();
+    }
+    if (t >= 1 && t <= kGuardMinLevel && v) low_occupied = 1;
+    if (t == 0 && total_px > part[0]) low_occupied = 1; // level 0 is occupied
+    __syncthreads();
+    const bool recount = !low_occupied;
+    if (t == 0) flags[blockIdx.x] = recount ? 1u : 0u;
+    if (recount) lh[t] = 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_level_hist_if_flagged(const uint8_t *__restrict__ in, size_t pitch, uint32_t rows,
+                                                               uint32_t cols, unsigned long long *__restrict__ hist,
+                                                               const uint32_t *__restrict__ flag) {
+    if (!*flag) return;
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t total = (uint64_t)rows * cols;
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+        const uint32_t r = (uint32_t)(idx / cols), c = (uint32_t)(idx - (uint64_t)r * cols);
+        atomicAdd(&h[in[(size_t)r * pitch + c]], 1u);
+    }
+    __syncthreads();
+    const uint32_t n = h[threadIdx.x];
+    if (n && threadIdx.x) atomicAdd(&hist[threadIdx.x], (unsigned long long)n); // bin 0 stays implied, as the apply kernel leaves it
+}
+
 } // namespace
 
 hipError_t launch_chain_stats(const ChainStatsArgs &a, int nbands, hipStream_t s) {
@@ -478,4 +533,18 @@ hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst
     return hipGetLastError();
 }
 
+} // namespace sarpro
+
+namespace sarpro {
+hipError_t launch_level_hist_guard(unsigned long long *level_hist, unsigned long long total_px, int nbands, uint32_t *d_flags,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(k_level_hist_guard, dim3(nbands), dim3(256), 0, s, level_hist, total_px, d_flags);
+    return hipGetLastError();
+}
+hipError_t launch_level_hist_if_flagged(const uint8_t *levels, size_t pitch, uint32_t rows, uint32_t cols,
+                                        unsigned long long *hist, const uint32_t *d_flag, hipStream_t s) {
+    if (!rows || !cols) return hipSuccess;
+    hipLaunchKernelGGL(k_level_hist_if_flagged, dim3(1024), dim3(256), 0, s, levels, pitch, rows, cols, hist, d_flag);
+    return hipGetLastError();
+}
 } // namespace sarpro

@@ -48,6 +48,7 @@ struct ClaheApplyArgs {
     double max_val;                         // 255.0 or 65535.0
     const struct ChainBandState *dev_state;  // chain mode: win_hi is read from device memory (null: use win_hi[])
     uint32_t lut_cap;                       // speculative kernel: LDS capacity of the offset table (entries)
+    uint32_t partial_hist;                  // speculative kernel: levels >= 64 are only counted in bulk (see k_level_hist_guard)
 };
 
 struct LutApplyArgs {

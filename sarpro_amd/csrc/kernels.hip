@@ -375,6 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     serialise the no-data wedge (measured: +7 % on the whole kernel).
 // ------------------------------------------------------------------------------------
 constexpr float kSpecDeltaEdge = 1.0f / 512.0f, kSpecDeltaInner = 1.0f / 2048.0f;
+constexpr uint32_t kPartialHistLevels = 64; // partial level histogram: levels below this are counted one by one
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr uint32_t kSpecLutMaxEntries = 16384; // u16 offsets: 32 KiB of LDS at most
@@ -406,7 +407,12 @@ struct SpecLds { // byte offsets into dynamic LDS
 };
 // (1 - dx) and (1 - dy) are recomputed as 1.0 - d: the reference's own expression (autoscale.rs:327-329)
 
-template <bool LUT_LDS>
+// The dynamic LDS block of this kernel starts at LDS address 0 (it holds no static __shared__), so a byte offset
+// IS the address: going through the `extern __shared__` symbol makes the compiler add its (zero) link-time
+// address to every computed LDS address, one VALU instruction per access.
+#define LDS_AT(T, off) (*reinterpret_cast<__attribute__((address_space(3))) T *>((uint32_t)(off)))
+
+template <bool LUT_LDS, bool PARTIAL_HIST>
 __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const Rect &rc, int band, unsigned char *lds,
                                                 uint32_t win_hi) {
     constexpr int VEC = 8;
@@ -424,41 +430,41 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         dxf[j] = (float)d;
         omdxf[j] = (float)(1.0 - d);
     }
-    const uint32_t dummy = SpecLds::hist + (256u + (uint32_t)lane_id()) * 4u;
     const uint32_t copy_off = ((uint32_t)lane_id() & (kCdfCopies - 1)) * 16u; // this lane's copy of the f32 CDF table
     const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner; // pad[0] bit 0: extrapolating cell
+    const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
+    uint32_t lane_max = 0u, lane_high = 0u; // PARTIAL_HIST: this lane's highest level and its count of levels >= kPartialHistLevels
 
     auto process_row = [&](int r, const U16Vec<VEC> &v) {
         const double dy = *reinterpret_cast<const double *>(lds + SpecLds::roww + (r - rc.r0) * 8); // wave-uniform
         const double omdy = 1.0 - dy;
         const float wy1 = (float)omdy * 255.0f, wy2 = (float)dy * 255.0f;
         uint32_t off[VEC];
-        float fr[VEC];
-        uint32_t pk[2] = {0u, 0u}; // the 8 levels, packed as they will be stored
-        float closest = 1.0f;      // min |frac(y - 0.5) - 0.5| over the lane's pixels: one compare decides "all certain"
+        uint32_t pk[2] = {0u, 0u}, pb[2] = {0u, 0u}; // the 8 levels, packed as they will be stored
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const uint32_t i = min(v.get(j), win_hi);
-            off[j] = LUT_LDS ? (uint32_t)*reinterpret_cast<const uint16_t *>(lds + SpecLds::lut + i * 2u)
+            off[j] = LUT_LDS ? (uint32_t)LDS_AT(uint16_t, SpecLds::lut + i * 2u)
                              : SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(lds + off[j] + copy_off); // (c00, c10, c01, c11)
+            const v4f c4 = LDS_AT(v4f, off[j] + copy_off); // (c00, c10, c01, c11)
             const float top = fmaf(c4.z, dxf[j], c4.x * omdxf[j]);
             const float bottom = fmaf(c4.w, dxf[j], c4.y * omdxf[j]);
-            // ym = y - 0.5: v_cvt_pk_u8_f32 rounds to nearest-even and saturates, so cvt(ym) = floor(y) clamped to
-            // 0..255 for every y that is not within the margin of an integer (those go to the exact path)
-            const float ym = fmaf(bottom, wy2, fmaf(top, wy1, -0.5f));
-            const float g = fabsf(__builtin_amdgcn_fractf(ym) - 0.5f); // distance of y from the nearest integer
-            fr[j] = g;
-            pk[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(ym, j & 3, pk[j >> 2]);
-            closest = fminf(closest, g);
+            // ya = y - 0.5 - delta, yb = y - 0.5 + delta: v_cvt_pk_u8_f32 rounds to nearest-even and saturates, so both
+            // give the same byte n only if y lies in (n + (delta - err), n + 1 - (delta - err)): then n = floor(y)
+            // clamped to 0..255.  Where the bytes differ the pixel goes to the exact path.
+            const float ya = fmaf(bottom, wy2, fmaf(top, wy1, bias));
+            const float yb = ya + two_delta;
+            pk[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(ya, j & 3, pk[j >> 2]);
+            pb[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(yb, j & 3, pb[j >> 2]);
         }
-        if (closest < near_delta) { // rare: some pixel of this lane lies within the margin of an integer -> exact path
+        const uint32_t d0 = pk[0] ^ pb[0], d1 = pk[1] ^ pb[1];
+        if (d0 | d1) { // rare: some pixel of this lane lies within the margin of an integer -> exact path
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                if (fr[j] < near_delta) { // reference op order (autoscale.rs:327-329, 602)
+                if (((j < 4 ? d0 : d1) >> (8 * (j & 3))) & 0xFFu) { // reference op order (autoscale.rs:327-329, 602)
                     const double4 c4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + cdf32_entry(off[j] - SpecLds::cdf32) * 32u);
                     const double dx = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
                     const double top = c4.x * (1.0 - dx) + c4.y * dx;
@@ -471,12 +477,48 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 }
             }
         }
-        if (count_levels) { // level 0 (incl. masked edge samples) goes to a per-lane dummy word: bin 0 = pixels - others
+        if (count_levels) { // level 0 (incl. masked edge samples) is not counted: bin 0 = pixels - others
+            // one predicated ds_add_u32 per pixel, EXEC narrowed to the lanes that count (a shared bin 0 would serialise
+            // the no-data wedge); written out because the compiler wraps each predicated atomic in a branch
+            const uint32_t one = 1u, two = 2u, zero = 0u, lim = kPartialHistLevels;
+            unsigned long long sv, sw;
+            uint32_t haddr;
+            if (!PARTIAL_HIST) {
+#define SPEC_HIST_BYTE(P, K)                                                                                                   \
+    asm volatile("v_cmp_ne_u32_sdwa vcc, %2, %5 src0_sel:BYTE_" #K " src1_sel:DWORD\n\t"                                    \
+                 "v_lshlrev_b32_sdwa %0, %4, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K "\n\t" \
+                 "s_and_saveexec_b64 %1, vcc\n\t"                                                                             \
+                 "ds_add_u32 %0, %3 offset:%6\n\t"                                                                            \
+                 "s_mov_b64 exec, %1"                                                                                         \
+                 : "=&v"(haddr), "=&s"(sv) : "v"(P), "v"(one), "v"(two), "v"(zero), "n"(SpecLds::hist) : "vcc", "memory")
+                SPEC_HIST_BYTE(pk[0], 0); SPEC_HIST_BYTE(pk[0], 1); SPEC_HIST_BYTE(pk[0], 2); SPEC_HIST_BYTE(pk[0], 3);
+                SPEC_HIST_BYTE(pk[1], 0); SPEC_HIST_BYTE(pk[1], 1); SPEC_HIST_BYTE(pk[1], 2); SPEC_HIST_BYTE(pk[1], 3);
+#undef SPEC_HIST_BYTE
+            } else {
+                // Only levels 1 .. kPartialHistLevels-1 are counted one by one (a quarter of the lanes on equalised data:
+                // the LDS atomics, not the arithmetic, are what the histogram costs).  Of the levels above the lane keeps
+                // their number and its highest level; they are added to that level's bin after the rows.  The consumers
+                // (rescale range, synRGB floor) only need the exact low bins, the total and the highest level present --
+                // see chain_kernels.hip k_level_hist_guard for the proof and the fallback when the low bins are empty.
+#define SPEC_HIST_BYTE(P, K)                                                                                                   \
+    asm volatile("v_cmp_ne_u32_sdwa vcc, %3, %6 src0_sel:BYTE_" #K " src1_sel:DWORD\n\t"                                    \
+                 "v_cmp_lt_u32_sdwa %2, %3, %7 src0_sel:BYTE_" #K " src1_sel:DWORD\n\t"                                     \
+                 "v_lshlrev_b32_sdwa %0, %5, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K "\n\t" \
+                 "s_and_b64 vcc, vcc, %2\n\t"                                                                                 \
+                 "s_and_saveexec_b64 %1, vcc\n\t"                                                                             \
+                 "ds_add_u32 %0, %4 offset:%8\n\t"                                                                            \
+                 "s_mov_b64 exec, %1"                                                                                         \
+                 : "=&v"(haddr), "=&s"(sv), "=&s"(sw) : "v"(P), "v"(one), "v"(two), "v"(zero), "v"(lim), "n"(SpecLds::hist) : "vcc", "memory")
+                SPEC_HIST_BYTE(pk[0], 0); SPEC_HIST_BYTE(pk[0], 1); SPEC_HIST_BYTE(pk[0], 2); SPEC_HIST_BYTE(pk[0], 3);
+                SPEC_HIST_BYTE(pk[1], 0); SPEC_HIST_BYTE(pk[1], 1); SPEC_HIST_BYTE(pk[1], 2); SPEC_HIST_BYTE(pk[1], 3);
+#undef SPEC_HIST_BYTE
+                static_assert(kPartialHistLevels == 64, "the high-level count below tests the top two bits of a level");
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const uint32_t lv = (pk[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                const uint32_t h = lv ? SpecLds::hist + lv * 4u : dummy;
-                atomicAdd(reinterpret_cast<uint32_t *>(lds + h), 1u);
+                for (int h = 0; h < 2; ++h) {
+                    lane_high += (uint32_t)__builtin_popcount((pk[h] | (pk[h] << 1)) & 0x80808080u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lane_max = max(lane_max, (pk[h] >> (8 * k)) & 0xFFu);
+                }
             }
         }
         uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out[band]) + (size_t)r * a.out_pitch + col;
@@ -506,6 +548,8 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
             }
         }
     }
+    if (PARTIAL_HIST && count_levels && lane_high) // lane_high > 0 implies lane_max >= kPartialHistLevels
+        atomicAdd(reinterpret_cast<uint32_t *>(lds + SpecLds::hist) + lane_max, lane_high);
 }
 
 __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a) {
@@ -561,8 +605,13 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u));
     }
     __syncthreads();
-    if (lut_lds) clahe_spec_rows<true>(a, rc, band, lds, win_hi);
-    else clahe_spec_rows<false>(a, rc, band, lds, win_hi);
+    if (a.partial_hist) {
+        if (lut_lds) clahe_spec_rows<true, true>(a, rc, band, lds, win_hi);
+        else clahe_spec_rows<false, true>(a, rc, band, lds, win_hi);
+    } else {
+        if (lut_lds) clahe_spec_rows<true, false>(a, rc, band, lds, win_hi);
+        else clahe_spec_rows<false, false>(a, rc, band, lds, win_hi);
+    }
     if (ghist) {
         __syncthreads();
         const uint32_t n = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[threadIdx.x];

@@ -195,3 +195,32 @@ def test_device_chain_non_identity_rescale(ctx):
     rgb, u1, u2 = ctx.dualpol_synrgb(dn, dn2, St.Clahe, want_u8=True)
     rc, rrgb, r1, r2 = oracle.dualpol_synrgb(dn.astype(np.float32), dn2.astype(np.float32), int(St.Clahe))
     assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb)
+
+
+@pytest.mark.parametrize("kind", ["two_values", "high_plateau", "natural", "constant"])
+def test_partial_level_histogram_and_its_recount_fallback(ctx, kind, monkeypatch):
+    """The chain's apply kernel only counts levels < 64 one by one (levels above in bulk at the lane's highest level);
+    k_level_hist_guard proves that enough or flags the band for a recount of its level raster.  Rasters whose CLAHE
+    levels all lie above 27 take the recount; SARPRO_HIP_FULL_LEVEL_HIST=1 is the full histogram.  All equal the oracle."""
+    rng = np.random.default_rng(11)
+    rows, cols = 264, 512
+    if kind == "two_values":      # two populated bins: levels ~127 and 255 only
+        b1 = rng.choice(np.array([120, 4000], np.uint16), size=(rows, cols))
+        b2 = rng.choice(np.array([300, 900], np.uint16), size=(rows, cols))
+    elif kind == "high_plateau":  # 80 % of the pixels in the lowest bin: its CDF foot is already at ~0.8
+        b1 = np.where(rng.random((rows, cols)) < 0.8, 50, rng.integers(51, 6000, (rows, cols))).astype(np.uint16)
+        b2 = np.where(rng.random((rows, cols)) < 0.5, 70, rng.integers(71, 3000, (rows, cols))).astype(np.uint16)
+    elif kind == "constant":
+        b1 = np.full((rows, cols), 777, np.uint16)
+        b2 = np.full((rows, cols), 12, np.uint16)
+    else:
+        b1, b2 = scene(rows, cols, 0), scene(rows, cols, 1)
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1.astype(np.float32), b2.astype(np.float32), int(St.Clahe))
+    assert rc == 0
+    for full in ("", "1"):
+        if full:
+            monkeypatch.setenv("SARPRO_HIP_FULL_LEVEL_HIST", full)
+        else:
+            monkeypatch.delenv("SARPRO_HIP_FULL_LEVEL_HIST", raising=False)
+        rgb, u1, u2 = ctx.dualpol_synrgb(b1, b2, St.Clahe, want_u8=True)
+        assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), (kind, full)
