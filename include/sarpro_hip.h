@@ -96,7 +96,8 @@ int sarpro_hip_ctx_synchronize(sarpro_hip_ctx *ctx);
  * (io/gdal.rs:123-131).  U8: fills out_u8 (out_u16 may be NULL); U16: fills out_u16.
  * The dB buffer / mask the reference also returns are not materialised (callers only
  * use their dims, save.rs:331; see sarpro_hip_db_mask_f32 for the buffers themselves).
- * stats_out may be NULL. */
+ * stats_out may be NULL (the f32 flavour then skips the per-sample dB moments, which only the statistics and the
+ * Adaptive strategy read). */
 int sarpro_hip_autoscale_band_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols,
                                   int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16,
                                   sarpro_hip_stats *stats_out);

@@ -244,10 +244,11 @@ class Context:
         return st
 
     def dev_autoscale_band_f32(self, d_in: int, rows: int, cols: int, in_pitch: int, strategy, bit_depth,
-                               d_out: int, out_pitch: int) -> Stats:
-        st = Stats()
+                               d_out: int, out_pitch: int, want_stats: bool = True) -> Stats | None:
+        """want_stats=False passes stats_out = NULL: the pre-pass then skips the per-sample dB moments."""
+        st = Stats() if want_stats else None
         self._chk(lib.sarpro_hip_autoscale_band_f32_dev(self._h, _vp(d_in), rows, cols, in_pitch, int(strategy),
-                                                        int(bit_depth), _vp(d_out), out_pitch, C.byref(st)))
+                                                        int(bit_depth), _vp(d_out), out_pitch, C.byref(st) if want_stats else None))
         return st
 
     def dev_dualpol_synrgb_u16(self, d_b1: int, d_b2: int, rows: int, cols: int, in_pitch: int, strategy, mode,

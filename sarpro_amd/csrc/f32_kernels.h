@@ -10,14 +10,25 @@ struct F32Partial { // one per block of the pre-pass
     float minv, maxv;  // of the valid samples
 };
 
+// Where a step table is linear in dB (4096-bin index, CLAHE bin, level with gamma = 1) the kernels first ESTIMATE
+// the step from log2(x * inv_x0) * scale + bias (hardware v_log_f32) and then VERIFY it against the two neighbouring
+// thresholds; only a failed check (samples within float error of a threshold, or use == 0) takes the binary search.
+// The thresholds alone decide the result, so the estimate's quality only affects speed.
+struct F32StepEstimate {
+    float inv_x0, scale, bias; // t = log2(x * inv_x0) * scale (the clipped window maps to 0..1), step = t^gamma * nsteps + bias
+    float gamma, nsteps;
+    int use;
+};
+
 struct F32LevelArgs {
     const float *in;
     void *out; // u8 or u16
     size_t in_pitch, out_pitch;
     uint32_t rows, cols;
     float t_valid;
-    const float *thr;                // [256] (u8) or [65536] (u16); thr[0] unused
+    const float *thr;                // [256] (u8) or [65536 + 1] (u16: thr[65536] = +inf sentinel); thr[0] unused
     unsigned long long *level_hist;  // [256], u8 only
+    F32StepEstimate est;
 };
 
 struct F32TileHistArgs {
@@ -27,6 +38,7 @@ struct F32TileHistArgs {
     float t_valid;
     const float *thr;                // [256]
     unsigned long long *tile_bins;   // [64][256], zeroed by the caller
+    F32StepEstimate est;
 };
 
 struct F32ClaheApplyArgs {
@@ -40,13 +52,15 @@ struct F32ClaheApplyArgs {
     const RowWeight *row_w, *col_w;
     unsigned long long *level_hist;  // [256], u8 only
     double max_val;
+    F32StepEstimate est;
 };
 
 int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec);
-hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
+// moments = false: count / min / max only (no per-sample f64 log10: the pass is then memory-bound)
+hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, bool moments,
                               F32Partial *d_partials, int grid, hipStream_t s);
 hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
-                               const float *d_thr, unsigned long long *d_hist, hipStream_t s);
+                               const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s);
 hipError_t launch_f32_level(const F32LevelArgs &a, bool vec, bool out16, hipStream_t s);
 hipError_t launch_f32_tile_hist(const F32TileHistArgs &a, int nrects, bool vec, hipStream_t s);
 hipError_t launch_f32_clahe_apply(const F32ClaheApplyArgs &a, int nrects, bool vec, bool out16, hipStream_t s);

@@ -29,6 +29,18 @@ __device__ inline uint32_t step_search(const float *thr, float v) {
     return idx;
 }
 
+// The same count by estimate + verification: thr[0] = -inf and thr[N + 1] = +inf must be readable.  k is right iff
+// thr[k] <= v < thr[k + 1] (ascending table), whatever produced k; otherwise the binary search decides.
+template <int N>
+__device__ inline uint32_t est_search(const float *thr, float v, const F32StepEstimate &e) {
+    float t = fminf(fmaxf(__builtin_amdgcn_logf(v * e.inv_x0) * e.scale, 0.0f), 1.0f); // log2; NaN -> 0
+    if (e.gamma != 1.0f) t = __builtin_amdgcn_exp2f(e.gamma * __builtin_amdgcn_logf(t)); // t^gamma (t = 0: exp2(-inf) = 0)
+    const uint32_t k = (uint32_t)fminf(fmaxf(t * e.nsteps + e.bias, 0.0f), (float)N);
+    const float t0 = thr[k], t1 = thr[k + 1];
+    if (t0 <= v && v < t1) return k;
+    return step_search<N>(thr, v);
+}
+
 template <int VEC> struct F32Vec;
 template <> struct F32Vec<4> {
     float4 v;
@@ -41,11 +53,26 @@ template <> struct F32Vec<1> {
     __device__ float get(int) const { return v; }
 };
 
+// VEC levels of one lane -> the output raster: one 4- or 8-byte store when the whole vector lies inside the row
+// and the raster allows it (16-byte-aligned base is the callers' contract for VEC = 4, pitch % 4 == 0 checked here).
+template <int VEC, bool OUT16>
+__device__ inline void store_levels(void *out, size_t elem, const uint32_t *lv, int n, bool vec_ok) {
+    if (VEC == 4 && n == 4 && vec_ok) {
+        if (OUT16) *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(out) + elem) = make_uint2(lv[0] | (lv[1] << 16), lv[2 % VEC] | (lv[3 % VEC] << 16));
+        else *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(out) + elem) = lv[0] | (lv[1 % VEC] << 8) | (lv[2 % VEC] << 16) | (lv[3 % VEC] << 24);
+    } else {
+        for (int j = 0; j < n; ++j) {
+            if (OUT16) reinterpret_cast<uint16_t *>(out)[elem + j] = (uint16_t)lv[j];
+            else reinterpret_cast<uint8_t *>(out)[elem + j] = (uint8_t)lv[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // a. pre-pass: count / min / max of the valid samples and the dB moments (deterministic:
 //    per-block partials, reduced by the host in block order).
 // ------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, bool MOMENTS>
 __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict__ in, size_t pitch, uint32_t rows,
                                                         uint32_t cols, float t_valid, F32Partial *__restrict__ out) {
     const uint32_t vpr = (cols + VEC - 1) / VEC;
@@ -64,9 +91,11 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
                 ++cnt;
                 mn = fminf(mn, x);
                 mx = fmaxf(mx, x);
-                const double db = 10.0 * log10((double)x);
-                sum += db;
-                sumsq += db * db;
+                if (MOMENTS) {
+                    const double db = 10.0 * log10((double)x);
+                    sum += db;
+                    sumsq += db * db;
+                }
             }
         }
     }
@@ -91,10 +120,11 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict__ in, size_t pitch, uint32_t rows,
                                                          uint32_t cols, float t_valid, const float *__restrict__ g_thr,
-                                                         unsigned long long *__restrict__ g_hist) {
-    __shared__ float thr[4096];
+                                                         unsigned long long *__restrict__ g_hist, F32StepEstimate est) {
+    __shared__ float thr[4096 + 1];
     __shared__ uint32_t hist[4096];
-    for (int i = threadIdx.x; i < 4096; i += kBlock) { thr[i] = g_thr[i]; hist[i] = 0; }
+    for (int i = threadIdx.x; i < 4096; i += kBlock) { thr[i] = i ? g_thr[i] : -INFINITY; hist[i] = 0; }
+    if (threadIdx.x == 0) thr[4096] = INFINITY;
     __syncthreads();
     const uint32_t vpr = (cols + VEC - 1) / VEC;
     const uint64_t total = (uint64_t)rows * vpr;
@@ -105,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float x = v.get(j);
-            if (col + j < cols && x >= t_valid) atomicAdd(&hist[step_search<4095>(thr, x)], 1u);
+            if (col + j < cols && x >= t_valid) atomicAdd(&hist[est.use ? est_search<4095>(thr, x, est) : step_search<4095>(thr, x)], 1u);
         }
     }
     __syncthreads();
@@ -120,30 +150,32 @@ __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict
 // ------------------------------------------------------------------------------------
 template <int VEC, bool OUT16>
 __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
-    __shared__ float thr[256];
+    __shared__ float thr[256 + 1];
     __shared__ uint32_t hist[256];
-    if (!OUT16) { thr[threadIdx.x] = a.thr[threadIdx.x]; hist[threadIdx.x] = 0; }
+    if (!OUT16) { thr[threadIdx.x] = threadIdx.x ? a.thr[threadIdx.x] : -INFINITY; hist[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) thr[256] = INFINITY;
     __syncthreads();
     const uint32_t vpr = (a.cols + VEC - 1) / VEC;
     const uint64_t total = (uint64_t)a.rows * vpr;
+    const bool vec_store = a.out_pitch % VEC == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     uint32_t zeros = 0;
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
         const uint32_t r = (uint32_t)(idx / vpr);
         const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
         const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.in_pitch + col);
+        uint32_t lvs[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            if (col + j >= a.cols) continue;
             const float x = v.get(j);
             uint32_t lv = 0;
-            if (x >= a.t_valid) lv = OUT16 ? step_search<65535>(a.thr, x) : step_search<255>(thr, x);
-            if (OUT16) {
-                reinterpret_cast<uint16_t *>(a.out)[(size_t)r * a.out_pitch + col + j] = (uint16_t)lv;
-            } else {
-                reinterpret_cast<uint8_t *>(a.out)[(size_t)r * a.out_pitch + col + j] = (uint8_t)lv;
-                if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u);
+            if (col + j < a.cols && x >= a.t_valid) {
+                if (a.est.use) lv = OUT16 ? est_search<65535>(a.thr, x, a.est) : est_search<255>(thr, x, a.est);
+                else lv = OUT16 ? step_search<65535>(a.thr, x) : step_search<255>(thr, x);
             }
+            lvs[j] = lv;
+            if (!OUT16 && col + j < a.cols) { if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u); }
         }
+        store_levels<VEC, OUT16>(a.out, (size_t)r * a.out_pitch + col, lvs, (int)min((uint32_t)VEC, a.cols - col), vec_store);
     }
     if (!OUT16) {
         if (zeros) atomicAdd(&hist[0], zeros);
@@ -157,9 +189,10 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
 // ------------------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
-    __shared__ float thr[256];
+    __shared__ float thr[256 + 1];
     __shared__ uint32_t hist[256];
-    thr[threadIdx.x] = a.thr[threadIdx.x];
+    thr[threadIdx.x] = threadIdx.x ? a.thr[threadIdx.x] : -INFINITY;
+    if (threadIdx.x == 0) thr[256] = INFINITY;
     hist[threadIdx.x] = 0;
     __syncthreads();
     const Rect rc = a.rects[blockIdx.x];
@@ -171,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
             for (int j = 0; j < VEC; ++j) {
                 const int c = col + j;
                 const float x = v.get(j);
-                if (c >= rc.c0 && c < rc.c1 && x >= a.t_valid) atomicAdd(&hist[step_search<255>(thr, x)], 1u);
+                if (c >= rc.c0 && c < rc.c1 && x >= a.t_valid) atomicAdd(&hist[a.est.use ? est_search<255>(thr, x, a.est) : step_search<255>(thr, x)], 1u);
             }
         }
     }
@@ -187,19 +220,21 @@ __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
 template <int VEC, bool OUT16>
 __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a) {
     __shared__ __align__(16) double cdf4[256 * 4];
-    __shared__ float thr[256];
+    __shared__ float thr[256 + 1];
     __shared__ uint32_t hist[256];
     const Rect rc = a.rects[blockIdx.x];
     {
         const int b = threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) cdf4[b * 4 + k] = a.cdfs[(size_t)rc.id[k] * 256 + b];
-        thr[b] = a.thr[b];
+        thr[b] = b ? a.thr[b] : -INFINITY;
+        if (b == 0) thr[256] = INFINITY;
         hist[b] = 0;
     }
     __syncthreads();
     const int col = rc.cstart + lane_id() * VEC;
     const bool lane_on = col < rc.c1 && col + VEC > rc.c0;
+    const bool vec_store = a.out_pitch % VEC == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     uint32_t zeros = 0;
     double dx[VEC], omdx[VEC];
 #pragma unroll
@@ -213,14 +248,15 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
         for (int r = rc.r0 + wave_id(); r < rc.r1; r += kWavesPerBlock) {
             const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.in_pitch + col);
             const RowWeight rw = a.row_w[r];
+            uint32_t lvs[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int c = col + j;
-                if (c < rc.c0 || c >= rc.c1) continue;
+                const bool own = c >= rc.c0 && c < rc.c1;
                 const float x = v.get(j);
                 uint32_t lv = 0;
-                if (x >= a.t_valid) {
-                    const uint32_t bin = step_search<255>(thr, x);
+                if (own && x >= a.t_valid) {
+                    const uint32_t bin = a.est.use ? est_search<255>(thr, x, a.est) : step_search<255>(thr, x);
                     const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
                     const double top = c4.x * omdx[j] + c4.y * dx[j];
                     const double bottom = c4.z * omdx[j] + c4.w * dx[j];
@@ -228,11 +264,18 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
                     o = fmin(fmax(o, 0.0), 1.0);
                     lv = (uint32_t)(o * a.max_val);
                 }
-                if (OUT16) {
-                    reinterpret_cast<uint16_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint16_t)lv;
-                } else {
-                    reinterpret_cast<uint8_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint8_t)lv;
-                    if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u);
+                lvs[j] = lv;
+                if (!OUT16 && own) { if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u); }
+            }
+            if (col >= rc.c0 && col + VEC <= rc.c1) {
+                store_levels<VEC, OUT16>(a.out, (size_t)r * a.out_pitch + col, lvs, VEC, vec_store);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int c = col + j;
+                    if (c < rc.c0 || c >= rc.c1) continue;
+                    if (OUT16) reinterpret_cast<uint16_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint16_t)lvs[j];
+                    else reinterpret_cast<uint8_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint8_t)lvs[j];
                 }
             }
         }
@@ -269,19 +312,24 @@ int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec) {
     return stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4);
 }
 
-hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
+hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, bool moments,
                               F32Partial *d_partials, int grid, hipStream_t s) {
-    if (vec) hipLaunchKernelGGL(k_f32_prepass<4>, dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
-    else hipLaunchKernelGGL(k_f32_prepass<1>, dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+    if (vec) {
+        if (moments) hipLaunchKernelGGL((k_f32_prepass<4, true>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+        else hipLaunchKernelGGL((k_f32_prepass<4, false>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+    } else {
+        if (moments) hipLaunchKernelGGL((k_f32_prepass<1, true>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+        else hipLaunchKernelGGL((k_f32_prepass<1, false>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
-                               const float *d_thr, unsigned long long *d_hist, hipStream_t s) {
+                               const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s) {
     const int V = vec ? 4 : 1;
     dim3 grid(stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4));
-    if (vec) hipLaunchKernelGGL(k_f32_hist4096<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist);
-    else hipLaunchKernelGGL(k_f32_hist4096<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist);
+    if (vec) hipLaunchKernelGGL(k_f32_hist4096<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est);
+    else hipLaunchKernelGGL(k_f32_hist4096<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est);
     return hipGetLastError();
 }
 

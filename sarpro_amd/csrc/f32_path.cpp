@@ -4,6 +4,7 @@
 // binary search.  No CPU fallback: all rasters come from the kernels in f32_kernels.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,7 +40,7 @@ constexpr size_t kOffPartials = 0;                                   // 2048 x 3
 constexpr size_t kOffThr4096 = 64 * 1024;                            // 16 KiB
 constexpr size_t kOffHist4096 = kOffThr4096 + 16 * 1024;             // 32 KiB
 constexpr size_t kOffThrLevel = kOffHist4096 + 32 * 1024;            // 256 KiB
-constexpr size_t kOffTileBins = kOffThrLevel + 256 * 1024;           // 128 KiB
+constexpr size_t kOffTileBins = kOffThrLevel + 256 * 1024 + 4096;    // 128 KiB (the level table carries a sentinel entry)
 constexpr size_t kOffLevelHist = kOffTileBins + 128 * 1024;          // 2 KiB
 constexpr size_t kOffCdfs = kOffLevelHist + 4 * 1024;                // 128 KiB
 constexpr size_t kOffMap = kOffCdfs + 128 * 1024;                    // 256 B
@@ -53,8 +54,19 @@ struct F32Band {
     void *d_out = nullptr;
     size_t out_pitch = 0;
     sarpro_hip_stats stats{};
+    bool want_moments = true;   // mean / std of dB: reported statistics and the Adaptive strategy only
     uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
 };
+
+// estimate of a step table that is linear in dB: step = (dB(x) - low_db) / range_db * nsteps + bias, dB = 10 log10
+F32StepEstimate step_estimate(double low_db, double range_db, double nsteps, double bias, double gamma = 1.0) {
+    F32StepEstimate e{};
+    const double inv_x0 = std::pow(10.0, -low_db / 10.0), scale = 3.010299956639812 / range_db; // 10 log10(2)
+    e.inv_x0 = (float)inv_x0; e.scale = (float)scale; e.bias = (float)bias; e.gamma = (float)gamma; e.nsteps = (float)nsteps;
+    e.use = std::isfinite(e.inv_x0) && e.inv_x0 > 1e-30f && std::isfinite(e.scale) && e.scale * e.nsteps < 3.0e6f &&
+            !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
+    return e;
+}
 
 int rescale_in_place(F32Band &B, const uint64_t *level_hist) {
     sarpro_hip_ctx *ctx = B.ctx;
@@ -106,12 +118,13 @@ int f32_band_run(F32Band &B) {
     const float t_valid = valid_threshold_f32();
     const size_t esz = u8o ? 1 : 2;
 
-    // ---- pass a: count / min / max / dB moments ----
+    // ---- pass a: count / min / max (+ dB moments when somebody reads them) ----
     const int pgrid = f32_prepass_grid(rows, cols, vec);
     F32Partial *d_part = reinterpret_cast<F32Partial *>(ws + kOffPartials);
+    const bool moments = B.want_moments || (B.strategy == SARPRO_STRATEGY_ADAPTIVE && !B.tamed);
     {
         KernelTimer t(ctx, "f32_prepass");
-        HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, t_valid, vec, d_part, pgrid, ctx->stream));
+        HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, t_valid, vec, moments, d_part, pgrid, ctx->stream));
     }
     F32Partial *h_part = ctx->h_small.as<F32Partial>();
     HIPCHK(ctx, hipMemcpyAsync(h_part, d_part, sizeof(F32Partial) * (size_t)pgrid, hipMemcpyDeviceToHost, ctx->stream));
@@ -147,7 +160,8 @@ int f32_band_run(F32Band &B) {
         HIPCHK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * 4096, ctx->stream));
         {
             KernelTimer t(ctx, "f32_hist4096");
-            HIPCHK(ctx, launch_f32_hist4096(B.d_in, B.in_pitch, rows, cols, t_valid, vec, d_thr, d_hist, ctx->stream));
+            HIPCHK(ctx, launch_f32_hist4096(B.d_in, B.in_pitch, rows, cols, t_valid, vec, d_thr, d_hist,
+                                            step_estimate(min_db, max_db - min_db, 4096.0, 0.0), ctx->stream));
         }
         HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -164,8 +178,10 @@ int f32_band_run(F32Band &B) {
         float *thr = ctx->h_upload.as<float>();
         build_level_thresholds(B.stats, nlevels, thr);
         float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
-        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * (size_t)(nlevels + 1), hipMemcpyHostToDevice, ctx->stream));
+        thr[nlevels + 1] = INFINITY; // sentinel read by the estimate's verification
+        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * (size_t)(nlevels + 2), hipMemcpyHostToDevice, ctx->stream));
         F32LevelArgs a{};
+        a.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), (double)nlevels, 0.0, B.stats.gamma);
         a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
         a.rows = rows; a.cols = cols; a.t_valid = t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
         KernelTimer t(ctx, "f32_level");
@@ -183,6 +199,7 @@ int f32_band_run(F32Band &B) {
         F32TileHistArgs ta{};
         ta.in = B.d_in; ta.pitch = B.in_pitch; ta.rects = plan->d_hist_rects_tiled.as<Rect>();
         ta.t_valid = t_valid; ta.thr = d_thr; ta.tile_bins = d_tile_bins;
+        ta.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
         {
             KernelTimer t(ctx, "f32_tile_hist");
             HIPCHK(ctx, launch_f32_tile_hist(ta, (int)plan->hist_rects_tiled.size(), vec, ctx->stream));
@@ -199,6 +216,7 @@ int f32_band_run(F32Band &B) {
         a.rects = plan->d_apply_rects.as<Rect>(); a.cdfs = d_cdfs; a.t_valid = t_valid; a.thr = d_thr;
         a.row_w = plan->d_row_w.as<RowWeight>(); a.col_w = plan->d_col_w.as<RowWeight>();
         a.level_hist = d_level_hist; a.max_val = u8o ? 255.0 : 65535.0;
+        a.est = ta.est;
         KernelTimer t(ctx, "f32_clahe_apply");
         HIPCHK(ctx, launch_f32_clahe_apply(a, (int)plan->apply_rects.size(), vec, !u8o, ctx->stream));
     }
@@ -228,6 +246,7 @@ extern "C" int sarpro_hip_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, const floa
     F32Band B;
     B.ctx = ctx; B.d_in = d_in; B.rows = rows; B.cols = cols; B.in_pitch = in_pitch;
     B.strategy = strategy; B.bit_depth = bit_depth; B.d_out = d_out; B.out_pitch = out_pitch;
+    B.want_moments = stats_out != nullptr;
     int rc = f32_band_run(B);
     if (rc == SARPRO_HIP_OK && stats_out) *stats_out = B.stats;
     return rc;
@@ -249,6 +268,7 @@ static int host_band_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size
     B.ctx = ctx; B.d_in = ctx->stage_in[0].as<float>(); B.rows = rows; B.cols = cols; B.in_pitch = pitch;
     B.strategy = tamed ? SARPRO_STRATEGY_TAMED : strategy; B.bit_depth = u8o ? SARPRO_BITDEPTH_U8 : SARPRO_BITDEPTH_U16;
     B.tamed = tamed; B.d_out = ctx->stage_out[0].p; B.out_pitch = pitch;
+    B.want_moments = stats_out != nullptr;
     RETCHK(f32_band_run(B));
     if (stats_out) *stats_out = B.stats;
     return fetch_out_2d(ctx, u8o ? (void *)out_u8 : (void *)out_u16, ctx->stage_out[0].p, pitch * osz, cols * osz, rows);
@@ -311,6 +331,7 @@ extern "C" int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *b
         B.strategy = strategy; B.bit_depth = SARPRO_BITDEPTH_U8;
         B.tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? kTamedCopol : kTamedCrosspol) : 0;
         B.d_out = ctx->levels[b].p; B.out_pitch = pitch;
+        B.want_moments = stats_out != nullptr;
         RETCHK(f32_band_run(B));
         if (stats_out) stats_out[b] = B.stats;
         for (int i = 0; i < 256; ++i) combined[i] += B.final_hist[i];

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 namespace sarpro {
 
@@ -629,17 +631,29 @@ static void step_thresholds(F fn, G inv_db, int n, float *thr) {
     const uint32_t lo0 = f32_to_bits(valid_threshold_f32());
     thr[0] = 0.0f;
     const int64_t top = fn(db_of_f32(bits_to_f32(kMaxFiniteBits)));
-    uint32_t lo = lo0;
-    for (int k = 1; k <= n; ++k) {
-        if ((int64_t)k > top) { thr[k] = INFINITY; continue; }
-        double gdb = inv_db(k);
-        double gv = std::pow(10.0, gdb / 10.0);
-        uint32_t guess = (gv > 0.0 && gv < 3.0e38) ? f32_to_bits((float)gv) : lo;
-        uint32_t b = find_first_bits([&](uint32_t x) { return fn(db_of_f32(bits_to_f32(x))) >= (int64_t)k; }, lo,
-                                     kMaxFiniteBits, guess);
-        thr[k] = bits_to_f32(b);
-        lo = b; // thresholds are non-decreasing in k
+    auto run = [&](int k0, int k1) { // thresholds k0..k1-1; the lower bracket restarts at the validity threshold
+        uint32_t lo = lo0;
+        for (int k = k0; k < k1; ++k) {
+            if ((int64_t)k > top) { thr[k] = INFINITY; continue; }
+            double gdb = inv_db(k);
+            double gv = std::pow(10.0, gdb / 10.0);
+            uint32_t guess = (gv > 0.0 && gv < 3.0e38) ? f32_to_bits((float)gv) : lo;
+            uint32_t b = find_first_bits([&](uint32_t x) { return fn(db_of_f32(bits_to_f32(x))) >= (int64_t)k; }, lo,
+                                         kMaxFiniteBits, guess);
+            thr[k] = bits_to_f32(b);
+            lo = b; // thresholds are non-decreasing in k
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = n >= 8192 ? (int)std::min<unsigned>(16u, std::max<unsigned>(1u, hw)) : 1; // the 65535-level tables
+    if (nthreads <= 1) { run(1, n + 1); return; }
+    std::vector<std::thread> pool;
+    const int per = (n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        const int k0 = 1 + t * per, k1 = std::min(n + 1, k0 + per);
+        if (k0 < k1) pool.emplace_back(run, k0, k1);
     }
+    for (auto &th : pool) th.join();
 }
 
 void build_bin4096_thresholds(double min_db, double max_db, float *thr) {

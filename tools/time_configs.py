@@ -45,8 +45,17 @@ for x in f:
 ratio = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
 out["cfg3_logratio_polop_ms"] = timed(lambda: ctx.dev_polop_f32(Op.LogRatio, f[0].data_ptr(), f[1].data_ptr(), rows * cols, ratio.data_ptr()))
 del f
-out["cfg3_ratio_f32_clahe_u16_ms"] = timed(lambda: ctx.dev_autoscale_band_f32(ratio.data_ptr(), rows, cols, cols, St.Clahe, Bd.U16, o16.data_ptr(), pitch), n=3, warm=1)
+out["cfg3_ratio_f32_clahe_u16_with_stats_ms"] = timed(lambda: ctx.dev_autoscale_band_f32(ratio.data_ptr(), rows, cols, cols, St.Clahe, Bd.U16, o16.data_ptr(), pitch), n=3, warm=1)
+out["cfg3_ratio_f32_clahe_u16_ms"] = timed(lambda: ctx.dev_autoscale_band_f32(ratio.data_ptr(), rows, cols, cols, St.Clahe, Bd.U16, o16.data_ptr(), pitch, want_stats=False), n=3, warm=1)
 out["cfg3_ratio_f32_kernels"] = {k: round(v, 3) for k, v in ctx.last_kernel_times() if not k.startswith("host:")}
+o8f = torch.empty((rows, pitch), dtype=torch.uint8, device="cuda")
+out["f32_robust_u8_ms"] = timed(lambda: ctx.dev_autoscale_band_f32(ratio.data_ptr(), rows, cols, cols, St.Robust, Bd.U8, o8f.data_ptr(), pitch, want_stats=False), n=3, warm=1)
+out["f32_robust_u8_kernels"] = {k: round(v, 3) for k, v in ctx.last_kernel_times() if not k.startswith("host:")}
+out["f32_standard_u8_ms"] = timed(lambda: ctx.dev_autoscale_band_f32(ratio.data_ptr(), rows, cols, cols, St.Standard, Bd.U8, o8f.data_ptr(), pitch, want_stats=False), n=3, warm=1)
+out["f32_standard_u8_kernels"] = {k: round(v, 3) for k, v in ctx.last_kernel_times() if not k.startswith("host:")}
+out["f32_robust_u16_ms"] = timed(lambda: ctx.dev_autoscale_band_f32(ratio.data_ptr(), rows, cols, cols, St.Robust, Bd.U16, o16.data_ptr(), pitch, want_stats=False), n=3, warm=1)
+out["f32_robust_u16_kernels"] = {k: round(v, 3) for k, v in ctx.last_kernel_times() if not k.startswith("host:")}
+del o8f
 del ratio, o16
 # config 1: 2048 x 2048 f32, Standard, U8
 n1 = 2048
