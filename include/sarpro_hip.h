@@ -43,6 +43,7 @@ extern "C" {
 #define SARPRO_HIP_ERR_RCCL (-5)
 #define SARPRO_HIP_ERR_OOM (-6)
 #define SARPRO_HIP_ERR_NO_DEVICE (-7)
+#define SARPRO_HIP_ERR_IO (-8) /* a row reader / sink / TIFF file failed */
 
 /* ---- src/types.rs discriminants ---- */
 typedef enum { /* types.rs:115-123 */
@@ -244,6 +245,51 @@ int sarpro_hip_stripe_phase3(sarpro_hip_stripe *s, uint64_t **d_buf, size_t *cou
 int sarpro_hip_stripe_phase4(sarpro_hip_stripe *s, uint8_t *d_rgb, size_t rgb_pitch_px,
                              sarpro_hip_stats *stats_out);
 void sarpro_hip_stripe_end(sarpro_hip_stripe *s);
+
+/* ================= streaming ingest / egress (north-star: "staged to device via pinned
+ * hipMemcpyAsync overlapped on a side stream") =================
+ * The caller keeps its decoder (GDAL RasterIO, the strip-TIFF reader below, a socket ...): `reader` fills `nrows`
+ * rows of band 0 or 1 starting at `row0` into a PINNED buffer of the library (`dst_pitch` elements per row);
+ * `sink` receives finished interleaved RGB rows (`src_pitch_bytes` per row, cols * 3 valid).  Both return 0 or an
+ * error code of their own, which aborts the call with SARPRO_HIP_ERR_IO.  While the reader produces chunk k + 1,
+ * chunk k crosses PCIe on a side stream and the DN-histogram work items of the rows that have arrived run on the
+ * compute stream; the RGB leaves chunk by chunk the same way.  Replaces the read loop + processing + write of
+ * save_processed_multiband_image_sequential's JPEG branch at native resolution (save.rs:317-367, io/gdal.rs:107-141).
+ * chunk_rows = 0 picks ~32 MiB chunks. */
+typedef int (*sarpro_hip_row_reader)(void *user, int band, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch);
+typedef int (*sarpro_hip_row_sink)(void *user, size_t row0, size_t nrows, const uint8_t *src, size_t src_pitch_bytes);
+int sarpro_hip_dualpol_synrgb_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *reader_user, size_t rows,
+                                         size_t cols, int strategy, int mode, size_t chunk_rows, sarpro_hip_row_sink sink,
+                                         void *sink_user, sarpro_hip_stats *stats_out);
+
+/* ---- file shims for the two callbacks: uncompressed strip TIFF / BigTIFF (what Sentinel-1 GRD measurement rasters
+ * are; io/gdal.rs:107-141 and io/writers/tiff.rs:6-78 go through GDAL).  Baseline TIFF 6.0 + BigTIFF, II or MM,
+ * Compression = 1, strips, 8- / 16-bit unsigned samples, chunky or planar; anything else fails with
+ * SARPRO_HIP_ERR_IO and a message (sarpro_hip_tiff_last_error, per thread).  No GPU involved. ---- */
+typedef struct sarpro_hip_tiff sarpro_hip_tiff;
+typedef struct sarpro_hip_tiff_writer sarpro_hip_tiff_writer;
+typedef struct {
+    uint64_t width, height, rows_per_strip;
+    uint32_t bits_per_sample, samples_per_pixel, sample_format, planar, compression, big_endian, bigtiff, tiled;
+    uint32_t has_geo;        /* bit 0: pixel_scale, bit 1: tiepoint, bit 2: GeoKey directory */
+    uint32_t tiepoint_count; /* GRD products carry a GCP grid: only the first tiepoint is returned here */
+    double pixel_scale[3], tiepoint[6];
+} sarpro_hip_tiff_info;
+int sarpro_hip_tiff_open(const char *path, sarpro_hip_tiff **out, sarpro_hip_tiff_info *info_out);
+int sarpro_hip_tiff_read_rows_u16(sarpro_hip_tiff *t, int sample, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch);
+void sarpro_hip_tiff_close(sarpro_hip_tiff *t);
+/* a sarpro_hip_row_reader over two single-band files: user = sarpro_hip_tiff *[2] (band 0, band 1) */
+int sarpro_hip_tiff_pair_reader(void *user, int band, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch);
+/* geotransform6 (GDAL order, north-up) and geo_keys_from (GeoKey directory carried over verbatim) may be NULL */
+int sarpro_hip_tiff_create(const char *path, uint64_t width, uint64_t height, uint32_t samples, uint32_t bits,
+                           const double *geotransform6, const sarpro_hip_tiff *geo_keys_from, sarpro_hip_tiff_writer **out);
+int sarpro_hip_tiff_write_rows(sarpro_hip_tiff_writer *w, size_t row0, size_t nrows, const void *src, size_t src_pitch_bytes);
+/* a sarpro_hip_row_sink: user = sarpro_hip_tiff_writer * */
+int sarpro_hip_tiff_row_sink(void *user, size_t row0, size_t nrows, const uint8_t *src, size_t src_pitch_bytes);
+int sarpro_hip_tiff_finish(sarpro_hip_tiff_writer *w); /* writes the directory, closes and frees the writer */
+const char *sarpro_hip_tiff_last_error(void);
+/* the geotransform of a resized / padded product, save.rs:71-81 (pixel size by cols / final_cols, origin by the padding) */
+void sarpro_hip_host_update_geotransform(double gt[6], size_t cols, size_t rows, const sarpro_hip_resize_meta *m);
 
 /* The same stripe in ONE call per rank, reductions over the library's communicator (sarpro_hip_comm_init
  * must have been called): the device-resident chains with their small all-reduces enqueued on the stream,

@@ -60,6 +60,9 @@ pub struct sarpro_hip_batch_report { pub processed: usize, pub skipped: usize, p
 pub const SARPRO_HIP_OK: c_int = 0;
 pub const SARPRO_HIP_ERR_UNSUPPORTED_SHAPE: c_int = -3;
 
+pub type sarpro_hip_row_reader = Option<unsafe extern "C" fn(user: *mut c_void, band: c_int, row0: usize, nrows: usize, dst: *mut u16, dst_pitch: usize) -> c_int>;
+pub type sarpro_hip_row_sink = Option<unsafe extern "C" fn(user: *mut c_void, row0: usize, nrows: usize, src: *const u8, src_pitch_bytes: usize) -> c_int>;
+
 extern "C" {
     pub fn sarpro_hip_ctx_create(device: c_int, flags: c_uint, ctx_out: *mut *mut sarpro_hip_ctx) -> c_int;
     pub fn sarpro_hip_ctx_destroy(ctx: *mut sarpro_hip_ctx);
@@ -97,6 +100,17 @@ extern "C" {
         pad: c_int, continue_on_error: c_int, report: *mut sarpro_hip_batch_report) -> c_int;
     // device-pointer, stripe, comm and host-half entry points: see include/sarpro_hip.h
     pub fn sarpro_hip_ctx_stream(ctx: *mut sarpro_hip_ctx) -> *mut c_void;
+    /// streaming ingest / egress: the decoder's read loop and the encoder's write loop as callbacks
+    pub fn sarpro_hip_dualpol_synrgb_stream_u16(ctx: *mut sarpro_hip_ctx, reader: sarpro_hip_row_reader, reader_user: *mut c_void,
+        rows: usize, cols: usize, strategy: c_int, mode: c_int, chunk_rows: usize, sink: sarpro_hip_row_sink,
+        sink_user: *mut c_void, stats_out: *mut sarpro_hip_stats) -> c_int;
+    pub fn sarpro_hip_tiff_open(path: *const c_char, out: *mut *mut c_void, info_out: *mut c_void) -> c_int;
+    pub fn sarpro_hip_tiff_close(t: *mut c_void);
+    pub fn sarpro_hip_tiff_pair_reader(user: *mut c_void, band: c_int, row0: usize, nrows: usize, dst: *mut u16, dst_pitch: usize) -> c_int;
+    pub fn sarpro_hip_tiff_create(path: *const c_char, width: u64, height: u64, samples: u32, bits: u32, geotransform6: *const f64,
+        geo_keys_from: *const c_void, out: *mut *mut c_void) -> c_int;
+    pub fn sarpro_hip_tiff_row_sink(user: *mut c_void, row0: usize, nrows: usize, src: *const u8, src_pitch_bytes: usize) -> c_int;
+    pub fn sarpro_hip_tiff_finish(w: *mut c_void) -> c_int;
 }
 
 /// Error type a sarpro integration maps onto `Error::Processing` (src/error.rs:39-46).

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libsarpro_hip.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_SHAPE_MISMATCH, ERR_UNSUPPORTED_SHAPE = -1, -2, -3
-ERR_HIP, ERR_RCCL, ERR_OOM, ERR_NO_DEVICE = -4, -5, -6, -7
+ERR_HIP, ERR_RCCL, ERR_OOM, ERR_NO_DEVICE, ERR_IO = -4, -5, -6, -7, -8
 
 
 class Stats(C.Structure):
@@ -31,6 +31,17 @@ class Stats(C.Structure):
 class ResizeMeta(C.Structure):
     _fields_ = [("final_cols", C.c_size_t), ("final_rows", C.c_size_t), ("scale_x", C.c_double), ("scale_y", C.c_double),
                 ("pad_left", C.c_size_t), ("pad_top", C.c_size_t)]
+
+
+class TiffInfo(C.Structure):
+    _fields_ = [("width", C.c_uint64), ("height", C.c_uint64), ("rows_per_strip", C.c_uint64)] + [
+        (n, C.c_uint32) for n in ("bits_per_sample", "samples_per_pixel", "sample_format", "planar", "compression",
+                                  "big_endian", "bigtiff", "tiled", "has_geo", "tiepoint_count")
+    ] + [("pixel_scale", C.c_double * 3), ("tiepoint", C.c_double * 6)]
+
+
+ROW_READER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t)
+ROW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t)
 
 
 class BatchScene(C.Structure):
@@ -54,6 +65,9 @@ SYMBOLS = [
     "sarpro_hip_last_kernel_times",
     "sarpro_hip_stripe_begin_u16", "sarpro_hip_stripe_phase1", "sarpro_hip_stripe_phase2",
     "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end", "sarpro_hip_stripe_run_u16",
+    "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
+    "sarpro_hip_tiff_pair_reader", "sarpro_hip_tiff_create", "sarpro_hip_tiff_write_rows", "sarpro_hip_tiff_row_sink",
+    "sarpro_hip_tiff_finish", "sarpro_hip_tiff_last_error", "sarpro_hip_host_update_geotransform",
     "sarpro_hip_comm_unique_id", "sarpro_hip_comm_init", "sarpro_hip_comm_allreduce_sum_u64",
     "sarpro_hip_comm_destroy",
     "sarpro_hip_host_stats_from_dn_hist", "sarpro_hip_host_window", "sarpro_hip_host_level_lut_u16",
@@ -163,3 +177,14 @@ _proto("sarpro_hip_process_band_resized_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _s
 _proto("sarpro_hip_batch_dualpol_synrgb_resized_u16", _i, C.POINTER(_i), _i, C.POINTER(BatchScene), _sz, _i, _i, _sz, _i, _i,
        C.POINTER(BatchReport))
 _proto("sarpro_hip_stripe_run_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
+_proto("sarpro_hip_dualpol_synrgb_stream_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _vp, _vp, _S)
+_proto("sarpro_hip_tiff_open", _i, C.c_char_p, C.POINTER(_vp), C.POINTER(TiffInfo))
+_proto("sarpro_hip_tiff_read_rows_u16", _i, _vp, _i, _sz, _sz, _vp, _sz)
+_proto("sarpro_hip_tiff_close", None, _vp)
+_proto("sarpro_hip_tiff_pair_reader", _i, _vp, _i, _sz, _sz, _vp, _sz)
+_proto("sarpro_hip_tiff_create", _i, C.c_char_p, _u64, _u64, C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(_vp))
+_proto("sarpro_hip_tiff_write_rows", _i, _vp, _sz, _sz, _vp, _sz)
+_proto("sarpro_hip_tiff_row_sink", _i, _vp, _sz, _sz, _vp, _sz)
+_proto("sarpro_hip_tiff_finish", _i, _vp)
+_proto("sarpro_hip_tiff_last_error", C.c_char_p)
+_proto("sarpro_hip_host_update_geotransform", None, _vp, _sz, _sz, _M)

@@ -289,6 +289,45 @@ class Context:
                                                 int(strategy), int(mode), _vp(d_rgb), rgb_pitch_px, st))
         return [st[0], st[1]]
 
+    def dualpol_synrgb_stream(self, reader, rows: int, cols: int, strategy, mode, sink, chunk_rows: int = 0,
+                              want_stats: bool = False):
+        """Streaming ingest / egress (sarpro_hip_dualpol_synrgb_stream_u16).
+
+        `reader(band, row0, nrows, dst)` fills `dst`, a (nrows, cols) uint16 view of the library's pinned ring, and
+        `sink(row0, nrows, rgb)` consumes an (nrows, cols, 3) uint8 view; both may return a non-zero int to abort.
+        Alternatively pass the C callbacks themselves: `reader=(fn_ptr, user_ptr)` / `sink=(fn_ptr, user_ptr)`
+        (e.g. TiffPair.reader(), TiffWriter.sink())."""
+        def as_reader(r):
+            if isinstance(r, tuple):
+                return r[0], r[1], None
+            def cb(_user, band, row0, nrows, dst, pitch):
+                try:
+                    buf = (C.c_uint16 * (nrows * pitch)).from_address(dst)
+                    view = np.frombuffer(buf, np.uint16).reshape(nrows, pitch)[:, :cols]
+                    return int(r(band, row0, nrows, view) or 0)
+                except Exception:  # never unwind through the C frames
+                    return -1
+            f = _lib.ROW_READER(cb)
+            return C.cast(f, C.c_void_p), None, f
+        def as_sink(k):
+            if isinstance(k, tuple):
+                return k[0], k[1], None
+            def cb(_user, row0, nrows, src, pitch_bytes):
+                try:
+                    buf = (C.c_uint8 * (nrows * pitch_bytes)).from_address(src)
+                    view = np.frombuffer(buf, np.uint8).reshape(nrows, pitch_bytes)[:, :cols * 3].reshape(nrows, cols, 3)
+                    return int(k(row0, nrows, view) or 0)
+                except Exception:
+                    return -1
+            f = _lib.ROW_SINK(cb)
+            return C.cast(f, C.c_void_p), None, f
+        rf, ru, _keep_r = as_reader(reader)
+        sf, su, _keep_s = as_sink(sink)
+        st = (Stats * 2)() if want_stats else None
+        self._chk(lib.sarpro_hip_dualpol_synrgb_stream_u16(self._h, rf, ru, rows, cols, int(strategy), int(mode), chunk_rows,
+                                                           sf, su, st))
+        return [st[0], st[1]] if want_stats else None
+
     def comm_init(self, nranks: int, rank: int, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._chk(lib.sarpro_hip_comm_init(self._h, nranks, rank, buf))
@@ -482,3 +521,75 @@ def batch_dualpol_synrgb_resized(devices, scenes, strategy, target_size, pad, mo
                                                          int(pad), int(continue_on_error), C.byref(rep))
     st = [stats[i] for i in range(n)]
     return [o if s == 0 else None for o, s in zip(outs, st)], rep, st, rc
+
+
+# ---- uncompressed strip TIFF / BigTIFF shims (no GPU) ----
+def _tiff_chk(rc):
+    if rc != _lib.OK:
+        raise SarproHipError(rc, (lib.sarpro_hip_tiff_last_error() or b"").decode())
+
+
+class TiffReader:
+    """sarpro_hip_tiff_open / read_rows_u16 / close."""
+
+    def __init__(self, path: str):
+        h = C.c_void_p()
+        self.info = _lib.TiffInfo()
+        _tiff_chk(lib.sarpro_hip_tiff_open(path.encode(), C.byref(h), C.byref(self.info)))
+        self._h = h
+
+    def read_rows(self, row0: int, nrows: int, sample: int = 0) -> np.ndarray:
+        out = np.empty((nrows, int(self.info.width)), np.uint16)
+        _tiff_chk(lib.sarpro_hip_tiff_read_rows_u16(self._h, sample, row0, nrows, _vp(out), out.shape[1]))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sarpro_hip_tiff_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class TiffPair:
+    """Two single-band files as the (fn, user) row reader of Context.dualpol_synrgb_stream."""
+
+    def __init__(self, a: TiffReader, b: TiffReader):
+        self._arr = (C.c_void_p * 2)(a._h, b._h)
+        self._keep = (a, b)
+
+    def reader(self):
+        return C.cast(lib.sarpro_hip_tiff_pair_reader, C.c_void_p), C.cast(self._arr, C.c_void_p)
+
+
+class TiffWriter:
+    """sarpro_hip_tiff_create / write_rows / finish."""
+
+    def __init__(self, path: str, width: int, height: int, samples: int, bits: int, geotransform=None,
+                 geo_keys_from: TiffReader | None = None):
+        h = C.c_void_p()
+        gt = (C.c_double * 6)(*geotransform) if geotransform is not None else None
+        _tiff_chk(lib.sarpro_hip_tiff_create(path.encode(), width, height, samples, bits, gt,
+                                             geo_keys_from._h if geo_keys_from else None, C.byref(h)))
+        self._h = h
+
+    def write_rows(self, row0: int, data: np.ndarray):
+        data = np.ascontiguousarray(data)
+        nrows = data.shape[0]
+        _tiff_chk(lib.sarpro_hip_tiff_write_rows(self._h, row0, nrows, _vp(data), data.nbytes // max(nrows, 1)))
+
+    def sink(self):
+        return C.cast(lib.sarpro_hip_tiff_row_sink, C.c_void_p), self._h
+
+    def finish(self):
+        h, self._h = self._h, None
+        if h:
+            _tiff_chk(lib.sarpro_hip_tiff_finish(h))
+
+
+def host_update_geotransform(gt, cols: int, rows: int, meta: dict):
+    """save.rs:71-81"""
+    g = (C.c_double * 6)(*gt)
+    m = _lib.ResizeMeta(meta["final_cols"], meta["final_rows"], meta["scale_x"], meta["scale_y"], meta["pad_left"], meta["pad_top"])
+    lib.sarpro_hip_host_update_geotransform(g, cols, rows, C.byref(m))
+    return list(g)

@@ -80,6 +80,8 @@ HostTimer::~HostTimer() {
     const long long t1 = std::chrono::steady_clock::now().time_since_epoch().count();
     const double ms = (double)(t1 - t0) * (double)std::chrono::steady_clock::period::num /
                       (double)std::chrono::steady_clock::period::den * 1e3;
+    for (auto &h : ctx->host_times) // segments that repeat inside one call (reader / sink chunks) add up
+        if (h.first == name) { h.second += (float)ms; return; }
     ctx->host_times.push_back({name, (float)ms});
 }
 
@@ -134,6 +136,9 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     ctx->resize_tmp.release(); ctx->resize_coef[0].release(); ctx->resize_coef[1].release(); ctx->resized[0].release(); ctx->resized[1].release();
     ctx->h_ghist.release(); ctx->h_small.release(); ctx->h_upload.release();
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t &e : ctx->ring_evt) if (e) (void)hipEventDestroy(e);
+    ctx->h_ring.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -307,6 +312,7 @@ struct U16Job {
     int tamed_force = 0; // single band tamed_synrgb entry point: 1 copol, 2 crosspol
     bool vec = false;
     bool reduce = false; // row stripe of a multi-rank scene: histograms are all-reduced over ctx->comm, on the stream
+    bool hist_done = false; // phase 1 already ran (streaming ingest: chunk by chunk, under the upload)
     StripePlan *plan = nullptr;
     // host-side state between phases
     sarpro_hip_stats stats[kMaxBands];
@@ -349,27 +355,34 @@ static int job_init(U16Job &J) {
 }
 
 // phase 1: local DN histograms -> ctx->ghist (u64 [nbands][65536]) on the device
-static int job_phase1(U16Job &J) {
+// The histogram pass can be issued in pieces (streaming ingest: the work items whose rows have arrived):
+// `begin` clears the tile histograms, [first, last) are indices into the plan's item list (sorted by row),
+// `end` folds the tile histograms into the band histogram.  The default is the whole pass.
+static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1, bool end = true) {
     sarpro_hip_ctx *ctx = J.ctx;
+    if (J.hist_done) return SARPRO_HIP_OK;
     const bool tiled = J.clahe();
     const int ntiles = tiled ? kTiles * kTiles : 1;
     HIPCHK(ctx, ctx->ghist.reserve(sizeof(uint64_t) * 65536 * kMaxBands));
     DnHistArgs a{};
     for (int b = 0; b < J.nbands; ++b) {
         HIPCHK(ctx, ctx->tile_hist[b].reserve(sizeof(uint32_t) * 65536 * (size_t)ntiles));
-        HIPCHK(ctx, hipMemsetAsync(ctx->tile_hist[b].p, 0, sizeof(uint32_t) * 65536 * (size_t)ntiles, ctx->stream));
+        if (begin) HIPCHK(ctx, hipMemsetAsync(ctx->tile_hist[b].p, 0, sizeof(uint32_t) * 65536 * (size_t)ntiles, ctx->stream));
         a.in[b] = J.d_in[b];
         a.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
     }
     a.pitch = J.in_pitch;
-    a.rects = (tiled ? J.plan->d_hist_rects_tiled : J.plan->d_hist_rects_flat).as<Rect>();
+    const int nall = (int)(tiled ? J.plan->hist_rects_tiled.size() : J.plan->hist_rects_flat.size());
+    if (last < 0 || last > nall) last = nall;
+    a.rects = (tiled ? J.plan->d_hist_rects_tiled : J.plan->d_hist_rects_flat).as<Rect>() + first;
     a.lds_bins = 8192;
-    const int nrects = (int)(tiled ? J.plan->hist_rects_tiled.size() : J.plan->hist_rects_flat.size());
-    {
+    const int nrects = last - first;
+    if (nrects > 0) {
         KernelTimer t(ctx, "dn_hist_u16");
         if (J.vec) HIPCHK(ctx, launch_dn_hist_u16_interior(a, nrects, J.nbands, ctx->stream));
         else HIPCHK(ctx, launch_dn_hist_u16(a, nrects, J.nbands, false, ctx->stream));
     }
+    if (!end) return SARPRO_HIP_OK;
     if (J.vec && !(tiled ? J.plan->hist_sliver_tiled : J.plan->hist_sliver_flat).empty()) { // unused unless the planner splits slivers
         const int ns = (int)(tiled ? J.plan->hist_sliver_tiled.size() : J.plan->hist_sliver_flat.size());
         a.rects = (tiled ? J.plan->d_hist_sliver_tiled : J.plan->d_hist_sliver_flat).as<Rect>();
@@ -1143,6 +1156,120 @@ static int host_band_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, s
     void *outs[kMaxBands] = {ctx->stage_out[0].p, nullptr};
     RETCHK(job_run_all(J, outs, pitch, nullptr, 0, stats_out));
     return fetch_out_2d(ctx, u8o ? (void *)out_u8 : (void *)out_u16, ctx->stage_out[0].p, pitch * osz, cols * osz, rows);
+}
+
+// ---------------------------------------------------------------------------------------
+// Streaming ingest / egress: the two u16 bands arrive through a row-chunk reader (a GDAL
+// RasterIO loop, the strip-TIFF reader of tiff_io.cpp, ...) into a ring of pinned buffers; each chunk goes to
+// the device with hipMemcpy2DAsync on a side stream while the reader fills the next one, and the DN-histogram
+// work items whose rows have arrived run on the compute stream behind an event -- when the last chunk lands
+// the first pass of the chain is already done.  The RGB leaves the same way, chunk by chunk, to a row sink.
+// ---------------------------------------------------------------------------------------
+static int stream_prepare(sarpro_hip_ctx *ctx, size_t ring_bytes) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->ring_evt)
+        if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(ctx, ctx->h_ring.reserve(ring_bytes));
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *reader_user, size_t rows,
+                                                    size_t cols, int strategy, int mode, size_t chunk_rows, sarpro_hip_row_sink sink,
+                                                    void *sink_user, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (!reader || !sink) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null reader / sink");
+    timing_reset(ctx);
+    if (rows * cols == 0) return SARPRO_HIP_OK;
+    constexpr int kSlots = 3;
+    const size_t pitch = round_up(cols, 64);
+    if (!chunk_rows) chunk_rows = std::max<size_t>(16, (32u << 20) / (pitch * 2 * 2)); // ~32 MiB per slot (both bands)
+    chunk_rows = std::min(chunk_rows, rows);
+    const size_t in_slot = 2 * chunk_rows * pitch * sizeof(uint16_t), out_chunk_rows = std::max<size_t>(1, in_slot / (pitch * 3));
+    const size_t slot_bytes = std::max(in_slot, out_chunk_rows * pitch * 3);
+    RETCHK(stream_prepare(ctx, kSlots * slot_bytes));
+    HIPCHK(ctx, ctx->stage_in[0].reserve(rows * pitch * 2));
+    HIPCHK(ctx, ctx->stage_in[1].reserve(rows * pitch * 2));
+    HIPCHK(ctx, ctx->stage_out[0].reserve(rows * pitch * 3));
+    U16Job J;
+    J.ctx = ctx; J.nbands = 2; J.d_in[0] = ctx->stage_in[0].as<uint16_t>(); J.d_in[1] = ctx->stage_in[1].as<uint16_t>();
+    J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = pitch;
+    J.strategy = strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.mode = mode; J.synrgb = true;
+    RETCHK(job_init(J));
+
+    // ---- ingest: reader -> pinned slot -> device, histogram items behind each chunk ----
+    const std::vector<Rect> &items = J.clahe() ? J.plan->hist_rects_tiled : J.plan->hist_rects_flat;
+    bool sorted = true;
+    for (size_t i = 1; i < items.size() && sorted; ++i) sorted = items[i - 1].r0 <= items[i].r0;
+    int issued = 0;
+    bool begun = false;
+    uint8_t *ring = ctx->h_ring.as<uint8_t>();
+    size_t chunk = 0;
+    for (size_t r0 = 0; r0 < rows; r0 += chunk_rows, ++chunk) {
+        const int slot = (int)(chunk % kSlots);
+        const size_t n = std::min(chunk_rows, rows - r0);
+        if (chunk >= (size_t)kSlots) HIPCHK(ctx, hipEventSynchronize(ctx->ring_evt[slot])); // the slot's previous upload has left it
+        uint16_t *h[2] = {reinterpret_cast<uint16_t *>(ring + slot * slot_bytes), reinterpret_cast<uint16_t *>(ring + slot * slot_bytes) + chunk_rows * pitch};
+        {
+            HostTimer t(ctx, "host:reader");
+            for (int b = 0; b < 2; ++b)
+                if (int rc = reader(reader_user, b, r0, n, h[b], pitch)) {
+                    (void)hipStreamSynchronize(ctx->copy_stream);
+                    (void)hipStreamSynchronize(ctx->stream);
+                    ctx->err = "row reader failed (code " + std::to_string(rc) + ")";
+                    return SARPRO_HIP_ERR_IO;
+                }
+        }
+        for (int b = 0; b < 2; ++b)
+            HIPCHK(ctx, hipMemcpyAsync(const_cast<uint16_t *>(J.d_in[b]) + r0 * pitch, h[b], n * pitch * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ring_evt[slot], ctx->copy_stream));
+        if (sorted) {
+            int last = issued;
+            while (last < (int)items.size() && (size_t)items[last].r1 <= r0 + n) ++last;
+            if (last > issued || !begun) {
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_evt[slot], 0));
+                RETCHK(job_phase1(J, !begun, issued, last, false));
+                begun = true;
+                issued = last;
+            }
+        }
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_evt[(chunk - 1) % kSlots], 0));
+    RETCHK(job_phase1(J, !begun, issued, -1, true)); // whatever is left, then the band histograms
+    J.hist_done = true;
+
+    // ---- the rest of the chain, device-resident ----
+    void *outs[kMaxBands] = {nullptr, nullptr};
+    uint8_t *d_rgb = ctx->stage_out[0].as<uint8_t>();
+    {
+        HostTimer t(ctx, "host:chain(enqueue+final sync)");
+        if (chain_eligible(J)) RETCHK(job_run_chain(J, outs, 0, d_rgb, pitch, stats_out));
+        else if (chain_levels_eligible(J, outs, d_rgb, pitch)) RETCHK(job_run_chain_levels(J, d_rgb, pitch, stats_out));
+        else return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "streaming ingest needs the device chain (SARPRO_HIP_NO_CHAIN is set)");
+    }
+
+    // ---- egress: device -> pinned slot -> sink, the copy of chunk k+1 under the sink of chunk k ----
+    size_t ochunk = 0;
+    const size_t nout = (rows + out_chunk_rows - 1) / out_chunk_rows;
+    auto enqueue_out = [&](size_t k) -> int {
+        const size_t r0 = k * out_chunk_rows, n = std::min(out_chunk_rows, rows - r0);
+        HIPCHK(ctx, hipMemcpyAsync(ring + (k % kSlots) * slot_bytes, d_rgb + r0 * pitch * 3, n * pitch * 3, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ring_evt[k % kSlots], ctx->copy_stream));
+        return SARPRO_HIP_OK;
+    };
+    for (size_t k = 0; k < std::min<size_t>(kSlots - 1, nout); ++k) RETCHK(enqueue_out(k));
+    for (; ochunk < nout; ++ochunk) {
+        if (ochunk + kSlots - 1 < nout) RETCHK(enqueue_out(ochunk + kSlots - 1));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ring_evt[ochunk % kSlots]));
+        const size_t r0 = ochunk * out_chunk_rows, n = std::min(out_chunk_rows, rows - r0);
+        HostTimer t(ctx, "host:sink");
+        if (int rc = sink(sink_user, r0, n, ring + (ochunk % kSlots) * slot_bytes, pitch * 3)) {
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            ctx->err = "row sink failed (code " + std::to_string(rc) + ")";
+            return SARPRO_HIP_ERR_IO;
+        }
+    }
+    return SARPRO_HIP_OK;
 }
 
 extern "C" int sarpro_hip_autoscale_band_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size_t rows, size_t cols,

@@ -92,6 +92,10 @@ struct sarpro_hip_ctx {
     uint32_t chain_lut_cap = 4096;               // LDS capacity (entries) of the apply kernel's offset table
     // pinned host mirrors
     sarpro::PinnedBuf h_ghist, h_small, h_upload;
+    // streaming ingest / egress: pinned ring on a side stream
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ring_evt[3] = {nullptr, nullptr, nullptr};
+    sarpro::PinnedBuf h_ring;
 
     std::map<std::tuple<size_t, size_t, size_t, size_t, int>, sarpro::StripePlan *> plans;
 
