@@ -735,7 +735,8 @@ static int chain_prepare(sarpro_hip_ctx *ctx) {
 
 static bool chain_eligible(const U16Job &J) {
     if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
-    return J.clahe() && J.u8_out() && J.vec && !J.tamed_force && (J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total));
+    // u16 output (no rescale, no composition) takes the same chain up to the blend, with the exact f64 kernel
+    return J.clahe() && (J.u8_out() || !J.synrgb) && J.vec && !J.tamed_force && (J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total));
 }
 
 // row-stripe mode: merge a small integer buffer across ranks without leaving the stream
@@ -804,11 +805,30 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     a.row_w = J.plan->d_row_w.as<RowWeight>();
     a.col_w = J.plan->d_col_w.as<RowWeight>();
     a.row_off = (int32_t)J.row0;
-    a.max_val = 255.0;
+    const bool u16o = !J.u8_out();
+    a.max_val = u16o ? 65535.0 : 255.0;
     a.dev_state = d_state;
     a.lut_cap = ctx->chain_lut_cap;
     if (a.out_pitch % 8 != 0 || !ptr_aligned16(a.out[0]) || (J.nbands > 1 && !ptr_aligned16(a.out[1])))
         return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
+    if (u16o) { // autoscale.rs:600-606 at max_val 65535: no u8 rescale, nothing downstream needs a level histogram
+        for (int b = 0; b < J.nbands; ++b) a.level_hist[b] = nullptr;
+        {
+            KernelTimer t(ctx, "clahe_apply_u16");
+            HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, true, true, ctx->stream));
+        }
+        ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
+        HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t hi = 0;
+        for (int b = 0; b < J.nbands; ++b) {
+            J.stats[b] = h_state[b].stats;
+            if (stats_out) stats_out[b] = J.stats[b];
+            hi = std::max(hi, h_state[b].win_hi);
+        }
+        ctx->chain_lut_cap = std::min<uint32_t>(16384, std::max<uint32_t>(1024, (hi + 1 + 255) / 256 * 256));
+        return SARPRO_HIP_OK;
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
     // whole scene on this device: levels >= 64 are only counted in bulk (chain_kernels.hip k_level_hist_guard); a row
     // stripe keeps the full histogram, which is what the ranks sum

@@ -242,8 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
     const uint16_t *__restrict__ in = a.in[band];
     const double *__restrict__ cdfs = a.cdfs[band];
     const uint8_t *__restrict__ glut = a.binlut[band];
-    const uint32_t win_lo = a.win_lo[band], win_hi = a.win_hi[band];
-    const bool lut_lds = a.lut_in_lds != 0;
+    // chain mode: the window is only known on the device (k_chain_stats); the table is constant from win_hi on
+    const uint32_t win_lo = a.dev_state ? 0u : a.win_lo[band], win_hi = a.dev_state ? a.dev_state[band].win_hi : a.win_hi[band];
+    const bool lut_lds = a.dev_state ? win_hi < a.lut_cap : a.lut_in_lds != 0;
     unsigned long long *ghist = a.level_hist[band];
 
     {   // stage the four CDFs interleaved per bin: one pixel gathers 32 contiguous bytes
@@ -991,7 +992,8 @@ hipError_t launch_tile_bin_hist(const TileBinHistArgs &a, int ntiles, int nbands
 
 size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands) {
     size_t win = 0;
-    if (a.lut_in_lds)
+    if (a.dev_state) win = a.lut_cap; // window read from device memory: capacity chosen by the caller
+    else if (a.lut_in_lds)
         for (int b = 0; b < nbands; ++b) win = std::max<size_t>(win, a.win_hi[b] - a.win_lo[b] + 1);
     return 256 * 4 * 8 + 256 * 4 + ((win + 15) & ~(size_t)15);
 }

@@ -178,6 +178,9 @@ def test_device_chain_equals_host_orchestrated_path(ctx, shape, monkeypatch):
         assert np.array_equal(rgb, rrgb) and np.array_equal(u1, r1) and np.array_equal(u2, r2)
         u8, _, s1 = ctx.process_scalar_data_pipeline(b1, Bd.U8, St.Clahe, want_stats=True)
         assert np.array_equal(u8, r1)
+        _, u16, s16 = ctx.process_scalar_data_pipeline(b1, Bd.U16, St.Clahe, want_stats=True)  # u16 output: the chain up to the exact f64 blend
+        rc16, ref16 = oracle.pipeline(b1.astype(np.float32), 1, int(St.Clahe))
+        assert rc16 == 0 and np.array_equal(u16, ref16) and s16.p99 == s1.p99
         rc1, _, so = oracle.pipeline(b1.astype(np.float32), 0, int(St.Clahe), want_stats=True)
         for k in ("valid_count", "min_db", "max_db", "median_db", "p01", "p10", "p25", "p75", "p99", "low_clip", "high_clip"):
             assert getattr(s1, k) == getattr(so, k) == getattr(st[0], k), (k, no_chain)
