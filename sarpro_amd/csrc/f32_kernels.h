@@ -29,6 +29,13 @@ struct F32LevelArgs {
     const float *thr;                // [256] (u8) or [65536 + 1] (u16: thr[65536] = +inf sentinel); thr[0] unused
     unsigned long long *level_hist;  // [256], u8 only
     F32StepEstimate est;
+    // u16 output: the level evaluated in f64 with the reference's expression (autoscale.rs:437-447 / 647-655) decides
+    // unless it lies within 1e-6 of a level boundary (device libm vs glibc: differences of a few ulp, ~1e-10 levels);
+    // those samples, a few per scene, are resolved against the exact thresholds.  t_first / t_last are thr[1] and
+    // thr[65535]: samples outside them are level 0 / 65535 by definition of the table.
+    double low, high, range, gamma, max_val; // range = max(high - low, 1)
+    float t_first, t_last;
+    int f64_levels;
 };
 
 struct F32TileHistArgs {

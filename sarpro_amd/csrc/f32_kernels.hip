@@ -169,7 +169,17 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
             const float x = v.get(j);
             uint32_t lv = 0;
             if (col + j < a.cols && x >= a.t_valid) {
-                if (a.est.use) lv = OUT16 ? est_search<65535>(a.thr, x, a.est) : est_search<255>(thr, x, a.est);
+                if (OUT16 && a.f64_levels) {
+                    if (x >= a.t_last) lv = 65535u;
+                    else if (x < a.t_first) lv = 0u;
+                    else {
+                        const double db = 10.0 * log10((double)x);
+                        const double t = (fmin(fmax(db, a.low), a.high) - a.low) / a.range;
+                        const double y = fmin(fmax((a.gamma == 1.0 ? t : pow(t, a.gamma)) * a.max_val, 0.0), a.max_val);
+                        const double r = rint(y);
+                        lv = (fabs(y - r) < 1e-6 || !(y == y)) ? step_search<65535>(a.thr, x) : (uint32_t)y;
+                    }
+                } else if (a.est.use) lv = OUT16 ? est_search<65535>(a.thr, x, a.est) : est_search<255>(thr, x, a.est);
                 else lv = OUT16 ? step_search<65535>(a.thr, x) : step_search<255>(thr, x);
             }
             lvs[j] = lv;

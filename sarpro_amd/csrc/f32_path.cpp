@@ -182,6 +182,12 @@ int f32_band_run(F32Band &B) {
         HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * (size_t)(nlevels + 2), hipMemcpyHostToDevice, ctx->stream));
         F32LevelArgs a{};
         a.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), (double)nlevels, 0.0, B.stats.gamma);
+        if (!u8o && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE")) { // 65535 levels: f64 evaluation, thresholds only near a boundary
+            a.low = B.stats.low_clip; a.high = B.stats.high_clip; a.range = std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0);
+            a.gamma = B.stats.gamma; a.max_val = (double)nlevels;
+            a.t_first = thr[1]; a.t_last = thr[nlevels];
+            a.f64_levels = 1;
+        }
         a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
         a.rows = rows; a.cols = cols; a.t_valid = t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
         KernelTimer t(ctx, "f32_level");
