@@ -16,6 +16,8 @@ namespace sarpro {
 namespace {
 
 constexpr int kStatsBlock = 1024;
+constexpr int kTileDns = 256;        // DNs per wave-private staging tile of k_chain_stats
+constexpr int kDnsPerWave = 65536 / (kStatsBlock / 64);
 
 __device__ inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
@@ -62,6 +64,12 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     __shared__ double scr_f64[kStatsBlock];
     __shared__ uint32_t scr_u32[kStatsBlock];
     __shared__ double pct[11];
+    // Passes that need a lane to walk CONSECUTIVE DNs (run-length aggregation) read the tables through these
+    // wave-private tiles: 256 DNs are loaded coalesced (4 per lane, stride 64) and consumed 4-contiguous per lane.
+    // Reading 64 consecutive table entries per thread straight from global memory costs one cache line per lane per
+    // load instruction -- that alone was half of this kernel's time.
+    __shared__ unsigned long long tile_h[kStatsBlock / 64][kTileDns];
+    __shared__ double tile_d[kStatsBlock / 64][kTileDns];
 
     const int band = blockIdx.x;
     const unsigned long long *__restrict__ h = a.ghist + (size_t)band * 65536;
@@ -69,19 +77,21 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     ChainBandState *out = a.state + band;
     uint8_t *binlut = a.binlut + (size_t)band * a.binlut_stride;
     const int t = threadIdx.x;
+    long long T0 = wall_clock64(), T1 = 0, T2 = 0, T3 = 0, T4 = 0;
 
     // ---- one sweep: count / min / max DN over valid samples (DN >= 1) and the dB moments.
     //      Each thread owns 64 DNs; loads are issued 8 at a time so they overlap. ----
     unsigned long long cnt = 0;
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
     double s1 = 0.0, s2 = 0.0;
-    for (uint32_t base = 0; base < 65536u; base += 8 * kStatsBlock) {
-        unsigned long long hv[8];
-        double dv[8];
+    constexpr int kSweep = 16; // loads of one thread in flight per batch (the sweeps are latency-bound: one CU, L2-resident tables)
+    for (uint32_t base = 0; base < 65536u; base += kSweep * kStatsBlock) {
+        unsigned long long hv[kSweep];
+        double dv[kSweep];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const uint32_t dn = base + k * kStatsBlock + t; hv[k] = h[dn]; dv[k] = db[dn]; }
+        for (int k = 0; k < kSweep; ++k) { const uint32_t dn = base + k * kStatsBlock + t; hv[k] = h[dn]; dv[k] = db[dn]; }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < kSweep; ++k) {
             const uint32_t dn = base + k * kStatsBlock + t;
             if (dn && hv[k]) {
                 cnt += hv[k]; mn = min(mn, dn); mx = max(mx, dn);
@@ -97,6 +107,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     const double sum1 = block_reduce(s1, scr_f64, [](double x, double y) { return x + y; });
     const double sum2 = block_reduce(s2, scr_f64, [](double x, double y) { return x + y; });
 
+    T1 = wall_clock64();
     sarpro_hip_stats st;
     st.valid_count = count;
     st.min_db = st.max_db = st.mean_db = st.std_db = st.median_db = 0.0;
@@ -126,19 +137,23 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         for (int i = t; i < kStatBins; i += kStatsBlock) hist[i] = 0;
         __syncthreads();
         const double span = max_db - min_db, inv_span = 1.0 / span;
-        // thread t owns the 64 consecutive DNs [64t, 64t+64): the bin index is monotone in DN, so equal
+        // a lane walks increasing DNs (4 consecutive per tile, tiles in order): the bin index is monotone in DN, so equal
         // indices form runs that are summed in a register and flushed with ONE LDS atomic per run
         // (bright DNs crowd into the top bins: per-DN atomics from 64 lanes would all hit one word)
         unsigned long long run = 0, run_idx = ~0ull;
-        for (uint32_t base = 64u * t; base < 64u * t + 64u; base += 8) {
-            unsigned long long hv[8];
-            double dv[8];
+        const int w = t >> 6, lane = t & 63;
+        for (uint32_t tb = (uint32_t)w * kDnsPerWave; tb < (uint32_t)(w + 1) * kDnsPerWave; tb += kTileDns) {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { hv[k] = h[base + k]; dv[k] = db[base + k]; }
+            for (int k = 0; k < kTileDns / 64; ++k) { tile_h[w][k * 64 + lane] = h[tb + k * 64 + lane]; tile_d[w][k * 64 + lane] = db[tb + k * 64 + lane]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (!(base + k) || !hv[k]) continue;
-                const double tt = clampd((dv[k] - min_db) * inv_span, 0.0, 1.0);
+            for (int m = 0; m < kTileDns / 64; ++m) {
+                const uint32_t dn = tb + lane * (kTileDns / 64) + m;
+                const unsigned long long hv = tile_h[w][lane * (kTileDns / 64) + m];
+                if (!dn || !hv) continue;
+                const double tt = clampd((tile_d[w][lane * (kTileDns / 64) + m] - min_db) * inv_span, 0.0, 1.0);
                 unsigned long long idx = (unsigned long long)(tt * (double)kStatBins);
                 if (idx >= (unsigned long long)kStatBins) idx = kStatBins - 1;
                 if (idx != run_idx) {
@@ -146,11 +161,12 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
                     run = 0;
                     run_idx = idx;
                 }
-                run += hv[k];
+                run += hv;
             }
         }
         if (run) atomicAdd(&hist[run_idx], run);
         __syncthreads();
+        T2 = wall_clock64();
         // ---- exclusive prefix over the bins: thread t owns bins 4t .. 4t+3 ----
         unsigned long long own[4], tot = 0;
 #pragma unroll
@@ -178,26 +194,36 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         st.median_db = pct[0]; st.p01 = pct[1]; st.p02 = pct[2]; st.p05 = pct[3]; st.p10 = pct[4]; st.p25 = pct[5];
         st.p75 = pct[6]; st.p90 = pct[7]; st.p95 = pct[8]; st.p98 = pct[9]; st.p99 = pct[10];
     }
+    T3 = wall_clock64();
     if (!a.levels_mode) {
         // ---- CLAHE window + DN -> bin table ----
         const double low = st.p01, high = st.p99;
         st.low_clip = low; st.high_clip = high; st.gamma = 1.0;
         const double range = fmax(high - low, 1.0);
         uint32_t first_hi = 65535u; // first DN >= 1 whose dB value reached the high clip: the table is constant from there
-        for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) {
-            uint8_t bin = 0;
-            if (dn) {
-                const double d = db[dn];
-                const double clipped = fmin(fmax(d, low), high);
-                const double v = clampd((clipped - low) / range, 0.0, 1.0);
-                long long b = (long long)round(v * 255.0);
-                b = b < 0 ? 0 : (b > 255 ? 255 : b);
-                bin = (uint8_t)b;
-                if (d >= high) first_hi = min(first_hi, dn);
+        for (uint32_t base = 0; base < 65536u; base += kSweep * kStatsBlock) {
+            double dv[kSweep];
+#pragma unroll
+            for (int k = 0; k < kSweep; ++k) dv[k] = db[base + k * kStatsBlock + t];
+#pragma unroll
+            for (int k = 0; k < kSweep; ++k) {
+                const uint32_t dn = base + k * kStatsBlock + t;
+                uint8_t bin = 0;
+                if (dn) {
+                    const double d = dv[k];
+                    const double clipped = fmin(fmax(d, low), high);
+                    const double v = clampd((clipped - low) / range, 0.0, 1.0);
+                    long long b = (long long)round(v * 255.0);
+                    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+                    bin = (uint8_t)b;
+                    if (d >= high) first_hi = min(first_hi, dn);
+                }
+                binlut[dn] = bin;
             }
-            binlut[dn] = bin;
         }
         const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+        T4 = wall_clock64();
+        if (t == 0 && band == 0) printf("STATS pass1 %lld hist %lld pct %lld table %lld (100MHz ticks)\n", T1 - T0, T2 - T1, T3 - T2, T4 - T3);
         if (t == 0) { out->stats = st; out->win_hi = win_hi; }
         return;
     }
@@ -260,18 +286,21 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         uint32_t first_hi = 65535u;
         unsigned long long run = 0;
         uint32_t run_level = 0xFFFFFFFFu;
-        for (uint32_t base = 64u * t; base < 64u * t + 64u; base += 8) { // contiguous DNs per thread: levels form runs
-            unsigned long long hv[8];
-            double dv[8];
+        const int w = t >> 6, lane = t & 63;
+        for (uint32_t tb = (uint32_t)w * kDnsPerWave; tb < (uint32_t)(w + 1) * kDnsPerWave; tb += kTileDns) { // a lane walks increasing DNs: levels form runs
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { hv[k] = h[base + k]; dv[k] = db[base + k]; } // 16 independent loads in flight
-            uint32_t lvl8[8];
+            for (int k = 0; k < kTileDns / 64; ++k) { tile_h[w][k * 64 + lane] = h[tb + k * 64 + lane]; tile_d[w][k * 64 + lane] = db[tb + k * 64 + lane]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            static_assert(kTileDns / 64 == 4, "one packed 4-byte table store per lane and tile");
+            uint32_t lvl4[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t dn = base + k;
+            for (int m = 0; m < 4; ++m) {
+                const uint32_t dn = tb + lane * 4 + m;
                 uint32_t level = 0;
                 if (dn) {
-                    const double d = dv[k];
+                    const double d = tile_d[w][lane * 4 + m];
                     const double clipped = fmin(fmax(d, low), high);
                     const double x = (clipped - low) / range;
                     if (gthr) {
@@ -286,18 +315,15 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
                     }
                     if (d >= high) first_hi = min(first_hi, dn);
                 }
-                lvl8[k] = level;
-                const unsigned long long n = dn ? hv[k] : (a.total_px - count); // DN = 0: every invalid pixel is level 0
+                lvl4[m] = level;
+                const unsigned long long n = dn ? tile_h[w][lane * 4 + m] : (a.total_px - count); // DN = 0: every invalid pixel is level 0
                 if (n) {
                     if (level != run_level) { if (run) atomicAdd(&lh[run_level], run); run = 0; run_level = level; }
                     run += n;
                 }
             }
-            // 8 consecutive table bytes in one store
-            uint2 pk;
-            pk.x = lvl8[0] | (lvl8[1] << 8) | (lvl8[2] << 16) | (lvl8[3] << 24);
-            pk.y = lvl8[4] | (lvl8[5] << 8) | (lvl8[6] << 16) | (lvl8[7] << 24);
-            *reinterpret_cast<uint2 *>(binlut + base) = pk;
+            // 4 consecutive table bytes in one store: a wave writes 256 contiguous bytes
+            *reinterpret_cast<uint32_t *>(binlut + tb + lane * 4) = lvl4[0] | (lvl4[1] << 8) | (lvl4[2] << 16) | (lvl4[3] << 24);
         }
         if (run) atomicAdd(&lh[run_level], run);
         const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
