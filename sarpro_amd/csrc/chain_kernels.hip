@@ -77,7 +77,6 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     ChainBandState *out = a.state + band;
     uint8_t *binlut = a.binlut + (size_t)band * a.binlut_stride;
     const int t = threadIdx.x;
-    long long T0 = wall_clock64(), T1 = 0, T2 = 0, T3 = 0, T4 = 0;
 
     // ---- one sweep: count / min / max DN over valid samples (DN >= 1) and the dB moments.
     //      Each thread owns 64 DNs; loads are issued 8 at a time so they overlap. ----
@@ -107,7 +106,6 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     const double sum1 = block_reduce(s1, scr_f64, [](double x, double y) { return x + y; });
     const double sum2 = block_reduce(s2, scr_f64, [](double x, double y) { return x + y; });
 
-    T1 = wall_clock64();
     sarpro_hip_stats st;
     st.valid_count = count;
     st.min_db = st.max_db = st.mean_db = st.std_db = st.median_db = 0.0;
@@ -166,7 +164,6 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         }
         if (run) atomicAdd(&hist[run_idx], run);
         __syncthreads();
-        T2 = wall_clock64();
         // ---- exclusive prefix over the bins: thread t owns bins 4t .. 4t+3 ----
         unsigned long long own[4], tot = 0;
 #pragma unroll
@@ -194,7 +191,6 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         st.median_db = pct[0]; st.p01 = pct[1]; st.p02 = pct[2]; st.p05 = pct[3]; st.p10 = pct[4]; st.p25 = pct[5];
         st.p75 = pct[6]; st.p90 = pct[7]; st.p95 = pct[8]; st.p98 = pct[9]; st.p99 = pct[10];
     }
-    T3 = wall_clock64();
     if (!a.levels_mode) {
         // ---- CLAHE window + DN -> bin table ----
         const double low = st.p01, high = st.p99;
@@ -222,8 +218,6 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
             }
         }
         const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
-        T4 = wall_clock64();
-        if (t == 0 && band == 0) printf("STATS pass1 %lld hist %lld pct %lld table %lld (100MHz ticks)\n", T1 - T0, T2 - T1, T3 - T2, T4 - T3);
         if (t == 0) { out->stats = st; out->win_hi = win_hi; }
         return;
     }
