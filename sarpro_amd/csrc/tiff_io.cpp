@@ -87,7 +87,12 @@ struct sarpro_hip_tiff {
 
 extern "C" const char *sarpro_hip_tiff_last_error(void) { return g_err.c_str(); }
 
+static int tiff_open_impl(const char *path, sarpro_hip_tiff **out, sarpro_hip_tiff_info *info_out);
 extern "C" int sarpro_hip_tiff_open(const char *path, sarpro_hip_tiff **out, sarpro_hip_tiff_info *info_out) {
+    try { return tiff_open_impl(path, out, info_out); }
+    catch (...) { if (out) *out = nullptr; return io_fail("out of memory or internal error while parsing the TIFF directory"); } // never unwind across the C ABI (a failed parse may leak its handle)
+}
+static int tiff_open_impl(const char *path, sarpro_hip_tiff **out, sarpro_hip_tiff_info *info_out) {
     if (!path || !out) return SARPRO_HIP_ERR_INVALID_ARG;
     *out = nullptr;
     FILE *f = fopen(path, "rb");
@@ -128,7 +133,7 @@ extern "C" int sarpro_hip_tiff_open(const char *path, sarpro_hip_tiff **out, sar
                             tag == kStripOffsets || tag == kSamplesPerPixel || tag == kRowsPerStrip || tag == kStripByteCounts ||
                             tag == kPlanarConfig || tag == kSampleFormat || tag == kTileWidth || tag == kModelPixelScale ||
                             tag == kModelTiepoint || tag == kGeoKeyDirectory || tag == kGeoDoubleParams || tag == kGeoAsciiParams;
-        if (!wanted) continue;
+        if (!wanted || count == 0) continue;
         if (count > (1ull << 28) || !t->values(type, count, val, cap, raw)) return bail("unreadable tag " + std::to_string(tag));
         const size_t ts = type_size(type);
         auto u = [&](uint64_t i) { return t->as_u64(type, raw.data() + i * ts); };
@@ -165,6 +170,10 @@ extern "C" int sarpro_hip_tiff_open(const char *path, sarpro_hip_tiff **out, sar
         }
     }
     if (!I.width || !I.height) return bail("no image dimensions");
+    if (I.width > 0x7FFFFFFFull || I.height > 0x7FFFFFFFull) return bail("implausible image dimensions");
+    if (I.samples_per_pixel < 1 || I.samples_per_pixel > 64) return bail("implausible SamplesPerPixel");
+    if (I.planar != 1 && I.planar != 2) return bail("bad PlanarConfiguration");
+    if (I.rows_per_strip == 0) return bail("RowsPerStrip = 0");
     if (I.tiled) return bail("tiled TIFFs are not supported by this shim");
     if (I.compression != 1) return bail("compressed TIFFs are not supported by this shim (Compression = " + std::to_string(I.compression) + ")");
     if (I.bits_per_sample != 8 && I.bits_per_sample != 16) return bail("only 8- and 16-bit samples are supported");
@@ -173,6 +182,15 @@ extern "C" int sarpro_hip_tiff_open(const char *path, sarpro_hip_tiff **out, sar
     const uint64_t strips_per_plane = (I.height + I.rows_per_strip - 1) / I.rows_per_strip;
     const uint64_t planes = I.planar == 2 ? I.samples_per_pixel : 1;
     if (t->strip_off.size() != strips_per_plane * planes) return bail("strip table does not match the image");
+    if (!t->strip_len.empty() && t->strip_len.size() != t->strip_off.size()) return bail("strip tables of different lengths");
+    { // every strip must hold its rows (StripByteCounts, when present, is checked rather than trusted)
+        const uint64_t bps = I.bits_per_sample / 8, px = I.planar == 2 ? bps : bps * I.samples_per_pixel;
+        for (size_t i = 0; i < t->strip_len.size(); ++i) {
+            const uint64_t s_in_plane = i % strips_per_plane;
+            const uint64_t rows_here = std::min<uint64_t>(I.rows_per_strip, I.height - s_in_plane * I.rows_per_strip);
+            if (t->strip_len[i] < rows_here * I.width * px) return bail("strip " + std::to_string(i) + " is shorter than its rows");
+        }
+    }
     *out = t;
     if (info_out) *info_out = I;
     return SARPRO_HIP_OK;
@@ -185,10 +203,15 @@ extern "C" void sarpro_hip_tiff_close(sarpro_hip_tiff *t) {
 }
 
 // rows [row0, row0 + nrows) of one sample as u16 (8-bit samples are widened)
+static int tiff_read_impl(sarpro_hip_tiff *t, int sample, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch);
 extern "C" int sarpro_hip_tiff_read_rows_u16(sarpro_hip_tiff *t, int sample, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch) {
+    try { return tiff_read_impl(t, sample, row0, nrows, dst, dst_pitch); }
+    catch (...) { return io_fail("out of memory while reading rows"); }
+}
+static int tiff_read_impl(sarpro_hip_tiff *t, int sample, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch) {
     if (!t || !dst) return SARPRO_HIP_ERR_INVALID_ARG;
     const sarpro_hip_tiff_info &I = t->info;
-    if (sample < 0 || (uint32_t)sample >= I.samples_per_pixel || row0 + nrows > I.height || dst_pitch < I.width) return io_fail("read outside the image");
+    if (sample < 0 || (uint32_t)sample >= I.samples_per_pixel || row0 > I.height || nrows > I.height - row0 || dst_pitch < I.width) return io_fail("read outside the image");
     const size_t bps = I.bits_per_sample / 8;
     const bool planar = I.planar == 2;
     const size_t px_stride = planar ? bps : bps * I.samples_per_pixel, row_bytes = (size_t)I.width * px_stride;
