@@ -789,16 +789,33 @@ __device__ __forceinline__ void lut_compose_rows(const LutComposeArgs &a, unsign
     const uint32_t vpr = (a.cols + 15) / 16, wpr = (vpr + 63) / 64;
     const uint64_t chunks = (uint64_t)a.rows * wpr;
     const uint64_t nwaves = (uint64_t)gridDim.x * (kComposeBlock / kWave);
-    for (uint64_t ch = (uint64_t)blockIdx.x * (kComposeBlock / kWave) + (threadIdx.x >> 6); ch < chunks; ch += nwaves) {
+    // software pipeline: the loads of the wave's NEXT chunk are issued before this chunk is looked up and stored
+    // (clamped to the last chunk, so the loads are unconditional and the compiler can count them)
+    auto chunk_ptr = [&](uint64_t ch, int band) {
+        const uint32_t r = (uint32_t)(ch / wpr);
+        const uint32_t col = ((uint32_t)(ch - (uint64_t)r * wpr) * 64 + lane) * 16;
+        return a.in[band] + (size_t)r * a.in_pitch + min(col, (a.in_pitch >= 16 ? (uint32_t)a.in_pitch - 16 : 0u));
+    };
+    uint64_t ch = (uint64_t)blockIdx.x * (kComposeBlock / kWave) + (threadIdx.x >> 6);
+    uint4 na, nb, nc, nd;
+    if (ch < chunks) {
+        const uint4 *q1 = reinterpret_cast<const uint4 *>(chunk_ptr(ch, 0)), *q2 = reinterpret_cast<const uint4 *>(chunk_ptr(ch, 1));
+        na = q1[0]; nb = q1[1]; nc = q2[0]; nd = q2[1];
+    }
+    for (; ch < chunks; ch += nwaves) {
         const uint32_t r = (uint32_t)(ch / wpr);
         const uint32_t v0 = (uint32_t)(ch - (uint64_t)r * wpr) * 64;
         const uint32_t col = (v0 + lane) * 16;
         const bool fullv = col + 16 <= a.cols;
         const uint32_t nfull = (a.cols / 16 > v0) ? min(64u, a.cols / 16 - v0) : 0u;
         const uint16_t *p1 = a.in[0] + (size_t)r * a.in_pitch + col, *p2 = a.in[1] + (size_t)r * a.in_pitch + col;
+        const uint4 qa = na, qb = nb, qc = nc, qd = nd;
+        {
+            const uint64_t nx = ch + nwaves < chunks ? ch + nwaves : ch;
+            const uint4 *q1 = reinterpret_cast<const uint4 *>(chunk_ptr(nx, 0)), *q2 = reinterpret_cast<const uint4 *>(chunk_ptr(nx, 1));
+            na = q1[0]; nb = q1[1]; nc = q2[0]; nd = q2[1];
+        }
         if (fullv) {
-            const uint4 qa = reinterpret_cast<const uint4 *>(p1)[0], qb = reinterpret_cast<const uint4 *>(p1)[1];
-            const uint4 qc = reinterpret_cast<const uint4 *>(p2)[0], qd = reinterpret_cast<const uint4 *>(p2)[1];
             const uint32_t w1[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
             const uint32_t w2[8] = {qc.x, qc.y, qc.z, qc.w, qd.x, qd.y, qd.z, qd.w};
             uint32_t o[12];
