@@ -262,6 +262,12 @@ int sarpro_hip_dualpol_synrgb_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_rea
                                          size_t cols, int strategy, int mode, size_t chunk_rows, sarpro_hip_row_sink sink,
                                          void *sink_user, sarpro_hip_stats *stats_out);
 
+/* save.rs:317-367 with its resize / pad (sarpro_hip_dualpol_synrgb_resized_u16) fed by the row reader: the product is
+ * small (target_size^2 x 3 bytes), so it is returned in one piece. */
+int sarpro_hip_dualpol_synrgb_resized_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *reader_user, size_t rows,
+                                                 size_t cols, int strategy, int mode, size_t target_size, int pad, uint8_t *rgb_out,
+                                                 sarpro_hip_resize_meta *meta);
+
 /* ---- file shims for the two callbacks: uncompressed strip TIFF / BigTIFF (what Sentinel-1 GRD measurement rasters
  * are; io/gdal.rs:107-141 and io/writers/tiff.rs:6-78 go through GDAL).  Baseline TIFF 6.0 + BigTIFF, II or MM,
  * Compression = 1, strips, 8- / 16-bit unsigned samples, chunky or planar; anything else fails with

@@ -104,6 +104,9 @@ extern "C" {
     pub fn sarpro_hip_dualpol_synrgb_stream_u16(ctx: *mut sarpro_hip_ctx, reader: sarpro_hip_row_reader, reader_user: *mut c_void,
         rows: usize, cols: usize, strategy: c_int, mode: c_int, chunk_rows: usize, sink: sarpro_hip_row_sink,
         sink_user: *mut c_void, stats_out: *mut sarpro_hip_stats) -> c_int;
+    pub fn sarpro_hip_dualpol_synrgb_resized_stream_u16(ctx: *mut sarpro_hip_ctx, reader: sarpro_hip_row_reader, reader_user: *mut c_void,
+        rows: usize, cols: usize, strategy: c_int, mode: c_int, target_size: usize, pad: c_int, rgb_out: *mut u8,
+        meta: *mut sarpro_hip_resize_meta) -> c_int;
     pub fn sarpro_hip_tiff_open(path: *const c_char, out: *mut *mut c_void, info_out: *mut c_void) -> c_int;
     pub fn sarpro_hip_tiff_close(t: *mut c_void);
     pub fn sarpro_hip_tiff_pair_reader(user: *mut c_void, band: c_int, row0: usize, nrows: usize, dst: *mut u16, dst_pitch: usize) -> c_int;

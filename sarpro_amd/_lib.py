@@ -65,7 +65,7 @@ SYMBOLS = [
     "sarpro_hip_last_kernel_times",
     "sarpro_hip_stripe_begin_u16", "sarpro_hip_stripe_phase1", "sarpro_hip_stripe_phase2",
     "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end", "sarpro_hip_stripe_run_u16",
-    "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
+    "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_dualpol_synrgb_resized_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
     "sarpro_hip_tiff_pair_reader", "sarpro_hip_tiff_create", "sarpro_hip_tiff_write_rows", "sarpro_hip_tiff_row_sink",
     "sarpro_hip_tiff_finish", "sarpro_hip_tiff_last_error", "sarpro_hip_host_update_geotransform",
     "sarpro_hip_comm_unique_id", "sarpro_hip_comm_init", "sarpro_hip_comm_allreduce_sum_u64",
@@ -188,3 +188,4 @@ _proto("sarpro_hip_tiff_row_sink", _i, _vp, _sz, _sz, _vp, _sz)
 _proto("sarpro_hip_tiff_finish", _i, _vp)
 _proto("sarpro_hip_tiff_last_error", C.c_char_p)
 _proto("sarpro_hip_host_update_geotransform", None, _vp, _sz, _sz, _M)
+_proto("sarpro_hip_dualpol_synrgb_resized_stream_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)

@@ -289,6 +289,22 @@ class Context:
                                                 int(strategy), int(mode), _vp(d_rgb), rgb_pitch_px, st))
         return [st[0], st[1]]
 
+    @staticmethod
+    def _as_reader(r, cols):
+        """(fn, user, keepalive) of a row reader given as a Python callable or as a (fn_ptr, user_ptr) pair"""
+        if isinstance(r, tuple):
+            return r[0], r[1], None
+
+        def cb(_user, band, row0, nrows, dst, pitch):
+            try:
+                buf = (C.c_uint16 * (nrows * pitch)).from_address(dst)
+                view = np.frombuffer(buf, np.uint16).reshape(nrows, pitch)[:, :cols]
+                return int(r(band, row0, nrows, view) or 0)
+            except Exception:  # never unwind through the C frames
+                return -1
+        f = _lib.ROW_READER(cb)
+        return C.cast(f, C.c_void_p), None, f
+
     def dualpol_synrgb_stream(self, reader, rows: int, cols: int, strategy, mode, sink, chunk_rows: int = 0,
                               want_stats: bool = False):
         """Streaming ingest / egress (sarpro_hip_dualpol_synrgb_stream_u16).
@@ -297,18 +313,6 @@ class Context:
         `sink(row0, nrows, rgb)` consumes an (nrows, cols, 3) uint8 view; both may return a non-zero int to abort.
         Alternatively pass the C callbacks themselves: `reader=(fn_ptr, user_ptr)` / `sink=(fn_ptr, user_ptr)`
         (e.g. TiffPair.reader(), TiffWriter.sink())."""
-        def as_reader(r):
-            if isinstance(r, tuple):
-                return r[0], r[1], None
-            def cb(_user, band, row0, nrows, dst, pitch):
-                try:
-                    buf = (C.c_uint16 * (nrows * pitch)).from_address(dst)
-                    view = np.frombuffer(buf, np.uint16).reshape(nrows, pitch)[:, :cols]
-                    return int(r(band, row0, nrows, view) or 0)
-                except Exception:  # never unwind through the C frames
-                    return -1
-            f = _lib.ROW_READER(cb)
-            return C.cast(f, C.c_void_p), None, f
         def as_sink(k):
             if isinstance(k, tuple):
                 return k[0], k[1], None
@@ -321,12 +325,24 @@ class Context:
                     return -1
             f = _lib.ROW_SINK(cb)
             return C.cast(f, C.c_void_p), None, f
-        rf, ru, _keep_r = as_reader(reader)
+        rf, ru, _keep_r = self._as_reader(reader, cols)
         sf, su, _keep_s = as_sink(sink)
         st = (Stats * 2)() if want_stats else None
         self._chk(lib.sarpro_hip_dualpol_synrgb_stream_u16(self._h, rf, ru, rows, cols, int(strategy), int(mode), chunk_rows,
                                                            sf, su, st))
         return [st[0], st[1]] if want_stats else None
+
+    def dualpol_synrgb_resized_stream(self, reader, rows: int, cols: int, strategy, target_size: int | None, pad: bool,
+                                      mode=SyntheticRgbMode.Default):
+        """sarpro_hip_dualpol_synrgb_resized_stream_u16: the resized / padded synRGB product from a row reader."""
+        fc, fr = resize_output_dims(cols, rows, target_size, pad)
+        rgb = np.empty((fr, fc, 3), np.uint8)
+        meta = _lib.ResizeMeta()
+        rf, ru, _keep = self._as_reader(reader, cols)
+        self._chk(lib.sarpro_hip_dualpol_synrgb_resized_stream_u16(self._h, rf, ru, rows, cols, int(strategy), int(mode),
+                                                                   target_size or 0, 1 if pad else 0, _vp(rgb), C.byref(meta)))
+        return rgb, dict(final_cols=meta.final_cols, final_rows=meta.final_rows, scale_x=meta.scale_x, scale_y=meta.scale_y,
+                         pad_left=meta.pad_left, pad_top=meta.pad_top)
 
     def comm_init(self, nranks: int, rank: int, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)

@@ -1194,6 +1194,39 @@ static int stream_prepare(sarpro_hip_ctx *ctx, size_t ring_bytes) {
     return SARPRO_HIP_OK;
 }
 
+namespace sarpro {
+int stream_upload_band(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *user, int band, size_t rows, size_t cols,
+                       uint16_t *d_dst, size_t pitch, size_t chunk_rows) {
+    if (!reader) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null reader");
+    if (rows * cols == 0) return SARPRO_HIP_OK;
+    constexpr int kSlots = 3;
+    if (!chunk_rows) chunk_rows = std::max<size_t>(16, (32u << 20) / (pitch * 2));
+    chunk_rows = std::min(chunk_rows, rows);
+    const size_t slot_bytes = chunk_rows * pitch * sizeof(uint16_t);
+    RETCHK(stream_prepare(ctx, kSlots * slot_bytes));
+    uint8_t *ring = ctx->h_ring.as<uint8_t>();
+    size_t chunk = 0;
+    for (size_t r0 = 0; r0 < rows; r0 += chunk_rows, ++chunk) {
+        const int slot = (int)(chunk % kSlots);
+        const size_t n = std::min(chunk_rows, rows - r0);
+        if (chunk >= (size_t)kSlots) HIPCHK(ctx, hipEventSynchronize(ctx->ring_evt[slot]));
+        uint16_t *h = reinterpret_cast<uint16_t *>(ring + slot * slot_bytes);
+        {
+            HostTimer t(ctx, "host:reader");
+            if (int rc = reader(user, band, r0, n, h, pitch)) {
+                (void)hipStreamSynchronize(ctx->copy_stream);
+                ctx->err = "row reader failed (code " + std::to_string(rc) + ")";
+                return SARPRO_HIP_ERR_IO;
+            }
+        }
+        HIPCHK(ctx, hipMemcpyAsync(d_dst + r0 * pitch, h, n * pitch * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ring_evt[slot], ctx->copy_stream));
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_evt[(chunk - 1) % kSlots], 0)); // the compute stream sees the band
+    return SARPRO_HIP_OK;
+}
+} // namespace sarpro
+
 extern "C" int sarpro_hip_dualpol_synrgb_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *reader_user, size_t rows,
                                                     size_t cols, int strategy, int mode, size_t chunk_rows, sarpro_hip_row_sink sink,
                                                     void *sink_user, sarpro_hip_stats *stats_out) {

@@ -28,6 +28,10 @@ int stage_in_2d(sarpro_hip_ctx *ctx, DevBuf &buf, const void *host, size_t rows,
 int fetch_out_2d(sarpro_hip_ctx *ctx, void *host, const void *dev, size_t pitch_bytes, size_t row_bytes, size_t rows);
 
 // one band -> final u8 raster on the device (pipeline.rs:42 at U8; tamed: 1 copol / 2 crosspol -> autoscale.rs:710)
+// one band through the row reader into a pitched device raster: pinned ring, hipMemcpyAsync on the side stream,
+// the reader fills chunk k + 1 while chunk k crosses PCIe (api.cpp, streaming ingest)
+int stream_upload_band(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *user, int band, size_t rows, size_t cols,
+                       uint16_t *d_dst, size_t pitch, size_t chunk_rows);
 int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
                 uint8_t *d_out, size_t out_pitch);
 int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);

@@ -162,14 +162,35 @@ extern "C" int sarpro_hip_resize_image_data(sarpro_hip_ctx *ctx, const void *dat
 // save.rs:317-367 including the resize / pad steps between the per-band autoscale and the composition
 // (the reference's order: autoscale -> resize -> pad -> synRGB; the suppressed floor therefore sees
 // the zero padding, synthetic_rgb.rs:92-99).  Host u16 bands in, final_rows x final_cols RGB out.
+// The same product with the bands arriving through a row reader (streaming ingest): reading, the PCIe upload of
+// the previous chunk and -- across bands -- nothing else overlap; the 2048^2 result is small enough for one copy.
+static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const host_bands[2], sarpro_hip_row_reader reader, void *reader_user,
+                                size_t rows, size_t cols, int strategy, int mode, size_t target_size, int pad, uint8_t *rgb_out,
+                                sarpro_hip_resize_meta *meta);
+
+extern "C" int sarpro_hip_dualpol_synrgb_resized_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *reader_user,
+                                                            size_t rows, size_t cols, int strategy, int mode, size_t target_size,
+                                                            int pad, uint8_t *rgb_out, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (!reader || (rows * cols && !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null reader / raster");
+    const uint16_t *none[2] = {nullptr, nullptr};
+    return dualpol_resized_impl(ctx, none, reader, reader_user, rows, cols, strategy, mode, target_size, pad, rgb_out, meta);
+}
+
 extern "C" int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *band1, const uint16_t *band2, size_t rows,
                                                      size_t cols, int strategy, int mode, size_t target_size, int pad,
                                                      uint8_t *rgb_out, sarpro_hip_resize_meta *meta) {
     if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
     if (rows * cols && (!band1 || !band2 || !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    const uint16_t *bands[2] = {band1, band2};
+    return dualpol_resized_impl(ctx, bands, nullptr, nullptr, rows, cols, strategy, mode, target_size, pad, rgb_out, meta);
+}
+
+static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands[2], sarpro_hip_row_reader reader, void *reader_user,
+                                size_t rows, size_t cols, int strategy, int mode, size_t target_size, int pad, uint8_t *rgb_out,
+                                sarpro_hip_resize_meta *meta) {
     if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
     if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
-    const uint16_t *bands[2] = {band1, band2};
     size_t fc = 0, fr = 0;
     RETCHK(sarpro_hip_resize_output_dims(cols, rows, target_size, pad, &fc, &fr));
     const size_t r1 = std::max<size_t>(rows, 1);
@@ -177,7 +198,15 @@ extern "C" int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const 
     sarpro_hip_resize_meta m{};
     for (int b = 0; b < 2; ++b) {
         size_t pitch = 0;
-        RETCHK(stage_in_2d(ctx, ctx->stage_in[0], bands[b], rows, cols, 2, &pitch));
+        if (reader) {
+            pitch = round_up(std::max<size_t>(cols, 1), 64);
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            HIPCHK(ctx, ctx->stage_in[0].reserve(r1 * pitch * 2));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the previous band's kernels have read the staging raster
+            RETCHK(stream_upload_band(ctx, reader, reader_user, b, rows, cols, ctx->stage_in[0].as<uint16_t>(), pitch, 0));
+        } else {
+            RETCHK(stage_in_2d(ctx, ctx->stage_in[0], bands[b], rows, cols, 2, &pitch));
+        }
         HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * pitch));
         // per-band u8 at native resolution (pipeline.rs:42; Tamed: autoscale.rs:710 with the band's polarisation)
         const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0;

@@ -96,3 +96,20 @@ def test_tiff_files_in_tiff_file_out(ctx, tmp_path, strategy):
     got = np.stack([r.read_rows(0, rows, sample=s) for s in range(3)], axis=-1).astype(np.uint8)
     rc, rrgb, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(strategy))
     assert rc == 0 and np.array_equal(got, rrgb)
+
+
+@pytest.mark.parametrize("strategy", [St.Robust, St.Clahe])
+@pytest.mark.parametrize("target,pad", [(128, True), (96, False), (None, True)])
+def test_resized_product_from_a_row_reader_equals_the_host_pointer_entry(ctx, strategy, target, pad):
+    """sarpro_hip_dualpol_synrgb_resized_stream_u16 == sarpro_hip_dualpol_synrgb_resized_u16 (itself checked against
+    the oracle in test_gpu_resize.py): only the way the bands reach the device differs."""
+    rows, cols = 420, 610
+    b = _scene(rows, cols)
+    want, m = ctx.dualpol_synrgb_resized(b[0], b[1], strategy, target, pad)
+
+    def reader(band, row0, nrows, dst):
+        dst[:] = b[band][row0:row0 + nrows]
+
+    got, meta = ctx.dualpol_synrgb_resized_stream(reader, rows, cols, strategy, target, pad)
+    assert np.array_equal(got, want)
+    assert (meta["final_cols"], meta["final_rows"], meta["pad_left"], meta["pad_top"]) == (m.final_cols, m.final_rows, m.pad_left, m.pad_top)
