@@ -131,7 +131,7 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     for (int b = 0; b < kMaxBands; ++b) { ctx->tile_hist[b].release(); ctx->levels[b].release(); ctx->stage_in[b].release(); }
     for (auto &b : ctx->stage_out) b.release();
     ctx->ghist.release(); ctx->tile_bins.release(); ctx->cdfs.release(); ctx->luts.release();
-    ctx->level_hist.release(); ctx->hist_flags.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
+    ctx->level_hist.release(); ctx->hist_flags.release(); ctx->chain_scratch.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
     ctx->chain_consts.release(); ctx->chain_state.release();
     ctx->resize_tmp.release(); ctx->resize_coef[0].release(); ctx->resize_coef[1].release(); ctx->resized[0].release(); ctx->resized[1].release();
     ctx->h_ghist.release(); ctx->h_small.release(); ctx->h_upload.release();
@@ -739,6 +739,14 @@ static bool chain_eligible(const U16Job &J) {
     return J.clahe() && (J.u8_out() || !J.synrgb) && J.vec && !J.tamed_force && (J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total));
 }
 
+static int chain_stats_scratch(sarpro_hip_ctx *ctx, ChainStatsArgs *sa) {
+    const size_t part_bytes = (sizeof(ChainStatsPartial) * kChainStatsParts * kMaxBands + 255) & ~(size_t)255;
+    HIPCHK(ctx, ctx->chain_scratch.reserve(part_bytes + sizeof(uint64_t) * 4096 * kMaxBands));
+    sa->partials = ctx->chain_scratch.as<ChainStatsPartial>();
+    sa->bins4096 = reinterpret_cast<unsigned long long *>(ctx->chain_scratch.as<uint8_t>() + part_bytes);
+    return SARPRO_HIP_OK;
+}
+
 // row-stripe mode: merge a small integer buffer across ranks without leaving the stream
 static int chain_reduce(U16Job &J, void *d_buf, size_t count_u64, const char *what) {
     if (!J.reduce) return SARPRO_HIP_OK;
@@ -770,6 +778,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         sa.binlut = ctx->luts.as<uint8_t>();
         sa.binlut_stride = 131072;
         KernelTimer t(ctx, "chain_stats");
+        RETCHK(chain_stats_scratch(ctx, &sa));
         HIPCHK(ctx, launch_chain_stats(sa, J.nbands, ctx->stream));
     }
     {
@@ -934,6 +943,7 @@ static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, 
         sa.level_hist = ctx->level_hist.as<unsigned long long>();
         sa.gamma_thr = reinterpret_cast<const double *>(consts + kChainOffGamma);
         KernelTimer t(ctx, "chain_stats");
+        RETCHK(chain_stats_scratch(ctx, &sa));
         HIPCHK(ctx, launch_chain_stats(sa, 2, ctx->stream));
     }
     {

@@ -10,6 +10,13 @@ struct ChainBandState { // lives in device memory, one per band
     uint32_t pad;
 };
 
+struct ChainStatsPartial { // one per (band, 4096-DN slice): kernel A of the statistics step
+    unsigned long long count;
+    uint32_t min_dn, max_dn;
+    double sum1, sum2;
+};
+constexpr int kChainStatsParts = 16;
+
 struct ChainStatsArgs {
     const unsigned long long *ghist; // [nbands][65536]
     const double *db;                // [65536] dB value of every DN (host-built, glibc)
@@ -23,6 +30,8 @@ struct ChainStatsArgs {
     unsigned long long total_px;     // pixels per band (level 0 also counts the invalid ones)
     unsigned long long *level_hist;  // [nbands][256], levels mode only
     const double *gamma_thr;         // [3][256]: x-thresholds of trunc(pow(x, g) * 255) for g = 0.8, 0.9, 1.1 (host-built)
+    ChainStatsPartial *partials;     // scratch [nbands][kChainStatsParts]
+    unsigned long long *bins4096;    // scratch [nbands][4096]
 };
 
 struct ChainFinishArgs {

@@ -15,96 +15,153 @@
 namespace sarpro {
 namespace {
 
-constexpr int kStatsBlock = 1024;
-constexpr int kTileDns = 256;        // DNs per wave-private staging tile of k_chain_stats
-constexpr int kDnsPerWave = 65536 / (kStatsBlock / 64);
+constexpr int kStatsBlock = 1024;      // k_chain_finish
+constexpr int kTileDns = 256;          // DNs per wave-private staging tile of the statistics kernels
 
 __device__ inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// deterministic block reduction over kStatsBlock threads: butterfly inside each wave (shuffles, no
-// barrier), then the 16 wave results through LDS in a fixed order
+// ------------------------------------------------------------------------------------
+// compute_histogram_stats (autoscale.rs:35-160) over the DN histogram + the window of the strategy + the table
+// of every DN (CLAHE bin: autoscale.rs:583-591, 262-265; u8 level: 440-442 / 649-651 / 734-736).
+// Three kernels, kStatsParts workgroups per band each (a 65536-entry sweep by ONE workgroup runs at ~45 GB/s:
+// 23 us; as one kernel the three dependent sweeps took 80-100 us):
+//   A  partial count / min / max / dB moments of each 4096-DN slice; clears the scratch of B and C
+//   B  the 4096-bin histogram (autoscale.rs:103-117): every workgroup reduces the partials to min / max, bins its
+//      slice in LDS (run-length aggregated) and adds the occupied bins to the band's global bins
+//   C  every workgroup scans the bins, inverts the 11 percentiles and selects the window (identical arithmetic in
+//      all of them), then writes its slice of the table; workgroup 0 publishes the statistics
+// The f64 sums are taken in a fixed order (thread-strided inside a slice, butterfly + wave order, slice order).
+// ------------------------------------------------------------------------------------
+constexpr int kStatsParts = kChainStatsParts;       // workgroups per band
+constexpr int kPartBlock = 256;                    // threads per workgroup
+constexpr int kPartDns = 65536 / kStatsParts;      // 4096 DNs per workgroup
+constexpr int kPartWaveDns = kPartDns / (kPartBlock / 64);
+
 template <typename T, typename Op>
-__device__ T block_reduce(T v, T *scratch /*[>= 16]*/, Op op) {
+__device__ T part_reduce(T v, T *scratch /*[>= 4]*/, Op op) { // deterministic reduction over kPartBlock threads
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
-    __syncthreads(); // scratch may still be read from a previous call
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
     T r = scratch[0];
 #pragma unroll
-    for (int w = 1; w < kStatsBlock / 64; ++w) r = op(r, scratch[w]);
+    for (int w = 1; w < kPartBlock / 64; ++w) r = op(r, scratch[w]);
     return r;
 }
 
-// exclusive prefix sum of one u64 per thread over the block (integers: order-free)
-__device__ unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long *scratch /*[>= 16]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long up = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += up;
+struct BandTotals { unsigned long long count; uint32_t min_dn, max_dn; double sum1, sum2; };
+__device__ BandTotals reduce_partials(const ChainStatsPartial *p) { // the same order in every workgroup
+    BandTotals r{0ull, 0xFFFFFFFFu, 0u, 0.0, 0.0};
+    for (int k = 0; k < kStatsParts; ++k) {
+        r.count += p[k].count; r.min_dn = min(r.min_dn, p[k].min_dn); r.max_dn = max(r.max_dn, p[k].max_dn);
+        r.sum1 += p[k].sum1; r.sum2 += p[k].sum2;
     }
-    __syncthreads();
-    if (lane == 63) scratch[wave] = incl;
-    __syncthreads();
-    unsigned long long base = 0;
-    for (int w = 0; w < wave; ++w) base += scratch[w];
-    return base + incl - v;
+    return r;
 }
 
-// ------------------------------------------------------------------------------------
-// compute_histogram_stats (autoscale.rs:35-160) over the DN histogram + the CLAHE window
-// (autoscale.rs:544-548, 564) + the DN -> bin table (autoscale.rs:583-591, 262-265).
-// One block per band.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
-    __shared__ unsigned long long hist[kStatBins];
-    __shared__ unsigned long long scr_u64[kStatsBlock];
-    __shared__ double scr_f64[kStatsBlock];
-    __shared__ uint32_t scr_u32[kStatsBlock];
-    __shared__ double pct[11];
-    // Passes that need a lane to walk CONSECUTIVE DNs (run-length aggregation) read the tables through these
-    // wave-private tiles: 256 DNs are loaded coalesced (4 per lane, stride 64) and consumed 4-contiguous per lane.
-    // Reading 64 consecutive table entries per thread straight from global memory costs one cache line per lane per
-    // load instruction -- that alone was half of this kernel's time.
-    __shared__ unsigned long long tile_h[kStatsBlock / 64][kTileDns];
-    __shared__ double tile_d[kStatsBlock / 64][kTileDns];
+__global__ __launch_bounds__(kPartBlock) void k_chain_stats_a(ChainStatsArgs a) {
+    __shared__ unsigned long long scr_u64[4];
+    __shared__ double scr_f64[4];
+    __shared__ uint32_t scr_u32[4];
+    const int band = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
+    const unsigned long long *__restrict__ h = a.ghist + (size_t)band * 65536;
+    const double *__restrict__ db = a.db;
+    if (part == 0) { // scratch of the next two kernels
+        for (int i = t; i < kStatBins; i += kPartBlock) a.bins4096[(size_t)band * kStatBins + i] = 0ull;
+        if (a.levels_mode) a.level_hist[(size_t)band * 256 + t] = 0ull;
+        if (t == 0) a.state[band].win_hi = 65535u;
+    }
+    unsigned long long cnt = 0;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    double s1 = 0.0, s2 = 0.0;
+    constexpr int kPer = kPartDns / kPartBlock; // 16 DNs per thread, all loads in flight at once
+    unsigned long long hv[kPer];
+    double dv[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { const uint32_t dn = part * kPartDns + k * kPartBlock + t; hv[k] = h[dn]; dv[k] = db[dn]; }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const uint32_t dn = part * kPartDns + k * kPartBlock + t;
+        if (dn && hv[k]) {
+            cnt += hv[k]; mn = min(mn, dn); mx = max(mx, dn);
+            const double w = (double)hv[k];
+            s1 += w * dv[k];
+            s2 += w * dv[k] * dv[k];
+        }
+    }
+    ChainStatsPartial r;
+    r.count = part_reduce(cnt, scr_u64, [](unsigned long long x, unsigned long long y) { return x + y; });
+    r.min_dn = part_reduce(mn, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+    r.max_dn = part_reduce(mx, scr_u32, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+    r.sum1 = part_reduce(s1, scr_f64, [](double x, double y) { return x + y; });
+    r.sum2 = part_reduce(s2, scr_f64, [](double x, double y) { return x + y; });
+    if (t == 0) a.partials[band * kStatsParts + part] = r;
+}
 
-    const int band = blockIdx.x;
+__global__ __launch_bounds__(kPartBlock) void k_chain_stats_b(ChainStatsArgs a) {
+    __shared__ unsigned long long hist[kStatBins];
+    // a lane walks CONSECUTIVE DNs (run-length aggregation); the tables reach it through wave-private tiles so the
+    // global reads stay coalesced: 256 DNs are loaded 4 per lane at stride 64 and consumed 4-contiguous per lane
+    __shared__ unsigned long long tile_h[kPartBlock / 64][kTileDns];
+    __shared__ double tile_d[kPartBlock / 64][kTileDns];
+    const int band = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
+    const unsigned long long *__restrict__ h = a.ghist + (size_t)band * 65536;
+    const double *__restrict__ db = a.db;
+    const BandTotals tot = reduce_partials(a.partials + band * kStatsParts);
+    if (tot.count == 0) return;
+    const double min_db = db[tot.min_dn], max_db = db[tot.max_dn];
+    if (fabs(max_db - min_db) < DBL_EPSILON) return; // autoscale.rs:81-100: no histogram in the degenerate case
+    for (int i = t; i < kStatBins; i += kPartBlock) hist[i] = 0;
+    __syncthreads();
+    const double span = max_db - min_db, inv_span = 1.0 / span; // autoscale.rs:105-106
+    // the bin index is monotone in DN, so equal indices form runs that are summed in a register and flushed with ONE
+    // LDS atomic per run (bright DNs crowd into the top bins: per-DN atomics from 64 lanes would all hit one word)
+    unsigned long long run = 0, run_idx = ~0ull;
+    const int w = t >> 6, lane = t & 63;
+    const uint32_t wave_base = (uint32_t)part * kPartDns + (uint32_t)w * kPartWaveDns;
+    for (uint32_t tb = wave_base; tb < wave_base + kPartWaveDns; tb += kTileDns) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < kTileDns / 64; ++k) { tile_h[w][k * 64 + lane] = h[tb + k * 64 + lane]; tile_d[w][k * 64 + lane] = db[tb + k * 64 + lane]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < kTileDns / 64; ++m) {
+            const uint32_t dn = tb + lane * (kTileDns / 64) + m;
+            const unsigned long long hv = tile_h[w][lane * (kTileDns / 64) + m];
+            if (!dn || !hv) continue;
+            const double tt = clampd((tile_d[w][lane * (kTileDns / 64) + m] - min_db) * inv_span, 0.0, 1.0);
+            unsigned long long idx = (unsigned long long)(tt * (double)kStatBins);
+            if (idx >= (unsigned long long)kStatBins) idx = kStatBins - 1;
+            if (idx != run_idx) {
+                if (run) atomicAdd(&hist[run_idx], run);
+                run = 0;
+                run_idx = idx;
+            }
+            run += hv;
+        }
+    }
+    if (run) atomicAdd(&hist[run_idx], run);
+    __syncthreads();
+    for (int i = t; i < kStatBins; i += kPartBlock)
+        if (hist[i]) atomicAdd(&a.bins4096[(size_t)band * kStatBins + i], hist[i]);
+}
+
+__global__ __launch_bounds__(kPartBlock) void k_chain_stats_c(ChainStatsArgs a) {
+    __shared__ unsigned long long scr_u64[4];
+    __shared__ uint32_t scr_u32[4];
+    __shared__ double pct[11];
+    __shared__ unsigned long long lh[256];
+    __shared__ unsigned long long tile_h[kPartBlock / 64][kTileDns];
+    __shared__ double tile_d[kPartBlock / 64][kTileDns];
+    const int band = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
     const unsigned long long *__restrict__ h = a.ghist + (size_t)band * 65536;
     const double *__restrict__ db = a.db;
     ChainBandState *out = a.state + band;
     uint8_t *binlut = a.binlut + (size_t)band * a.binlut_stride;
-    const int t = threadIdx.x;
-
-    // ---- one sweep: count / min / max DN over valid samples (DN >= 1) and the dB moments.
-    //      Each thread owns 64 DNs; loads are issued 8 at a time so they overlap. ----
-    unsigned long long cnt = 0;
-    uint32_t mn = 0xFFFFFFFFu, mx = 0;
-    double s1 = 0.0, s2 = 0.0;
-    constexpr int kSweep = 16; // loads of one thread in flight per batch (the sweeps are latency-bound: one CU, L2-resident tables)
-    for (uint32_t base = 0; base < 65536u; base += kSweep * kStatsBlock) {
-        unsigned long long hv[kSweep];
-        double dv[kSweep];
-#pragma unroll
-        for (int k = 0; k < kSweep; ++k) { const uint32_t dn = base + k * kStatsBlock + t; hv[k] = h[dn]; dv[k] = db[dn]; }
-#pragma unroll
-        for (int k = 0; k < kSweep; ++k) {
-            const uint32_t dn = base + k * kStatsBlock + t;
-            if (dn && hv[k]) {
-                cnt += hv[k]; mn = min(mn, dn); mx = max(mx, dn);
-                const double w = (double)hv[k];
-                s1 += w * dv[k];
-                s2 += w * dv[k] * dv[k];
-            }
-        }
-    }
-    const unsigned long long count = block_reduce(cnt, scr_u64, [](unsigned long long x, unsigned long long y) { return x + y; });
-    const uint32_t min_dn = block_reduce(mn, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
-    const uint32_t max_dn = block_reduce(mx, scr_u32, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
-    const double sum1 = block_reduce(s1, scr_f64, [](double x, double y) { return x + y; });
-    const double sum2 = block_reduce(s2, scr_f64, [](double x, double y) { return x + y; });
+    const BandTotals tot = reduce_partials(a.partials + band * kStatsParts);
+    const unsigned long long count = tot.count;
 
     sarpro_hip_stats st;
     st.valid_count = count;
@@ -114,61 +171,46 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
     st.gamma = 1.0;
     st.skew_factor = st.tail_heaviness = 0.0;
 
-    if (count == 0) { // no valid pixel: every DN is invalid, the bin table is irrelevant (autoscale.rs:466-468)
-        for (uint32_t dn = t; dn < 65536u; dn += kStatsBlock) binlut[dn] = 0;
-        if (a.levels_mode && t < 256) a.level_hist[(size_t)band * 256 + t] = t == 0 ? a.total_px : 0ull;
-        if (t == 0) { out->stats = st; out->win_hi = 1; }
+    if (count == 0) { // no valid pixel: every DN is invalid, the table is irrelevant (autoscale.rs:466-468)
+        for (uint32_t dn = (uint32_t)part * kPartDns + t; dn < (uint32_t)(part + 1) * kPartDns; dn += kPartBlock) binlut[dn] = 0;
+        if (part == 0) {
+            if (a.levels_mode && t == 0) a.level_hist[(size_t)band * 256] = a.total_px; // the other bins were cleared by kernel A
+            if (t == 0) { out->stats = st; out->win_hi = 1; }
+        }
         return;
     }
-    const double min_db = db[min_dn], max_db = db[max_dn];
-
+    const double min_db = db[tot.min_dn], max_db = db[tot.max_dn];
     // ---- mean / std (informational): var = E[x^2] - mean^2 ----
-    const double mean = sum1 / (double)count;
+    const double mean = tot.sum1 / (double)count;
     st.min_db = min_db; st.max_db = max_db; st.mean_db = mean;
-    st.std_db = count > 1 ? sqrt(fmax(sum2 / (double)count - mean * mean, 0.0)) : 0.0;
+    st.std_db = count > 1 ? sqrt(fmax(tot.sum2 / (double)count - mean * mean, 0.0)) : 0.0;
 
     if (fabs(max_db - min_db) < DBL_EPSILON) { // autoscale.rs:81-100
         st.median_db = st.p01 = st.p02 = st.p05 = st.p10 = st.p25 = min_db;
         st.p75 = st.p90 = st.p95 = st.p98 = st.p99 = max_db;
     } else {
-        // ---- 4096-bin histogram over [min, max] (autoscale.rs:103-117) ----
-        for (int i = t; i < kStatBins; i += kStatsBlock) hist[i] = 0;
-        __syncthreads();
-        const double span = max_db - min_db, inv_span = 1.0 / span;
-        // a lane walks increasing DNs (4 consecutive per tile, tiles in order): the bin index is monotone in DN, so equal
-        // indices form runs that are summed in a register and flushed with ONE LDS atomic per run
-        // (bright DNs crowd into the top bins: per-DN atomics from 64 lanes would all hit one word)
-        unsigned long long run = 0, run_idx = ~0ull;
-        const int w = t >> 6, lane = t & 63;
-        for (uint32_t tb = (uint32_t)w * kDnsPerWave; tb < (uint32_t)(w + 1) * kDnsPerWave; tb += kTileDns) {
-            __builtin_amdgcn_wave_barrier();
+        const double span = max_db - min_db;
+        // ---- exclusive prefix over the bins: thread t owns bins 16t .. 16t+15 ----
+        constexpr int kOwn = kStatBins / kPartBlock;
+        unsigned long long own[kOwn], totb = 0;
 #pragma unroll
-            for (int k = 0; k < kTileDns / 64; ++k) { tile_h[w][k * 64 + lane] = h[tb + k * 64 + lane]; tile_d[w][k * 64 + lane] = db[tb + k * 64 + lane]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < kOwn; ++k) { own[k] = a.bins4096[(size_t)band * kStatBins + kOwn * t + k]; totb += own[k]; }
+        unsigned long long excl;
+        { // block exclusive scan (integers: order-free)
+            const int lane = t & 63, wave = t >> 6;
+            unsigned long long incl = totb;
 #pragma unroll
-            for (int m = 0; m < kTileDns / 64; ++m) {
-                const uint32_t dn = tb + lane * (kTileDns / 64) + m;
-                const unsigned long long hv = tile_h[w][lane * (kTileDns / 64) + m];
-                if (!dn || !hv) continue;
-                const double tt = clampd((tile_d[w][lane * (kTileDns / 64) + m] - min_db) * inv_span, 0.0, 1.0);
-                unsigned long long idx = (unsigned long long)(tt * (double)kStatBins);
-                if (idx >= (unsigned long long)kStatBins) idx = kStatBins - 1;
-                if (idx != run_idx) {
-                    if (run) atomicAdd(&hist[run_idx], run);
-                    run = 0;
-                    run_idx = idx;
-                }
-                run += hv;
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
             }
+            __syncthreads();
+            if (lane == 63) scr_u64[wave] = incl;
+            __syncthreads();
+            unsigned long long base = 0;
+            for (int w = 0; w < wave; ++w) base += scr_u64[w];
+            excl = base + incl - totb;
         }
-        if (run) atomicAdd(&hist[run_idx], run);
-        __syncthreads();
-        // ---- exclusive prefix over the bins: thread t owns bins 4t .. 4t+3 ----
-        unsigned long long own[4], tot = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { own[k] = hist[4 * t + k]; tot += own[k]; }
-        const unsigned long long excl = block_exclusive_scan(tot, scr_u64);
         // ---- percentile inversion (autoscale.rs:120-140) ----
         const double ps[11] = {0.5, 0.01, 0.02, 0.05, 0.10, 0.25, 0.75, 0.90, 0.95, 0.98, 0.99};
 #pragma unroll
@@ -177,11 +219,11 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
             if (target >= count) target = count - 1;
             unsigned long long e = excl;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < kOwn; ++k) {
                 if (own[k] && target >= e && target < e + own[k]) {
                     const double frac = (double)(target - e) / (double)own[k];
                     const double bin_width = span / (double)kStatBins;
-                    const double bin_start = min_db + (double)(4 * t + k) * bin_width;
+                    const double bin_start = min_db + (double)(kOwn * t + k) * bin_width;
                     pct[q] = bin_start + frac * bin_width;
                 }
                 e += own[k];
@@ -191,34 +233,37 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         st.median_db = pct[0]; st.p01 = pct[1]; st.p02 = pct[2]; st.p05 = pct[3]; st.p10 = pct[4]; st.p25 = pct[5];
         st.p75 = pct[6]; st.p90 = pct[7]; st.p95 = pct[8]; st.p98 = pct[9]; st.p99 = pct[10];
     }
+    const uint32_t dn0 = (uint32_t)part * kPartDns;
     if (!a.levels_mode) {
-        // ---- CLAHE window + DN -> bin table ----
+        // ---- CLAHE window + this workgroup's slice of the DN -> bin table ----
         const double low = st.p01, high = st.p99;
         st.low_clip = low; st.high_clip = high; st.gamma = 1.0;
         const double range = fmax(high - low, 1.0);
         uint32_t first_hi = 65535u; // first DN >= 1 whose dB value reached the high clip: the table is constant from there
-        for (uint32_t base = 0; base < 65536u; base += kSweep * kStatsBlock) {
-            double dv[kSweep];
+        constexpr int kPer = kPartDns / kPartBlock;
+        double dv[kPer];
 #pragma unroll
-            for (int k = 0; k < kSweep; ++k) dv[k] = db[base + k * kStatsBlock + t];
+        for (int k = 0; k < kPer; ++k) dv[k] = db[dn0 + k * kPartBlock + t];
 #pragma unroll
-            for (int k = 0; k < kSweep; ++k) {
-                const uint32_t dn = base + k * kStatsBlock + t;
-                uint8_t bin = 0;
-                if (dn) {
-                    const double d = dv[k];
-                    const double clipped = fmin(fmax(d, low), high);
-                    const double v = clampd((clipped - low) / range, 0.0, 1.0);
-                    long long b = (long long)round(v * 255.0);
-                    b = b < 0 ? 0 : (b > 255 ? 255 : b);
-                    bin = (uint8_t)b;
-                    if (d >= high) first_hi = min(first_hi, dn);
-                }
-                binlut[dn] = bin;
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t dn = dn0 + k * kPartBlock + t;
+            uint8_t bin = 0;
+            if (dn) {
+                const double d = dv[k];
+                const double clipped = fmin(fmax(d, low), high);
+                const double v = clampd((clipped - low) / range, 0.0, 1.0);
+                long long b = (long long)round(v * 255.0);
+                b = b < 0 ? 0 : (b > 255 ? 255 : b);
+                bin = (uint8_t)b;
+                if (d >= high) first_hi = min(first_hi, dn);
             }
+            binlut[dn] = bin;
         }
-        const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
-        if (t == 0) { out->stats = st; out->win_hi = win_hi; }
+        const uint32_t wh = part_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+        if (t == 0) {
+            if (wh != 65535u) atomicMin(&out->win_hi, wh);
+            if (part == 0) out->stats = st;
+        }
         return;
     }
     // ---- percentile strategies: window (autoscale.rs:404-429, 491-564, 721-729) ----
@@ -266,22 +311,21 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
         }
         st.low_clip = low; st.high_clip = high; st.gamma = gamma;
     }
-    // ---- u8 level of every DN (autoscale.rs:440-442 / 649-651 / 734-736) + the level histogram.
+    // ---- u8 level of every DN of the slice (autoscale.rs:440-442 / 649-651 / 734-736) + the level histogram.
     //      gamma != 1: trunc(pow(x, g) * 255) is resolved against host-built thresholds of x (glibc pow),
     //      so no pow runs here and the level is exactly the reference's. ----
     {
         const double low = st.low_clip, high = st.high_clip, gamma = st.gamma;
         const double range = fmax(high - low, 1.0);
         const double *gthr = gamma == 0.8 ? a.gamma_thr : (gamma == 0.9 ? a.gamma_thr + 256 : (gamma == 1.1 ? a.gamma_thr + 512 : nullptr));
-        unsigned long long *lh = hist; // reuse the 4096-bin LDS array: first 256 words
-        __syncthreads();
-        for (int i = t; i < 256; i += kStatsBlock) lh[i] = 0;
+        lh[t] = 0;
         __syncthreads();
         uint32_t first_hi = 65535u;
         unsigned long long run = 0;
         uint32_t run_level = 0xFFFFFFFFu;
         const int w = t >> 6, lane = t & 63;
-        for (uint32_t tb = (uint32_t)w * kDnsPerWave; tb < (uint32_t)(w + 1) * kDnsPerWave; tb += kTileDns) { // a lane walks increasing DNs: levels form runs
+        const uint32_t wave_base = dn0 + (uint32_t)w * kPartWaveDns;
+        for (uint32_t tb = wave_base; tb < wave_base + kPartWaveDns; tb += kTileDns) { // a lane walks increasing DNs: levels form runs
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < kTileDns / 64; ++k) { tile_h[w][k * 64 + lane] = h[tb + k * 64 + lane]; tile_d[w][k * 64 + lane] = db[tb + k * 64 + lane]; }
@@ -320,10 +364,13 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_stats(ChainStatsArgs a) {
             *reinterpret_cast<uint32_t *>(binlut + tb + lane * 4) = lvl4[0] | (lvl4[1] << 8) | (lvl4[2] << 16) | (lvl4[3] << 24);
         }
         if (run) atomicAdd(&lh[run_level], run);
-        const uint32_t win_hi = block_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+        const uint32_t wh = part_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
         __syncthreads();
-        if (t < 256) a.level_hist[(size_t)band * 256 + t] = lh[t];
-        if (t == 0) { out->stats = st; out->win_hi = win_hi; }
+        if (lh[t]) atomicAdd(&a.level_hist[(size_t)band * 256 + t], lh[t]);
+        if (t == 0) {
+            if (wh != 65535u) atomicMin(&out->win_hi, wh);
+            if (part == 0) out->stats = st;
+        }
     }
 }
 
@@ -532,7 +579,9 @@ __global__ __launch_bounds__(256) void k_level_hist_if_flagged(const uint8_t *__
 } // namespace
 
 hipError_t launch_chain_stats(const ChainStatsArgs &a, int nbands, hipStream_t s) {
-    hipLaunchKernelGGL(k_chain_stats, dim3(nbands), dim3(kStatsBlock), 0, s, a);
+    hipLaunchKernelGGL(k_chain_stats_a, dim3(nbands, kStatsParts), dim3(kPartBlock), 0, s, a);
+    hipLaunchKernelGGL(k_chain_stats_b, dim3(nbands, kStatsParts), dim3(kPartBlock), 0, s, a);
+    hipLaunchKernelGGL(k_chain_stats_c, dim3(nbands, kStatsParts), dim3(kPartBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_chain_cdfs(const unsigned long long *tile_bins, double *cdfs, uint32_t rows, uint32_t cols, int nbands,

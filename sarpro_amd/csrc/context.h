@@ -86,6 +86,7 @@ struct sarpro_hip_ctx {
     uint32_t resize_key[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // (in, out, elem, precision) of the cached coefficient tables
     sarpro::DevBuf resize_tmp, resize_coef[2], resized[2]; // resize path: intermediate image, coefficient tables, resized bands
     sarpro::DevBuf chain_consts;                 // device-resident chain: dB table | suppressed lut_r/g per floor | blue pairs
+    sarpro::DevBuf chain_scratch;               // statistics step: per-slice partials | 4096 bins per band
     sarpro::DevBuf chain_state;                  // ChainBandState[2] | resc[2][256] | identity[2] | floor
     bool chain_ready = false;
     uint32_t chain_levels_cap = 4096;            // LDS bytes per band of the fused pass's DN tables (percentile chain)
