@@ -435,33 +435,46 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
     }
     if (t < 256) combined[t] = 0;
     __syncthreads();
-    if (t < a.nbands && !a.levels_mode) { // level 0 is not counted by the apply kernel: it is what is left of the scene
-        unsigned long long others = 0;
-        for (int k = 1; k < 256; ++k) others += lh[t][k];
-        lh[t][0] = a.total_px - others;
-    }
-    __syncthreads();
-    if (t < a.nbands) {
-        unsigned mn = 0, mx = 0;
-        bool any = false;
-        for (unsigned k = 0; k < 256; ++k)
-            if (lh[t][k]) { if (!any) mn = k; mx = k; any = true; }
+    // waves 0 and 1 take one band each (lane-parallel over the 256 levels, 4 per lane) -- as serial loops of one
+    // thread per band these few hundred dependent steps were a third of the kernel
+    __shared__ unsigned s_mn[2], s_mx[2];
+    const int wb = t >> 6, ln = t & 63;
+    if (wb < a.nbands) {
+        unsigned long long v[4], others = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = lh[wb][ln * 4 + k]; if (ln * 4 + k) others += v[k]; }
+        if (!a.levels_mode) { // level 0 is not counted by the apply kernel: it is what is left of the scene
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) others += __shfl_xor(others, m, 64);
+            if (ln == 0) { v[0] = a.total_px - others; lh[wb][0] = v[0]; }
+        }
+        unsigned mn = 256u, mx = 0u; // lowest / highest occupied level (autoscale.rs:349-352 over the raster = over its histogram)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (v[k]) { mn = min(mn, (unsigned)(ln * 4 + k)); mx = max(mx, (unsigned)(ln * 4 + k)); }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, m, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, m, 64)); }
+        if (mn == 256u) mn = 0u; // empty histogram
+        if (ln == 0) { s_mn[wb] = mn; s_mx[wb] = mx; }
         const float fmn = (float)mn, fmx = (float)mx;
         const float scale = fmx > fmn ? 255.0f / (fmx - fmn) : 1.0f;
-        for (unsigned x = 0; x < 256; ++x) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned x = ln * 4 + k;
             float val = roundf(((float)x - fmn) * scale);
             val = val < 0.0f ? 0.0f : (val > 255.0f ? 255.0f : val);
-            resc[t][x] = a.no_rescale[t] ? (uint8_t)x : (uint8_t)val;
+            resc[wb][x] = a.no_rescale[wb] ? (uint8_t)x : (uint8_t)val;
         }
     }
     __syncthreads();
     if (t < 256) for (int b = 0; b < a.nbands; ++b) atomicAdd(&combined[resc[b][t]], lh[b][t]);
     const bool lead = blockIdx.x == 0;
     if (lead && t < 512 && a.resc_out) a.resc_out[t] = (t >> 8) < a.nbands ? resc[t >> 8][t & 255] : (uint8_t)(t & 255);
-    if (lead && t < a.nbands && a.identity_out) {
+    if (lead && wb < a.nbands && a.identity_out) {
         bool ident = true;
-        for (int k = 0; k < 256; ++k) if (lh[t][k] && resc[t][k] != k) ident = false;
-        a.identity_out[t] = ident ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (lh[wb][ln * 4 + k] && resc[wb][ln * 4 + k] != ln * 4 + k) ident = false;
+        const bool all = __builtin_amdgcn_ballot_w64(!ident) == 0ull;
+        if (ln == 0) a.identity_out[wb] = all ? 1 : 0;
     }
     __syncthreads();
     if (a.levels_mode) // DN -> level tables become DN -> final u8 tables; the compose tables then take final values
