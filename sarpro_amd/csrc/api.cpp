@@ -355,6 +355,8 @@ static int job_init(U16Job &J) {
 }
 
 // phase 1: local DN histograms -> ctx->ghist (u64 [nbands][65536]) on the device
+static uint32_t *tile_hist_of(sarpro_hip_ctx *ctx, int band, int ntiles) { return ctx->tile_hist[0].as<uint32_t>() + (size_t)band * 65536 * (size_t)ntiles; }
+
 // The histogram pass can be issued in pieces (streaming ingest: the work items whose rows have arrived):
 // `begin` clears the tile histograms, [first, last) are indices into the plan's item list (sorted by row),
 // `end` folds the tile histograms into the band histogram.  The default is the whole pass.
@@ -365,11 +367,13 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     const int ntiles = tiled ? kTiles * kTiles : 1;
     HIPCHK(ctx, ctx->ghist.reserve(sizeof(uint64_t) * 65536 * kMaxBands));
     DnHistArgs a{};
+    // both bands' tile histograms in one allocation (band b at tile_hist_of(ctx, b, ntiles)): one fill instead of two
+    const size_t band_bytes = sizeof(uint32_t) * 65536 * (size_t)ntiles;
+    HIPCHK(ctx, ctx->tile_hist[0].reserve(band_bytes * kMaxBands));
+    if (begin) HIPCHK(ctx, hipMemsetAsync(ctx->tile_hist[0].p, 0, band_bytes * (size_t)J.nbands, ctx->stream));
     for (int b = 0; b < J.nbands; ++b) {
-        HIPCHK(ctx, ctx->tile_hist[b].reserve(sizeof(uint32_t) * 65536 * (size_t)ntiles));
-        if (begin) HIPCHK(ctx, hipMemsetAsync(ctx->tile_hist[b].p, 0, sizeof(uint32_t) * 65536 * (size_t)ntiles, ctx->stream));
         a.in[b] = J.d_in[b];
-        a.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+        a.tile_hist[b] = tile_hist_of(ctx, b, ntiles);
     }
     a.pitch = J.in_pitch;
     const int nall = (int)(tiled ? J.plan->hist_rects_tiled.size() : J.plan->hist_rects_flat.size());
@@ -393,7 +397,7 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     {
         SumTileHistArgs sa{};
         for (int b = 0; b < J.nbands; ++b) {
-            sa.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+            sa.tile_hist[b] = tile_hist_of(ctx, b, ntiles);
             sa.out[b] = ctx->ghist.as<unsigned long long>() + (size_t)b * 65536;
         }
         KernelTimer t(ctx, "sum_tile_hists");
@@ -469,7 +473,7 @@ static int job_phase2(U16Job &J) {
         uint8_t *stage = ctx->h_upload.as<uint8_t>() + (size_t)b * 65536;
         for (int i = 0; i < 65536; ++i) stage[i] = (uint8_t)J.lut[b].full[i];
         HIPCHK(ctx, hipMemcpyAsync(ctx->luts.as<uint8_t>() + (size_t)b * 131072, stage, 65536, hipMemcpyHostToDevice, ctx->stream));
-        ta.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+        ta.tile_hist[b] = tile_hist_of(ctx, b, kTiles * kTiles);
         ta.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
         ta.out[b] = ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256;
     }
@@ -777,6 +781,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         sa.state = d_state;
         sa.binlut = ctx->luts.as<uint8_t>();
         sa.binlut_stride = 131072;
+        sa.level_hist = ctx->level_hist.as<unsigned long long>(); // cleared here for the apply kernel (one fill kernel less)
         KernelTimer t(ctx, "chain_stats");
         RETCHK(chain_stats_scratch(ctx, &sa));
         HIPCHK(ctx, launch_chain_stats(sa, J.nbands, ctx->stream));
@@ -784,7 +789,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     {
         TileBinHistArgs ta{};
         for (int b = 0; b < J.nbands; ++b) {
-            ta.tile_hist[b] = ctx->tile_hist[b].as<uint32_t>();
+            ta.tile_hist[b] = tile_hist_of(ctx, b, kTiles * kTiles);
             ta.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
             ta.out[b] = ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256;
         }
@@ -838,7 +843,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         ctx->chain_lut_cap = std::min<uint32_t>(16384, std::max<uint32_t>(1024, (hi + 1 + 255) / 256 * 256));
         return SARPRO_HIP_OK;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
+    // (the level histogram was cleared by the statistics kernels)
     // whole scene on this device: levels >= 64 are only counted in bulk (chain_kernels.hip k_level_hist_guard); a row
     // stripe keeps the full histogram, which is what the ranks sum
     a.partial_hist = (!J.reduce && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_a(ChainStatsArgs a) 
     const double *__restrict__ db = a.db;
     if (part == 0) { // scratch of the next two kernels
         for (int i = t; i < kStatBins; i += kPartBlock) a.bins4096[(size_t)band * kStatBins + i] = 0ull;
-        if (a.levels_mode) a.level_hist[(size_t)band * 256 + t] = 0ull;
+        if (a.level_hist) a.level_hist[(size_t)band * 256 + t] = 0ull; // levels mode: filled by kernel C; CLAHE: by the apply kernel
         if (t == 0) a.state[band].win_hi = 65535u;
     }
     unsigned long long cnt = 0;

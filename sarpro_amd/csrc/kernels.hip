@@ -189,35 +189,41 @@ __global__ __launch_bounds__(kBlock) void k_dn_hist_u16_interior(DnHistArgs a) {
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_sum_tile_hists(SumTileHistArgs a, int ntiles) {
     const uint32_t *__restrict__ th = a.tile_hist[blockIdx.y];
-    const uint32_t dn = blockIdx.x * kBlock + threadIdx.x;
-    unsigned long long s = 0;
-    for (int t = 0; t < ntiles; ++t) s += th[(size_t)t * 65536u + dn];
-    a.out[blockIdx.y][dn] = s;
+    const uint32_t dn = (blockIdx.x * kBlock + threadIdx.x) * 4; // 4 consecutive DNs per thread: 16-byte loads
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 16
+    for (int t = 0; t < ntiles; ++t) { // independent loads: many in flight
+        const uint4 v = *reinterpret_cast<const uint4 *>(th + (size_t)t * 65536u + dn);
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    unsigned long long *o = a.out[blockIdx.y] + dn;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
 }
 
 // ------------------------------------------------------------------------------------
 // 3. Per-tile 256-bin CLAHE histogram from the per-tile DN histogram and the DN -> bin table
 //    (autoscale.rs:259-268 without touching the pixels again).  One block per tile.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_tile_bin_hist(TileBinHistArgs a) {
+constexpr int kTileBinBlock = 1024; // one workgroup sweeps a tile's 65536 counters: the sweep is latency-bound, so a wide one
+__global__ __launch_bounds__(kTileBinBlock) void k_tile_bin_hist(TileBinHistArgs a) {
     __shared__ unsigned long long h[256];
     const int band = blockIdx.y;
     const uint32_t *__restrict__ t = a.tile_hist[band] + (size_t)blockIdx.x * 65536u;
     const uint8_t *__restrict__ binlut = a.binlut[band];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < 65536u; base += 8 * kBlock) { // 8 independent loads in flight per thread
-        uint32_t n[8], bin[8];
+    for (uint32_t base = 0; base < 65536u; base += 16 * kTileBinBlock) { // 32 independent loads in flight per thread
+        uint32_t n[16], bin[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const uint32_t dn = base + k * kBlock + threadIdx.x; n[k] = t[dn]; bin[k] = binlut[dn]; }
+        for (int k = 0; k < 16; ++k) { const uint32_t dn = base + k * kTileBinBlock + threadIdx.x; n[k] = t[dn]; bin[k] = binlut[dn]; }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t dn = base + k * kBlock + threadIdx.x;
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t dn = base + k * kTileBinBlock + threadIdx.x;
             if (n[k] && dn) atomicAdd(&h[bin[k]], (unsigned long long)n[k]); // DN = 0 is invalid: not counted
         }
     }
     __syncthreads();
-    a.out[band][(size_t)blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < 256) a.out[band][(size_t)blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------
@@ -998,12 +1004,12 @@ hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nban
 }
 
 hipError_t launch_sum_tile_hists(const SumTileHistArgs &a, int ntiles, int nbands, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_tile_hists, dim3(65536 / kBlock, nbands), dim3(kBlock), 0, s, a, ntiles);
+    hipLaunchKernelGGL(k_sum_tile_hists, dim3(65536 / kBlock / 4, nbands), dim3(kBlock), 0, s, a, ntiles);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_bin_hist(const TileBinHistArgs &a, int ntiles, int nbands, hipStream_t s) {
-    hipLaunchKernelGGL(k_tile_bin_hist, dim3(ntiles, nbands), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(k_tile_bin_hist, dim3(ntiles, nbands), dim3(kTileBinBlock), 0, s, a);
     return hipGetLastError();
 }
 
