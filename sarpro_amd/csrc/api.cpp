@@ -856,10 +856,11 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         HIPCHK(ctx, ctx->hist_flags.reserve(sizeof(uint32_t) * kMaxBands));
         HIPCHK(ctx, launch_level_hist_guard(ctx->level_hist.as<unsigned long long>(), (unsigned long long)J.rows_total * J.cols, J.nbands,
                                             ctx->hist_flags.as<uint32_t>(), ctx->stream));
-        for (int b = 0; b < J.nbands; ++b)
-            HIPCHK(ctx, launch_level_hist_if_flagged(reinterpret_cast<const uint8_t *>(a.out[b]), a.out_pitch, (uint32_t)J.rows_local, cols,
-                                                     ctx->level_hist.as<unsigned long long>() + (size_t)b * 256,
-                                                     ctx->hist_flags.as<uint32_t>() + b, ctx->stream));
+        LevelRecountArgs ra{};
+        for (int b = 0; b < J.nbands; ++b) ra.levels[b] = reinterpret_cast<const uint8_t *>(a.out[b]);
+        ra.pitch = a.out_pitch; ra.rows = (uint32_t)J.rows_local; ra.cols = cols;
+        ra.level_hist = ctx->level_hist.as<unsigned long long>(); ra.flags = ctx->hist_flags.as<uint32_t>();
+        HIPCHK(ctx, launch_level_hist_if_flagged(ra, J.nbands, ctx->stream));
     }
     RETCHK(chain_reduce(J, ctx->level_hist.p, 256 * kMaxBands, "allreduce_level_hist"));
     {

@@ -63,8 +63,14 @@ hipError_t launch_chain_finish(const ChainFinishArgs &a, hipStream_t s);
 // it and flag the band; the second kernel recounts a flagged band from its level raster
 hipError_t launch_level_hist_guard(unsigned long long *level_hist, unsigned long long total_px, int nbands, uint32_t *d_flags,
                                    hipStream_t s);
-hipError_t launch_level_hist_if_flagged(const uint8_t *levels, size_t pitch, uint32_t rows, uint32_t cols,
-                                        unsigned long long *hist, const uint32_t *d_flag, hipStream_t s);
+struct LevelRecountArgs {
+    const uint8_t *levels[kMaxBands];  // level rasters
+    size_t pitch;
+    uint32_t rows, cols;
+    unsigned long long *level_hist;    // [nbands][256]
+    const uint32_t *flags;             // [nbands], written by k_level_hist_guard
+};
+hipError_t launch_level_hist_if_flagged(const LevelRecountArgs &a, int nbands, hipStream_t s);
 // dst = map[src] unless skip_flag && *skip_flag (device byte) is non-zero and src == dst
 hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, uint32_t rows,
                               uint32_t cols, const uint8_t *d_map, const uint8_t *d_skip_flag, hipStream_t s);

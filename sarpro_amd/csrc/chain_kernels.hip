@@ -572,10 +572,13 @@ __global__ __launch_bounds__(256) void k_level_hist_guard(unsigned long long *le
     if (recount) lh[t] = 0ull;
 }
 
-__global__ __launch_bounds__(256) void k_level_hist_if_flagged(const uint8_t *__restrict__ in, size_t pitch, uint32_t rows,
-                                                               uint32_t cols, unsigned long long *__restrict__ hist,
-                                                               const uint32_t *__restrict__ flag) {
-    if (!*flag) return;
+__global__ __launch_bounds__(256) void k_level_hist_if_flagged(LevelRecountArgs a) {
+    const int band = blockIdx.y;
+    if (!a.flags[band]) return;
+    const uint8_t *__restrict__ in = a.levels[band];
+    const size_t pitch = a.pitch;
+    const uint32_t rows = a.rows, cols = a.cols;
+    unsigned long long *__restrict__ hist = a.level_hist + (size_t)band * 256;
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -623,10 +626,9 @@ hipError_t launch_level_hist_guard(unsigned long long *level_hist, unsigned long
     hipLaunchKernelGGL(k_level_hist_guard, dim3(nbands), dim3(256), 0, s, level_hist, total_px, d_flags);
     return hipGetLastError();
 }
-hipError_t launch_level_hist_if_flagged(const uint8_t *levels, size_t pitch, uint32_t rows, uint32_t cols,
-                                        unsigned long long *hist, const uint32_t *d_flag, hipStream_t s) {
-    if (!rows || !cols) return hipSuccess;
-    hipLaunchKernelGGL(k_level_hist_if_flagged, dim3(1024), dim3(256), 0, s, levels, pitch, rows, cols, hist, d_flag);
+hipError_t launch_level_hist_if_flagged(const LevelRecountArgs &a, int nbands, hipStream_t s) {
+    if (!a.rows || !a.cols) return hipSuccess;
+    hipLaunchKernelGGL(k_level_hist_if_flagged, dim3(1024, nbands), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 } // namespace sarpro
