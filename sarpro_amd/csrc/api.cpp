@@ -381,7 +381,10 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     a.rects = (tiled ? J.plan->d_hist_rects_tiled : J.plan->d_hist_rects_flat).as<Rect>() + first;
     a.lds_bins = 8192;
     const int nrects = last - first;
-    if (nrects > 0) {
+    if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_LINEAR_HIST")) {
+        KernelTimer t(ctx, "dn_hist_u16"); // whole untiled pass in one go: the in-order sweep
+        HIPCHK(ctx, launch_dn_hist_u16_linear(a, (uint32_t)J.rows_local, (uint32_t)J.cols, J.nbands, ctx->stream));
+    } else if (nrects > 0) {
         KernelTimer t(ctx, "dn_hist_u16");
         if (J.vec) HIPCHK(ctx, launch_dn_hist_u16_interior(a, nrects, J.nbands, ctx->stream));
         else HIPCHK(ctx, launch_dn_hist_u16(a, nrects, J.nbands, false, ctx->stream));

@@ -71,6 +71,8 @@ struct ComposeArgs {
 
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);
 hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nbands, hipStream_t s);
+// untiled histogram (tile_hist[b] = one 65536-bin histogram per band) of a rows x cols raster whose pitch is a multiple of 8
+hipError_t launch_dn_hist_u16_linear(const DnHistArgs &a, uint32_t rows, uint32_t cols, int nbands, hipStream_t s);
 struct SumTileHistArgs {
     const uint32_t *tile_hist[kMaxBands]; // [ntiles][65536]
     unsigned long long *out[kMaxBands];   // [65536]

@@ -185,6 +185,73 @@ __global__ __launch_bounds__(kBlock) void k_dn_hist_u16_interior(DnHistArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// 1c. The whole-raster (untiled) DN histogram of the percentile strategies as a LINEAR sweep: persistent workgroups,
+//     each wave takes 1024 consecutive pixels of a row (2 KiB: two 1-KiB load instructions) at a time in launch order,
+//     the next chunk in flight while this one is counted.  Same counting as 1b (one unconditional ds_add_u32 per
+//     pixel, DN = 0 and the bright tail to a per-lane dummy word, tail pixels to the global histogram).  The strip
+//     walk of 1b exists for the CLAHE tiles; without tiles the in-order sweep reads faster.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_dn_hist_u16_linear(DnHistArgs a, uint32_t rows, uint32_t cols) {
+    extern __shared__ uint32_t lds_hist[];
+    const int band = blockIdx.y;
+    const uint16_t *__restrict__ in = a.in[band];
+    uint32_t *__restrict__ gh = a.tile_hist[band];
+    const uint32_t W = a.lds_bins;
+    for (uint32_t i = threadIdx.x; i < W + kWave; i += kBlock) lds_hist[i] = 0;
+    __syncthreads();
+    const int lane = lane_id();
+    const uint32_t dummy = (W + (uint32_t)lane) * 4u;
+    unsigned char *lds_bytes = reinterpret_cast<unsigned char *>(lds_hist);
+    auto consume = [&](const uint4 &q) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        uint32_t big = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t d = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu);
+            const bool in_lds = d - 1u < W - 1u; // 1 <= d < W
+            big |= (d >= W ? 1u : 0u) << j;
+            const uint32_t off = in_lds ? d * 4u : dummy;
+            atomicAdd(reinterpret_cast<uint32_t *>(lds_bytes + off), 1u);
+        }
+        if (big) { // bright tail: rare
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((big >> j) & 1u) atomicAdd(&gh[(j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu)], 1u);
+        }
+    };
+    // chunk c of a row: pixels [c * 1024, c * 1024 + 1024); lane l owns pixels l*8 .. l*8+7 of each 512-pixel half
+    const uint32_t cpr = (cols + 1023) / 1024;
+    const uint64_t chunks = (uint64_t)rows * cpr, nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    const uint32_t last_col = a.pitch >= 8 ? (uint32_t)a.pitch - 8 : 0u; // clamp: masked lanes load inside the row's pitch
+    auto load = [&](uint64_t ch, int half) {
+        const uint32_t r = (uint32_t)(ch / cpr), col = (uint32_t)(ch - (uint64_t)r * cpr) * 1024 + half * 512 + lane * 8;
+        return *reinterpret_cast<const uint4 *>(in + (size_t)r * a.pitch + min(col, last_col));
+    };
+    uint64_t ch = (uint64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    if (ch < chunks) {
+        uint4 n0 = load(ch, 0), n1 = load(ch, 1);
+        for (; ch < chunks; ch += nwaves) {
+            uint4 q0 = n0, q1 = n1;
+            const uint64_t nx = ch + nwaves < chunks ? ch + nwaves : ch;
+            n0 = load(nx, 0); n1 = load(nx, 1);
+            const uint32_t r = (uint32_t)(ch / cpr), c0 = (uint32_t)(ch - (uint64_t)r * cpr) * 1024 + lane * 8;
+            if (c0 + 520 > cols) { // the row's last chunk: samples past the last column become DN = 0 (never counted)
+                const EdgeMask m0((int)c0, 0, (int)cols), m1((int)c0 + 512, 0, (int)cols);
+                q0.x &= m0.m[0]; q0.y &= m0.m[1]; q0.z &= m0.m[2]; q0.w &= m0.m[3];
+                q1.x &= m1.m[0]; q1.y &= m1.m[1]; q1.z &= m1.m[2]; q1.w &= m1.m[3];
+            }
+            consume(q0);
+            consume(q1);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x + 1; i < W; i += kBlock) { // bin 0 is restored by the consumer
+        const uint32_t n = lds_hist[i];
+        if (n) atomicAdd(&gh[i], n);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // 2. Sum the per-tile histograms into the band's global 65536-bin histogram (u64).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_sum_tile_hists(SumTileHistArgs a, int ntiles) {
@@ -1000,6 +1067,13 @@ hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nban
     if (nrects <= 0) return hipSuccess;
     const size_t lds = ((size_t)a.lds_bins + kWave) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_dn_hist_u16_interior, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dn_hist_u16_linear(const DnHistArgs &a, uint32_t rows, uint32_t cols, int nbands, hipStream_t s) {
+    if (!rows || !cols) return hipSuccess;
+    const size_t lds = ((size_t)a.lds_bins + kWave) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_dn_hist_u16_linear, dim3(256 * 4, nbands), dim3(kBlock), lds, s, a, rows, cols);
     return hipGetLastError();
 }
 
