@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsarpro_hip.so")
+# SARPRO_HIP_LIB: another build of the same library (A/B timing of kernel variants inside one process tree)
+LIB_PATH = os.environ.get("SARPRO_HIP_LIB") or os.path.join(_HERE, "libsarpro_hip.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_SHAPE_MISMATCH, ERR_UNSUPPORTED_SHAPE = -1, -2, -3
