@@ -919,14 +919,22 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
 // u8 level of every DN + level histogram (k_chain_stats, levels mode) -> rescale / floor / tables and DN -> final
 // u8 tables (k_chain_finish) -> ONE fused pass DN,DN -> RGB (k_lut_compose_u16).  No host synchronisation in
 // between; gamma != 1 is resolved against host-built thresholds, so no pow runs on the device.
-static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands], const uint8_t *d_rgb, size_t rgb_pitch_px) {
+// dual-pol -> RGB (fused pass) and / or per-band u8 rasters (table pass), all with device-built tables
+static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, const uint8_t *d_rgb,
+                                  size_t rgb_pitch_px) {
     if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
-    return !J.clahe() && J.synrgb && J.nbands == 2 && !d_out[0] && !d_out[1] && J.vec && J.in_pitch % 16 == 0 &&
-           rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb) && (J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total));
+    if (J.clahe() || !J.u8_out() || !J.vec || !(J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total))) return false;
+    if (J.synrgb && !(J.nbands == 2 && J.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb))) return false;
+    bool any_out = false;
+    for (int b = 0; b < J.nbands; ++b)
+        if (d_out[b]) { any_out = true; if (out_pitch % 8 != 0 || !ptr_aligned16(d_out[b])) return false; }
+    return J.synrgb || any_out;
 }
 
-static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
+static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
+                                sarpro_hip_stats *stats_out) {
     sarpro_hip_ctx *ctx = J.ctx;
+    const int nb = J.nbands;
     RETCHK(chain_prepare(ctx));
     HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
     HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
@@ -937,7 +945,7 @@ static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, 
     const bool suppressed = J.strategy == SARPRO_STRATEGY_TAMED; // CLAHE is not handled here
 
     RETCHK(job_phase1(J)); // DN histograms -> ctx->ghist
-    RETCHK(chain_reduce(J, ctx->ghist.p, 65536 * 2, "allreduce_dn_hist"));
+    RETCHK(chain_reduce(J, ctx->ghist.p, 65536 * (size_t)nb, "allreduce_dn_hist"));
     {
         ChainStatsArgs sa{};
         sa.ghist = ctx->ghist.as<unsigned long long>();
@@ -947,27 +955,27 @@ static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, 
         sa.binlut_stride = 131072;
         sa.levels_mode = 1;
         sa.strategy = J.strategy;
-        for (int b = 0; b < 2; ++b) sa.tamed_kind[b] = J.tamed_kind(b);
+        for (int b = 0; b < nb; ++b) sa.tamed_kind[b] = J.tamed_kind(b);
         sa.total_px = (unsigned long long)J.rows_total * J.cols;
         sa.level_hist = ctx->level_hist.as<unsigned long long>();
         sa.gamma_thr = reinterpret_cast<const double *>(consts + kChainOffGamma);
         KernelTimer t(ctx, "chain_stats");
         RETCHK(chain_stats_scratch(ctx, &sa));
-        HIPCHK(ctx, launch_chain_stats(sa, 2, ctx->stream));
+        HIPCHK(ctx, launch_chain_stats(sa, nb, ctx->stream));
     }
     {
         ChainFinishArgs fa{};
         fa.level_hist = ctx->level_hist.as<unsigned long long>();
         fa.total_px = (unsigned long long)J.rows_total * J.cols;
-        fa.nbands = 2;
+        fa.nbands = nb;
         fa.resc_out = state + kStateOffResc;
         fa.identity_out = state + kStateOffIdent;
-        fa.tables = ctx->tables.as<uint8_t>();
+        fa.tables = J.synrgb ? ctx->tables.as<uint8_t>() : nullptr; // no composition: only the DN -> final u8 tables
         fa.supp_rg = consts + kChainOffSupp;
         fa.blue_pair_supp = consts + kChainOffBlue;
         fa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
         fa.levels_mode = 1;
-        for (int b = 0; b < 2; ++b) fa.no_rescale[b] = J.tamed_kind(b) != kNotTamedSynrgb;
+        for (int b = 0; b < nb; ++b) fa.no_rescale[b] = J.tamed_kind(b) != kNotTamedSynrgb;
         fa.suppressed = suppressed ? 1 : 0;
         fa.dn_tables = ctx->luts.as<uint8_t>();
         fa.dn_table_stride = 131072;
@@ -976,7 +984,17 @@ static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, 
         KernelTimer t(ctx, "chain_finish");
         HIPCHK(ctx, launch_chain_finish(fa, ctx->stream));
     }
-    {
+    for (int b = 0; b < nb; ++b) { // per-band u8 rasters: out = table[DN]
+        if (!d_out[b]) continue;
+        LutApplyArgs la{};
+        la.in = J.d_in[b]; la.out = d_out[b]; la.in_pitch = J.in_pitch; la.out_pitch = out_pitch;
+        la.rows = (uint32_t)J.rows_local; la.cols = (uint32_t)J.cols;
+        la.lut = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+        la.dev_state = d_state; la.band = b; la.lut_cap = ctx->chain_levels_cap;
+        KernelTimer t(ctx, "lut_apply_u16");
+        HIPCHK(ctx, launch_lut_apply_u16(la, true, false, ctx->stream));
+    }
+    if (J.synrgb) {
         LutComposeArgs f{};
         for (int b = 0; b < 2; ++b) { f.in[b] = J.d_in[b]; f.lut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072; }
         f.rgb = d_rgb; f.in_pitch = J.in_pitch; f.rgb_pitch_px = rgb_pitch_px;
@@ -988,10 +1006,10 @@ static int job_run_chain_levels(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px, 
         HIPCHK(ctx, launch_lut_compose_u16(f, ctx->stream));
     }
     ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
-    HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
     uint32_t hi = 0;
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < nb; ++b) {
         J.stats[b] = h_state[b].stats;
         if (stats_out) stats_out[b] = J.stats[b];
         hi = std::max(hi, h_state[b].win_hi);
@@ -1013,9 +1031,9 @@ static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch
         HostTimer t(J.ctx, "host:chain(enqueue+final sync)");
         return job_run_chain(J, d_out, out_pitch, d_rgb, rgb_pitch_px, stats_out);
     }
-    if (chain_levels_eligible(J, d_out, d_rgb, rgb_pitch_px)) {
+    if (chain_levels_eligible(J, d_out, out_pitch, d_rgb, rgb_pitch_px)) {
         HostTimer t(J.ctx, "host:chain(enqueue+final sync)");
-        return job_run_chain_levels(J, d_rgb, rgb_pitch_px, stats_out);
+        return job_run_chain_levels(J, d_out, out_pitch, d_rgb, rgb_pitch_px, stats_out);
     }
     { HostTimer t(J.ctx, "host:phase1_launch"); RETCHK(job_phase1(J)); }
     // (row-stripe mode without the device chain: the same phases with a synchronous all-reduce after each)
@@ -1316,7 +1334,7 @@ extern "C" int sarpro_hip_dualpol_synrgb_stream_u16(sarpro_hip_ctx *ctx, sarpro_
     {
         HostTimer t(ctx, "host:chain(enqueue+final sync)");
         if (chain_eligible(J)) RETCHK(job_run_chain(J, outs, 0, d_rgb, pitch, stats_out));
-        else if (chain_levels_eligible(J, outs, d_rgb, pitch)) RETCHK(job_run_chain_levels(J, d_rgb, pitch, stats_out));
+        else if (chain_levels_eligible(J, outs, 0, d_rgb, pitch)) RETCHK(job_run_chain_levels(J, outs, 0, d_rgb, pitch, stats_out));
         else return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "streaming ingest needs the device chain (SARPRO_HIP_NO_CHAIN is set)");
     }
 

@@ -59,6 +59,9 @@ struct LutApplyArgs {
     const void *lut;            // full 65536-entry table of u8 (OUT16 = false) or u16 entries
     uint32_t win_lo, win_hi;
     uint32_t lut_in_lds;
+    const struct ChainBandState *dev_state; // chain mode: the window is [0, dev_state[band].win_hi], staged in LDS when it is below lut_cap entries
+    int band;
+    uint32_t lut_cap;
 };
 
 struct ComposeArgs {

@@ -704,8 +704,8 @@ __global__ __launch_bounds__(kBlock) void k_lut_apply_u16(LutApplyArgs a) {
     using Entry = typename std::conditional<OUT16, uint16_t, uint8_t>::type;
     Entry *lds_lut = reinterpret_cast<Entry *>(lds_raw);
     const Entry *__restrict__ glut = reinterpret_cast<const Entry *>(a.lut);
-    const uint32_t win_lo = a.win_lo, win_hi = a.win_hi;
-    const bool lut_lds = a.lut_in_lds != 0;
+    const uint32_t win_lo = a.dev_state ? 0u : a.win_lo, win_hi = a.dev_state ? a.dev_state[a.band].win_hi : a.win_hi;
+    const bool lut_lds = a.dev_state ? win_hi < a.lut_cap : a.lut_in_lds != 0;
     if (lut_lds) {
         for (uint32_t i = threadIdx.x; i <= win_hi - win_lo; i += kBlock) lds_lut[i] = glut[win_lo + i];
         __syncthreads();
@@ -1130,7 +1130,8 @@ hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nband
 hipError_t launch_lut_apply_u16(const LutApplyArgs &a, bool vec, bool out16, hipStream_t s) {
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
     const size_t esz = out16 ? 2 : 1;
-    const size_t lds = a.lut_in_lds ? (((size_t)(a.win_hi - a.win_lo + 1) * esz + 15) & ~(size_t)15) : 0;
+    const size_t lds = a.dev_state ? (((size_t)a.lut_cap * esz + 15) & ~(size_t)15)
+                                   : (a.lut_in_lds ? (((size_t)(a.win_hi - a.win_lo + 1) * esz + 15) & ~(size_t)15) : 0);
     const int V = vec ? 8 : 1;
     const uint64_t items = (uint64_t)a.rows * ((a.cols + V - 1) / V);
     dim3 grid(stream_grid(items, kBlock));

@@ -11,6 +11,7 @@ import oracle
 from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, SyntheticRgbMode as Mode
 from sarpro_amd import SarproHipError, synth
 from sarpro_amd import _lib
+import sarpro_amd as S
 
 pytestmark = pytest.mark.gpu
 
@@ -227,3 +228,22 @@ def test_partial_level_histogram_and_its_recount_fallback(ctx, kind, monkeypatch
             monkeypatch.delenv("SARPRO_HIP_FULL_LEVEL_HIST", raising=False)
         rgb, u1, u2 = ctx.dualpol_synrgb(b1, b2, St.Clahe, want_u8=True)
         assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), (kind, full)
+
+
+@pytest.mark.parametrize("strategy", [St.Standard, St.Robust, St.Adaptive, St.Equalized, St.Tamed, St.Default])
+def test_single_band_percentile_chain_equals_host_orchestrated_path(strategy, monkeypatch):
+    """Single-band u8 of the percentile strategies runs as a device chain too (statistics, window, level table, rescale
+    by kernels, then one table pass); SARPRO_HIP_NO_CHAIN=1 is the host-orchestrated route.  Also the tamed-synRGB entry."""
+    rows, cols = 300, 520
+    b1 = scene(rows, cols, 0)
+    rc, ref = oracle.pipeline(b1.astype(np.float32), 0, int(strategy))
+    assert rc == 0
+    tam = oracle.tamed_synrgb_u8(b1.astype(np.float32), True)
+    with S.Context(0, timing=True) as c:
+        for no_chain in ("0", "1"):
+            monkeypatch.setenv("SARPRO_HIP_NO_CHAIN", no_chain)
+            u8, _, st = c.process_scalar_data_pipeline(b1, Bd.U8, strategy, want_stats=True)
+            assert np.array_equal(u8, ref), (strategy, no_chain)
+            names = [n for n, _ in c.last_kernel_times()]
+            assert ("chain_stats" in names) == (no_chain == "0")
+            assert np.array_equal(c.autoscale_db_image_tamed_synrgb_u8(b1, True), tam)
