@@ -187,11 +187,17 @@ int sarpro_hip_process_band_resized_f32(sarpro_hip_ctx *ctx, const float *in, si
  * decoded into host memory: one worker thread + context per listed device (a device may be listed
  * more than once), scenes dealt dynamically, no collective.  continue_on_error = 0 stops handing out
  * scenes after the first failure (the rest count as skipped) and returns that failure's status. */
+/* row-chunk callbacks of the streaming entry points (described with sarpro_hip_dualpol_synrgb_stream_u16 below) */
+typedef int (*sarpro_hip_row_reader)(void *user, int band, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch);
+typedef int (*sarpro_hip_row_sink)(void *user, size_t row0, size_t nrows, const uint8_t *src, size_t src_pitch_bytes);
 typedef struct {
-    const uint16_t *band1, *band2; /* rows x cols each */
+    const uint16_t *band1, *band2; /* rows x cols each; ignored when `reader` is set */
     size_t rows, cols;
     uint8_t *rgb_out;              /* final_rows * final_cols * 3 (sarpro_hip_resize_output_dims) */
     int *status_out;               /* optional per-scene status */
+    sarpro_hip_row_reader reader;  /* optional: the scene's bands come through this row reader (a batch of SAFE scenes
+                                      does not fit host memory as arrays: api/mod.rs:484-533 opens them one by one) */
+    void *reader_user;
 } sarpro_hip_batch_scene;
 typedef struct { size_t processed, skipped, errors; } sarpro_hip_batch_report;
 int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, const sarpro_hip_batch_scene *scenes,
@@ -256,8 +262,6 @@ void sarpro_hip_stripe_end(sarpro_hip_stripe *s);
  * compute stream; the RGB leaves chunk by chunk the same way.  Replaces the read loop + processing + write of
  * save_processed_multiband_image_sequential's JPEG branch at native resolution (save.rs:317-367, io/gdal.rs:107-141).
  * chunk_rows = 0 picks ~32 MiB chunks. */
-typedef int (*sarpro_hip_row_reader)(void *user, int band, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch);
-typedef int (*sarpro_hip_row_sink)(void *user, size_t row0, size_t nrows, const uint8_t *src, size_t src_pitch_bytes);
 int sarpro_hip_dualpol_synrgb_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *reader_user, size_t rows,
                                          size_t cols, int strategy, int mode, size_t chunk_rows, sarpro_hip_row_sink sink,
                                          void *sink_user, sarpro_hip_stats *stats_out);

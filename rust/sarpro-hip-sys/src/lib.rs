@@ -44,12 +44,18 @@ pub struct sarpro_hip_resize_meta {
 }
 
 /// One scene of a batch (`process_directory_to_path`, api/mod.rs:474-536).
+pub type sarpro_hip_row_reader = Option<unsafe extern "C" fn(user: *mut c_void, band: c_int, row0: usize, nrows: usize, dst: *mut u16, dst_pitch: usize) -> c_int>;
+pub type sarpro_hip_row_sink = Option<unsafe extern "C" fn(user: *mut c_void, row0: usize, nrows: usize, src: *const u8, src_pitch_bytes: usize) -> c_int>;
+
 #[repr(C)]
 pub struct sarpro_hip_batch_scene {
     pub band1: *const u16, pub band2: *const u16,
     pub rows: usize, pub cols: usize,
     pub rgb_out: *mut u8,
     pub status_out: *mut c_int,
+    /// optional: the scene's bands come through this row reader (band1 / band2 are then ignored)
+    pub reader: sarpro_hip_row_reader,
+    pub reader_user: *mut c_void,
 }
 
 /// `BatchReport` (api/mod.rs:453-458).
@@ -59,9 +65,6 @@ pub struct sarpro_hip_batch_report { pub processed: usize, pub skipped: usize, p
 
 pub const SARPRO_HIP_OK: c_int = 0;
 pub const SARPRO_HIP_ERR_UNSUPPORTED_SHAPE: c_int = -3;
-
-pub type sarpro_hip_row_reader = Option<unsafe extern "C" fn(user: *mut c_void, band: c_int, row0: usize, nrows: usize, dst: *mut u16, dst_pitch: usize) -> c_int>;
-pub type sarpro_hip_row_sink = Option<unsafe extern "C" fn(user: *mut c_void, row0: usize, nrows: usize, src: *const u8, src_pitch_bytes: usize) -> c_int>;
 
 extern "C" {
     pub fn sarpro_hip_ctx_create(device: c_int, flags: c_uint, ctx_out: *mut *mut sarpro_hip_ctx) -> c_int;

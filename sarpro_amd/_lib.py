@@ -47,7 +47,7 @@ ROW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, 
 
 class BatchScene(C.Structure):
     _fields_ = [("band1", C.c_void_p), ("band2", C.c_void_p), ("rows", C.c_size_t), ("cols", C.c_size_t),
-                ("rgb_out", C.c_void_p), ("status_out", C.POINTER(C.c_int))]
+                ("rgb_out", C.c_void_p), ("status_out", C.POINTER(C.c_int)), ("reader", C.c_void_p), ("reader_user", C.c_void_p)]
 
 
 class BatchReport(C.Structure):  # api/mod.rs:453-458

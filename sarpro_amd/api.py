@@ -515,13 +515,25 @@ def resize_output_dims(cols: int, rows: int, target_size: int | None, pad: bool)
 
 def batch_dualpol_synrgb_resized(devices, scenes, strategy, target_size, pad, mode=SyntheticRgbMode.Default,
                                  continue_on_error: bool = True):
-    """process_directory_to_path semantics (api/mod.rs:474-536) for in-memory scenes.
-    scenes: list of (band1_u16, band2_u16).  Returns (list of RGB arrays or None, BatchReport, statuses)."""
+    """process_directory_to_path semantics (api/mod.rs:474-536).
+    scenes: list of (band1_u16, band2_u16) arrays, or of (reader, rows, cols) with reader a (fn_ptr, user_ptr) pair such as
+    TiffPair.reader() -- the scene is then streamed from its files by the worker that picks it up.
+    Returns (list of RGB arrays or None, BatchReport, statuses, rc)."""
     from ._lib import BatchReport, BatchScene
     n = len(scenes)
     arr = (BatchScene * max(n, 1))()
     keep, outs, stats = [], [], (C.c_int * max(n, 1))()
-    for i, (b1, b2) in enumerate(scenes):
+    for i, sc in enumerate(scenes):
+        if len(sc) == 3:  # (reader, rows, cols)
+            (rf, ru), rows, cols = sc
+            fc, fr = resize_output_dims(cols, rows, target_size, pad)
+            rgb = np.empty((fr, fc, 3), np.uint8)
+            keep.append(sc)
+            outs.append(rgb)
+            arr[i] = BatchScene(None, None, rows, cols, rgb.ctypes.data,
+                                C.cast(C.byref(stats, i * C.sizeof(C.c_int)), C.POINTER(C.c_int)), rf, ru)
+            continue
+        b1, b2 = sc
         b1 = np.ascontiguousarray(b1, np.uint16)
         b2 = np.ascontiguousarray(b2, np.uint16)
         rows, cols = b1.shape
@@ -530,7 +542,7 @@ def batch_dualpol_synrgb_resized(devices, scenes, strategy, target_size, pad, mo
         keep.append((b1, b2))
         outs.append(rgb)
         arr[i] = BatchScene(b1.ctypes.data, b2.ctypes.data if b2.shape == b1.shape else None, rows, cols, rgb.ctypes.data,
-                            C.cast(C.byref(stats, i * C.sizeof(C.c_int)), C.POINTER(C.c_int)))
+                            C.cast(C.byref(stats, i * C.sizeof(C.c_int)), C.POINTER(C.c_int)), None, None)
     dev = (C.c_int * len(devices))(*devices)
     rep = BatchReport()
     rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_u16(dev, len(devices), arr, n, int(strategy), int(mode), target_size or 0,

@@ -95,7 +95,8 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, i
             const size_t i = next.fetch_add(1);
             if (i >= nscenes) break;
             const sarpro_hip_batch_scene &sc = scenes[i];
-            rc = sarpro_hip_dualpol_synrgb_resized_u16(ctx, sc.band1, sc.band2, sc.rows, sc.cols, strategy, mode, target_size, pad,
+            if (sc.reader) rc = sarpro_hip_dualpol_synrgb_resized_stream_u16(ctx, sc.reader, sc.reader_user, sc.rows, sc.cols, strategy, mode, target_size, pad, sc.rgb_out, nullptr);
+            else rc = sarpro_hip_dualpol_synrgb_resized_u16(ctx, sc.band1, sc.band2, sc.rows, sc.cols, strategy, mode, target_size, pad,
                                                        sc.rgb_out, nullptr);
             status[i] = rc;
             if (rc == SARPRO_HIP_OK) {

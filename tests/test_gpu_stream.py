@@ -113,3 +113,28 @@ def test_resized_product_from_a_row_reader_equals_the_host_pointer_entry(ctx, st
     got, meta = ctx.dualpol_synrgb_resized_stream(reader, rows, cols, strategy, target, pad)
     assert np.array_equal(got, want)
     assert (meta["final_cols"], meta["final_rows"], meta["pad_left"], meta["pad_top"]) == (m.final_cols, m.final_rows, m.pad_left, m.pad_top)
+
+
+def test_batch_of_scenes_streamed_from_tiff_files(tmp_path):
+    """Config 5's shape: a batch whose scenes are opened from files by the worker that picks them up (C reader
+    callbacks, no arrays in host memory) equals the in-memory batch; a missing band file is a per-scene error."""
+    shapes = [(300, 420), (257, 333), (410, 512)]
+    scenes_mem, scenes_file, keep = [], [], []
+    for i, (rows, cols) in enumerate(shapes):
+        b = [synth.scene_u16(rows, cols, k, seed=synth.SEED_SCENE_A + i) for k in (0, 1)]
+        scenes_mem.append((b[0], b[1]))
+        readers = []
+        for k in (0, 1):
+            p = str(tmp_path / f"s{i}_b{k}.tif")
+            w = S.TiffWriter(p, cols, rows, 1, 16)
+            w.write_rows(0, b[k])
+            w.finish()
+            readers.append(S.TiffReader(p))
+        pair = S.TiffPair(*readers)
+        keep.append(pair)
+        scenes_file.append((pair.reader(), rows, cols))
+    want, rep_m, st_m, rc_m = S.batch_dualpol_synrgb_resized([0], scenes_mem, St.Robust, 128, True)
+    got, rep_f, st_f, rc_f = S.batch_dualpol_synrgb_resized([0], scenes_file, St.Robust, 128, True)
+    assert rc_m == 0 and rc_f == 0 and rep_f.processed == 3 and rep_f.errors == 0
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
