@@ -179,6 +179,12 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
     __shared__ uint32_t hist[256];
     if (!OUT16) { thr[threadIdx.x] = threadIdx.x ? a.thr[threadIdx.x] : -INFINITY; hist[threadIdx.x] = 0; }
     if (threadIdx.x == 0) thr[256] = INFINITY;
+    __shared__ double logc[256], invc[256]; // table of db_of_f32_fast (u16 levels)
+    if (OUT16) {
+        const double c = 1.0 + ((double)threadIdx.x + 0.5) / 256.0;
+        logc[threadIdx.x] = log2(c);
+        invc[threadIdx.x] = 1.0 / c;
+    }
     __syncthreads();
     const uint32_t vpr = (a.cols + VEC - 1) / VEC;
     const uint64_t total = (uint64_t)a.rows * vpr;
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
                     if (x >= a.t_last) lv = 65535u;
                     else if (x < a.t_first) lv = 0u;
                     else {
-                        const double db = 10.0 * log10((double)x);
+                        const double db = db_of_f32_fast(x, logc, invc); // within ~1e-14 of glibc's value: far inside the 1e-6 margin below
                         const double t = (fmin(fmax(db, a.low), a.high) - a.low) / a.range;
                         const double y = fmin(fmax((a.gamma == 1.0 ? t : pow(t, a.gamma)) * a.max_val, 0.0), a.max_val);
                         const double r = rint(y);
