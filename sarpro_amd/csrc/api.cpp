@@ -923,7 +923,8 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
 static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, const uint8_t *d_rgb,
                                   size_t rgb_pitch_px) {
     if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
-    if (J.clahe() || !J.u8_out() || !J.vec || !(J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total))) return false;
+    if (J.clahe() || !J.vec || !(J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total))) return false;
+    if (!J.u8_out() && J.synrgb) return false; // u16 levels: per-band rasters only
     if (J.synrgb && !(J.nbands == 2 && J.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb))) return false;
     bool any_out = false;
     for (int b = 0; b < J.nbands; ++b)
@@ -931,10 +932,13 @@ static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands],
     return J.synrgb || any_out;
 }
 
+constexpr int kRerunOnHostRoute = 1; // u16 levels with gamma != 1 that the device could not certify (see k_chain_stats_c)
+
 static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
                                 sarpro_hip_stats *stats_out) {
     sarpro_hip_ctx *ctx = J.ctx;
     const int nb = J.nbands;
+    const bool u16o = !J.u8_out();
     RETCHK(chain_prepare(ctx));
     HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
     HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
@@ -953,7 +957,8 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
         sa.state = d_state;
         sa.binlut = ctx->luts.as<uint8_t>();
         sa.binlut_stride = 131072;
-        sa.levels_mode = 1;
+        sa.levels_mode = u16o ? 2 : 1;
+        sa.lut16 = ctx->luts.as<uint16_t>();
         sa.strategy = J.strategy;
         for (int b = 0; b < nb; ++b) sa.tamed_kind[b] = J.tamed_kind(b);
         sa.total_px = (unsigned long long)J.rows_total * J.cols;
@@ -963,7 +968,7 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
         RETCHK(chain_stats_scratch(ctx, &sa));
         HIPCHK(ctx, launch_chain_stats(sa, nb, ctx->stream));
     }
-    {
+    if (!u16o) { // u16 levels have no rescale (autoscale.rs:689-703) and are never composed
         ChainFinishArgs fa{};
         fa.level_hist = ctx->level_hist.as<unsigned long long>();
         fa.total_px = (unsigned long long)J.rows_total * J.cols;
@@ -989,10 +994,10 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
         LutApplyArgs la{};
         la.in = J.d_in[b]; la.out = d_out[b]; la.in_pitch = J.in_pitch; la.out_pitch = out_pitch;
         la.rows = (uint32_t)J.rows_local; la.cols = (uint32_t)J.cols;
-        la.lut = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+        la.lut = ctx->luts.as<uint8_t>() + (size_t)b * 131072; // u8 final values, or u16 levels (65536 x 2 bytes) at the same offset
         la.dev_state = d_state; la.band = b; la.lut_cap = ctx->chain_levels_cap;
         KernelTimer t(ctx, "lut_apply_u16");
-        HIPCHK(ctx, launch_lut_apply_u16(la, true, false, ctx->stream));
+        HIPCHK(ctx, launch_lut_apply_u16(la, true, u16o, ctx->stream));
     }
     if (J.synrgb) {
         LutComposeArgs f{};
@@ -1009,11 +1014,15 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
     HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
     uint32_t hi = 0;
+    bool uncertain = false;
     for (int b = 0; b < nb; ++b) {
         J.stats[b] = h_state[b].stats;
         if (stats_out) stats_out[b] = J.stats[b];
         hi = std::max(hi, h_state[b].win_hi);
+        uncertain = uncertain || (u16o && h_state[b].uncertain);
     }
+    if (u16o && getenv("SARPRO_HIP_FORCE_UNCERTAIN")) uncertain = true; // test hook: exercise the rerun
+    if (uncertain) return kRerunOnHostRoute;
     // LDS capacity (bytes per band) of the NEXT scene's DN tables (speed only)
     ctx->chain_levels_cap = std::min<uint32_t>(16384, std::max<uint32_t>(2048, (hi + 1 + 1023) / 1024 * 1024));
     return SARPRO_HIP_OK;
@@ -1033,7 +1042,8 @@ static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch
     }
     if (chain_levels_eligible(J, d_out, out_pitch, d_rgb, rgb_pitch_px)) {
         HostTimer t(J.ctx, "host:chain(enqueue+final sync)");
-        return job_run_chain_levels(J, d_out, out_pitch, d_rgb, rgb_pitch_px, stats_out);
+        const int rc = job_run_chain_levels(J, d_out, out_pitch, d_rgb, rgb_pitch_px, stats_out);
+        if (rc != kRerunOnHostRoute) return rc;
     }
     { HostTimer t(J.ctx, "host:phase1_launch"); RETCHK(job_phase1(J)); }
     // (row-stripe mode without the device chain: the same phases with a synchronous all-reduce after each)

@@ -6,8 +6,8 @@ namespace sarpro {
 
 struct ChainBandState { // lives in device memory, one per band
     sarpro_hip_stats stats;
-    uint32_t win_hi; // first DN whose dB value reached the high clip (the bin table is constant above)
-    uint32_t pad;
+    uint32_t win_hi;    // first DN whose dB value reached the high clip (the bin table is constant above)
+    uint32_t uncertain; // u16 levels with gamma != 1: some DN's level could not be certified (rerun on the host route)
 };
 
 struct ChainStatsPartial { // one per (band, 4096-DN slice): kernel A of the statistics step
@@ -24,7 +24,8 @@ struct ChainStatsArgs {
     uint8_t *binlut;                 // per band, binlut_stride bytes apart: CLAHE bin or u8 level of every DN
     size_t binlut_stride;
     // percentile strategies (levels mode): window by strategy, u8 level of every DN, level histogram
-    int levels_mode;                 // 0: CLAHE bins (window p01..p99); 1: u8 levels of `strategy`
+    int levels_mode;                 // 0: CLAHE bins (window p01..p99); 1: u8 levels of `strategy`; 2: u16 levels of `strategy`
+    uint16_t *lut16;                 // levels_mode 2: [nbands][65536] u16 level of every DN
     int strategy;
     int tamed_kind[kMaxBands];       // 0 / 1 copol / 2 crosspol (autoscale.rs:721-727)
     unsigned long long total_px;     // pixels per band (level 0 also counts the invalid ones)

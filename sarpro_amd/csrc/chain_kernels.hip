@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_a(ChainStatsArgs a) 
     if (part == 0) { // scratch of the next two kernels
         for (int i = t; i < kStatBins; i += kPartBlock) a.bins4096[(size_t)band * kStatBins + i] = 0ull;
         if (a.level_hist) a.level_hist[(size_t)band * 256 + t] = 0ull; // levels mode: filled by kernel C; CLAHE: by the apply kernel
-        if (t == 0) a.state[band].win_hi = 65535u;
+        if (t == 0) { a.state[band].win_hi = 65535u; a.state[band].uncertain = 0u; }
     }
     unsigned long long cnt = 0;
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_c(ChainStatsArgs a) 
     if (count == 0) { // no valid pixel: every DN is invalid, the table is irrelevant (autoscale.rs:466-468)
         for (uint32_t dn = (uint32_t)part * kPartDns + t; dn < (uint32_t)(part + 1) * kPartDns; dn += kPartBlock) binlut[dn] = 0;
         if (part == 0) {
-            if (a.levels_mode && t == 0) a.level_hist[(size_t)band * 256] = a.total_px; // the other bins were cleared by kernel A
+            if (a.levels_mode == 1 && t == 0) a.level_hist[(size_t)band * 256] = a.total_px; // the other bins were cleared by kernel A
+            if (a.levels_mode == 2) for (uint32_t dn = (uint32_t)part * kPartDns + t; dn < (uint32_t)(part + 1) * kPartDns; dn += kPartBlock) a.lut16[(size_t)band * 65536 + dn] = 0;
             if (t == 0) { out->stats = st; out->win_hi = 1; }
         }
         return;
@@ -310,6 +311,44 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_c(ChainStatsArgs a) 
         default: low = st.p05; high = st.p95; break; // Default (Standard never reaches the advanced arm)
         }
         st.low_clip = low; st.high_clip = high; st.gamma = gamma;
+    }
+    if (a.levels_mode == 2) {
+        // ---- u16 level of every DN of the slice (autoscale.rs:440-442 / 649-651 at max_val 65535; no rescale follows).
+        //      gamma = 1: the same f64 operations as the host, exact.  gamma != 1: the device pow is a few ulp from
+        //      glibc's (~1e-11 levels); a DN whose value comes within 1e-7 of a level boundary marks the band
+        //      `uncertain` and the caller reruns it on the host-orchestrated route (odds ~1e-4 per band). ----
+        const double low = st.low_clip, high = st.high_clip, gamma = st.gamma;
+        const double range = fmax(high - low, 1.0);
+        uint16_t *lut16 = a.lut16 + (size_t)band * 65536;
+        uint32_t first_hi = 65535u, uncertain = 0u;
+        constexpr int kPer = kPartDns / kPartBlock;
+        double dv[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) dv[k] = db[dn0 + k * kPartBlock + t];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t dn = dn0 + k * kPartBlock + t;
+            uint32_t level = 0;
+            if (dn) {
+                const double d = dv[k];
+                const double clipped = fmin(fmax(d, low), high);
+                const double x = (clipped - low) / range;
+                const double y = clampd((gamma == 1.0 ? x : pow(x, gamma)) * 65535.0, 0.0, 65535.0);
+                level = (y == y) ? (uint32_t)y : 0u;
+                // (x = 0 and x = 1 are exact in every libm: pow(0, g) = 0, pow(1, g) = 1)
+                if (gamma != 1.0 && x > 0.0 && x < 1.0 && fabs(y - rint(y)) < 1e-7 && rint(y) >= 1.0) uncertain = 1u;
+                if (d >= high) first_hi = min(first_hi, dn);
+            }
+            lut16[dn] = (uint16_t)level;
+        }
+        const uint32_t wh = part_reduce(first_hi, scr_u32, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+        const uint32_t unc = part_reduce(uncertain, scr_u32, [](uint32_t x, uint32_t y) { return x | y; });
+        if (t == 0) {
+            if (wh != 65535u) atomicMin(&out->win_hi, wh);
+            if (unc) atomicOr(&out->uncertain, 1u);
+            if (part == 0) out->stats = st;
+        }
+        return;
     }
     // ---- u8 level of every DN of the slice (autoscale.rs:440-442 / 649-651 / 734-736) + the level histogram.
     //      gamma != 1: trunc(pow(x, g) * 255) is resolved against host-built thresholds of x (glibc pow),

@@ -247,3 +247,17 @@ def test_single_band_percentile_chain_equals_host_orchestrated_path(strategy, mo
             names = [n for n, _ in c.last_kernel_times()]
             assert ("chain_stats" in names) == (no_chain == "0")
             assert np.array_equal(c.autoscale_db_image_tamed_synrgb_u8(b1, True), tam)
+            # u16 output: the chain builds the 65535-level table of every DN on the device (gamma != 1 through the device
+            # pow with a certification margin; SARPRO_HIP_FORCE_UNCERTAIN exercises the rerun on the host route)
+            rc16, ref16 = oracle.pipeline(b1.astype(np.float32), 1, int(strategy))
+            for force in (False, True):
+                if force:
+                    monkeypatch.setenv("SARPRO_HIP_FORCE_UNCERTAIN", "1")
+                else:
+                    monkeypatch.delenv("SARPRO_HIP_FORCE_UNCERTAIN", raising=False)
+                _, u16, _ = c.process_scalar_data_pipeline(b1, Bd.U16, strategy, want_stats=True)
+                assert rc16 == 0 and np.array_equal(u16, ref16), (strategy, no_chain, force)
+                names = [n for n, _ in c.last_kernel_times()]
+                assert ("chain_stats" in names) == (no_chain == "0")
+                assert ("host:phase1_launch" in names) == (no_chain == "1" or force)
+            monkeypatch.delenv("SARPRO_HIP_FORCE_UNCERTAIN", raising=False)

@@ -1,3 +1,4 @@
+"""Single-band timings (400 MP u16 band resident in HBM): u8 and u16 output of a few strategies."""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch, numpy as np
@@ -14,4 +15,11 @@ for st in (St.Robust, St.Standard, St.Clahe):
         torch.cuda.synchronize(); t=time.perf_counter()
         ctx.dev_autoscale_band_u16(band.data_ptr(), rows, cols, pitch, st, Bd.U8, out.data_ptr(), pitch)
         dt=(time.perf_counter()-t)*1e3
-    print(st.name, round(dt,3), {k: round(v,3) for k,v in ctx.last_kernel_times()})
+    print(st.name, "u8", round(dt,3), {k: round(v,3) for k,v in ctx.last_kernel_times()})
+out16=torch.empty((rows,pitch),dtype=torch.int16,device="cuda")
+for st in (St.Robust, St.Standard):
+    for i in range(4):
+        torch.cuda.synchronize(); t=time.perf_counter()
+        ctx.dev_autoscale_band_u16(band.data_ptr(), rows, cols, pitch, st, Bd.U16, out16.data_ptr(), pitch)
+        dt=(time.perf_counter()-t)*1e3
+    print(st.name, "u16", round(dt,3), {k: round(v,3) for k,v in ctx.last_kernel_times()})
