@@ -136,11 +136,13 @@ def main():
         roofline = None
         if dom:
             local_px = rows_local * cols
-            bytes_launch = alg_bpp.get(dom, 0.0) * local_px
+            # alg_bpp covers both bands; a kernel launched once per band (the staggered two-stream chain) moves half per launch
+            bytes_launch = alg_bpp.get(dom, 0.0) * local_px / max(launches[dom], 1.0)
             achieved = bytes_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic_gb(dom, rows_local * cols),
+                        "traffic": pmc_traffic_gb(dom, rows_local * cols / max(launches[dom], 1.0)),
+                        "launches_per_step": launches[dom],
                         "ms_per_launch": round(per_launch[dom], 4),
                         "kernels_ms_per_step": {k: round(total_ms[k], 4) for k in sorted(total_ms)}}
         out = {
