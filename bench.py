@@ -200,7 +200,8 @@ def cpu_baseline(ctx, q, side, strategy, torch, dev):
     dt = time.perf_counter() - t0
     assert rc == 0
     out = {"value": round(side * side / dt / 1e6, 2), "unit": "Mpix/s", "cores": 1, "kind": "port",
-           "sample": f"{side}x{side} dual-pol scene (same generator), whole path, {dt:.1f} s on 1 of {os.cpu_count()} host threads"}
+           "sample": f"{side}x{side} dual-pol scene (same generator), whole path, {dt:.1f} s on 1 of {os.cpu_count()} host threads",
+           "context": "the reference's README quotes ~40 s per 400 MP dual-band native synRGB scene incl. I/O on an M4 Pro (README.md:63); not measured here"}
     # Not the reference's behaviour (its hot path has no threads), reported next to it as SURVEY 8d asks: what the
     # host's cores give on a BATCH -- N independent single-thread runs of the same oracle (ctypes releases the GIL).
     try:
