@@ -540,6 +540,8 @@ static int job_phase3(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch)
         const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out[0]) && (J.nbands < 2 || ptr_aligned16(a.out[1]));
         if (vec != J.vec) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
         if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands)) {
+            HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
+            a.dump = ctx->spec_dump.as<uint8_t>();
             KernelTimer t(ctx, "clahe_apply_u8_spec");
             HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
         } else {
@@ -850,6 +852,8 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     // whole scene on this device: levels >= 64 are only counted in bulk (chain_kernels.hip k_level_hist_guard); a row
     // stripe keeps the full histogram, which is what the ranks sum
     a.partial_hist = (!J.reduce && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;
+    HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
+    a.dump = ctx->spec_dump.as<uint8_t>();
     {
         KernelTimer t(ctx, "clahe_apply_u8_spec");
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));

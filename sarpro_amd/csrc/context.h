@@ -76,6 +76,7 @@ struct sarpro_hip_ctx {
     sarpro::DevBuf cdfs;                         // f64 [2][64][256]
     sarpro::DevBuf luts;                         // 2 x 128 KiB: per-band DN table (u8 or u16 entries)
     sarpro::DevBuf level_hist;                   // u64 [2][256]
+    sarpro::DevBuf spec_dump;                    // kSpecDumpBytes: write-only scratch of the speculative apply kernel
     sarpro::DevBuf hist_flags;                   // u32 [2]: band whose partial level histogram had to be recounted
     sarpro::DevBuf tables;                       // compose tables 66048 B
     sarpro::DevBuf levels[sarpro::kMaxBands];    // u8 level rasters (intermediate)

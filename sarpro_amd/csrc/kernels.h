@@ -49,6 +49,7 @@ struct ClaheApplyArgs {
     const struct ChainBandState *dev_state;  // chain mode: win_hi is read from device memory (null: use win_hi[])
     uint32_t lut_cap;                       // speculative kernel: LDS capacity of the offset table (entries)
     uint32_t partial_hist;                  // speculative kernel: levels >= 64 are only counted in bulk (see k_level_hist_guard)
+    uint8_t *dump;                          // speculative kernel: kSpecDumpBytes of scratch that edge lanes' full-width stores go to
 };
 
 struct LutApplyArgs {
@@ -72,6 +73,7 @@ struct ComposeArgs {
     const uint8_t *tables;         // R2[256] | G2[256] | B2[65536]
 };
 
+constexpr size_t kSpecDumpBytes = 256 * 1024;
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);
 hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nbands, hipStream_t s);
 // untiled histogram (tile_hist[b] = one 65536-bin histogram per band) of a rows x cols raster whose pitch is a multiple of 8

@@ -431,13 +431,14 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     pixels (~0.1 % in interior cells) are recomputed with the reference's exact f64 sequence (CDFs and column
 //     weights as f64 in LDS), so the raster is bit-identical to kernel 4's.
 //     Error bound of the f32 value y32 against the reference's y = o*255 (u = 2^-24):
-//       inputs are the f64 CDFs / weights rounded once to f32 (1+e, |e| <= u); with
-//       S = |c00 (1-dx)| + |c01 dx| <= 2 (dx in [-0.5, 1): the first half tile extrapolates),
-//       top32 = fma(c01, dx, c00*(1-dx)) carries <= 3u per product + u for the sum:  |dtop| <= 4uS <= 8u,
+//       inputs are the f64 CDFs / weights rounded once to f32 (1+e, |e| <= u); with dx in [-0.5, 1) (the first
+//       half tile extrapolates), top32 = fma(c01 - c00, dx, c00) carries the input roundings
+//       u (|c00| |1-dx| + |c01| |dx|) <= 2u, u |c01 - c00| |dx| each for the subtraction and for dx, and u |top| <= 2u
+//       for the fma:  |dtop| <= 6u <= 8u,
 //       the same for bottom, and |top|, |bottom| <= 2;  the row weights hold the 255 factor
 //       (2 roundings), p = (top, bottom) * wy adds one more, the final add one more:
 //       |y32 - y| <= 255 (|1-dy| + |dy|) (8u + 3u*2) + u |y|  <=  255*2*14u + 1020u  =  4.9e-4.
-//     In interior cells (every weight in [0,1], S <= 1, weight pairs sum to 1) the same steps give
+//     In interior cells (every weight in [0,1], weight pairs sum to 1, |top| <= 1) the same four terms are <= u each:
 //       |dtop| <= 4u, |y32 - y| <= 255 (4u + 3u) + 255u = 255*8u = 1.2e-4.
 //     The margin is therefore chosen per work item: kSpecDeltaEdge = 1/512 = 1.95e-3 where the cell
 //     extrapolates (first half tile row / column), kSpecDeltaInner = 1/2048 = 4.9e-4 elsewhere --
@@ -461,7 +462,10 @@ constexpr uint32_t kSpecLutMaxEntries = 16384; // u16 offsets: 32 KiB of LDS at 
 // Measured on MI355X (400 MP scene): R = 2 costs 4 KiB of LDS per workgroup, which drops residency from
 // 6 to 5 workgroups per CU, and the kernel gets SLOWER (0.78 -> 0.82 ms): it is more sensitive to resident
 // waves than to gather conflicts.  Kept as a tunable; 1 = a single copy.
-constexpr uint32_t kCdfCopies = 1;
+#ifndef SARPRO_CDF_COPIES
+#define SARPRO_CDF_COPIES 1
+#endif
+constexpr uint32_t kCdfCopies = SARPRO_CDF_COPIES;
 constexpr uint32_t kCdfPerRow = 16 / kCdfCopies;                         // entries per 256-B row
 constexpr uint32_t kCdf32Bytes = ((257 + kCdfPerRow - 1) / kCdfPerRow) * 256;
 __host__ __device__ constexpr uint32_t cdf32_offset(uint32_t entry) {    // byte offset of copy 0 of `entry`
@@ -476,9 +480,9 @@ struct SpecLds { // byte offsets into dynamic LDS
     static constexpr uint32_t cdf32 = 257 * 32 + 224;         // kCdfCopies interleaved copies of [257] float4 (256-B aligned)
     static constexpr uint32_t colw = cdf32 + kCdf32Bytes;     // [512] double: exact dx of the strip's columns
     static constexpr uint32_t hist = colw + 512 * 8;          // [256 + 64] u32
-    static constexpr uint32_t roww = hist + (256 + 64) * 4;   // [256] double: exact dy of the item's rows
-    static constexpr uint32_t lut = roww + 256 * 8;           // [lut_cap] u16
+    static constexpr uint32_t lut = hist + (256 + 64) * 4;    // [lut_cap] u16
 };
+// The row weights stay in global memory: one wave-uniform load per row, prefetched with the row.
 // (1 - dx) and (1 - dy) are recomputed as 1.0 - d: the reference's own expression (autoscale.rs:327-329)
 
 // The dynamic LDS block of this kernel starts at LDS address 0 (it holds no static __shared__), so a byte offset
@@ -486,33 +490,48 @@ struct SpecLds { // byte offsets into dynamic LDS
 // address to every computed LDS address, one VALU instruction per access.
 #define LDS_AT(T, off) (*reinterpret_cast<__attribute__((address_space(3))) T *>((uint32_t)(off)))
 
+// wave-uniform values moved to SGPRs (the row weights: they would otherwise hold VGPRs across the whole row)
+__device__ __forceinline__ float to_sgpr(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double to_sgpr(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 template <bool LUT_LDS, bool PARTIAL_HIST>
 __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const Rect &rc, int band, unsigned char *lds,
                                                 uint32_t win_hi) {
     constexpr int VEC = 8;
     const uint16_t *__restrict__ in = a.in[band];
     const uint8_t *__restrict__ glut = a.binlut[band];
+    const RowWeight *__restrict__ row_w = a.row_w + a.row_off;
     const bool count_levels = a.level_hist[band] != nullptr;
     const int col = rc.cstart + lane_id() * VEC;
     const bool full = col >= rc.c0 && col + VEC <= rc.c1;
-    const EdgeMask em(col, rc.c0, rc.c1); // edge lanes: out-of-range samples become DN = 0 (level 0, uncounted, unstored)
-
-    float dxf[VEC], omdxf[VEC];
+    // edge lanes: samples outside the item are computed like the others (whatever DN the row holds there), then their
+    // level bytes are masked to 0 -- uncounted -- and never stored; masking the 8 levels costs 2 operations per row,
+    // masking the 8 input samples cost 8
+    uint32_t keep[2] = {0u, 0u};
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const double d = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
-        dxf[j] = (float)d;
-        omdxf[j] = (float)(1.0 - d);
-    }
+    for (int j = 0; j < VEC; ++j)
+        if (col + j >= rc.c0 && col + j < rc.c1) keep[j >> 2] |= 0xFFu << (8 * (j & 3));
+    uint8_t *dump = a.dump + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave_id()) % (kSpecDumpBytes / 512)) * 512 +
+                    lane_id() * 8; // one 512-B line per wave, shared round-robin
+
+    float dxf[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dxf[j] = (float)*reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
     const uint32_t copy_off = ((uint32_t)lane_id() & (kCdfCopies - 1)) * 16u; // this lane's copy of the f32 CDF table
     const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner; // pad[0] bit 0: extrapolating cell
     const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
     uint32_t lane_max = 0u, lane_high = 0u; // PARTIAL_HIST: this lane's highest level and its count of levels >= kPartialHistLevels
 
-    auto process_row = [&](int r, const U16Vec<VEC> &v) {
-        const double dy = *reinterpret_cast<const double *>(lds + SpecLds::roww + (r - rc.r0) * 8); // wave-uniform
-        const double omdy = 1.0 - dy;
-        const float wy1 = (float)omdy * 255.0f, wy2 = (float)dy * 255.0f;
+    auto process_row = [&](int r, const U16Vec<VEC> &v, const double dy_v) { // dy: wave-uniform
+        const double dy = to_sgpr(dy_v), omdy = to_sgpr(1.0 - dy);
+        const float wy1 = to_sgpr((float)omdy * 255.0f), wy2 = to_sgpr((float)dy * 255.0f);
         uint32_t off[VEC];
         uint32_t pk[2] = {0u, 0u}, pb[2] = {0u, 0u}; // the 8 levels, packed as they will be stored
 #pragma unroll
@@ -524,8 +543,8 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const v4f c4 = LDS_AT(v4f, off[j] + copy_off); // (c00, c10, c01, c11)
-            const float top = fmaf(c4.z, dxf[j], c4.x * omdxf[j]);
-            const float bottom = fmaf(c4.w, dxf[j], c4.y * omdxf[j]);
+            const float top = fmaf(c4.z - c4.x, dxf[j], c4.x); // c00 + dx (c01 - c00): no (1 - dx) to keep in registers
+            const float bottom = fmaf(c4.w - c4.y, dxf[j], c4.y);
             // ya = y - 0.5 - delta, yb = y - 0.5 + delta: v_cvt_pk_u8_f32 rounds to nearest-even and saturates, so both
             // give the same byte n only if y lies in (n + (delta - err), n + 1 - (delta - err)): then n = floor(y)
             // clamped to 0..255.  Where the bytes differ the pixel goes to the exact path.
@@ -551,6 +570,8 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 }
             }
         }
+        pk[0] &= keep[0];
+        pk[1] &= keep[1];
         if (count_levels) { // level 0 (incl. masked edge samples) is not counted: bin 0 = pixels - others
             // one predicated ds_add_u32 per pixel, EXEC narrowed to the lanes that count (a shared bin 0 would serialise
             // the no-data wedge); written out because the compiler wraps each predicated atomic in a branch
@@ -596,29 +617,43 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
             }
         }
         uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out[band]) + (size_t)r * a.out_pitch + col;
-        if (full) {
-            *reinterpret_cast<uint2 *>(o8) = make_uint2(pk[0], pk[1]);
-        } else {
+        // Every lane issues the 8-byte store, edge lanes into the scratch line: a store inside a divergent branch sits
+        // behind an `execz` skip, the waitcnt pass then sees a path through the row without a store and makes the next
+        // row wait for vmcnt(0) -- i.e. for this row's store to be acknowledged -- before it may use its prefetched data.
+        *reinterpret_cast<uint2 *>(full ? o8 : dump) = make_uint2(pk[0], pk[1]);
+        if (!full) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                if (em.keep(j)) o8[j] = (uint8_t)(pk[j >> 2] >> (8 * (j & 3)));
+                if ((keep[j >> 2] >> (8 * (j & 3))) & 1u) o8[j] = (uint8_t)(pk[j >> 2] >> (8 * (j & 3)));
         }
     };
 
     if (col < rc.c1 && col + VEC > rc.c0) {
         const int step = kWavesPerBlock;
         const uint16_t *p = in + col;
-        int r = rc.r0 + wave_id();
+        int r = __builtin_amdgcn_readfirstlane(rc.r0 + wave_id());
         // the next row is always loaded (clamped to the item's last row: at worst one redundant load), so the
         // load is unconditional and the compiler can wait with vmcnt(1) -- a conditional prefetch made it wait
         // vmcnt(0) right after issuing it, i.e. no overlap at all inside a wave
         if (r < rc.r1) {
             U16Vec<VEC> cur = U16Vec<VEC>::load(p + (size_t)r * a.in_pitch);
-            for (; r < rc.r1; r += step) {
-                const U16Vec<VEC> nxt = U16Vec<VEC>::load(p + (size_t)min(r + step, rc.r1 - 1) * a.in_pitch);
-                em.apply(cur);
-                process_row(r, cur);
+            double dy = row_w[r].d; // exact dy of the row, wave-uniform, prefetched like the row itself
+            { // first row peeled: the loop is then entered with the same operations in flight as on its back edge
+                const int rn = min(r + step, rc.r1 - 1);
+                const U16Vec<VEC> nxt = U16Vec<VEC>::load(p + (size_t)rn * a.in_pitch);
+                const double dyn = row_w[rn].d;
+                process_row(r, cur, dy);
                 cur = nxt;
+                dy = dyn;
+                r += step;
+            }
+            for (; r < rc.r1; r += step) {
+                const int rn = min(r + step, rc.r1 - 1);
+                const U16Vec<VEC> nxt = U16Vec<VEC>::load(p + (size_t)rn * a.in_pitch);
+                const double dyn = row_w[rn].d;
+                process_row(r, cur, dy);
+                cur = nxt;
+                dy = dyn;
             }
         }
     }
@@ -642,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = cdfs[(size_t)rc.id[k] * 256 + b];
         *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + b * 32) = make_double4(c[0], c[1], c[2], c[3]);
-        // f32 copy laid out (c00, c10 | c01, c11): (top, bottom) = (x,y)*(1-dx) + (z,w)*dx are two packed-f32 ops.
+        // f32 copy laid out (c00, c10 | c01, c11): (top, bottom) = (x,y) + dx*((z,w) - (x,y)) are two packed-f32 ops.
         // Saturated bins (all four CDFs exactly 1.0: at least the top bin, i.e. every pixel above p99) blend
         // to y = 255 +- rounding, which the margin test would send to the exact path for ~1 % of all pixels.
         // In an interior cell their exact result is known: with dx in [0,1), fl(fl(1-dx) + dx) = 1.0 exactly
@@ -668,8 +703,6 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
                 *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + cdf32_offset(256) + cc * 16) = make_float4(kz, kz, kz, kz);
         }
         for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
-        for (int i = b; i < rc.r1 - rc.r0; i += kBlock) // exact dy of this item's rows (<= 256 rows per item)
-            *reinterpret_cast<double *>(lds + SpecLds::roww + i * 8) = a.row_w[a.row_off + rc.r0 + i].d;
         for (int i = b; i < 512; i += kBlock) { // exact column weights of this strip, for the f64 path
             const int c2 = rc.cstart + i;
             *reinterpret_cast<double *>(lds + SpecLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
@@ -1107,7 +1140,10 @@ hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, 
         for (int b = 0; b < nbands; ++b) hi = std::max(hi, a.win_hi[b]);
         a.lut_cap = std::min<uint32_t>(hi + 1, kSpecLutMaxEntries);
     }
-    const size_t lds = SpecLds::lut + (((size_t)a.lut_cap) * 2 + 15 & ~(size_t)15);
+#ifndef SARPRO_LDS_PAD
+#define SARPRO_LDS_PAD 0
+#endif
+    const size_t lds = SpecLds::lut + (((size_t)a.lut_cap) * 2 + 15 & ~(size_t)15) + SARPRO_LDS_PAD;
     hipLaunchKernelGGL(k_clahe_apply_u8_spec, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
