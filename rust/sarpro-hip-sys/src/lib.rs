@@ -103,6 +103,7 @@ extern "C" {
         pad: c_int, continue_on_error: c_int, report: *mut sarpro_hip_batch_report) -> c_int;
     // device-pointer, stripe, comm and host-half entry points: see include/sarpro_hip.h
     pub fn sarpro_hip_ctx_stream(ctx: *mut sarpro_hip_ctx) -> *mut c_void;
+    pub fn sarpro_hip_ctx_time_only(ctx: *mut sarpro_hip_ctx, kernel_name: *const c_char) -> c_int;
     /// streaming ingest / egress: the decoder's read loop and the encoder's write loop as callbacks
     pub fn sarpro_hip_dualpol_synrgb_stream_u16(ctx: *mut sarpro_hip_ctx, reader: sarpro_hip_row_reader, reader_user: *mut c_void,
         rows: usize, cols: usize, strategy: c_int, mode: c_int, chunk_rows: usize, sink: sarpro_hip_row_sink,

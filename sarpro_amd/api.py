@@ -45,9 +45,10 @@ def _vp(a):
 class Context:
     """One sarpro_hip_ctx: a device, a stream, a grow-only workspace.  One per host thread."""
 
-    def __init__(self, device: int = 0, timing: bool = False):
+    def __init__(self, device: int = 0, timing: bool = False, async_dev: bool = False):
         h = C.c_void_p()
-        rc = lib.sarpro_hip_ctx_create(device, 1 if timing else 0, C.byref(h))
+        # async_dev: SARPRO_HIP_CTX_ASYNC_DEV -- dev_dualpol_synrgb_u16 returns once enqueued; call synchronize()
+        rc = lib.sarpro_hip_ctx_create(device, (1 if timing else 0) | (2 if async_dev else 0), C.byref(h))
         if rc != _lib.OK:
             raise SarproHipError(rc, (lib.sarpro_hip_last_error(None) or b"").decode())
         self._h = h
@@ -82,10 +83,14 @@ class Context:
         self._chk(lib.sarpro_hip_ctx_synchronize(self._h))
 
     def last_kernel_times(self):
-        names = (C.c_char_p * 64)()
-        ms = (C.c_float * 64)()
-        n = lib.sarpro_hip_last_kernel_times(self._h, names, ms, 64)
+        names = (C.c_char_p * 1024)()
+        ms = (C.c_float * 1024)()
+        n = lib.sarpro_hip_last_kernel_times(self._h, names, ms, 1024)
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
+
+    def time_only(self, kernel_name=None):
+        """Bracket only this kernel with events (None: every kernel); see sarpro_hip_ctx_time_only."""
+        self._chk(lib.sarpro_hip_ctx_time_only(self._h, kernel_name.encode() if kernel_name else None))
 
     # ------------------------------------------------------------------ pipeline.rs:42
     def process_scalar_data_pipeline(self, processed: np.ndarray, bit_depth: BitDepth,
@@ -253,12 +258,14 @@ class Context:
 
     def dev_dualpol_synrgb_u16(self, d_b1: int, d_b2: int, rows: int, cols: int, in_pitch: int, strategy, mode,
                                d_rgb: int, rgb_pitch_px: int, d_u8_1: int | None = None, d_u8_2: int | None = None,
-                               u8_pitch: int = 0):
-        st = (Stats * 2)()
+                               u8_pitch: int = 0, want_stats: bool = True):
+        """want_stats=False passes stats_out = NULL: on a Context(async_dev=True) the call then returns once the
+        device chain is enqueued (synchronize() before reading the rasters)."""
+        st = (Stats * 2)() if want_stats else None
         self._chk(lib.sarpro_hip_dualpol_synrgb_u16_dev(self._h, _vp(d_b1), _vp(d_b2), rows, cols, in_pitch,
                                                         int(strategy), int(mode), _vp(d_rgb), rgb_pitch_px,
                                                         _vp(d_u8_1), _vp(d_u8_2), u8_pitch, st))
-        return [st[0], st[1]]
+        return [st[0], st[1]] if want_stats else None
 
     def dev_polop_f32(self, op, d_a: int, d_b: int, n: int, d_out: int):
         self._chk(lib.sarpro_hip_polop_f32_dev(self._h, int(op), _vp(d_a), _vp(d_b), n, _vp(d_out)))

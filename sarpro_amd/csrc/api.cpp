@@ -44,6 +44,7 @@ static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
 namespace sarpro {
 
 void timing_reset(sarpro_hip_ctx *ctx) {
+    if (ctx->async_pending && ctx->events_used < 4096) return; // calls enqueued without a synchronisation: their events are read (and dropped) together
     ctx->times.clear();
     ctx->host_times.clear();
     ctx->events_used = 0;
@@ -60,6 +61,7 @@ static hipEvent_t next_event(sarpro_hip_ctx *ctx) {
 
 KernelTimer::KernelTimer(sarpro_hip_ctx *c, const char *name) : ctx(c) {
     if (!ctx->timing) return;
+    if (!ctx->time_only.empty() && ctx->time_only != name) return;
     KernelTime t{name, next_event(ctx), next_event(ctx)};
     if (!t.start || !t.stop) return;
     (void)hipEventRecord(t.start, ctx->stream);
@@ -106,7 +108,8 @@ extern "C" int sarpro_hip_ctx_create(int device, unsigned flags, sarpro_hip_ctx 
     sarpro_hip_ctx *ctx = new sarpro_hip_ctx();
     ctx->device = device;
     ctx->flags = flags;
-    ctx->timing = (flags & 1u) != 0;
+    ctx->timing = (flags & SARPRO_HIP_CTX_TIMING) != 0;
+    ctx->async_dev = (flags & SARPRO_HIP_CTX_ASYNC_DEV) != 0;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_err = hipGetErrorString(e);
         delete ctx;
@@ -153,6 +156,12 @@ extern "C" int sarpro_hip_ctx_synchronize(sarpro_hip_ctx *ctx) {
     return SARPRO_HIP_OK;
 }
 
+extern "C" int sarpro_hip_ctx_time_only(sarpro_hip_ctx *ctx, const char *kernel_name) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    ctx->time_only = kernel_name ? kernel_name : "";
+    return SARPRO_HIP_OK;
+}
+
 extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **names, float *ms, int max_entries) {
     if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
     int n = 0;
@@ -170,6 +179,7 @@ extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **na
         if (ms) ms[n] = h.second;
         ++n;
     }
+    ctx->async_pending = false; // read: the next call starts a fresh list
     return n;
 }
 
@@ -313,6 +323,7 @@ struct U16Job {
     bool vec = false;
     bool reduce = false; // row stripe of a multi-rank scene: histograms are all-reduced over ctx->comm, on the stream
     bool hist_done = false; // phase 1 already ran (streaming ingest: chunk by chunk, under the upload)
+    bool allow_async = false; // the entry point may return once the device chain is enqueued (SARPRO_HIP_CTX_ASYNC_DEV)
     StripePlan *plan = nullptr;
     // host-side state between phases
     sarpro_hip_stats stats[kMaxBands];
@@ -904,6 +915,10 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         HIPCHK(ctx, launch_chain_remap(reinterpret_cast<uint8_t *>(d_out[0]), out_pitch, reinterpret_cast<uint8_t *>(d_out[0]), out_pitch, rows,
                                        cols, state + kStateOffResc, state + kStateOffIdent, ctx->stream));
     }
+    if (ctx->async_dev && J.allow_async && !stats_out && !J.reduce) { // stream-ordered: nothing is read back, the LDS capacity keeps its value
+        ctx->async_pending = ctx->timing;
+        return SARPRO_HIP_OK;
+    }
     ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
     HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
@@ -1014,6 +1029,10 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
         KernelTimer t(ctx, "lut_compose_u16");
         HIPCHK(ctx, launch_lut_compose_u16(f, ctx->stream));
     }
+    if (ctx->async_dev && J.allow_async && !stats_out && !u16o && !J.reduce) { // stream-ordered (u16 levels need their `uncertain` flag read back)
+        ctx->async_pending = ctx->timing;
+        return SARPRO_HIP_OK;
+    }
     ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
     HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
@@ -1107,6 +1126,7 @@ extern "C" int sarpro_hip_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, const uint
     J.ctx = ctx; J.nbands = 2; J.d_in[0] = d_band1; J.d_in[1] = d_band2;
     J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = in_pitch;
     J.strategy = strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.mode = mode; J.synrgb = true;
+    J.allow_async = true; // SARPRO_HIP_CTX_ASYNC_DEV applies to this entry point only
     void *outs[kMaxBands] = {d_u8_band1, d_u8_band2};
     return job_run_all(J, outs, u8_pitch, d_rgb, rgb_pitch_px, stats_out);
 }

@@ -103,6 +103,9 @@ struct sarpro_hip_ctx {
 
     // per-kernel timing of the last call
     bool timing = false;
+    bool async_dev = false;                      // SARPRO_HIP_CTX_ASYNC_DEV
+    bool async_pending = false;                  // event pairs of enqueued-but-unread calls are kept until read
+    std::string time_only;                       // when set, only the kernel of this name is bracketed by events
     std::vector<sarpro::KernelTime> times;
     std::vector<std::pair<const char *, float>> host_times;
     std::vector<hipEvent_t> event_pool;

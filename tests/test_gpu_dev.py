@@ -69,6 +69,48 @@ def test_kernel_times_are_recorded():
         c.process_scalar_data_pipeline(dn, Bd.U8, St.Clahe)
         names = [n for n, ms in c.last_kernel_times() if ms >= 0.0]
         assert "dn_hist_u16" in names and "clahe_apply_u8_spec" in names
+        # events on one kernel only (what bench.py's timed region uses), then on all of them again
+        c.time_only("clahe_apply_u8_spec")
+        want, _ = c.process_scalar_data_pipeline(dn, Bd.U8, St.Clahe)
+        names = [n for n, _ in c.last_kernel_times() if not n.startswith("host:")]
+        assert names == ["clahe_apply_u8_spec"]
+        c.time_only(None)
+        got, _ = c.process_scalar_data_pipeline(dn, Bd.U8, St.Clahe)
+        assert "dn_hist_u16" in [n for n, _ in c.last_kernel_times()] and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("strategy", [St.Clahe, St.Robust])
+def test_stream_ordered_dev_calls_match_synchronous_ones(strategy):
+    """SARPRO_HIP_CTX_ASYNC_DEV: three different scenes enqueued back to back without a host round trip give the
+    rasters of the synchronous calls; the event pairs of all three are read afterwards."""
+    rows, cols, pitch = 520, 712, 768
+    scenes = []
+    for k in range(3):
+        b = [torch.zeros((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+        for i in range(2):
+            b[i][:, :cols] = torch.from_numpy(synth.scene_u16(rows, cols, i, seed=synth.SEED_SCENE_A + k).view(np.int16)).cuda()
+        scenes.append(b)
+    want = []
+    with S.Context(0) as c:
+        for b in scenes:
+            rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+            c.dev_dualpol_synrgb_u16(b[0].data_ptr(), b[1].data_ptr(), rows, cols, pitch, strategy, Mode.Default, rgb.data_ptr(), pitch)
+            want.append(rgb.cpu().numpy())
+    with S.Context(0, timing=True, async_dev=True) as c:
+        outs = [torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda") for _ in scenes]
+        for b, rgb in zip(scenes, outs):
+            assert c.dev_dualpol_synrgb_u16(b[0].data_ptr(), b[1].data_ptr(), rows, cols, pitch, strategy, Mode.Default, rgb.data_ptr(), pitch,
+                                            want_stats=False) is None
+        c.synchronize()
+        names = [n for n, _ in c.last_kernel_times()]
+        assert names.count("dn_hist_u16") == 3
+        for rgb, w in zip(outs, want):
+            assert np.array_equal(rgb.cpu().numpy(), w)
+        # with statistics requested the call is synchronous again
+        rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+        st = c.dev_dualpol_synrgb_u16(scenes[0][0].data_ptr(), scenes[0][1].data_ptr(), rows, cols, pitch, strategy, Mode.Default,
+                                      rgb.data_ptr(), pitch, want_stats=True)
+        assert st is not None and np.array_equal(rgb.cpu().numpy(), want[0])
 
 
 # ---------------------------------------------------------------------------- row stripes
