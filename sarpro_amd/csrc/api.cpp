@@ -550,7 +550,7 @@ static int job_phase3(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch)
         if (u8o) HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
         const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out[0]) && (J.nbands < 2 || ptr_aligned16(a.out[1]));
         if (vec != J.vec) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
-        if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands)) {
+        if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands) && !getenv("SARPRO_HIP_NO_SPEC")) {
             HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
             a.dump = ctx->spec_dump.as<uint8_t>();
             KernelTimer t(ctx, "clahe_apply_u8_spec");
@@ -862,10 +862,14 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     // (the level histogram was cleared by the statistics kernels)
     // whole scene on this device: levels >= 64 are only counted in bulk (chain_kernels.hip k_level_hist_guard); a row
     // stripe keeps the full histogram, which is what the ranks sum
-    a.partial_hist = (!J.reduce && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;
-    HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
-    a.dump = ctx->spec_dump.as<uint8_t>();
-    {
+    const bool exact_only = getenv("SARPRO_HIP_NO_SPEC") != nullptr; // cross-check: every pixel through the exact f64 blend
+    a.partial_hist = (!J.reduce && !exact_only && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;
+    if (exact_only) {
+        KernelTimer t(ctx, "clahe_apply_u16");
+        HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, true, false, ctx->stream));
+    } else {
+        HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
+        a.dump = ctx->spec_dump.as<uint8_t>();
         KernelTimer t(ctx, "clahe_apply_u8_spec");
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
     }

@@ -251,6 +251,31 @@ def test_full_size_400mp_parity_by_decomposition(ctx):
         assert torch.equal(img[r0:r0 + 2500], exp)
 
 
+@pytest.mark.parametrize("shape", [(20000, 20000), (3001, 2777)])
+def test_speculative_apply_equals_exact_blend_full_raster(shape, monkeypatch):
+    """Every pixel of the scene: the speculative f32 blend with its exact fallback (product path) against the same
+    chain with every pixel through the reference's f64 blend (SARPRO_HIP_NO_SPEC=1), at BASELINE's full size."""
+    rows, cols = shape
+    pitch = (cols + 63) // 64 * 64
+    q = synth.q_tables()
+    ctx = S.Context(0, timing=True)
+    band = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+    for b in range(2):
+        ctx.dev_synth_scene_u16(synth.SEED_SCENE_A + 77, b, q, rows, cols, 0, rows, band[b].data_ptr(), pitch)
+    rgb = [torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    for which in (0, 1):
+        if which:
+            monkeypatch.setenv("SARPRO_HIP_NO_SPEC", "1")
+        ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default,
+                                   rgb[which].data_ptr(), pitch)
+        names = [n for n, _ in ctx.last_kernel_times()]
+        assert ("clahe_apply_u16" if which else "clahe_apply_u8_spec") in names and len([n for n in names if n.startswith("clahe_apply")]) == 1
+    ctx.close()
+    a, b = (t.view(rows, pitch, 3)[:, :cols] for t in rgb)
+    assert int((a != b).sum().item()) == 0
+    assert int(a.max().item()) > 0
+
+
 def test_library_rccl_communicator_single_rank():
     """The library-owned RCCL communicator (dlopen'ed librccl, ncclAllReduce(sum, u64) on the context's
     stream) driving the stripe protocol; one rank is all a 1-GPU box offers, the N-rank arithmetic is
