@@ -527,6 +527,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
     const uint32_t copy_off = ((uint32_t)lane_id() & (kCdfCopies - 1)) * 16u; // this lane's copy of the f32 CDF table
     const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner; // pad[0] bit 0: extrapolating cell
     const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
+    const uint32_t win_hi2 = win_hi | (win_hi << 16);
     uint32_t lane_max = 0u, lane_high = 0u; // PARTIAL_HIST: this lane's highest level and its count of levels >= kPartialHistLevels
 
     auto process_row = [&](int r, const U16Vec<VEC> &v, const double dy_v) { // dy: wave-uniform
@@ -534,11 +535,27 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         const float wy1 = to_sgpr((float)omdy * 255.0f), wy2 = to_sgpr((float)dy * 255.0f);
         uint32_t off[VEC];
         uint32_t pk[2] = {0u, 0u}, pb[2] = {0u, 0u}; // the 8 levels, packed as they will be stored
+        if (LUT_LDS) {
+            // win_hi < 16384 here: both samples of a dword are clamped at once (v_pk_min_u16), then one SDWA shift per sample
+            // selects its half and doubles it into the byte offset of its u16 table entry
+            const uint32_t w[4] = {v.v.x, v.v.y, v.v.z, v.v.w};
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const uint32_t i = min(v.get(j), win_hi);
-            off[j] = LUT_LDS ? (uint32_t)LDS_AT(uint16_t, SpecLds::lut + i * 2u)
-                             : SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u);
+            for (int k = 0; k < 4; ++k) {
+                typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+                const v2us c = __builtin_elementwise_min(__builtin_bit_cast(v2us, w[k]), __builtin_bit_cast(v2us, win_hi2));
+                const uint32_t cw = __builtin_bit_cast(uint32_t, c);
+                uint32_t a0, a1;
+                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(1u), "v"(cw));
+                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(1u), "v"(cw));
+                off[2 * k] = (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a0);
+                off[2 * k + 1] = (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const uint32_t i = min(v.get(j), win_hi);
+                off[j] = SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u);
+            }
         }
         constexpr int kAhead = 2; // CDF gathers issued ahead of their use (3 in flight; measured: 1 -> 2 -1.4 %, 4 no better)
         v4f cq[VEC];
