@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     weights as f64 in LDS), so the raster is bit-identical to kernel 4's.
 //     Error bound of the f32 value y32 against the reference's y = o*255 (u = 2^-24):
 //       inputs are the f64 CDFs / weights rounded once to f32 (1+e, |e| <= u); with dx in [-0.5, 1) (the first
-//       half tile extrapolates), top32 = fma(c01 - c00, dx, c00) carries the input roundings
+//       half tile extrapolates), top32 = fma(fl(c01 - c00), dx, c00) carries the input roundings
 //       u (|c00| |1-dx| + |c01| |dx|) <= 2u, u |c01 - c00| |dx| each for the subtraction and for dx, and u |top| <= 2u
 //       for the fma:  |dtop| <= 6u <= 8u,
 //       the same for bottom, and |top|, |bottom| <= 2;  the row weights hold the 255 factor
@@ -564,9 +564,9 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (j + kAhead < VEC) cq[j + kAhead] = LDS_AT(v4f, off[j + kAhead] + copy_off);
-            const v4f c4 = cq[j]; // (c00, c10, c01, c11)
-            const float top = fmaf(c4.z - c4.x, dxf[j], c4.x); // c00 + dx (c01 - c00): no (1 - dx) to keep in registers
-            const float bottom = fmaf(c4.w - c4.y, dxf[j], c4.y);
+            const v4f c4 = cq[j]; // (c00, c10, c01 - c00, c11 - c10): the differences are taken once, when the table is staged
+            const float top = fmaf(c4.z, dxf[j], c4.x); // c00 + dx (c01 - c00): no (1 - dx) to keep in registers
+            const float bottom = fmaf(c4.w, dxf[j], c4.y);
             // ya = y - 0.5 - delta, yb = y - 0.5 + delta: v_cvt_pk_u8_f32 rounds to nearest-even and saturates, so both
             // give the same byte n only if y lies in (n + (delta - err), n + 1 - (delta - err)): then n = floor(y)
             // clamped to 0..255.  Where the bytes differ the pixel goes to the exact path.
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = cdfs[(size_t)rc.id[k] * 256 + b];
         *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + b * 32) = make_double4(c[0], c[1], c[2], c[3]);
-        // f32 copy laid out (c00, c10 | c01, c11): (top, bottom) = (x,y) + dx*((z,w) - (x,y)) are two packed-f32 ops.
+        // f32 copy laid out (c00, c10 | c01 - c00, c11 - c10): (top, bottom) = (x,y) + dx*(z,w), one FMA each.
         // Saturated bins (all four CDFs exactly 1.0: at least the top bin, i.e. every pixel above p99) blend
         // to y = 255 +- rounding, which the margin test would send to the exact path for ~1 % of all pixels.
         // In an interior cell their exact result is known: with dx in [0,1), fl(fl(1-dx) + dx) = 1.0 exactly
@@ -712,9 +712,10 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
         // level 0, never "near" -- no separate zero test per pixel.
         const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
         const float kz = 0.5f / 255.0f;
-        const float4 e32 = saturated ? make_float4(1.001f, 1.001f, 1.001f, 1.001f)
-                           : zero    ? make_float4(kz, kz, kz, kz)
-                                     : make_float4((float)c[0], (float)c[2], (float)c[1], (float)c[3]);
+        const float c00 = (float)c[0], c01 = (float)c[1], c10 = (float)c[2], c11 = (float)c[3];
+        const float4 e32 = saturated ? make_float4(1.001f, 1.001f, 0.0f, 0.0f)
+                           : zero    ? make_float4(kz, kz, 0.0f, 0.0f)
+                                     : make_float4(c00, c10, c01 - c00, c11 - c10);
 #pragma unroll
         for (uint32_t cc = 0; cc < kCdfCopies; ++cc)
             *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + cdf32_offset(b) + cc * 16) = e32;
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             *reinterpret_cast<double4 *>(lds + SpecLds::cdf64 + 256 * 32) = make_double4(0.0, 0.0, 0.0, 0.0);
 #pragma unroll
             for (uint32_t cc = 0; cc < kCdfCopies; ++cc)
-                *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + cdf32_offset(256) + cc * 16) = make_float4(kz, kz, kz, kz);
+                *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + cdf32_offset(256) + cc * 16) = make_float4(kz, kz, 0.0f, 0.0f);
         }
         for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
         for (int i = b; i < 512; i += kBlock) { // exact column weights of this strip, for the f64 path
