@@ -66,6 +66,21 @@ def test_random_shapes_dualpol(ctx, seed):
         assert np.array_equal(ctx.dualpol_synrgb(b1, b2, strategy), rrgb), (seed, rows, cols, strategy, "no per-band outputs")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_medium_shapes_clahe(ctx, seed):
+    """Shapes with several 512-column strips and several row items per interpolation cell (the apply kernel's edge lanes,
+    scratch-line stores and item boundaries at arbitrary columns), widths of every residue mod 8."""
+    rng = np.random.default_rng(7000 + seed)
+    rows, cols = int(rng.integers(600, 2600)), int(rng.integers(600, 2600)) | (seed & 7)
+    b1, b2 = random_band(rng, rows, cols), random_band(rng, rows, cols)
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1.astype(np.float32), b2.astype(np.float32), int(St.Clahe))
+    assert rc == 0
+    rgb, u1, u2 = ctx.dualpol_synrgb(b1, b2, St.Clahe, want_u8=True)
+    assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), (seed, rows, cols)
+    rc, ref = oracle.pipeline(b1.astype(np.float32), int(Bd.U16), int(St.Clahe))
+    assert rc == 0 and np.array_equal(ctx.process_scalar_data_pipeline(b1, Bd.U16, St.Clahe)[1], ref), (seed, rows, cols, "u16")
+
+
 @pytest.mark.parametrize("seed", range(15))
 def test_random_f32_bands(ctx, seed):
     rng = np.random.default_rng(9000 + seed)
