@@ -65,6 +65,9 @@ pub struct sarpro_hip_batch_report { pub processed: usize, pub skipped: usize, p
 
 pub const SARPRO_HIP_OK: c_int = 0;
 pub const SARPRO_HIP_ERR_UNSUPPORTED_SHAPE: c_int = -3;
+pub const SARPRO_HIP_CTX_TIMING: c_uint = 1;
+/// stream-ordered `sarpro_hip_dualpol_synrgb_u16_dev` (returns once enqueued when `stats_out` is null)
+pub const SARPRO_HIP_CTX_ASYNC_DEV: c_uint = 2;
 
 extern "C" {
     pub fn sarpro_hip_ctx_create(device: c_int, flags: c_uint, ctx_out: *mut *mut sarpro_hip_ctx) -> c_int;
@@ -133,9 +136,10 @@ pub struct RasterCore { ctx: *mut sarpro_hip_ctx }
 unsafe impl Send for RasterCore {}
 
 impl RasterCore {
-    pub fn new(device: i32) -> Result<Self, HipError> {
+    pub fn new(device: i32) -> Result<Self, HipError> { Self::with_flags(device, 0) }
+    pub fn with_flags(device: i32, flags: c_uint) -> Result<Self, HipError> {
         let mut ctx = std::ptr::null_mut();
-        let rc = unsafe { sarpro_hip_ctx_create(device, 0, &mut ctx) };
+        let rc = unsafe { sarpro_hip_ctx_create(device, flags, &mut ctx) };
         if rc != SARPRO_HIP_OK { return Err(Self::err(std::ptr::null(), rc)); }
         Ok(Self { ctx })
     }
