@@ -246,7 +246,7 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     build_clahe_geometry(rows_total, cols, &P->geom);
     const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
     const size_t target_items = 4096;
-    const size_t chunk_rows = std::min<size_t>(256, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 256: the apply kernel stages one item's row weights in LDS
+    const size_t chunk_rows = std::min<size_t>(256, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 256 rows: taller apply items measured slower (320: +3 %, 625: +10 %, a whole 1250-row cell: +30 % -- the resident workgroups drift apart and lose the sweep's DRAM locality), 96..234 rows all the same
     const ClaheGeometry &g = P->geom;
     const bool split = false; // edge lanes are masked inside the vector kernels; no separate sliver items
     for (size_t ty = 0; ty < (size_t)kTiles; ++ty) {
