@@ -323,6 +323,8 @@ struct U16Job {
     bool vec = false;
     bool reduce = false; // row stripe of a multi-rank scene: histograms are all-reduced over ctx->comm, on the stream
     bool hist_done = false; // phase 1 already ran (streaming ingest: chunk by chunk, under the upload)
+    bool clear_after_sum = false; // untiled chain: k_sum_tile_hists is the last reader of the tile histogram and zeroes it
+    size_t tile_hist_bytes = 0;   // footprint of this job's histogram pass in ctx->tile_hist[0]
     bool allow_async = false; // the entry point may return once the device chain is enqueued (SARPRO_HIP_CTX_ASYNC_DEV)
     StripePlan *plan = nullptr;
     // host-side state between phases
@@ -365,6 +367,13 @@ static int job_init(U16Job &J) {
     return get_plan(ctx, J.rows_total, J.cols, J.row0, J.rows_local, J.vec ? 8 : 1, &J.plan);
 }
 
+// the tile histograms were zeroed again by their last reader (enqueued): the next histogram pass may skip its fill
+static void mark_tile_hist_clean(U16Job &J) {
+    if (!J.tile_hist_bytes) return; // the pass was not begun by this job object (cannot know its footprint)
+    J.ctx->tile_hist_clean_ptr = J.ctx->tile_hist[0].p;
+    J.ctx->tile_hist_clean_bytes = J.tile_hist_bytes;
+}
+
 // phase 1: local DN histograms -> ctx->ghist (u64 [nbands][65536]) on the device
 static uint32_t *tile_hist_of(sarpro_hip_ctx *ctx, int band, int ntiles) { return ctx->tile_hist[0].as<uint32_t>() + (size_t)band * 65536 * (size_t)ntiles; }
 
@@ -381,7 +390,15 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     // both bands' tile histograms in one allocation (band b at tile_hist_of(ctx, b, ntiles)): one fill instead of two
     const size_t band_bytes = sizeof(uint32_t) * 65536 * (size_t)ntiles;
     HIPCHK(ctx, ctx->tile_hist[0].reserve(band_bytes * kMaxBands));
-    if (begin) HIPCHK(ctx, hipMemsetAsync(ctx->tile_hist[0].p, 0, band_bytes * (size_t)J.nbands, ctx->stream));
+    if (begin) {
+        // the chain's last reader of the tile histograms zeroes what it read: a scene that follows one of the same or a
+        // larger footprint on this context starts on clean bins (the fill of 32 MiB and its launch: ~12 us)
+        const size_t need = band_bytes * (size_t)J.nbands;
+        if (!(ctx->tile_hist_clean_ptr == ctx->tile_hist[0].p && ctx->tile_hist_clean_bytes >= need))
+            HIPCHK(ctx, hipMemsetAsync(ctx->tile_hist[0].p, 0, need, ctx->stream));
+        ctx->tile_hist_clean_bytes = 0; // dirty from here on
+        J.tile_hist_bytes = need;
+    }
     for (int b = 0; b < J.nbands; ++b) {
         a.in[b] = J.d_in[b];
         a.tile_hist[b] = tile_hist_of(ctx, b, ntiles);
@@ -414,8 +431,10 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
             sa.tile_hist[b] = tile_hist_of(ctx, b, ntiles);
             sa.out[b] = ctx->ghist.as<unsigned long long>() + (size_t)b * 65536;
         }
+        sa.clear = J.clear_after_sum ? 1u : 0u;
         KernelTimer t(ctx, "sum_tile_hists");
         HIPCHK(ctx, launch_sum_tile_hists(sa, ntiles, J.nbands, ctx->stream));
+        if (sa.clear) mark_tile_hist_clean(J);
     }
     return SARPRO_HIP_OK;
 }
@@ -809,8 +828,10 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
             ta.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
             ta.out[b] = ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256;
         }
+        ta.clear = 1u; // the last reader of the tile histograms
         KernelTimer t(ctx, "tile_bin_hist");
         HIPCHK(ctx, launch_tile_bin_hist(ta, kTiles * kTiles, J.nbands, ctx->stream));
+        mark_tile_hist_clean(J);
     }
     RETCHK(chain_reduce(J, ctx->tile_bins.p, 64 * 256 * (size_t)J.nbands, "allreduce_tile_hists"));
     {
@@ -971,6 +992,7 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
     ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
     const bool suppressed = J.strategy == SARPRO_STRATEGY_TAMED; // CLAHE is not handled here
 
+    J.clear_after_sum = true; // untiled: k_sum_tile_hists is the only reader of the histogram
     RETCHK(job_phase1(J)); // DN histograms -> ctx->ghist
     RETCHK(chain_reduce(J, ctx->ghist.p, 65536 * (size_t)nb, "allreduce_dn_hist"));
     {

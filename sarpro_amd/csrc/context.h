@@ -71,6 +71,8 @@ struct sarpro_hip_ctx {
 
     // workspace (device)
     sarpro::DevBuf tile_hist[sarpro::kMaxBands]; // u32 [ntiles][65536]
+    size_t tile_hist_clean_bytes = 0;            // leading bytes of tile_hist[0] that the last chain left zeroed (stream order)
+    const void *tile_hist_clean_ptr = nullptr;   // ... of this allocation
     sarpro::DevBuf ghist;                        // u64 [2][65536]
     sarpro::DevBuf tile_bins;                    // u64 [2][64][256]
     sarpro::DevBuf cdfs;                         // f64 [2][64][256]

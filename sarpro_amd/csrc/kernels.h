@@ -79,14 +79,16 @@ hipError_t launch_dn_hist_u16_interior(const DnHistArgs &a, int nrects, int nban
 // untiled histogram (tile_hist[b] = one 65536-bin histogram per band) of a rows x cols raster whose pitch is a multiple of 8
 hipError_t launch_dn_hist_u16_linear(const DnHistArgs &a, uint32_t rows, uint32_t cols, int nbands, hipStream_t s);
 struct SumTileHistArgs {
-    const uint32_t *tile_hist[kMaxBands]; // [ntiles][65536]
+    uint32_t *tile_hist[kMaxBands];       // [ntiles][65536]
     unsigned long long *out[kMaxBands];   // [65536]
+    uint32_t clear;                       // last reader of the tile histograms: zero what was read (the next scene skips its fill)
 };
 hipError_t launch_sum_tile_hists(const SumTileHistArgs &a, int ntiles, int nbands, hipStream_t s);
 struct TileBinHistArgs {
-    const uint32_t *tile_hist[kMaxBands]; // [ntiles][65536]
+    uint32_t *tile_hist[kMaxBands];       // [ntiles][65536]
     const uint8_t *binlut[kMaxBands];     // [65536]
     unsigned long long *out[kMaxBands];   // [ntiles][256]
+    uint32_t clear;                       // last reader of the tile histograms: zero what was read (the next scene skips its fill)
 };
 hipError_t launch_tile_bin_hist(const TileBinHistArgs &a, int ntiles, int nbands, hipStream_t s);
 hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,

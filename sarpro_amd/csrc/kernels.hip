@@ -255,13 +255,14 @@ __global__ __launch_bounds__(kBlock) void k_dn_hist_u16_linear(DnHistArgs a, uin
 // 2. Sum the per-tile histograms into the band's global 65536-bin histogram (u64).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_sum_tile_hists(SumTileHistArgs a, int ntiles) {
-    const uint32_t *__restrict__ th = a.tile_hist[blockIdx.y];
+    uint32_t *__restrict__ th = a.tile_hist[blockIdx.y];
     const uint32_t dn = (blockIdx.x * kBlock + threadIdx.x) * 4; // 4 consecutive DNs per thread: 16-byte loads
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll 16
     for (int t = 0; t < ntiles; ++t) { // independent loads: many in flight
         const uint4 v = *reinterpret_cast<const uint4 *>(th + (size_t)t * 65536u + dn);
         s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        if (a.clear && (v.x | v.y | v.z | v.w)) *reinterpret_cast<uint4 *>(th + (size_t)t * 65536u + dn) = make_uint4(0u, 0u, 0u, 0u);
     }
     unsigned long long *o = a.out[blockIdx.y] + dn;
     o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
@@ -275,7 +276,7 @@ constexpr int kTileBinBlock = 1024; // one workgroup sweeps a tile's 65536 count
 __global__ __launch_bounds__(kTileBinBlock) void k_tile_bin_hist(TileBinHistArgs a) {
     __shared__ unsigned long long h[256];
     const int band = blockIdx.y;
-    const uint32_t *__restrict__ t = a.tile_hist[band] + (size_t)blockIdx.x * 65536u;
+    uint32_t *__restrict__ t = a.tile_hist[band] + (size_t)blockIdx.x * 65536u;
     const uint8_t *__restrict__ binlut = a.binlut[band];
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(kTileBinBlock) void k_tile_bin_hist(TileBinHistArgs
         for (int k = 0; k < 16; ++k) {
             const uint32_t dn = base + k * kTileBinBlock + threadIdx.x;
             if (n[k] && dn) atomicAdd(&h[bin[k]], (unsigned long long)n[k]); // DN = 0 is invalid: not counted
+            if (a.clear && n[k]) t[dn] = 0u; // only the occupied bins are written: a few thousand of the 65536 per tile
         }
     }
     __syncthreads();

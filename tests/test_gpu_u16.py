@@ -261,3 +261,32 @@ def test_single_band_percentile_chain_equals_host_orchestrated_path(strategy, mo
                 assert ("chain_stats" in names) == (no_chain == "0")
                 assert ("host:phase1_launch" in names) == (no_chain == "1" or force)
             monkeypatch.delenv("SARPRO_HIP_FORCE_UNCERTAIN", raising=False)
+
+
+def test_tile_histograms_left_clean_by_the_previous_scene():
+    """The chains' last reader of the tile histograms zeroes them and the next scene skips its fill: scenes of different
+    footprints, strategies and band counts on ONE context, with a failing call and a host-route call in between."""
+    import os
+    rng = np.random.default_rng(77)
+    def band(rows, cols):
+        return np.clip(rng.rayleigh(rng.uniform(50, 2000), (rows, cols)), 0, 65535).astype(np.uint16)
+    with S.Context(0) as c:
+        seq = [(St.Clahe, 300, 500, 2), (St.Robust, 120, 90, 2), (St.Clahe, 90, 130, 2), (St.Clahe, 700, 900, 2), (St.Adaptive, 700, 900, 2),
+               (St.Clahe, 64, 64, 1), (St.Tamed, 300, 500, 2), (St.Clahe, 300, 500, 2)]
+        for k, (strategy, rows, cols, nb) in enumerate(seq):
+            b = [band(rows, cols) for _ in range(2)]
+            if k == 3:  # a call that fails after validation, then one through the host-orchestrated phases
+                with pytest.raises(S.SarproHipError):
+                    c.dualpol_synrgb(band(5, 300), band(5, 300), St.Clahe)
+                os.environ["SARPRO_HIP_NO_CHAIN"] = "1"
+                try:
+                    rc, rrgb, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(St.Clahe))
+                    assert rc == 0 and np.array_equal(c.dualpol_synrgb(b[0], b[1], St.Clahe), rrgb)
+                finally:
+                    os.environ.pop("SARPRO_HIP_NO_CHAIN")
+            if nb == 2:
+                rc, rrgb, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(strategy))
+                assert rc == 0 and np.array_equal(c.dualpol_synrgb(b[0], b[1], strategy), rrgb), (k, strategy)
+            else:
+                rc, ref = oracle.pipeline(b[0].astype(np.float32), int(Bd.U8), int(strategy))
+                assert rc == 0 and np.array_equal(c.process_scalar_data_pipeline(b[0], Bd.U8, strategy)[0], ref), (k, strategy)
