@@ -161,7 +161,7 @@ def main():
             per_launch[dom] = float(np.mean(dtimes))
             launches[dom] = len(dtimes) / args.steps
         # algorithmic bytes per pixel PER LAUNCH (both bands), DESIGN.md section 4
-        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0, "lut_compose_u16": 7.0}
+        alg_bpp = {"dn_hist_u16": 4.0, "clahe_fused_rgb": 7.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0, "lut_compose_u16": 7.0}
         roofline = None
         if dom:
             local_px = rows_local * cols

@@ -241,6 +241,20 @@ int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **names_out, fl
  * dozen kernels timed one by one runs ~6 % slower than untimed, timed on its dominant kernel only ~0.5 %. */
 int sarpro_hip_ctx_time_only(sarpro_hip_ctx *ctx, const char *kernel_name);
 
+/* Diagnostics of the last fused CLAHE pass of this context (dual-pol CLAHE -> synRGB of a whole scene takes it: both DN
+ * rasters in, RGB out, with a predicted synRGB floor that the pass verifies; csrc/fused_kernels.hip).  Synchronises the
+ * context's stream.  spec_ok: the speculative pass ran; verdict 0: its RGB stood, 1: the prediction was refuted and
+ * the exact passes ran (also when spec_ok is 0); the raster is the reference's either way. */
+typedef struct {
+    uint32_t spec_ok, direct, verdict;
+    int32_t floor_pred;
+    uint64_t n_lt[2];      /* band-pixels with level < floor_pred, < floor_pred + 1 (speculative pass) */
+    uint64_t queued[4];    /* uncertain pixels queued per pass (sample, speculative, histogram, final) */
+    uint32_t overflowed[4];/* workgroups whose queue overflowed per pass (their share was redone exactly) */
+    uint64_t dbg[8];       /* builds with -DFUSED_DIAG: origin of the queued pixels (interior / extrapolating cells, ...) */
+} sarpro_hip_fused_report;
+int sarpro_hip_ctx_fused_report(sarpro_hip_ctx *ctx, sarpro_hip_fused_report *out);
+
 /* ================= row-stripe (multi-GPU) protocol ================= */
 /* One scene split into row stripes, one per rank.  Each phase
  * ends in a small integer reduction that the caller merges across ranks (RCCL

@@ -88,6 +88,14 @@ class Context:
         n = lib.sarpro_hip_last_kernel_times(self._h, names, ms, 1024)
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
 
+    def fused_report(self) -> dict:
+        """Diagnostics of the last fused CLAHE pass (sarpro_hip_ctx_fused_report); synchronises the stream."""
+        from ._lib import FusedReport
+        r = FusedReport()
+        self._chk(lib.sarpro_hip_ctx_fused_report(self._h, C.byref(r)))
+        return {"spec_ok": int(r.spec_ok), "direct": int(r.direct), "verdict": int(r.verdict), "floor_pred": int(r.floor_pred),
+                "n_lt": [int(x) for x in r.n_lt], "queued": [int(x) for x in r.queued], "overflowed": [int(x) for x in r.overflowed], "dbg": [int(x) for x in r.dbg]}
+
     def time_only(self, kernel_name=None):
         """Bracket only this kernel with events (None: every kernel); see sarpro_hip_ctx_time_only."""
         self._chk(lib.sarpro_hip_ctx_time_only(self._h, kernel_name.encode() if kernel_name else None))

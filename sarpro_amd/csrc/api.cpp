@@ -116,6 +116,7 @@ extern "C" int sarpro_hip_ctx_create(int device, unsigned flags, sarpro_hip_ctx 
         return SARPRO_HIP_ERR_HIP;
     }
     (void)db_table_u16(); // build the constant dB table once, outside any timed region
+    if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->cu_count = 0;
     *out = ctx;
     return SARPRO_HIP_OK;
 }
@@ -131,17 +132,10 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
         kv.second->release_all();
         delete kv.second;
     }
-    for (int b = 0; b < kMaxBands; ++b) { ctx->tile_hist[b].release(); ctx->levels[b].release(); ctx->stage_in[b].release(); }
-    for (auto &b : ctx->stage_out) b.release();
-    ctx->ghist.release(); ctx->tile_bins.release(); ctx->cdfs.release(); ctx->luts.release();
-    ctx->level_hist.release(); ctx->hist_flags.release(); ctx->chain_scratch.release(); ctx->tables.release(); ctx->qtab.release(); ctx->f32ws.release();
-    ctx->chain_consts.release(); ctx->chain_state.release();
-    ctx->resize_tmp.release(); ctx->resize_coef[0].release(); ctx->resize_coef[1].release(); ctx->resized[0].release(); ctx->resized[1].release();
-    ctx->h_ghist.release(); ctx->h_small.release(); ctx->h_upload.release();
+    // workspace buffers (DevBuf / PinnedBuf members) free themselves when the context is deleted, below
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t &e : ctx->ring_evt) if (e) (void)hipEventDestroy(e);
-    ctx->h_ring.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -159,6 +153,27 @@ extern "C" int sarpro_hip_ctx_synchronize(sarpro_hip_ctx *ctx) {
 extern "C" int sarpro_hip_ctx_time_only(sarpro_hip_ctx *ctx, const char *kernel_name) {
     if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
     ctx->time_only = kernel_name ? kernel_name : "";
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_ctx_fused_report(sarpro_hip_ctx *ctx, sarpro_hip_fused_report *out) {
+    if (!ctx || !out) return SARPRO_HIP_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    if (!ctx->fused_state.p) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no fused CLAHE pass has run on this context");
+    std::vector<unsigned char> buf(sizeof(sarpro::FusedState));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(buf.data(), ctx->fused_state.p, buf.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const sarpro::FusedState *fs = reinterpret_cast<const sarpro::FusedState *>(buf.data());
+    out->spec_ok = fs->spec_ok; out->direct = fs->direct; out->verdict = fs->verdict; out->floor_pred = fs->floor_pred;
+    out->n_lt[0] = fs->n_lt[0]; out->n_lt[1] = fs->n_lt[1];
+    for (int k = 0; k < 8; ++k) out->dbg[k] = fs->dbg[k];
+    if (getenv("SARPRO_HIP_FUSED_DIAG_DUMP")) for (uint32_t k = 0; k < std::min(fs->dbg_n, 64u); ++k) { const uint32_t *o = fs->dbg_samples[k]; { float f[5]; memcpy(f, o + 2, 20); fprintf(stderr, "[fused diag] r %u c %u entry %.6f %.6f %.6f %.6f dy %.6f addr %u\n", o[0], o[1], f[0], f[1], f[2], f[3], f[4], o[7]); } }
+    for (int m = 0; m < 4; ++m)
+        for (int k = 0; k < sarpro::kFusedMaxGrid; ++k) {
+            const uint32_t q = fs->qcount[m][k];
+            if (q & 0x80000000u) out->overflowed[m] += 1; else out->queued[m] += q;
+        }
     return SARPRO_HIP_OK;
 }
 
@@ -232,14 +247,101 @@ static int upload_vec(sarpro_hip_ctx *ctx, DevBuf &d, const void *src, size_t by
     return SARPRO_HIP_OK;
 }
 
+// Fused CLAHE pass: the scene as strips of 1, 2, 4, 8 or 16 wave columns (256 px each) inside one interpolation cell,
+// cut into row ranges so that each of the `grid` persistent workgroups gets the same cost (rows x wave columns, the
+// ragged last column included).  Cell-major order: a workgroup's pieces are neighbours, it restages its tables rarely.
+static void build_fused_pieces(StripePlan *P, int grid) {
+    const ClaheGeometry &g = P->geom;
+    struct Strip { FusedItem it; double cost_per_row; };
+    std::vector<Strip> strips;
+    double total = 0.0;
+    // cells = ranges of constant (t0, t1), cut again where the weight changes sign -- the first half tile extrapolates (d < 0,
+    // autoscale.rs:308-313) and takes the wider speculation margin, the half tile after it has the same tiles but d >= 0 --
+    // and at the tile boundaries (a cell is offset by half a tile: the sample pass's strata are per tile)
+    auto cuts = [](const std::vector<size_t> &starts, const std::vector<RowWeight> &w, size_t tile) {
+        std::vector<size_t> out;
+        for (size_t i = 0; i + 1 < starts.size(); ++i) {
+            out.push_back(starts[i]);
+            for (size_t k = starts[i] + 1; k < starts[i + 1]; ++k)
+                if ((w[k - 1].d < 0.0) != (w[k].d < 0.0) || k % tile == 0) out.push_back(k);
+        }
+        out.push_back(starts.empty() ? 0 : starts.back());
+        return out;
+    };
+    const std::vector<size_t> rcut = cuts(g.row_cell_start, g.row_w, g.tile_h), ccut = cuts(g.col_cell_start, g.col_w, g.tile_w);
+    for (size_t ri = 0; ri + 1 < rcut.size(); ++ri) {
+        const size_t r0 = rcut[ri], r1 = rcut[ri + 1];
+        if (r0 >= r1) continue;
+        const RowWeight &rw = g.row_w[r0];
+        for (size_t ci = 0; ci + 1 < ccut.size(); ++ci) {
+            const size_t c0 = ccut[ci], c1 = ccut[ci + 1];
+            if (c0 >= c1) continue;
+            const RowWeight &cw = g.col_w[c0];
+            const bool neg = rw.d < 0.0 || cw.d < 0.0; // constant sign inside the cut cell
+            const size_t cstart = c0 / 4 * 4;
+            size_t nch = (c1 - cstart + 255) / 256, off = 0;
+            while (nch > 0) {
+                int lg = 4;
+                while ((size_t(1) << lg) > nch) --lg;
+                const size_t gw = size_t(1) << lg;
+                Strip st{};
+                st.it.r0 = (int32_t)r0; st.it.r1 = (int32_t)r1;
+                st.it.cstart = (int32_t)(cstart + off * 256);
+                st.it.c0 = (int32_t)std::max(c0, cstart + off * 256);
+                st.it.c1 = (int32_t)std::min(c1, cstart + (off + gw) * 256);
+                st.it.gx_log2 = lg;
+                st.it.flags = neg ? 1 : 0;
+                st.it.id[0] = rw.t0 * kTiles + cw.t0; st.it.id[1] = rw.t0 * kTiles + cw.t1;
+                st.it.id[2] = rw.t1 * kTiles + cw.t0; st.it.id[3] = rw.t1 * kTiles + cw.t1;
+                st.it.tile = (int32_t)(std::min<size_t>(r0 / g.tile_h, kTiles - 1) * kTiles + std::min<size_t>(c0 / g.tile_w, kTiles - 1));
+                st.cost_per_row = (double)gw;
+                total += st.cost_per_row * (double)(r1 - r0);
+                strips.push_back(st);
+                nch -= gw; off += gw;
+            }
+        }
+    }
+    P->fused_grid = grid;
+    P->fused_items.clear();
+    P->fused_first.assign((size_t)grid + 1, 0);
+    const double share = total / (double)grid;
+    double acc = 0.0;
+    int k = 0;
+    for (const Strip &st : strips) {
+        const int gy = 16 >> st.it.gx_log2;
+        int r = st.it.r0;
+        while (r < st.it.r1) {
+            int take = st.it.r1 - r;
+            if (k < grid - 1) {
+                const double room = share * (double)(k + 1) - acc;
+                int rows = (int)(room / st.cost_per_row);
+                rows = std::max(gy, (rows + gy - 1) / gy * gy); // whole steps of the 16 waves
+                take = std::min(take, rows);
+            }
+            FusedItem it = st.it;
+            it.r0 = r; it.r1 = r + take;
+            P->fused_items.push_back(it);
+            P->fused_first[(size_t)k + 1] = (int32_t)P->fused_items.size();
+            acc += st.cost_per_row * (double)take;
+            r += take;
+            if (k < grid - 1 && acc >= share * (double)(k + 1) - 1e-9) ++k;
+        }
+    }
+    for (int i = 1; i <= grid; ++i) P->fused_first[(size_t)i] = std::max(P->fused_first[(size_t)i], P->fused_first[(size_t)i - 1]);
+}
+
 int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,
              StripePlan **out) {
     auto key = std::make_tuple(rows_total, cols, row0, rows_local, vecw);
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) { *out = it->second; return SARPRO_HIP_OK; }
-    if (ctx->plans.size() > 16) { // bounded cache
-        for (auto &kv : ctx->plans) { kv.second->release_all(); delete kv.second; }
-        ctx->plans.clear();
+    if (ctx->plans.size() > 16) { // bounded cache; plans held by an open stripe handle stay
+        for (auto jt = ctx->plans.begin(); jt != ctx->plans.end();) {
+            if (jt->second->refs > 0) { ++jt; continue; }
+            jt->second->release_all();
+            delete jt->second;
+            jt = ctx->plans.erase(jt);
+        }
     }
     StripePlan *P = new StripePlan();
     P->rows_total = rows_total; P->cols = cols; P->row0 = row0; P->rows_local = rows_local; P->vecw = vecw;
@@ -290,7 +392,18 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
         sweep_order(P->hist_rects_flat);
         sweep_order(P->apply_rects);
     }
+    if (vecw == 8 && row0 == 0 && rows_local == rows_total && ctx->cu_count > 0) build_fused_pieces(P, std::min(ctx->cu_count, kFusedMaxGrid));
     int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_fused_items, P->fused_items.data(), P->fused_items.size() * sizeof(FusedItem));
+    if (!rc) rc = upload_vec(ctx, P->d_fused_first, P->fused_first.data(), P->fused_first.size() * sizeof(int32_t));
+    if (!rc && P->fused_grid > 0) {
+        std::vector<float> wf(g.row_w.size());
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = (float)g.row_w[i].d;
+        rc = upload_vec(ctx, P->d_row_wf, wf.data(), wf.size() * sizeof(float));
+        wf.resize(g.col_w.size());
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = (float)g.col_w[i].d;
+        if (!rc) rc = upload_vec(ctx, P->d_col_wf, wf.data(), wf.size() * sizeof(float));
+    }
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_tiled, P->hist_sliver_tiled.data(), P->hist_sliver_tiled.size() * sizeof(Rect));
@@ -793,6 +906,140 @@ static int chain_reduce(U16Job &J, void *d_buf, size_t count_u64, const char *wh
     return comm_allreduce_sum_u64_async(J.ctx, reinterpret_cast<uint64_t *>(d_buf), count_u64);
 }
 
+// End of a device-resident chain: return at once on a stream-ordered context, else read the statistics back.
+static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_state) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    if (ctx->async_dev && J.allow_async && !stats_out && !J.reduce) { // stream-ordered: nothing is read back, the LDS capacity keeps its value
+        ctx->async_pending = ctx->timing;
+        return SARPRO_HIP_OK;
+    }
+    ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
+    HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
+    uint32_t hi = 0;
+    for (int b = 0; b < J.nbands; ++b) {
+        J.stats[b] = h_state[b].stats;
+        if (stats_out) stats_out[b] = J.stats[b];
+        hi = std::max(hi, h_state[b].win_hi);
+    }
+    // size the LDS offset table of the NEXT scene from this scene's window (speed only: a window larger
+    // than the capacity is gathered from global memory, with identical results)
+    ctx->chain_lut_cap = std::min<uint32_t>(16384, std::max<uint32_t>(1024, (hi + 1 + 255) / 256 * 256));
+    return SARPRO_HIP_OK;
+}
+
+// The fused CLAHE pass (fused_kernels.hip) after the CDFs: sample -> predicted floor and tables -> speculative pass
+// (DN, DN -> RGB, counts that prove the prediction) -> fixup of the queued pixels + verification; then, gated on the
+// device by the verdict, the exact passes: level histograms -> k_chain_finish -> final pass.  Nothing here synchronises.
+static uint32_t fused_force_flags() {
+    const char *e = getenv("SARPRO_HIP_FUSED_FORCE");
+    if (!e) return 0u;
+    uint32_t f = 0;
+    if (strstr(e, "nospec")) f |= kFusedForceNoSpec;
+    if (strstr(e, "mispredict")) f |= kFusedForceMispredict;
+    if (strstr(e, "twolevel")) f |= kFusedForceTwoLevel;
+    if (strstr(e, "tinyqueue")) f |= kFusedForceTinyQueue;
+    return f;
+}
+
+static int job_run_fused(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    const bool dbg = getenv("SARPRO_HIP_FUSED_DEBUG_SYNC") != nullptr; // diagnostics: synchronise and report after every launch
+#define FUSED_DBG(what) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[fused] %s: %s\n", what, hipGetErrorString(e_)); } } while (0)
+    StripePlan *P = J.plan;
+    const int grid = P->fused_grid;
+    if (!ctx->fused_ready) { HIPCHK(ctx, fused_configure()); ctx->fused_ready = true; }
+    HIPCHK(ctx, ctx->fused_state.reserve(sizeof(FusedState)));
+    HIPCHK(ctx, ctx->fused_queue.reserve(sizeof(uint4) * kFusedQueueCap * (size_t)grid));
+    if (!ctx->fused_hist3.p) { // zeroed once: its last reader (k_fused_predict) leaves it zeroed
+        HIPCHK(ctx, ctx->fused_hist3.reserve(sizeof(uint32_t) * kFusedHist3Words));
+        HIPCHK(ctx, hipMemsetAsync(ctx->fused_hist3.p, 0, sizeof(uint32_t) * kFusedHist3Words, ctx->stream));
+    }
+    HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
+    uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
+    ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
+    const unsigned long long total_px = (unsigned long long)J.rows_total * J.cols;
+    const uint32_t force = fused_force_flags();
+    FusedArgs a{};
+    for (int b = 0; b < 2; ++b) {
+        a.in[b] = J.d_in[b];
+        a.cdfs[b] = ctx->cdfs.as<double>() + (size_t)b * 64 * 256;
+        a.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+    }
+    a.in_pitch = J.in_pitch;
+    a.rgb = d_rgb; a.rgb_pitch_px = rgb_pitch_px;
+    a.items = P->d_fused_items.as<FusedItem>();
+    a.wg_first = P->d_fused_first.as<int32_t>();
+    a.state = d_state;
+    a.row_w = P->d_row_w.as<RowWeight>(); a.col_w = P->d_col_w.as<RowWeight>();
+    a.row_wf = P->d_row_wf.as<float>(); a.col_wf = P->d_col_wf.as<float>();
+    a.row_off = (int32_t)J.row0;
+    a.fs = ctx->fused_state.as<FusedState>();
+    a.tables = ctx->tables.as<uint8_t>();
+    a.queue = ctx->fused_queue.as<uint4>();
+    a.hist3 = ctx->fused_hist3.as<uint32_t>();
+    a.dump = ctx->spec_dump.as<uint8_t>();
+    a.level_hist = ctx->level_hist.as<unsigned long long>();
+    a.sample_stride = 32;
+    if (const char *e = getenv("SARPRO_HIP_FUSED_SAMPLE")) a.sample_stride = (uint32_t)std::max(1, atoi(e));
+    a.force = force;
+    a.qcap = kFusedQueueCap;
+    {
+        KernelTimer t(ctx, "fused_prep");
+        FusedPrepArgs pa{};
+        pa.fs = a.fs; pa.state = d_state; pa.tile_bins = ctx->tile_bins.as<unsigned long long>(); pa.cdfs = ctx->cdfs.as<double>();
+        pa.total_px = total_px; pa.force = force;
+        HIPCHK(ctx, launch_fused_prep(pa, ctx->stream)); FUSED_DBG("launch_fused_prep(pa, ctx->stream)");
+    }
+    {
+        KernelTimer t(ctx, "fused_sample");
+        HIPCHK(ctx, launch_fused_main(a, kFusedSample, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedSample, grid, ctx->stream)");
+    }
+    {
+        KernelTimer t(ctx, "fused_predict");
+        FusedPredictArgs pa{};
+        pa.fs = a.fs; pa.state = d_state; pa.tile_bins = ctx->tile_bins.as<unsigned long long>(); pa.hist3 = a.hist3; pa.total_px = total_px; pa.force = force;
+        HIPCHK(ctx, launch_fused_predict(pa, ctx->stream)); FUSED_DBG("launch_fused_predict");
+    }
+    {
+        KernelTimer t(ctx, "fused_tables");
+        FusedTablesArgs ta{};
+        ta.fs = a.fs; ta.tables = ctx->tables.as<uint8_t>(); ta.supp_rg = consts + kChainOffSupp; ta.blue_pair_supp = consts + kChainOffBlue;
+        ta.force = force;
+        HIPCHK(ctx, launch_fused_tables_predict(ta, ctx->stream)); FUSED_DBG("launch_fused_tables_predict(ta, ctx->stream)");
+    }
+    {
+        KernelTimer t(ctx, "clahe_fused_rgb");
+        HIPCHK(ctx, launch_fused_main(a, kFusedSpec, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedSpec, grid, ctx->stream)");
+    }
+    {
+        KernelTimer t(ctx, "fused_fixup");
+        HIPCHK(ctx, launch_fused_fixup(a, kFusedSpec, grid, total_px, ctx->stream)); FUSED_DBG("launch_fused_fixup(a, kFusedSpec, grid, total_px, ctx->stream)");
+    }
+    {   // exact passes: skipped on the device unless the preconditions failed or the prediction was refuted
+        KernelTimer t(ctx, "fused_exact_passes");
+        HIPCHK(ctx, launch_fused_main(a, kFusedHist, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedHist, grid, ctx->stream)");
+        HIPCHK(ctx, launch_fused_fixup(a, kFusedHist, grid, total_px, ctx->stream)); FUSED_DBG("launch_fused_fixup(a, kFusedHist, grid, total_px, ctx->stream)");
+        ChainFinishArgs fa{};
+        fa.level_hist = ctx->level_hist.as<unsigned long long>();
+        fa.total_px = total_px;
+        fa.nbands = 2;
+        fa.resc_out = state + kStateOffResc;
+        fa.identity_out = state + kStateOffIdent;
+        fa.tables = ctx->tables.as<uint8_t>();
+        fa.supp_rg = consts + kChainOffSupp;
+        fa.blue_pair_supp = consts + kChainOffBlue;
+        fa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        fa.suppressed = 1;
+        fa.gate = a.fs;
+        HIPCHK(ctx, launch_chain_finish(fa, ctx->stream)); FUSED_DBG("launch_chain_finish(fa, ctx->stream)");
+        HIPCHK(ctx, launch_fused_main(a, kFusedFinal, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedFinal, grid, ctx->stream)");
+        HIPCHK(ctx, launch_fused_fixup(a, kFusedFinal, grid, total_px, ctx->stream)); FUSED_DBG("launch_fused_fixup(a, kFusedFinal, grid, total_px, ctx->stream)");
+    }
+#undef FUSED_DBG
+    return SARPRO_HIP_OK;
+}
+
 static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
                          sarpro_hip_stats *stats_out) {
     sarpro_hip_ctx *ctx = J.ctx;
@@ -838,6 +1085,13 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         KernelTimer t(ctx, "chain_cdfs");
         HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
                                       J.nbands, ctx->stream));
+    }
+    // dual-pol RGB of a whole scene: the fused pass, no level rasters (per-band u8 copies, row stripes and the
+    // cross-check switches keep the apply + compose passes below)
+    if (J.synrgb && J.nbands == 2 && !J.reduce && !d_out[0] && !d_out[1] && d_rgb && rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb) &&
+        J.plan->fused_grid > 0 && !getenv("SARPRO_HIP_NO_FUSED_CLAHE") && !getenv("SARPRO_HIP_NO_SPEC") && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) {
+        RETCHK(job_run_fused(J, d_rgb, rgb_pitch_px));
+        return chain_tail(J, stats_out, d_state);
     }
     // apply: levels into the internal rasters (dual-pol) or straight into the caller's raster (single band)
     const bool direct = !J.synrgb;
@@ -940,23 +1194,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         HIPCHK(ctx, launch_chain_remap(reinterpret_cast<uint8_t *>(d_out[0]), out_pitch, reinterpret_cast<uint8_t *>(d_out[0]), out_pitch, rows,
                                        cols, state + kStateOffResc, state + kStateOffIdent, ctx->stream));
     }
-    if (ctx->async_dev && J.allow_async && !stats_out && !J.reduce) { // stream-ordered: nothing is read back, the LDS capacity keeps its value
-        ctx->async_pending = ctx->timing;
-        return SARPRO_HIP_OK;
-    }
-    ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
-    HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the only synchronisation of the chain
-    uint32_t hi = 0;
-    for (int b = 0; b < J.nbands; ++b) {
-        J.stats[b] = h_state[b].stats;
-        if (stats_out) stats_out[b] = J.stats[b];
-        hi = std::max(hi, h_state[b].win_hi);
-    }
-    // size the LDS offset table of the NEXT scene from this scene's window (speed only: a window larger
-    // than the capacity is gathered from global memory, with identical results)
-    ctx->chain_lut_cap = std::min<uint32_t>(16384, std::max<uint32_t>(1024, (hi + 1 + 255) / 256 * 256));
-    return SARPRO_HIP_OK;
+    return chain_tail(J, stats_out, d_state);
 }
 
 // Device-resident chain for the percentile strategies, dual-pol, RGB only: histogram -> statistics + window +

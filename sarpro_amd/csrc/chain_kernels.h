@@ -4,6 +4,8 @@
 
 namespace sarpro {
 
+struct FusedState; // fused_kernels.h
+
 struct ChainBandState { // lives in device memory, one per band
     sarpro_hip_stats stats;
     uint32_t win_hi;    // first DN whose dB value reached the high clip (the bin table is constant above)
@@ -54,6 +56,7 @@ struct ChainFinishArgs {
     size_t dn_table_stride;
     const uint8_t *default_rg;            // [512] default lut_r | lut_g (synthetic_rgb.rs:22-29)
     const uint8_t *blue_pair_default;     // [256][256]
+    const FusedState *gate;               // fused CLAHE chain: run only when its exact passes run (null: always)
 };
 
 hipError_t launch_chain_stats(const ChainStatsArgs &a, int nbands, hipStream_t s);

@@ -9,6 +9,7 @@
 // tables of the suppressed synRGB LUTs (one per possible floor) and the blue pair tables are
 // constant tables built once on the host with glibc and uploaded at context creation.
 #include "chain_kernels.h"
+#include "fused_kernels.h"
 
 #include <cfloat>
 
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(256) void k_chain_cdfs(const unsigned long long *__
 // (tiny) maps and builds its slice of the 65536-entry blue table; block 0 also publishes the maps.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a) {
+    if (a.gate && a.gate->spec_ok != 0 && a.gate->verdict == 0) return; // the speculative fused pass already wrote the final RGB
     __shared__ unsigned long long lh[2][256];
     __shared__ uint8_t resc[2][256];
     __shared__ unsigned long long combined[256];

@@ -20,3 +20,36 @@ def ctx():
     c = sarpro_amd.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _order_library_behind_torch(request):
+    """The `_dev` entry points run on the context's own non-blocking stream, which is not ordered against torch's stream
+    (include/sarpro_hip.h, "Stream ordering"): the GPU tests build inputs / outputs with torch, so every device-pointer
+    call of the Python mirror first waits for torch's work.  (A product caller orders sarpro_hip_ctx_stream behind its
+    producers with an event instead.)"""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    import functools
+
+    import torch
+
+    import sarpro_amd
+    saved = {}
+    for cls in (sarpro_amd.Context, getattr(sarpro_amd.api, "Stripe", None)):
+        if cls is None:
+            continue
+        for name, fn in list(vars(cls).items()):
+            if callable(fn) and (name.startswith("dev_") or name.startswith("stripe_") or name.startswith("phase")):
+                def wrap(f):
+                    @functools.wraps(f)
+                    def g(*a, **k):
+                        torch.cuda.synchronize()
+                        return f(*a, **k)
+                    return g
+                saved[(cls, name)] = fn
+                setattr(cls, name, wrap(fn))
+    yield
+    for (cls, name), fn in saved.items():
+        setattr(cls, name, fn)

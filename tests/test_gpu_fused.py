@@ -1,0 +1,149 @@
+"""GPU tests of the fused CLAHE pass (csrc/fused_kernels.hip): DN, DN -> RGB in one sweep, with a predicted synRGB
+floor that the pass verifies, a queue of uncertain pixels recomputed exactly, and gated exact passes behind it.
+Everything goes through the C ABI and is compared bit for bit with the oracle (autoscale.rs:572-608 per band,
+synthetic_rgb.rs:88-178) and with the apply + compose route (SARPRO_HIP_NO_FUSED_CLAHE=1)."""
+import numpy as np
+import pytest
+
+import oracle
+import sarpro_amd as S
+from sarpro_amd import AutoscaleStrategy as St, SyntheticRgbMode as Mode, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev_u16(a: np.ndarray, pitch: int):
+    rows, cols = a.shape
+    t = torch.zeros((rows, pitch), dtype=torch.int16, device="cuda")
+    t[:, :cols] = torch.from_numpy(a.view(np.int16)).cuda()
+    return t
+
+
+def run_dev(ctx, b, pitch=None):
+    rows, cols = b[0].shape
+    pitch = pitch or (cols + 63) // 64 * 64
+    d = [dev_u16(x, pitch) for x in b]
+    rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+    ctx.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
+    names = [n for n, _ in ctx.last_kernel_times()]
+    return rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], names, ctx.fused_report()
+
+
+def ref_rgb(b):
+    rc, rgb, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(St.Clahe))
+    assert rc == 0
+    return rgb
+
+
+SHAPES = [(384, 520), (97, 1031), (1500, 1130), (42, 42), (641, 2049), (2600, 5300)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fused_pass_equals_oracle(shape):
+    rows, cols = shape
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    with S.Context(0, timing=True) as c:
+        got, names, rep = run_dev(c, b)
+    assert "clahe_fused_rgb" in names and "compose_u8" not in names  # the fused route ran
+    assert np.array_equal(got, ref_rgb(b))
+    # the synthetic scenes have a no-data wedge and a bright tail: the speculative pass must be the one that ran
+    # (its verdict may still be 1 when the sampled floor was off by one: the exact passes then ran behind it)
+    if rows >= 300 and cols >= 300:
+        assert rep["spec_ok"] == 1, rep
+    assert rep["direct"] == 1 and rep["overflowed"] == [0, 0, 0, 0], rep
+
+
+@pytest.mark.parametrize("force", ["nospec", "mispredict", "twolevel", "tinyqueue", "twolevel,mispredict", "nospec,tinyqueue,twolevel"])
+@pytest.mark.parametrize("shape", [(1500, 1130), (333, 2600)])
+def test_fused_pass_forced_routes(force, shape, monkeypatch):
+    """The rare routes, forced: preconditions 'fail' (histogram pass -> exact tables -> final pass), a wrong predicted
+    floor (the verification must refute it), windows that 'do not fit' LDS (DN -> bin from global memory), a queue of
+    four entries (inline exact path)."""
+    rows, cols = shape
+    b = [synth.scene_u16(rows, cols, k, seed=synth.SEED_SCENE_A + 3) for k in (0, 1)]
+    monkeypatch.setenv("SARPRO_HIP_FUSED_FORCE", force)
+    with S.Context(0, timing=True) as c:
+        got, names, rep = run_dev(c, b)
+    assert "clahe_fused_rgb" in names
+    assert np.array_equal(got, ref_rgb(b))
+    if "nospec" in force:
+        assert rep["spec_ok"] == 0
+    elif "mispredict" in force:
+        assert rep["spec_ok"] == 1 and rep["verdict"] == 1  # the verification refuted the wrong floor
+    if "twolevel" in force:
+        assert rep["direct"] == 0
+    if "tinyqueue" in force:
+        assert sum(rep["overflowed"]) > 0
+
+
+def test_fused_pass_scene_without_invalid_pixels():
+    """No DN = 0 anywhere: level 0 is not guaranteed, the u8 rescale is not the identity -> the exact passes run."""
+    rows, cols = 900, 1200
+    b = [np.maximum(synth.scene_u16(rows, cols, k), 1).astype(np.uint16) for k in (0, 1)]
+    with S.Context(0, timing=True) as c:
+        got, _, rep = run_dev(c, b)
+    assert np.array_equal(got, ref_rgb(b))
+    assert rep["spec_ok"] == 0
+
+
+def test_fused_pass_degenerate_scenes():
+    rows, cols = 400, 640
+    rng = np.random.default_rng(5)
+    cases = [
+        [np.zeros((rows, cols), np.uint16)] * 2,                                        # nothing valid
+        [np.full((rows, cols), 777, np.uint16), np.full((rows, cols), 12, np.uint16)],  # constant bands
+        [rng.integers(0, 3, (rows, cols)).astype(np.uint16), rng.integers(0, 65536, (rows, cols)).astype(np.uint16)],  # tiny / huge window
+        [(rng.integers(0, 2, (rows, cols)) * 40000).astype(np.uint16), rng.integers(1, 9000, (rows, cols)).astype(np.uint16)],
+    ]
+    with S.Context(0, timing=True) as c:
+        for b in cases:
+            got, _, _ = run_dev(c, b)
+            assert np.array_equal(got, ref_rgb(b))
+
+
+@pytest.mark.parametrize("shape", [(3001, 2777), (5000, 8192)])
+def test_fused_pass_equals_apply_plus_compose(shape, monkeypatch):
+    rows, cols = shape
+    pitch = (cols + 63) // 64 * 64
+    q = synth.q_tables()
+    with S.Context(0, timing=True) as c:
+        d = [torch.zeros((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+        for k in range(2):
+            c.dev_synth_scene_u16(synth.SEED_SCENE_A + 9, k, q, rows, cols, 0, rows, d[k].data_ptr(), pitch)
+        out = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("SARPRO_HIP_NO_FUSED_CLAHE", env)
+            rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+            c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
+            names = [n for n, _ in c.last_kernel_times()]
+            assert ("clahe_fused_rgb" in names) == (env is None)
+            out.append(rgb.view(rows, pitch, 3)[:, :cols].clone())
+        assert torch.equal(out[0], out[1])
+
+
+def test_fused_pass_400mp_equals_apply_plus_compose_and_forced_routes(monkeypatch):
+    """BASELINE.json's headline scene at full size: the fused route, its forced exact route and the apply + compose
+    route give the same 1.2 GB raster."""
+    rows = cols = 20000
+    pitch = 20032
+    q = synth.q_tables()
+    with S.Context(0, timing=True) as c:
+        d = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+        for k in range(2):
+            c.dev_synth_scene_u16(synth.SEED_SCENE_A, k, q, rows, cols, 0, rows, d[k].data_ptr(), pitch)
+        def run():
+            rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+            c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
+            return rgb.view(rows, pitch, 3)[:, :cols]
+        fused = run()
+        rep = c.fused_report()
+        assert rep["spec_ok"] == 1 and rep["verdict"] == 0, rep  # the headline scene: the speculative pass's RGB stood
+        monkeypatch.setenv("SARPRO_HIP_FUSED_FORCE", "nospec")
+        assert torch.equal(fused, run())
+        monkeypatch.setenv("SARPRO_HIP_FUSED_FORCE", "mispredict")
+        assert torch.equal(fused, run())
+        monkeypatch.delenv("SARPRO_HIP_FUSED_FORCE")
+        monkeypatch.setenv("SARPRO_HIP_NO_FUSED_CLAHE", "1")
+        assert torch.equal(fused, run())
