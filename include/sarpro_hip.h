@@ -91,6 +91,10 @@ typedef struct sarpro_hip_ctx sarpro_hip_ctx;
  * idle for the ~30 us a host round trip per scene costs.  Every other call stays synchronous.  The reference's
  * functions are synchronous: this is an opt-in for callers that keep rasters in HBM. */
 #define SARPRO_HIP_CTX_ASYNC_DEV 2u
+/* Dual-pol CLAHE -> synRGB of a whole scene through the fused pass (csrc/fused_kernels.hip): both DN rasters in, RGB out in
+ * one sweep, 11 instead of 15 B/px of HBM traffic per scene, same raster.  Off by default: on MI355X the pass is bound by
+ * instruction issue, not by HBM, and a scene takes ~10 % longer than through the apply + compose passes. */
+#define SARPRO_HIP_CTX_FUSED_CLAHE 4u
 int sarpro_hip_ctx_create(int device, unsigned flags, sarpro_hip_ctx **ctx_out);
 void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx);
 const char *sarpro_hip_last_error(const sarpro_hip_ctx *ctx); /* ctx may be NULL: last ctx_create error */
@@ -252,6 +256,8 @@ typedef struct {
     uint64_t queued[4];    /* uncertain pixels queued per pass (sample, speculative, histogram, final) */
     uint32_t overflowed[4];/* workgroups whose queue overflowed per pass (their share was redone exactly) */
     uint64_t dbg[8];       /* builds with -DFUSED_DIAG: origin of the queued pixels (interior / extrapolating cells, ...) */
+    double cum_est[2];     /* the sample's estimate of n_lt[0], n_lt[1] (invalid pixels included) */
+    uint64_t total_px;     /* pixels per band */
 } sarpro_hip_fused_report;
 int sarpro_hip_ctx_fused_report(sarpro_hip_ctx *ctx, sarpro_hip_fused_report *out);
 

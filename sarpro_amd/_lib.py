@@ -149,7 +149,7 @@ _proto("sarpro_hip_ctx_time_only", _i, _vp, C.c_char_p)
 
 class FusedReport(C.Structure):
     _fields_ = [("spec_ok", C.c_uint32), ("direct", C.c_uint32), ("verdict", C.c_uint32), ("floor_pred", C.c_int32),
-                ("n_lt", C.c_uint64 * 2), ("queued", C.c_uint64 * 4), ("overflowed", C.c_uint32 * 4), ("dbg", C.c_uint64 * 8)]
+                ("n_lt", C.c_uint64 * 2), ("queued", C.c_uint64 * 4), ("overflowed", C.c_uint32 * 4), ("dbg", C.c_uint64 * 8), ("cum_est", C.c_double * 2), ("total_px", C.c_uint64)]
 
 
 _proto("sarpro_hip_ctx_fused_report", _i, _vp, C.POINTER(FusedReport))

@@ -45,10 +45,11 @@ def _vp(a):
 class Context:
     """One sarpro_hip_ctx: a device, a stream, a grow-only workspace.  One per host thread."""
 
-    def __init__(self, device: int = 0, timing: bool = False, async_dev: bool = False):
+    def __init__(self, device: int = 0, timing: bool = False, async_dev: bool = False, fused_clahe: bool = False):
         h = C.c_void_p()
         # async_dev: SARPRO_HIP_CTX_ASYNC_DEV -- dev_dualpol_synrgb_u16 returns once enqueued; call synchronize()
-        rc = lib.sarpro_hip_ctx_create(device, (1 if timing else 0) | (2 if async_dev else 0), C.byref(h))
+        # fused_clahe: SARPRO_HIP_CTX_FUSED_CLAHE -- dual-pol CLAHE -> synRGB through the one-sweep fused pass (same raster)
+        rc = lib.sarpro_hip_ctx_create(device, (1 if timing else 0) | (2 if async_dev else 0) | (4 if fused_clahe else 0), C.byref(h))
         if rc != _lib.OK:
             raise SarproHipError(rc, (lib.sarpro_hip_last_error(None) or b"").decode())
         self._h = h
@@ -94,7 +95,7 @@ class Context:
         r = FusedReport()
         self._chk(lib.sarpro_hip_ctx_fused_report(self._h, C.byref(r)))
         return {"spec_ok": int(r.spec_ok), "direct": int(r.direct), "verdict": int(r.verdict), "floor_pred": int(r.floor_pred),
-                "n_lt": [int(x) for x in r.n_lt], "queued": [int(x) for x in r.queued], "overflowed": [int(x) for x in r.overflowed], "dbg": [int(x) for x in r.dbg]}
+                "n_lt": [int(x) for x in r.n_lt], "queued": [int(x) for x in r.queued], "overflowed": [int(x) for x in r.overflowed], "cum_est": [float(x) for x in r.cum_est], "total_px": int(r.total_px)}
 
     def time_only(self, kernel_name=None):
         """Bracket only this kernel with events (None: every kernel); see sarpro_hip_ctx_time_only."""

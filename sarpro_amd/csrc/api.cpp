@@ -165,9 +165,22 @@ extern "C" int sarpro_hip_ctx_fused_report(sarpro_hip_ctx *ctx, sarpro_hip_fused
     HIPCHK(ctx, hipMemcpyAsync(buf.data(), ctx->fused_state.p, buf.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const sarpro::FusedState *fs = reinterpret_cast<const sarpro::FusedState *>(buf.data());
+    if (getenv("SARPRO_HIP_FUSED_DIAG_DUMP")) { fprintf(stderr, "[fused diag] queued per workgroup (speculative pass):"); for (int k = 0; k < 256; ++k) fprintf(stderr, " %u", fs->qcount[1][k] & 0x7FFFFFFFu); fprintf(stderr, "\n"); }
     out->spec_ok = fs->spec_ok; out->direct = fs->direct; out->verdict = fs->verdict; out->floor_pred = fs->floor_pred;
     out->n_lt[0] = fs->n_lt[0]; out->n_lt[1] = fs->n_lt[1];
     for (int k = 0; k < 8; ++k) out->dbg[k] = fs->dbg[k];
+    {
+        out->total_px = fs->total_px;
+        double inv = 0.0; // k_fused_predict adds the invalid pixels (level 0 in both bands) to its estimate
+        std::vector<unsigned char> sb(2 * sizeof(sarpro::ChainBandState));
+        if (ctx->chain_state.p && hipMemcpy(sb.data(), ctx->chain_state.p, sb.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            const sarpro::ChainBandState *st = reinterpret_cast<const sarpro::ChainBandState *>(sb.data());
+            for (int b = 0; b < 2; ++b) inv += (double)out->total_px - (double)st[b].stats.valid_count;
+        }
+        const int f = fs->floor_pred;
+        out->cum_est[0] = (f >= 1 && f <= 31) ? fs->cum_est[f - 1] + inv : 0.0;
+        out->cum_est[1] = (f >= 0 && f <= 30) ? fs->cum_est[f] + inv : 0.0;
+    }
     if (getenv("SARPRO_HIP_FUSED_DIAG_DUMP")) for (uint32_t k = 0; k < std::min(fs->dbg_n, 64u); ++k) { const uint32_t *o = fs->dbg_samples[k]; { float f[5]; memcpy(f, o + 2, 20); fprintf(stderr, "[fused diag] r %u c %u entry %.6f %.6f %.6f %.6f dy %.6f addr %u\n", o[0], o[1], f[0], f[1], f[2], f[3], f[4], o[7]); } }
     for (int m = 0; m < 4; ++m)
         for (int k = 0; k < sarpro::kFusedMaxGrid; ++k) {
@@ -282,6 +295,7 @@ static void build_fused_pieces(StripePlan *P, int grid) {
             size_t nch = (c1 - cstart + 255) / 256, off = 0;
             while (nch > 0) {
                 int lg = 4;
+                if (const char *e = getenv("SARPRO_HIP_FUSED_MAXG")) lg = std::min(4, std::max(0, atoi(e))); // experiment: widest strip = 2^lg wave columns
                 while ((size_t(1) << lg) > nch) --lg;
                 const size_t gw = size_t(1) << lg;
                 Strip st{};
@@ -328,6 +342,16 @@ static void build_fused_pieces(StripePlan *P, int grid) {
         }
     }
     for (int i = 1; i <= grid; ++i) P->fused_first[(size_t)i] = std::max(P->fused_first[(size_t)i], P->fused_first[(size_t)i - 1]);
+    P->fused_qoff.assign((size_t)grid + 1, 0u);
+    for (int w = 0; w < grid; ++w) {
+        double need = 0.0;
+        for (int i = P->fused_first[(size_t)w]; i < P->fused_first[(size_t)w + 1]; ++i) {
+            const FusedItem &it = P->fused_items[(size_t)i];
+            need += (double)(it.r1 - it.r0) * (double)(it.c1 - it.c0) * ((it.flags & 1) ? kFusedQueueRateEdge : kFusedQueueRateInner);
+        }
+        const uint32_t cap = (uint32_t)std::min(need + (double)kFusedQueueMin, 16.0e6);
+        P->fused_qoff[(size_t)w + 1] = P->fused_qoff[(size_t)w] + (cap + 63u) / 64u * 64u;
+    }
 }
 
 int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,
@@ -396,9 +420,21 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_fused_items, P->fused_items.data(), P->fused_items.size() * sizeof(FusedItem));
     if (!rc) rc = upload_vec(ctx, P->d_fused_first, P->fused_first.data(), P->fused_first.size() * sizeof(int32_t));
+    if (!rc) rc = upload_vec(ctx, P->d_fused_qoff, P->fused_qoff.data(), P->fused_qoff.size() * sizeof(uint32_t));
     if (!rc && P->fused_grid > 0) {
+        // f32 row weights; the last mantissa bit carries the level of a saturated pixel in this row of an extrapolating
+        // cell (fused_kernels.hip header): 1 <=> fl(fl(1 - dy) + dy) >= 1.0 <=> level 255, 0 <=> level 254
         std::vector<float> wf(g.row_w.size());
-        for (size_t i = 0; i < wf.size(); ++i) wf[i] = (float)g.row_w[i].d;
+        for (size_t i = 0; i < wf.size(); ++i) {
+            const double dy = g.row_w[i].d;
+            const volatile double t1 = 1.0 - dy;
+            const volatile double o = t1 + dy;
+            uint32_t bits;
+            const float f = (float)dy;
+            memcpy(&bits, &f, 4);
+            bits = (bits & ~1u) | (o >= 1.0 ? 1u : 0u);
+            memcpy(&wf[i], &bits, 4);
+        }
         rc = upload_vec(ctx, P->d_row_wf, wf.data(), wf.size() * sizeof(float));
         wf.resize(g.col_w.size());
         for (size_t i = 0; i < wf.size(); ++i) wf[i] = (float)g.col_w[i].d;
@@ -950,7 +986,7 @@ static int job_run_fused(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px) {
     const int grid = P->fused_grid;
     if (!ctx->fused_ready) { HIPCHK(ctx, fused_configure()); ctx->fused_ready = true; }
     HIPCHK(ctx, ctx->fused_state.reserve(sizeof(FusedState)));
-    HIPCHK(ctx, ctx->fused_queue.reserve(sizeof(uint4) * kFusedQueueCap * (size_t)grid));
+    HIPCHK(ctx, ctx->fused_queue.reserve(sizeof(uint4) * std::max<size_t>(P->fused_qoff.back(), 64)));
     if (!ctx->fused_hist3.p) { // zeroed once: its last reader (k_fused_predict) leaves it zeroed
         HIPCHK(ctx, ctx->fused_hist3.reserve(sizeof(uint32_t) * kFusedHist3Words));
         HIPCHK(ctx, hipMemsetAsync(ctx->fused_hist3.p, 0, sizeof(uint32_t) * kFusedHist3Words, ctx->stream));
@@ -977,13 +1013,14 @@ static int job_run_fused(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px) {
     a.fs = ctx->fused_state.as<FusedState>();
     a.tables = ctx->tables.as<uint8_t>();
     a.queue = ctx->fused_queue.as<uint4>();
+    a.qoff = P->d_fused_qoff.as<uint32_t>();
     a.hist3 = ctx->fused_hist3.as<uint32_t>();
     a.dump = ctx->spec_dump.as<uint8_t>();
     a.level_hist = ctx->level_hist.as<unsigned long long>();
-    a.sample_stride = 32;
+    // sample pass: every 32nd step of a full-size scene, denser on small rasters (a step is 1..16 rows)
+    a.sample_stride = (uint32_t)std::min<size_t>(32, std::max<size_t>(1, J.rows_total / 600));
     if (const char *e = getenv("SARPRO_HIP_FUSED_SAMPLE")) a.sample_stride = (uint32_t)std::max(1, atoi(e));
     a.force = force;
-    a.qcap = kFusedQueueCap;
     {
         KernelTimer t(ctx, "fused_prep");
         FusedPrepArgs pa{};
@@ -1086,10 +1123,12 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
                                       J.nbands, ctx->stream));
     }
-    // dual-pol RGB of a whole scene: the fused pass, no level rasters (per-band u8 copies, row stripes and the
-    // cross-check switches keep the apply + compose passes below)
+    // dual-pol RGB of a whole scene, opt-in (SARPRO_HIP_CTX_FUSED_CLAHE / SARPRO_HIP_FUSED_CLAHE=1): the fused pass, 7 B/px and no
+    // level rasters.  Measured on MI355X it is instruction-issue bound and ~10 % SLOWER per scene than the apply + compose passes
+    // below, which therefore stay the default; it moves 11 instead of 15 B/px over HBM.
     if (J.synrgb && J.nbands == 2 && !J.reduce && !d_out[0] && !d_out[1] && d_rgb && rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb) &&
-        J.plan->fused_grid > 0 && !getenv("SARPRO_HIP_NO_FUSED_CLAHE") && !getenv("SARPRO_HIP_NO_SPEC") && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) {
+        J.plan->fused_grid > 0 && ((ctx->flags & SARPRO_HIP_CTX_FUSED_CLAHE) || getenv("SARPRO_HIP_FUSED_CLAHE")) && !getenv("SARPRO_HIP_NO_SPEC") &&
+        !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) {
         RETCHK(job_run_fused(J, d_rgb, rgb_pitch_px));
         return chain_tail(J, stats_out, d_state);
     }

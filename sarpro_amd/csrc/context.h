@@ -64,11 +64,12 @@ struct StripePlan {
     // fused CLAHE pass (whole scene, vecw == 8): every workgroup's pieces, balanced by cost
     std::vector<FusedItem> fused_items;
     std::vector<int32_t> fused_first; // [fused_grid + 1]
+    std::vector<uint32_t> fused_qoff; // [fused_grid + 1]: each workgroup's slice of the queue of uncertain pixels
     int fused_grid = 0;
-    DevBuf d_fused_items, d_fused_first, d_row_wf, d_col_wf; // ... and the blend weights rounded to f32
+    DevBuf d_fused_items, d_fused_first, d_fused_qoff, d_row_wf, d_col_wf; // ... and the blend weights rounded to f32
     int refs = 0; // open stripe handles that hold this plan (the cache never evicts those)
     void release_all() {
-        d_fused_items.release(); d_fused_first.release(); d_row_wf.release(); d_col_wf.release();
+        d_fused_items.release(); d_fused_first.release(); d_fused_qoff.release(); d_row_wf.release(); d_col_wf.release();
         d_hist_rects_tiled.release(); d_hist_rects_flat.release(); d_apply_rects.release();
         d_hist_sliver_tiled.release(); d_hist_sliver_flat.release(); d_apply_sliver.release();
         d_row_w.release(); d_col_w.release();

@@ -21,8 +21,11 @@ static_assert(sizeof(FusedItem) == 48, "FusedItem layout");
 
 enum FusedMode { kFusedSample = 0, kFusedSpec = 1, kFusedHist = 2, kFusedFinal = 3 };
 constexpr int kFusedMaxGrid = 1024;
-constexpr uint32_t kFusedQueueCap = 65536;  // entries per workgroup (16 B each): ~0.3 % of a share's pixels are queued, ~4 % in the
-                                            // extrapolating cells; a queue that still overflows has its share redone by the fixup
+// queue capacity per workgroup (entries of 16 B), sized by the planner from the share's pixels: ~0.3 % of the pixels of an
+// interior cell are uncertain, but in an extrapolating cell every pixel of a saturated bin is (its level is 254 or 255
+// depending on the rounding of the weights) -- up to ~10 % in bright regions
+constexpr double kFusedQueueRateInner = 0.015, kFusedQueueRateEdge = 0.16;
+constexpr uint32_t kFusedQueueMin = 4096;    // a queue that still overflows has its share redone by the fixup
 // test switches (FusedArgs::force, from SARPRO_HIP_FUSED_FORCE)
 constexpr uint32_t kFusedForceNoSpec = 1u;      // preconditions "fail": histogram pass + exact tables + final pass
 constexpr uint32_t kFusedForceMispredict = 2u;  // predicted floor + 1: the verification must refute it
@@ -42,6 +45,7 @@ struct FusedState { // device memory, one per context; reset by k_fused_prep
     double cum_est[32];                // predicted cumulative count of band-pixels with level <= l (k_fused_predict)
     double unsampled;                  // valid pixels of strata the sample never hit
     uint32_t predict_done, pad1;
+    unsigned long long total_px;       // pixels per band of the scene
     unsigned long long dbg[8];         // diagnostics of the fixup (speculative pass): see sarpro_hip_fused_report
     uint32_t dbg_n, dbg_pad; uint32_t dbg_samples[64][8];
     uint32_t qcount[4][kFusedMaxGrid]; // per pass and workgroup: queued (uncertain) pixels; bit 31: the queue overflowed
@@ -62,13 +66,13 @@ struct FusedArgs {
     int32_t row_off;
     FusedState *fs;
     const uint8_t *tables;              // R2[256] | G2[256] | B2[65536]
-    uint4 *queue;                       // [grid][kFusedQueueCap] (row, column, DN1 | DN2 << 16, -) of the uncertain pixels
+    uint4 *queue;                       // (row, column, DN1 | DN2 << 16, -) of the uncertain pixels, workgroup w owns [qoff[w], qoff[w+1])
+    const uint32_t *qoff;               // [grid + 1]
     uint32_t *hist3;                    // sample pass: [2][64][256][32] sampled level counts per (band, tile, CLAHE bin)
     uint8_t *dump;                      // kSpecDumpBytes of write-only scratch
     unsigned long long *level_hist;     // [2][256], histogram pass (bin 0 stays implied)
     uint32_t sample_stride;             // sample pass: every sample_stride-th step
     uint32_t force;
-    uint32_t qcap;
 };
 
 struct FusedPrepArgs {
