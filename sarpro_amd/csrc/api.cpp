@@ -387,19 +387,33 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
         const int ids[4] = {0, 0, 0, 0};
         add_rects(P->hist_rects_flat, split ? &P->hist_sliver_flat : nullptr, *P, 0, rows_total, 0, cols, ids, chunk_rows, vecw);
     }
-    for (size_t ri = 0; ri + 1 < g.row_cell_start.size(); ++ri) {
-        const size_t r0 = g.row_cell_start[ri], r1 = g.row_cell_start[ri + 1];
+    // interpolation cells = ranges of constant (t0, t1), cut again where the weight changes sign: the first half tile
+    // extrapolates (d < 0, autoscale.rs:308-313) and takes the speculative kernel's wider margin, the half tile after it has the
+    // same tiles but d >= 0 and takes the interior margin (uncut, a third of the scene ran with the wide one)
+    auto sign_cuts = [](const std::vector<size_t> &starts, const std::vector<RowWeight> &w) {
+        std::vector<size_t> out;
+        for (size_t i = 0; i + 1 < starts.size(); ++i) {
+            out.push_back(starts[i]);
+            for (size_t k = starts[i] + 1; k < starts[i + 1]; ++k)
+                if ((w[k - 1].d < 0.0) != (w[k].d < 0.0)) out.push_back(k);
+        }
+        out.push_back(starts.empty() ? 0 : starts.back());
+        return out;
+    };
+    const std::vector<size_t> rcells = sign_cuts(g.row_cell_start, g.row_w), ccells = sign_cuts(g.col_cell_start, g.col_w);
+    for (size_t ri = 0; ri + 1 < rcells.size(); ++ri) {
+        const size_t r0 = rcells[ri], r1 = rcells[ri + 1];
+        if (r0 >= r1) continue;
         const RowWeight &rw = g.row_w[r0];
-        for (size_t ci = 0; ci + 1 < g.col_cell_start.size(); ++ci) {
-            const size_t c0 = g.col_cell_start[ci], c1 = g.col_cell_start[ci + 1];
+        for (size_t ci = 0; ci + 1 < ccells.size(); ++ci) {
+            const size_t c0 = ccells[ci], c1 = ccells[ci + 1];
+            if (c0 >= c1) continue;
             const RowWeight &cw = g.col_w[c0];
             const int ids[4] = {rw.t0 * kTiles + cw.t0, rw.t0 * kTiles + cw.t1, rw.t1 * kTiles + cw.t0,
                                 rw.t1 * kTiles + cw.t1};
-            // bit 0: the cell holds negative blend weights (dy < 0 or dx < 0: the first half tile extrapolates,
-            // autoscale.rs:308-313) -- the speculative apply kernel widens its f32 error margin there
-            bool neg = false;
-            for (size_t r = r0; r < r1 && !neg; ++r) neg = g.row_w[r].d < 0.0;
-            for (size_t c = c0; c < c1 && !neg; ++c) neg = g.col_w[c].d < 0.0;
+            // bit 0: the cell holds negative blend weights (dy < 0 or dx < 0) -- the speculative apply kernel widens its f32
+            // error margin there
+            const bool neg = rw.d < 0.0 || cw.d < 0.0;
             add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw, neg ? 1 : 0);
         }
     }

@@ -442,16 +442,16 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //       |y32 - y| <= 255 (|1-dy| + |dy|) (8u + 3u*2) + u |y|  <=  255*2*14u + 1020u  =  4.9e-4.
 //     In interior cells (every weight in [0,1], weight pairs sum to 1, |top| <= 1) the same four terms are <= u each:
 //       |dtop| <= 4u, |y32 - y| <= 255 (4u + 3u) + 255u = 255*8u = 1.2e-4.
-//     The margin is therefore chosen per work item: kSpecDeltaEdge = 1/512 = 1.95e-3 where the cell
-//     extrapolates (first half tile row / column), kSpecDeltaInner = 1/2048 = 4.9e-4 elsewhere --
-//     4x the respective worst case.  Outside the margin floor(y32) = floor(y), inside it the exact
+//     The margin is therefore chosen per work item: kSpecDeltaEdge = 1/1024 = 9.8e-4 where the cell
+//     extrapolates (first half tile row / column), kSpecDeltaInner = 1/4096 = 2.4e-4 elsewhere --
+//     2x the respective worst case (round 1 ran with 4x: twice as many pixels on the exact path).  Outside the margin floor(y32) = floor(y), inside it the exact
 //     path decides.  The reference's own f64 rounding (1e-13) is far below it.
 //     All-zero and all-one CDF entries, whose exact results are known, get biased f32 entries that land
 //     mid-interval (see the staging code), so they never reach the exact path.
 //     Level 0 goes to a per-lane dummy histogram word (bin 0 = pixels - other bins): a shared word would
 //     serialise the no-data wedge (measured: +7 % on the whole kernel).
 // ------------------------------------------------------------------------------------
-constexpr float kSpecDeltaEdge = 1.0f / 512.0f, kSpecDeltaInner = 1.0f / 2048.0f;
+constexpr float kSpecDeltaEdge = 1.0f / 1024.0f, kSpecDeltaInner = 1.0f / 4096.0f;
 constexpr uint32_t kPartialHistLevels = 64; // partial level histogram: levels below this are counted one by one
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
