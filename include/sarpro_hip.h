@@ -16,6 +16,12 @@
  *   - host entry points take HOST pointers (pageable or pinned) and are synchronous;
  *     `_dev` entry points take DEVICE pointers (+ pitch in elements) and run on the
  *     context's stream; they return after the result is complete on the device
+ *   - STREAM ORDERING of `_dev` entry points: they run on the context's own hipStreamNonBlocking stream
+ *     (sarpro_hip_ctx_stream), which is NOT ordered against any other stream, the NULL stream included.  The caller
+ *     must order that stream behind the producers of its input rasters and behind earlier users of its output
+ *     rasters -- hipStreamWaitEvent(sarpro_hip_ctx_stream(ctx), event recorded on the producer's stream), or a
+ *     device / stream synchronisation before the call -- and order consumers behind the context's stream the same
+ *     way unless the call was synchronous (every call is, except on a SARPRO_HIP_CTX_ASYNC_DEV context)
  *   - one context per host thread; contexts are independent (no global state)
  *   - nothing here falls back to a CPU implementation: without a usable HIP device
  *     ctx_create fails with SARPRO_HIP_ERR_NO_DEVICE

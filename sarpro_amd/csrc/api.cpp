@@ -1825,6 +1825,7 @@ extern "C" int sarpro_hip_stripe_begin_u16(sarpro_hip_ctx *ctx, const uint16_t *
     timing_reset(ctx);
     int rc = job_init(J);
     if (rc) { delete s; return rc; }
+    J.plan->refs += 1; // the plan cache never evicts a plan an open stripe handle works on
     *out = s;
     return SARPRO_HIP_OK;
 }
@@ -1872,7 +1873,11 @@ extern "C" int sarpro_hip_stripe_phase4(sarpro_hip_stripe *s, uint8_t *d_rgb, si
     return SARPRO_HIP_OK;
 }
 
-extern "C" void sarpro_hip_stripe_end(sarpro_hip_stripe *s) { delete s; }
+extern "C" void sarpro_hip_stripe_end(sarpro_hip_stripe *s) {
+    if (!s) return;
+    if (s->job.plan && s->job.plan->refs > 0) s->job.plan->refs -= 1;
+    delete s;
+}
 
 // One call per rank for one row stripe of a scene, reductions over the library's RCCL communicator
 // (sarpro_hip_comm_init): the device-resident chains run unchanged with three (CLAHE) or one (percentile

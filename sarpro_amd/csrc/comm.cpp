@@ -2,6 +2,7 @@
 // librccl is loaded lazily (dlopen) so single-GPU users never pay for it.  The only
 // collective the path needs is all-reduce(sum) over small u64 histogram buffers.
 #include <dlfcn.h>
+#include <rccl/rccl.h> // types and enums from RCCL's own header (the library itself is dlopen'ed: no link dependency)
 
 #include <cstring>
 #include <string>
@@ -9,25 +10,27 @@
 #include "internal.h"
 
 namespace {
-struct NcclUniqueId { char internal[128]; };
-using ncclComm_t = void *;
-enum { ncclSuccess = 0 };
-enum { ncclUint64 = 5 }; // ncclDataType_t
-enum { ncclSum = 0 };    // ncclRedOp_t
+static_assert(sizeof(ncclUniqueId) == 128, "sarpro_hip_comm_unique_id hands out 128 bytes");
 
 struct Rccl {
     void *lib = nullptr;
-    int (*GetUniqueId)(NcclUniqueId *) = nullptr;
-    int (*CommInitRank)(ncclComm_t *, int, NcclUniqueId, int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
 bool load_rccl(Rccl *r, std::string *err) {
     static Rccl cached;
     if (!cached.lib) {
-        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        // A process that already maps an RCCL (a torch process maps torch/lib/librccl.so) must not get a second instance: two
+        // RCCLs in one process each bootstrap their own transport state.  RTLD_NOLOAD returns the mapped one, by either name;
+        // ncclAllReduce already resolvable in the global scope means the same.  Only then load the system library.
+        void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib && dlsym(RTLD_DEFAULT, "ncclAllReduce")) lib = dlopen(nullptr, RTLD_NOW);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) { *err = std::string("cannot load librccl: ") + dlerror(); return false; }
         Rccl t;
@@ -54,7 +57,7 @@ extern "C" int sarpro_hip_comm_unique_id(uint8_t uid_out[128]) {
     Rccl r;
     std::string err;
     if (!load_rccl(&r, &err)) return SARPRO_HIP_ERR_RCCL;
-    NcclUniqueId id;
+    ncclUniqueId id;
     if (r.GetUniqueId(&id) != ncclSuccess) return SARPRO_HIP_ERR_RCCL;
     std::memcpy(uid_out, id.internal, 128);
     return SARPRO_HIP_OK;
@@ -66,10 +69,10 @@ extern "C" int sarpro_hip_comm_init(sarpro_hip_ctx *ctx, int nranks, int rank, c
     Rccl r;
     if (!load_rccl(&r, &ctx->err)) return SARPRO_HIP_ERR_RCCL;
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return SARPRO_HIP_ERR_HIP; }
-    NcclUniqueId id;
+    ncclUniqueId id;
     std::memcpy(id.internal, uid, 128);
     ncclComm_t comm = nullptr;
-    int rc = r.CommInitRank(&comm, nranks, id, rank);
+    ncclResult_t rc = r.CommInitRank(&comm, nranks, id, rank);
     if (rc != ncclSuccess) {
         ctx->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
         return SARPRO_HIP_ERR_RCCL;
@@ -87,7 +90,7 @@ int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t co
     if (!d_buf) return SARPRO_HIP_ERR_INVALID_ARG;
     Rccl r;
     if (!load_rccl(&r, &ctx->err)) return SARPRO_HIP_ERR_RCCL;
-    int rc = r.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, ctx->comm, ctx->stream);
+    ncclResult_t rc = r.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, static_cast<ncclComm_t>(ctx->comm), ctx->stream);
     if (rc != ncclSuccess) {
         ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
         return SARPRO_HIP_ERR_RCCL;
@@ -108,6 +111,6 @@ extern "C" void sarpro_hip_comm_destroy(sarpro_hip_ctx *ctx) {
     if (!ctx || !ctx->comm) return;
     Rccl r;
     std::string err;
-    if (load_rccl(&r, &err)) r.CommDestroy(ctx->comm);
+    if (load_rccl(&r, &err)) r.CommDestroy(static_cast<ncclComm_t>(ctx->comm));
     ctx->comm = nullptr;
 }

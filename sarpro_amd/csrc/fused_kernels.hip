@@ -743,10 +743,10 @@ __global__ __launch_bounds__(kFixupThreads) void k_fused_fixup(FusedArgs a, unsi
 // ------------------------------------------------------------------------------------
 hipError_t fused_configure() {
     hipError_t e;
-#define CFG(K) if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsTotal)) != hipSuccess) return e
-    CFG(k_fused_main<kFusedSample>); CFG(k_fused_main<kFusedSpec>); CFG(k_fused_main<kFusedHist>); CFG(k_fused_main<kFusedFinal>);
-#undef CFG
-    return hipSuccess;
+    if ((e = opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_fused_main<kFusedSample>))) != hipSuccess) return e;
+    if ((e = opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_fused_main<kFusedSpec>))) != hipSuccess) return e;
+    if ((e = opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_fused_main<kFusedHist>))) != hipSuccess) return e;
+    return opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_fused_main<kFusedFinal>));
 }
 
 hipError_t launch_fused_prep(const FusedPrepArgs &a, hipStream_t s) {

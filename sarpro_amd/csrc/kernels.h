@@ -121,6 +121,8 @@ hipError_t launch_hist256_u8(const uint8_t *in, size_t pitch, uint32_t rows, uin
                              unsigned long long *hist, hipStream_t s);
 
 size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands);
+// more than the default 64 KiB of dynamic LDS for `kernel` on the CURRENT device: once per (device, kernel), thread-safe, checked
+hipError_t opt_in_dynamic_lds(const void *kernel);
 constexpr uint32_t kLutLdsMaxBytes = 48 * 1024; // per-band window budget in LDS
 
 } // namespace sarpro

@@ -11,7 +11,10 @@
 #include "chain_kernels.h"
 
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 namespace sarpro {
 
@@ -1207,8 +1210,22 @@ hipError_t launch_lut_apply_u16(const LutApplyArgs &a, bool vec, bool out16, hip
     return hipGetLastError();
 }
 
+hipError_t opt_in_dynamic_lds(const void *kernel) {
+    static std::mutex m;
+    static std::set<std::pair<int, const void *>> done; // the attribute is per device: the batch driver runs one thread per GPU
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(m);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
+}
+
 hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s) {
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
+    if (hipError_t e = opt_in_dynamic_lds(vec == 16 ? reinterpret_cast<const void *>(k_compose_u8<16>) : reinterpret_cast<const void *>(k_compose_u8<1>))) return e; // ~115 KiB
     const uint64_t items = (uint64_t)a.rows * ((a.cols + vec - 1) / vec);
     dim3 grid(stream_grid(items, kComposeBlock, 2));
     if (vec == 16) hipLaunchKernelGGL(k_compose_u8<16>, grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
@@ -1225,12 +1242,7 @@ hipError_t launch_lut_compose_u16(const LutComposeArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
     const size_t lds = a.dev_state ? (size_t)kComposeTableBytes + kComposeStageBytes + 2 * (size_t)a.lut_cap
                                    : (size_t)kComposeTableBytes + kComposeStageBytes + ((a.win_hi[0] + 16) & ~15u) + ((a.win_hi[1] + 16) & ~15u);
-    static bool attr_set = false;
-    if (!attr_set) { // more than the default 64 KiB of dynamic LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lut_compose_u16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_compose_u8<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_lut_compose_u16))) return e;
     const uint64_t items = (uint64_t)a.rows * ((a.cols + 15) / 16);
     hipLaunchKernelGGL(k_lut_compose_u16, dim3(stream_grid(items, kComposeBlock, 1)), dim3(kComposeBlock), lds, s, a);
     return hipGetLastError();

@@ -18,6 +18,6 @@ struct ResizePassArgs {
 
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s);
 hipError_t launch_resize_v(const ResizePassArgs &a, int elem_size, hipStream_t s);
-constexpr size_t kResizeRowLdsMax = 64 * 1024; // one source row must fit in (default-limit) dynamic LDS
+constexpr size_t kResizeRowLdsMax = 160 * 1024; // a source row up to this size is staged in LDS; longer rows read their taps from memory
 
 } // namespace sarpro

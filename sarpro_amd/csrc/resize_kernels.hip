@@ -3,6 +3,7 @@
 // `fast_image_resize` crate the reference calls (resize.rs:32-89).  Horizontal pass into an integer
 // intermediate, then vertical pass.  Both passes are bound by reading their input once from HBM.
 #include "resize_kernels.h"
+#include "kernels.h"
 
 namespace sarpro {
 namespace {
@@ -11,14 +12,19 @@ constexpr int kBlock = 256;
 
 // Horizontal pass: one block per source row; the row is staged in LDS, then each thread produces
 // output pixels ox = t, t+256, ... (coefficients tap-major: lanes over ox read consecutive words).
-template <typename T, typename Acc>
+// STAGE = false: rows too long for LDS (the reference's resize takes any width, resize.rs:32-89) read the taps from memory.
+template <typename T, typename Acc, bool STAGE>
 __global__ __launch_bounds__(kBlock) void k_resize_h(ResizePassArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    T *row = reinterpret_cast<T *>(lds_raw);
     const uint32_t r = blockIdx.x;
     const T *__restrict__ src = reinterpret_cast<const T *>(a.src) + (size_t)r * a.src_pitch;
-    for (uint32_t x = threadIdx.x; x < a.in_size; x += kBlock) row[x] = src[x];
-    __syncthreads();
+    const T *row = src;
+    if (STAGE) {
+        T *lrow = reinterpret_cast<T *>(lds_raw);
+        for (uint32_t x = threadIdx.x; x < a.in_size; x += kBlock) lrow[x] = src[x];
+        __syncthreads();
+        row = lrow;
+    }
     T *__restrict__ dst = reinterpret_cast<T *>(a.dst) + (size_t)r * a.dst_pitch;
     const Acc initial = a.precision > 0 ? (Acc)1 << (a.precision - 1) : 0;
     for (uint32_t ox = threadIdx.x; ox < a.out_size; ox += kBlock) {
@@ -52,8 +58,16 @@ __global__ __launch_bounds__(kBlock) void k_resize_v(ResizePassArgs a) {
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s) {
     if (!rows || !a.out_size) return hipSuccess;
     const size_t lds = ((size_t)a.in_size * elem_size + 15) & ~(size_t)15;
-    if (elem_size == 1) hipLaunchKernelGGL((k_resize_h<uint8_t, int32_t>), dim3(rows), dim3(kBlock), lds, s, a);
-    else hipLaunchKernelGGL((k_resize_h<uint16_t, long long>), dim3(rows), dim3(kBlock), lds, s, a);
+    if (lds > kResizeRowLdsMax) {
+        if (elem_size == 1) hipLaunchKernelGGL((k_resize_h<uint8_t, int32_t, false>), dim3(rows), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_resize_h<uint16_t, long long, false>), dim3(rows), dim3(kBlock), 0, s, a);
+        return hipGetLastError();
+    }
+    const void *fn = elem_size == 1 ? reinterpret_cast<const void *>(k_resize_h<uint8_t, int32_t, true>) : reinterpret_cast<const void *>(k_resize_h<uint16_t, long long, true>);
+    if (lds > 64 * 1024)
+        if (hipError_t e = opt_in_dynamic_lds(fn)) return e;
+    if (elem_size == 1) hipLaunchKernelGGL((k_resize_h<uint8_t, int32_t, true>), dim3(rows), dim3(kBlock), lds, s, a);
+    else hipLaunchKernelGGL((k_resize_h<uint16_t, long long, true>), dim3(rows), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
 

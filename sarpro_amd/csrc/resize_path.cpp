@@ -104,7 +104,6 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
         return SARPRO_HIP_OK;
     }
     if (!nc || !nr) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "target size collapses a dimension to zero");
-    if (cols * elem_size > kResizeRowLdsMax) return fail(ctx, SARPRO_HIP_ERR_UNSUPPORTED_SHAPE, "source row too long for the LDS-staged horizontal pass");
     sx = (double)nc / (double)cols; sy = (double)nr / (double)rows; // resize.rs:168-169
     if (meta) { meta->scale_x = sx; meta->scale_y = sy; }
     // horizontal pass -> intermediate (rows x nc), vertical pass -> destination window

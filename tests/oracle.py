@@ -53,6 +53,31 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_lib_mt = None
+
+
+def lib_mt():
+    """Row-parallel variant of the headline path (oracle/sarpro_oracle_mt.c; OpenMP).  Not the reference's behaviour:
+    bench.py reports it next to the single-thread figure as 'what the host's cores would give'."""
+    global _lib_mt
+    if _lib_mt is None:
+        so = os.path.join(ORACLE_DIR, "libsarpro_oracle_mt.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("sarpro_oracle_mt.c", "sarpro_oracle.c")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libsarpro_oracle_mt.so"], stdout=subprocess.DEVNULL)
+        _lib_mt = C.CDLL(so)
+    return _lib_mt
+
+
+def dualpol_clahe_synrgb_mt(b1: np.ndarray, b2: np.ndarray):
+    b1 = np.ascontiguousarray(b1, np.float32)
+    b2 = np.ascontiguousarray(b2, np.float32)
+    rows, cols = b1.shape
+    rgb = np.empty((rows, cols, 3), np.uint8)
+    rc = lib_mt().sarpro_oracle_mt_dualpol_clahe_synrgb_f32(_p(b1), _p(b2), C.c_size_t(rows), C.c_size_t(cols), _p(rgb))
+    return rc, rgb
+
+
 def db_mask(x: np.ndarray):
     x = np.ascontiguousarray(x, np.float32)
     db = np.empty(x.shape, np.float64)
