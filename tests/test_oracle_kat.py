@@ -111,3 +111,89 @@ def test_resize_dimension_and_padding_rules():
     assert out.shape == (6, 10) and m["scale_x"] == 0.5 and m["scale_y"] == 0.5
     out, m = oracle.resize_image_data_with_meta(a, 100, False)   # target larger than the image: dimensions kept
     assert out.shape == (12, 20)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Hand-worked known answers (round 2).  Every expected number below was derived on paper from the Rust source
+# (/root/reference/src/core/processing), NOT printed from the oracle: they pin the restatement independently of
+# host_logic.cpp, which shares helper idioms with it.
+# ----------------------------------------------------------------------------------------------------------------------
+def test_clahe_clip_redistribute_remainder_worked_by_hand():
+    """autoscale.rs:271-302 on a 48 x 48 tile (2304 px): avg = 9.0, clip threshold = max(2.0 * 9.0, 1.0) = 18.0.
+    Bins above 18 are cut to 18 (a bin AT 18 is not `>` the threshold): excess = 982 + 482 + 2 + 38 = 1504;
+    add_per_bin = floor(1504 / 256) = 5; remainder = round(1504 - 1280) = 224 -> bins 0..223 get one more."""
+    h = np.zeros(256, np.uint32)
+    h[10], h[20], h[30], h[40], h[50] = 1000, 500, 20, 18, 17
+    h[100:199] = 7
+    h[199] = 56
+    assert int(h.sum()) == 2304
+    cdf = oracle.clahe_tile_cdf(h, 48, 48)
+    # final histogram by hand: empty bins 5 (+1 below 224) = 6 / 5; cut bins 18 + 5 + 1 = 24; bin 50: 17 + 5 + 1 = 23;
+    # bins 100..198: 7 + 5 + 1 = 13; total = 800 + 1280 + 224 = 2304 (this clip conserves the count)
+    cum = {0: 6, 9: 60, 10: 84, 19: 138, 20: 162, 30: 240, 40: 318, 49: 372, 50: 395, 99: 689, 198: 1976, 199: 2000, 223: 2144, 254: 2299, 255: 2304}
+    for b, c in cum.items():
+        assert cdf[b] == c / 2304.0, (b, cdf[b], c / 2304.0)
+
+
+def test_clahe_clip_truncation_loses_a_pixel_worked_by_hand():
+    """50 x 50 tile: avg = 9.765625, threshold = 19.53125; a bin of 1000 is cut to `19.53125 as u32` = 19 (truncation) while
+    excess takes 980.46875; add = floor(980.46875 / 256) = 3, remainder = round(212.46875) = 212: the total becomes 2499,
+    one pixel short -- the reference's non-conserving clip (autoscale.rs:278-283)."""
+    h = np.zeros(256, np.uint32)
+    h[7] = 1000
+    h[100:250] = 10
+    cdf = oracle.clahe_tile_cdf(h, 50, 50)
+    # bin 7: 19 + 3 + 1 = 23; bins 100..211: 14; 212..249: 13; empty: 4 below 212, 3 above
+    cum = {6: 28, 7: 51, 99: 419, 100: 433, 211: 1987, 212: 2000, 249: 2481, 250: 2484, 255: 2499}
+    for b, c in cum.items():
+        assert cdf[b] == c / 2499.0, (b, cdf[b] * 2499.0, c)
+    assert cdf[255] == 1.0
+
+
+def test_percentiles_worked_by_hand():
+    """autoscale.rs:103-140 with a span of exactly 4096 dB-units so that every bin is 1.0 wide: 1000 valid samples --
+    one at 0.0 (min), one at 4096.0 (max, lands in the capped last bin), 100 in bin 10, 400 in bin 20, 498 in bin 30.
+    target = floor(p * 1000); the percentile is bin_start + (target - cumsum) / h * 1.0."""
+    db = np.concatenate([[0.0], np.full(100, 10.25), np.full(400, 20.5), np.full(498, 30.75), [4096.0], [77.0, 99.0]])
+    mask = np.ones(db.size, np.uint8)
+    mask[-2:] = 0  # two invalid samples that must not count
+    s = oracle.stats(db, mask)
+    assert s.valid_count == 1000 and s.min_db == 0.0 and s.max_db == 4096.0
+    assert s.p01 == 10.0 + 9.0 / 100.0        # target 10, 1 sample before bin 10
+    assert s.p02 == 10.0 + 19.0 / 100.0
+    assert s.p05 == 10.0 + 49.0 / 100.0
+    assert s.p10 == 10.0 + 99.0 / 100.0       # target 100 is the last sample of bin 10 (cumsum 1 + 100 = 101)
+    assert s.p25 == 20.0 + 149.0 / 400.0      # target 250, 101 samples before bin 20
+    assert s.median_db == 20.0 + 399.0 / 400.0
+    assert s.p75 == 30.0 + 249.0 / 498.0      # target 750, 501 samples before bin 30
+    assert s.p90 == 30.0 + 399.0 / 498.0
+    assert s.p95 == 30.0 + 449.0 / 498.0
+    assert s.p98 == 30.0 + 479.0 / 498.0
+    assert s.p99 == 30.0 + 489.0 / 498.0
+
+
+def test_suppressed_floor_and_luts_worked_by_hand():
+    """synthetic_rgb.rs:92-156: combined histogram {0: 4, 1: 2, 2: 4, 100: 97, 200: 93}, total 200, target round(10.0) = 10;
+    cumulative 4, 6, 10 -> floor 2, cushion +3 -> 5.  LUT entries from a pocket calculator (f32 powf, far from .5):
+    lut_r[6] = round(0.004^1.15 * 255 = 0.446) = 0, lut_g[6] = round(0.587) = 1, lut_r[130] = round(114.91) = 115,
+    lut_g[130] = round(118.96) = 119, lut_r[200] = round(191.62) = 192, lut_g[100] = round(87.96) = 88,
+    blue(192, 88) = round((200 / 96)^0.1 * 255 * 0.18 = 49.40) = 49."""
+    b1 = np.array([0] * 4 + [2] * 3 + [200] * 93, np.uint8)
+    b2 = np.array([1] * 2 + [2] * 1 + [100] * 97, np.uint8)
+    r, g, b, fl = oracle.synrgb_luts(True, b1, b2)
+    assert fl == 5
+    assert not r[:6].any() and not g[:6].any()
+    assert (int(r[6]), int(g[6]), int(r[130]), int(g[130]), int(r[200]), int(g[100]), int(r[255]), int(g[255])) == (0, 1, 115, 119, 192, 88, 255, 255)
+    assert int(b[200, 100]) == 49
+    rgb = oracle.synrgb(0, 4, b1, b2).reshape(-1, 3)
+    assert rgb[0].tolist() == [0, 0, 0]          # (0, 1): both <= 5 -> water
+    assert rgb[99].tolist() == [192, 88, 49]     # (200, 100)
+    # (2, 2) is water too; (2, 100): R = lut_r[2] = 0, G = 88, blue of (0 + 8) / (88 + 8): (1/12)^0.1 * 45.9 = 35.80 -> 36
+    assert rgb[6].tolist() == [0, 88, 36]
+
+
+def test_scale_u16_to_u8_worked_by_hand():
+    """autoscale.rs:348-364 in f32: min 2, max 252 -> scale = 255 / 250 = 1.02; 2 -> 0, 252 -> 255, 127 -> round(127.5) = 128
+    (half away from zero), 3 -> round(1.02) = 1, 251 -> round(253.98) = 254."""
+    v = np.array([2, 252, 127, 3, 251], np.uint16)
+    assert oracle.scale_u16_to_u8(v).tolist() == [0, 255, 128, 1, 254]
