@@ -369,10 +369,16 @@ def secondary_records(ctx_main, torch, dev, rows, cols):
     del f
     ms_f32 = timed(lambda: ctx.dev_autoscale_band_f32(ratio.data_ptr(), rows, cols, cols, St.Clahe, Bd.U16, o16.data_ptr(), pitch, want_stats=False), n=3, warm=1)
     k_f32 = kernels()
+    # (ii) fused: the pol-op is computed from the u16 DN inside every pass of the f32 flavour, no f32 raster exists
+    ms_fused = timed(lambda: ctx.dev_polop_autoscale_band(Op.LogRatio, band[0].data_ptr(), band[1].data_ptr(), True, rows, cols, pitch, St.Clahe, Bd.U16,
+                                                          o16.data_ptr(), pitch, want_stats=False), n=3, warm=1)
+    k_fused = kernels()
     out["config3"] = {"what": "CLAHE u16 per band (i); log-ratio pol-op -> f32 band -> CLAHE u16 (ii); all resident in HBM",
                       "clahe_u16_per_band_ms": round(ms_band, 3), "clahe_u16_kernels_ms": k_band,
                       "logratio_polop_ms": round(ms_op, 3), "ratio_f32_clahe_u16_ms": round(ms_f32, 3), "ratio_f32_kernels_ms": k_f32,
-                      "scene_ms": round(2 * ms_band + ms_op + ms_f32, 3), "value": round(px / (2 * ms_band + ms_op + ms_f32) / 1e3, 1), "unit": "Mpix/s"}
+                      "ratio_fused_polop_clahe_u16_ms": round(ms_fused, 3), "ratio_fused_kernels_ms": k_fused,
+                      "scene_ms": round(2 * ms_band + ms_fused, 3), "scene_unfused_ms": round(2 * ms_band + ms_op + ms_f32, 3),
+                      "value": round(px / (2 * ms_band + ms_fused) / 1e3, 1), "unit": "Mpix/s"}
     ctx.close()
     return out
 

@@ -144,6 +144,18 @@ int sarpro_hip_tamed_synrgb_u8_u16(sarpro_hip_ctx *ctx, const uint16_t *in, size
 int sarpro_hip_polop_f32(sarpro_hip_ctx *ctx, int op, const float *a, const float *b, size_t n,
                          float *out);
 
+/* Pol-op band straight to its autoscaled raster: sum / difference / ratio / normalized_diff / log_ratio_arrays
+ * (ops.rs:4-44) followed by process_scalar_data_pipeline (pipeline.rs:42-67) on the result -- what
+ * io/sentinel1.rs:1501-1578 + save.rs do for a `PolarOp` product -- with the operation computed in registers inside
+ * every pass: the f32 pol-op raster is never written or read (12 B/px of traffic less than polop_f32 + autoscale_band_f32,
+ * same raster bit for bit).  a, b: the two co-registered bands, as f32 or as the u16 DN of a full-resolution GRD read. */
+int sarpro_hip_polop_autoscale_band_f32(sarpro_hip_ctx *ctx, int op, const float *a, const float *b, size_t rows, size_t cols,
+                                        int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16,
+                                        sarpro_hip_stats *stats_out);
+int sarpro_hip_polop_autoscale_band_u16(sarpro_hip_ctx *ctx, int op, const uint16_t *a, const uint16_t *b, size_t rows, size_t cols,
+                                        int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16,
+                                        sarpro_hip_stats *stats_out);
+
 /* create_synthetic_rgb_by_mode_and_strategy (synthetic_rgb.rs:182-197): interleaved RGB,
  * rgb_out holds 3*n bytes. */
 int sarpro_hip_synrgb_u8(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *band1,
@@ -237,6 +249,14 @@ int sarpro_hip_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_ban
                                       size_t in_pitch, int strategy, int mode, uint8_t *d_rgb,
                                       size_t rgb_pitch_px, uint8_t *d_u8_band1, uint8_t *d_u8_band2,
                                       size_t u8_pitch, sarpro_hip_stats *stats_out);
+/* device-pointer forms of sarpro_hip_polop_autoscale_band_*: in_pitch (elements) is shared by d_a and d_b; d_out is u8 or
+ * u16 by bit_depth, out_pitch in elements */
+int sarpro_hip_polop_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, int op, const float *d_a, const float *d_b, size_t rows, size_t cols,
+                                            size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
+                                            sarpro_hip_stats *stats_out);
+int sarpro_hip_polop_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, int op, const uint16_t *d_a, const uint16_t *d_b, size_t rows, size_t cols,
+                                            size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
+                                            sarpro_hip_stats *stats_out);
 int sarpro_hip_polop_f32_dev(sarpro_hip_ctx *ctx, int op, const float *d_a, const float *d_b,
                              size_t n, float *d_out);
 int sarpro_hip_synrgb_u8_dev(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *d_band1,

@@ -62,6 +62,7 @@ SYMBOLS = [
     "sarpro_hip_tamed_synrgb_u8_f32", "sarpro_hip_tamed_synrgb_u8_u16", "sarpro_hip_polop_f32",
     "sarpro_hip_synrgb_u8", "sarpro_hip_dualpol_synrgb_u16", "sarpro_hip_dualpol_synrgb_f32",
     "sarpro_hip_autoscale_band_u16_dev", "sarpro_hip_autoscale_band_f32_dev",
+    "sarpro_hip_polop_autoscale_band_f32", "sarpro_hip_polop_autoscale_band_u16", "sarpro_hip_polop_autoscale_band_f32_dev", "sarpro_hip_polop_autoscale_band_u16_dev",
     "sarpro_hip_dualpol_synrgb_u16_dev", "sarpro_hip_polop_f32_dev", "sarpro_hip_synrgb_u8_dev",
     "sarpro_hip_last_kernel_times",
     "sarpro_hip_ctx_time_only", "sarpro_hip_ctx_fused_report",
@@ -141,6 +142,10 @@ _proto("sarpro_hip_dualpol_synrgb_f32", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _vp
 _proto("sarpro_hip_autoscale_band_u16_dev", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
 _proto("sarpro_hip_autoscale_band_f32_dev", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
 _proto("sarpro_hip_dualpol_synrgb_u16_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _sz, _vp, _vp, _sz, _S)
+for _n in ("sarpro_hip_polop_autoscale_band_f32", "sarpro_hip_polop_autoscale_band_u16"):
+    _proto(_n, _i, _vp, _i, _vp, _vp, _sz, _sz, _i, _i, _vp, _vp, _S)
+for _n in ("sarpro_hip_polop_autoscale_band_f32_dev", "sarpro_hip_polop_autoscale_band_u16_dev"):
+    _proto(_n, _i, _vp, _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
 _proto("sarpro_hip_polop_f32_dev", _i, _vp, _i, _vp, _vp, _sz, _vp)
 _proto("sarpro_hip_synrgb_u8_dev", _i, _vp, _i, _i, _vp, _vp, _sz, _vp)
 _proto("sarpro_hip_last_kernel_times", _i, _vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i)

@@ -123,6 +123,33 @@ class Context:
         res = (out8, None) if bit_depth == BitDepth.U8 else (np.empty(0, np.uint8), out16)
         return res + (st,) if want_stats else res
 
+    def polop_autoscale_band(self, op, a: np.ndarray, b: np.ndarray, bit_depth: BitDepth, strategy: AutoscaleStrategy,
+                             want_stats: bool = False):
+        """ops.rs:4-44 followed by process_scalar_data_pipeline on the result (io/sentinel1.rs:1501-1578), fused: the f32 pol-op
+        raster is never materialised.  a, b: both f32 or both u16 DN.  Returns like process_scalar_data_pipeline."""
+        if a.shape != b.shape or a.ndim != 2:
+            raise SarproHipError(_lib.ERR_SHAPE_MISMATCH, "band shapes differ")
+        rows, cols = a.shape
+        st = Stats()
+        out8 = np.empty((rows, cols), np.uint8) if bit_depth == BitDepth.U8 else None
+        out16 = np.empty((rows, cols), np.uint16) if bit_depth == BitDepth.U16 else None
+        if a.dtype == np.uint16 and b.dtype == np.uint16:
+            fn, dt = lib.sarpro_hip_polop_autoscale_band_u16, np.uint16
+        else:
+            fn, dt = lib.sarpro_hip_polop_autoscale_band_f32, np.float32
+        x, y = np.ascontiguousarray(a, dt), np.ascontiguousarray(b, dt)
+        self._chk(fn(self._h, int(op), _vp(x), _vp(y), rows, cols, int(strategy), int(bit_depth), _vp(out8), _vp(out16), C.byref(st)))
+        res = (out8, None) if bit_depth == BitDepth.U8 else (np.empty(0, np.uint8), out16)
+        return res + (st,) if want_stats else res
+
+    def dev_polop_autoscale_band(self, op, d_a: int, d_b: int, u16_in: bool, rows: int, cols: int, in_pitch: int, strategy, bit_depth,
+                                 d_out: int, out_pitch: int, want_stats: bool = True) -> Stats | None:
+        st = Stats() if want_stats else None
+        fn = lib.sarpro_hip_polop_autoscale_band_u16_dev if u16_in else lib.sarpro_hip_polop_autoscale_band_f32_dev
+        self._chk(fn(self._h, int(op), _vp(d_a), _vp(d_b), rows, cols, in_pitch, int(strategy), int(bit_depth), _vp(d_out), out_pitch,
+                     C.byref(st) if want_stats else None))
+        return st
+
     # ------------------------------------------------------------------ pipeline.rs:8
     def process_scalar_data_inplace(self, processed: np.ndarray):
         x = np.ascontiguousarray(processed, np.float32)

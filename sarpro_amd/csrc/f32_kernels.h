@@ -20,6 +20,17 @@ struct F32StepEstimate {
     int use;
 };
 
+// Where the samples come from.  op < 0: the f32 raster `in` of the kernel.  op >= 0 (a sarpro_polop value): the samples are
+// op(a, b) of two co-registered rasters, computed in registers as ops.rs:4-44 computes them (IEEE f32, correctly rounded
+// divide) -- the f32 pol-op raster of io/sentinel1.rs:1501-1578 is never written or read.  u16 = 1: a and b hold u16 DN
+// (exact as f32), else f32.
+struct F32Pol {
+    const void *a = nullptr, *b = nullptr;
+    size_t pitch = 0; // elements
+    int op = -1;
+    int u16 = 0;
+};
+
 struct F32LevelArgs {
     const float *in;
     void *out; // u8 or u16
@@ -36,6 +47,7 @@ struct F32LevelArgs {
     double low, high, range, gamma, max_val; // range = max(high - low, 1)
     float t_first, t_last;
     int f64_levels;
+    F32Pol pol;
 };
 
 struct F32TileHistArgs {
@@ -46,6 +58,7 @@ struct F32TileHistArgs {
     const float *thr;                // [256]
     unsigned long long *tile_bins;   // [64][256], zeroed by the caller
     F32StepEstimate est;
+    F32Pol pol;
 };
 
 struct F32ClaheApplyArgs {
@@ -60,14 +73,15 @@ struct F32ClaheApplyArgs {
     unsigned long long *level_hist;  // [256], u8 only
     double max_val;
     F32StepEstimate est;
+    F32Pol pol;
 };
 
 int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec);
 // moments = false: count / min / max only (no per-sample f64 log10: the pass is then memory-bound)
 hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, bool moments,
-                              F32Partial *d_partials, int grid, hipStream_t s);
+                              F32Partial *d_partials, int grid, hipStream_t s, const F32Pol &pol = F32Pol());
 hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
-                               const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s);
+                               const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s, const F32Pol &pol = F32Pol());
 hipError_t launch_f32_level(const F32LevelArgs &a, bool vec, bool out16, hipStream_t s);
 hipError_t launch_f32_tile_hist(const F32TileHistArgs &a, int nrects, bool vec, hipStream_t s);
 hipError_t launch_f32_clahe_apply(const F32ClaheApplyArgs &a, int nrects, bool vec, bool out16, hipStream_t s);

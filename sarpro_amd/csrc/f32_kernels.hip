@@ -41,16 +41,52 @@ __device__ inline uint32_t est_search(const float *thr, float v, const F32StepEs
     return step_search<N>(thr, v);
 }
 
+// ops.rs:4-44, IEEE f32 (hipcc's default correctly rounded divide); the same function as kernels.hip k_polop_f32
+__device__ inline float pol_one(int op, float x, float y) {
+    switch (op) {
+    case SARPRO_OP_SUM: return x + y;
+    case SARPRO_OP_DIFF: return x - y;
+    case SARPRO_OP_RATIO:
+    case SARPRO_OP_LOGRATIO: return fabsf(y) > 1e-10f ? x / y : 0.0f;
+    default: { const float d = x + y; return fabsf(d) > 1e-10f ? (x - y) / d : 0.0f; }
+    }
+}
+
 template <int VEC> struct F32Vec;
 template <> struct F32Vec<4> {
     float4 v;
     __device__ static F32Vec load(const float *p) { F32Vec r; r.v = *reinterpret_cast<const float4 *>(p); return r; }
     __device__ float get(int j) const { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+    // the samples of row r, columns col .. col + 3: the raster, or the pol-op of two rasters computed here
+    __device__ static F32Vec fetch(const float *in, size_t pitch, const F32Pol &p, size_t r, size_t col) {
+        if (p.op < 0) return load(in + r * pitch + col);
+        float4 x, y;
+        if (p.u16) {
+            const ushort4 xa = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const uint16_t *>(p.a) + r * p.pitch + col);
+            const ushort4 xb = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const uint16_t *>(p.b) + r * p.pitch + col);
+            x = make_float4((float)xa.x, (float)xa.y, (float)xa.z, (float)xa.w);
+            y = make_float4((float)xb.x, (float)xb.y, (float)xb.z, (float)xb.w);
+        } else {
+            x = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.a) + r * p.pitch + col);
+            y = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.b) + r * p.pitch + col);
+        }
+        F32Vec o;
+        o.v = make_float4(pol_one(p.op, x.x, y.x), pol_one(p.op, x.y, y.y), pol_one(p.op, x.z, y.z), pol_one(p.op, x.w, y.w));
+        return o;
+    }
 };
 template <> struct F32Vec<1> {
     float v;
     __device__ static F32Vec load(const float *p) { F32Vec r; r.v = *p; return r; }
     __device__ float get(int) const { return v; }
+    __device__ static F32Vec fetch(const float *in, size_t pitch, const F32Pol &p, size_t r, size_t col) {
+        if (p.op < 0) return load(in + r * pitch + col);
+        const size_t i = r * p.pitch + col;
+        F32Vec o;
+        o.v = p.u16 ? pol_one(p.op, (float)reinterpret_cast<const uint16_t *>(p.a)[i], (float)reinterpret_cast<const uint16_t *>(p.b)[i])
+                    : pol_one(p.op, reinterpret_cast<const float *>(p.a)[i], reinterpret_cast<const float *>(p.b)[i]);
+        return o;
+    }
 };
 
 // VEC levels of one lane -> the output raster: one 4- or 8-byte store when the whole vector lies inside the row
@@ -91,7 +127,7 @@ __device__ inline double db_of_f32_fast(float x, const double *logc, const doubl
 
 template <int VEC, bool MOMENTS>
 __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict__ in, size_t pitch, uint32_t rows,
-                                                        uint32_t cols, float t_valid, F32Partial *__restrict__ out) {
+                                                        uint32_t cols, float t_valid, F32Partial *__restrict__ out, F32Pol pol) {
     const uint32_t vpr = (cols + VEC - 1) / VEC;
     const uint64_t total = (uint64_t)rows * vpr;
     unsigned long long cnt = 0;
@@ -108,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
         const uint32_t r = (uint32_t)(idx / vpr);
         const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
-        const F32Vec<VEC> v = F32Vec<VEC>::load(in + (size_t)r * pitch + col);
+        const F32Vec<VEC> v = F32Vec<VEC>::fetch(in, pitch, pol, r, col);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float x = v.get(j);
@@ -145,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict__ in, size_t pitch, uint32_t rows,
                                                          uint32_t cols, float t_valid, const float *__restrict__ g_thr,
-                                                         unsigned long long *__restrict__ g_hist, F32StepEstimate est) {
+                                                         unsigned long long *__restrict__ g_hist, F32StepEstimate est, F32Pol pol) {
     __shared__ float thr[4096 + 1];
     __shared__ uint32_t hist[4096];
     for (int i = threadIdx.x; i < 4096; i += kBlock) { thr[i] = i ? g_thr[i] : -INFINITY; hist[i] = 0; }
@@ -156,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
         const uint32_t r = (uint32_t)(idx / vpr);
         const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
-        const F32Vec<VEC> v = F32Vec<VEC>::load(in + (size_t)r * pitch + col);
+        const F32Vec<VEC> v = F32Vec<VEC>::fetch(in, pitch, pol, r, col);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float x = v.get(j);
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
         const uint32_t r = (uint32_t)(idx / vpr);
         const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
-        const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.in_pitch + col);
+        const F32Vec<VEC> v = F32Vec<VEC>::fetch(a.in, a.in_pitch, a.pol, r, col);
         uint32_t lvs[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -240,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
     const int col = rc.cstart + lane_id() * VEC;
     if (col < rc.c1 && col + VEC > rc.c0) {
         for (int r = rc.r0 + wave_id(); r < rc.r1; r += kWavesPerBlock) {
-            const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.pitch + col);
+            const F32Vec<VEC> v = F32Vec<VEC>::fetch(a.in, a.pitch, a.pol, r, col);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int c = col + j;
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
     }
     if (lane_on) {
         for (int r = rc.r0 + wave_id(); r < rc.r1; r += kWavesPerBlock) {
-            const F32Vec<VEC> v = F32Vec<VEC>::load(a.in + (size_t)r * a.in_pitch + col);
+            const F32Vec<VEC> v = F32Vec<VEC>::fetch(a.in, a.in_pitch, a.pol, r, col);
             const RowWeight rw = a.row_w[r];
             uint32_t lvs[VEC];
 #pragma unroll
@@ -354,23 +390,23 @@ int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec) {
 }
 
 hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, bool moments,
-                              F32Partial *d_partials, int grid, hipStream_t s) {
+                              F32Partial *d_partials, int grid, hipStream_t s, const F32Pol &pol) {
     if (vec) {
-        if (moments) hipLaunchKernelGGL((k_f32_prepass<4, true>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
-        else hipLaunchKernelGGL((k_f32_prepass<4, false>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+        if (moments) hipLaunchKernelGGL((k_f32_prepass<4, true>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials, pol);
+        else hipLaunchKernelGGL((k_f32_prepass<4, false>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials, pol);
     } else {
-        if (moments) hipLaunchKernelGGL((k_f32_prepass<1, true>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
-        else hipLaunchKernelGGL((k_f32_prepass<1, false>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials);
+        if (moments) hipLaunchKernelGGL((k_f32_prepass<1, true>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials, pol);
+        else hipLaunchKernelGGL((k_f32_prepass<1, false>), dim3(grid), dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials, pol);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
-                               const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s) {
+                               const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s, const F32Pol &pol) {
     const int V = vec ? 4 : 1;
     dim3 grid(stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4));
-    if (vec) hipLaunchKernelGGL(k_f32_hist4096<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est);
-    else hipLaunchKernelGGL(k_f32_hist4096<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est);
+    if (vec) hipLaunchKernelGGL(k_f32_hist4096<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est, pol);
+    else hipLaunchKernelGGL(k_f32_hist4096<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est, pol);
     return hipGetLastError();
 }
 

@@ -55,6 +55,7 @@ struct F32Band {
     size_t out_pitch = 0;
     sarpro_hip_stats stats{};
     bool want_moments = true;   // mean / std of dB: reported statistics and the Adaptive strategy only
+    F32Pol pol;                 // op >= 0: the samples are op(a, b) of two rasters, computed inside every kernel (d_in unused)
     uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
 };
 
@@ -100,7 +101,7 @@ int f32_band_run(F32Band &B) {
     sarpro_hip_ctx *ctx = B.ctx;
     const bool u8o = B.tamed || B.bit_depth == SARPRO_BITDEPTH_U8;
     const bool clahe = B.strategy == SARPRO_STRATEGY_CLAHE && !B.tamed;
-    if (B.in_pitch < B.cols || B.out_pitch < B.cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    if ((B.pol.op < 0 ? B.in_pitch : B.pol.pitch) < B.cols || B.out_pitch < B.cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
     if (B.rows > 0x7FFFFFFFull || B.cols > 0x7FFFFFFFull) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "raster too large");
     if (clahe && !clahe_shape_ok(B.rows, B.cols))
         return fail(ctx, SARPRO_HIP_ERR_UNSUPPORTED_SHAPE,
@@ -114,7 +115,8 @@ int f32_band_run(F32Band &B) {
     HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     const uint32_t rows = (uint32_t)B.rows, cols = (uint32_t)B.cols;
-    const bool vec = B.in_pitch % 4 == 0 && aligned16(B.d_in);
+    const bool vec = B.pol.op < 0 ? (B.in_pitch % 4 == 0 && aligned16(B.d_in))
+                                  : (B.pol.pitch % 4 == 0 && aligned16(B.pol.a) && aligned16(B.pol.b));
     const float t_valid = valid_threshold_f32();
     const size_t esz = u8o ? 1 : 2;
 
@@ -124,7 +126,7 @@ int f32_band_run(F32Band &B) {
     const bool moments = B.want_moments || (B.strategy == SARPRO_STRATEGY_ADAPTIVE && !B.tamed);
     {
         KernelTimer t(ctx, "f32_prepass");
-        HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, t_valid, vec, moments, d_part, pgrid, ctx->stream));
+        HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, t_valid, vec, moments, d_part, pgrid, ctx->stream, B.pol));
     }
     F32Partial *h_part = ctx->h_small.as<F32Partial>();
     HIPCHK(ctx, hipMemcpyAsync(h_part, d_part, sizeof(F32Partial) * (size_t)pgrid, hipMemcpyDeviceToHost, ctx->stream));
@@ -161,7 +163,7 @@ int f32_band_run(F32Band &B) {
         {
             KernelTimer t(ctx, "f32_hist4096");
             HIPCHK(ctx, launch_f32_hist4096(B.d_in, B.in_pitch, rows, cols, t_valid, vec, d_thr, d_hist,
-                                            step_estimate(min_db, max_db - min_db, 4096.0, 0.0), ctx->stream));
+                                            step_estimate(min_db, max_db - min_db, 4096.0, 0.0), ctx->stream, B.pol));
         }
         HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -190,6 +192,7 @@ int f32_band_run(F32Band &B) {
         }
         a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
         a.rows = rows; a.cols = cols; a.t_valid = t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
+        a.pol = B.pol;
         KernelTimer t(ctx, "f32_level");
         HIPCHK(ctx, launch_f32_level(a, vec, !u8o, ctx->stream));
     } else {
@@ -205,6 +208,7 @@ int f32_band_run(F32Band &B) {
         F32TileHistArgs ta{};
         ta.in = B.d_in; ta.pitch = B.in_pitch; ta.rects = plan->d_hist_rects_tiled.as<Rect>();
         ta.t_valid = t_valid; ta.thr = d_thr; ta.tile_bins = d_tile_bins;
+        ta.pol = B.pol;
         ta.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
         {
             KernelTimer t(ctx, "f32_tile_hist");
@@ -223,6 +227,7 @@ int f32_band_run(F32Band &B) {
         a.row_w = plan->d_row_w.as<RowWeight>(); a.col_w = plan->d_col_w.as<RowWeight>();
         a.level_hist = d_level_hist; a.max_val = u8o ? 255.0 : 65535.0;
         a.est = ta.est;
+        a.pol = B.pol;
         KernelTimer t(ctx, "f32_clahe_apply");
         HIPCHK(ctx, launch_f32_clahe_apply(a, (int)plan->apply_rects.size(), vec, !u8o, ctx->stream));
     }
@@ -256,6 +261,67 @@ extern "C" int sarpro_hip_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, const floa
     int rc = f32_band_run(B);
     if (rc == SARPRO_HIP_OK && stats_out) *stats_out = B.stats;
     return rc;
+}
+
+// Fused pol-op -> autoscale (io/sentinel1.rs:1501-1578: ops.rs:4-44, then pipeline.rs:42-67 on the result): the op is
+// computed inside every pass of the f32 flavour, the f32 pol-op raster is never materialised.
+static int polop_band_dev(sarpro_hip_ctx *ctx, int op, const void *d_a, const void *d_b, int elem_u16, size_t rows, size_t cols, size_t in_pitch,
+                          int strategy, int bit_depth, void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (op < SARPRO_OP_SUM || op > SARPRO_OP_LOGRATIO) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad polarisation operation");
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if ((!d_a || !d_b || !d_out) && rows * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    F32Band B;
+    B.ctx = ctx; B.rows = rows; B.cols = cols; B.in_pitch = in_pitch;
+    B.pol.a = d_a; B.pol.b = d_b; B.pol.pitch = in_pitch; B.pol.op = op; B.pol.u16 = elem_u16;
+    B.strategy = strategy; B.bit_depth = bit_depth; B.d_out = d_out; B.out_pitch = out_pitch;
+    B.want_moments = stats_out != nullptr;
+    int rc = f32_band_run(B);
+    if (rc == SARPRO_HIP_OK && stats_out) *stats_out = B.stats;
+    return rc;
+}
+
+extern "C" int sarpro_hip_polop_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, int op, const float *d_a, const float *d_b, size_t rows, size_t cols,
+                                                       size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
+                                                       sarpro_hip_stats *stats_out) {
+    if (ctx) timing_reset(ctx);
+    return polop_band_dev(ctx, op, d_a, d_b, 0, rows, cols, in_pitch, strategy, bit_depth, d_out, out_pitch, stats_out);
+}
+
+extern "C" int sarpro_hip_polop_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, int op, const uint16_t *d_a, const uint16_t *d_b, size_t rows,
+                                                       size_t cols, size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
+                                                       sarpro_hip_stats *stats_out) {
+    if (ctx) timing_reset(ctx);
+    return polop_band_dev(ctx, op, d_a, d_b, 1, rows, cols, in_pitch, strategy, bit_depth, d_out, out_pitch, stats_out);
+}
+
+static int host_polop_band(sarpro_hip_ctx *ctx, int op, const void *a, const void *b, int elem_u16, size_t rows, size_t cols, int strategy,
+                           int bit_depth, uint8_t *out_u8, uint16_t *out_u16, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    const bool u8o = bit_depth == SARPRO_BITDEPTH_U8;
+    if (rows * cols && (!a || !b || (u8o ? (void *)out_u8 : (void *)out_u16) == nullptr)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    timing_reset(ctx);
+    const size_t esz = elem_u16 ? 2 : 4;
+    size_t pitch = 0, pitch2 = 0;
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[0], a, rows, cols, esz, &pitch));
+    RETCHK(stage_in_2d(ctx, ctx->stage_in[1], b, rows, cols, esz, &pitch2));
+    const size_t osz = u8o ? 1 : 2;
+    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max<size_t>(rows, 1) * pitch * osz));
+    RETCHK(polop_band_dev(ctx, op, ctx->stage_in[0].p, ctx->stage_in[1].p, elem_u16, rows, cols, pitch, strategy, bit_depth, ctx->stage_out[0].p,
+                          pitch, stats_out));
+    return fetch_out_2d(ctx, u8o ? (void *)out_u8 : (void *)out_u16, ctx->stage_out[0].p, pitch * osz, cols * osz, rows);
+}
+
+extern "C" int sarpro_hip_polop_autoscale_band_f32(sarpro_hip_ctx *ctx, int op, const float *a, const float *b, size_t rows, size_t cols,
+                                                   int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16, sarpro_hip_stats *stats_out) {
+    return host_polop_band(ctx, op, a, b, 0, rows, cols, strategy, bit_depth, out_u8, out_u16, stats_out);
+}
+
+extern "C" int sarpro_hip_polop_autoscale_band_u16(sarpro_hip_ctx *ctx, int op, const uint16_t *a, const uint16_t *b, size_t rows, size_t cols,
+                                                   int strategy, int bit_depth, uint8_t *out_u8, uint16_t *out_u16, sarpro_hip_stats *stats_out) {
+    return host_polop_band(ctx, op, a, b, 1, rows, cols, strategy, bit_depth, out_u8, out_u16, stats_out);
 }
 
 static int host_band_f32(sarpro_hip_ctx *ctx, const float *in, size_t rows, size_t cols, int strategy, int bit_depth,
