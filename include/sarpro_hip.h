@@ -367,6 +367,42 @@ int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, cons
                               size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
                               uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out);
 
+/* ---- row stripes of the f32 flavour (a calibrated f32 band, or a polarisation operation of two bands computed on the
+ * fly): autoscale.rs:35-117 needs the scene's count / min / max before it can bin, and the scene's 4096 bins before it can
+ * select the window, so the protocol has one more reduction than the u16 one.  One open f32 stripe per context. ---- */
+typedef struct {
+    uint64_t count;           /* valid samples                      merge: sum */
+    double sum_db, sumsq_db;  /* of dB over the valid samples       merge: sum (in rank order: sarpro_hip_host_f32_merge_partials) */
+    float min_v, max_v;       /* of the valid samples (+inf / -inf when there is none)   merge: min / max */
+} sarpro_hip_f32_partial;
+typedef struct sarpro_hip_stripe_f32 sarpro_hip_stripe_f32;
+/* this rank owns rows [row0, row0 + rows_local) of the rows_total x cols scene; d_in / d_out are the local stripe */
+int sarpro_hip_stripe_begin_f32(sarpro_hip_ctx *ctx, const float *d_in, size_t rows_total, size_t cols, size_t row0,
+                                size_t rows_local, size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
+                                sarpro_hip_stripe_f32 **out);
+/* the samples are op(a, b) (ops.rs:4-44) of two f32 (elem_u16 = 0) or u16 DN (elem_u16 = 1) stripes */
+int sarpro_hip_stripe_begin_polop(sarpro_hip_ctx *ctx, int op, const void *d_a, const void *d_b, int elem_u16, size_t rows_total,
+                                  size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int bit_depth,
+                                  void *d_out, size_t out_pitch, sarpro_hip_stripe_f32 **out);
+/* phase 1: the stripe's count / min / max / dB moments, on the HOST (32 bytes); the caller gathers and merges them */
+int sarpro_hip_stripe_f32_phase1(sarpro_hip_stripe_f32 *s, sarpro_hip_f32_partial *local_out);
+int sarpro_hip_host_f32_merge_partials(const sarpro_hip_f32_partial *parts, size_t n, sarpro_hip_f32_partial *out);
+/* phase 2: the stripe's 4096-bin histogram over the scene's [min, max] (autoscale.rs:102-117) -> all-reduce(sum) */
+int sarpro_hip_stripe_f32_phase2(sarpro_hip_stripe_f32 *s, const sarpro_hip_f32_partial *global, uint64_t **d_buf, size_t *count);
+/* phase 3: statistics and window from the merged bins; CLAHE: the stripe's tile histograms -> all-reduce(sum) (else count 0) */
+int sarpro_hip_stripe_f32_phase3(sarpro_hip_stripe_f32 *s, uint64_t **d_buf, size_t *count);
+/* phase 4: the stripe's levels; u8: histogram of the pre-rescale levels -> all-reduce(sum) (u16: count 0) */
+int sarpro_hip_stripe_f32_phase4(sarpro_hip_stripe_f32 *s, uint64_t **d_buf, size_t *count);
+/* phase 5: u8 rescale in place (autoscale.rs:348-364); the stripe of the output raster is complete on return */
+int sarpro_hip_stripe_f32_phase5(sarpro_hip_stripe_f32 *s, sarpro_hip_stats *stats_out);
+void sarpro_hip_stripe_f32_end(sarpro_hip_stripe_f32 *s);
+/* the same in one call per rank over the library's communicator (every rank must make the call) */
+int sarpro_hip_stripe_run_f32(sarpro_hip_ctx *ctx, const float *d_in, size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                              size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out);
+int sarpro_hip_stripe_run_polop(sarpro_hip_ctx *ctx, int op, const void *d_a, const void *d_b, int elem_u16, size_t rows_total,
+                                size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int bit_depth,
+                                void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out);
+
 /* RCCL communicator owned by the library (optional: callers may reduce the phase buffers
  * with their own communicator, e.g. torch.distributed's).  uid is the 128-byte
  * ncclUniqueId produced by sarpro_hip_comm_unique_id on rank 0 and shipped to all ranks. */

@@ -29,6 +29,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class F32Partial(C.Structure):
+    """sarpro_hip_f32_partial: count / dB moments / min / max of the valid samples of one stripe."""
+    _fields_ = [("count", C.c_uint64), ("sum_db", C.c_double), ("sumsq_db", C.c_double), ("min_v", C.c_float), ("max_v", C.c_float)]
+
+
 class ResizeMeta(C.Structure):
     _fields_ = [("final_cols", C.c_size_t), ("final_rows", C.c_size_t), ("scale_x", C.c_double), ("scale_y", C.c_double),
                 ("pad_left", C.c_size_t), ("pad_top", C.c_size_t)]
@@ -71,6 +76,9 @@ SYMBOLS = [
     "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_dualpol_synrgb_resized_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
     "sarpro_hip_tiff_pair_reader", "sarpro_hip_tiff_create", "sarpro_hip_tiff_write_rows", "sarpro_hip_tiff_row_sink",
     "sarpro_hip_tiff_finish", "sarpro_hip_tiff_last_error", "sarpro_hip_host_update_geotransform",
+    "sarpro_hip_stripe_begin_f32", "sarpro_hip_stripe_begin_polop", "sarpro_hip_stripe_f32_phase1", "sarpro_hip_stripe_f32_phase2",
+    "sarpro_hip_stripe_f32_phase3", "sarpro_hip_stripe_f32_phase4", "sarpro_hip_stripe_f32_phase5", "sarpro_hip_stripe_f32_end",
+    "sarpro_hip_stripe_run_f32", "sarpro_hip_stripe_run_polop", "sarpro_hip_host_f32_merge_partials",
     "sarpro_hip_comm_unique_id", "sarpro_hip_comm_init", "sarpro_hip_comm_allreduce_sum_u64",
     "sarpro_hip_comm_destroy",
     "sarpro_hip_host_stats_from_dn_hist", "sarpro_hip_host_window", "sarpro_hip_host_level_lut_u16",
@@ -164,6 +172,17 @@ _proto("sarpro_hip_stripe_phase2", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
 _proto("sarpro_hip_stripe_phase3", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
 _proto("sarpro_hip_stripe_phase4", _i, _vp, _vp, _sz, _S)
 _proto("sarpro_hip_stripe_end", None, _vp)
+_proto("sarpro_hip_stripe_begin_f32", _i, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, C.POINTER(_vp))
+_proto("sarpro_hip_stripe_begin_polop", _i, _vp, _i, _vp, _vp, _i, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, C.POINTER(_vp))
+_proto("sarpro_hip_stripe_f32_phase1", _i, _vp, C.POINTER(F32Partial))
+_proto("sarpro_hip_stripe_f32_phase2", _i, _vp, C.POINTER(F32Partial), C.POINTER(_vp), C.POINTER(_sz))
+_proto("sarpro_hip_stripe_f32_phase3", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
+_proto("sarpro_hip_stripe_f32_phase4", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
+_proto("sarpro_hip_stripe_f32_phase5", _i, _vp, _S)
+_proto("sarpro_hip_stripe_f32_end", None, _vp)
+_proto("sarpro_hip_stripe_run_f32", _i, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
+_proto("sarpro_hip_stripe_run_polop", _i, _vp, _i, _vp, _vp, _i, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
+_proto("sarpro_hip_host_f32_merge_partials", _i, _vp, _sz, C.POINTER(F32Partial))
 _proto("sarpro_hip_comm_unique_id", _i, _vp)
 _proto("sarpro_hip_comm_init", _i, _vp, _i, _i, _vp)
 _proto("sarpro_hip_comm_allreduce_sum_u64", _i, _vp, _vp, _sz)

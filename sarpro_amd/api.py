@@ -22,7 +22,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Stats, lib
+from ._lib import F32Partial, Stats, lib
 from .types import AutoscaleStrategy, BitDepth, PolarizationOperation, SyntheticRgbMode
 
 
@@ -332,6 +332,35 @@ class Context:
                                                 int(strategy), int(mode), _vp(d_rgb), rgb_pitch_px, st))
         return [st[0], st[1]]
 
+    def stripe_begin_f32(self, d_in: int, rows_total: int, cols: int, row0: int, rows_local: int, in_pitch: int, strategy, bit_depth,
+                         d_out: int, out_pitch: int) -> "StripeF32":
+        h = C.c_void_p()
+        self._chk(lib.sarpro_hip_stripe_begin_f32(self._h, _vp(d_in), rows_total, cols, row0, rows_local, in_pitch, int(strategy),
+                                                  int(bit_depth), _vp(d_out), out_pitch, C.byref(h)))
+        return StripeF32(self, h)
+
+    def stripe_begin_polop(self, op, d_a: int, d_b: int, u16_in: bool, rows_total: int, cols: int, row0: int, rows_local: int,
+                           in_pitch: int, strategy, bit_depth, d_out: int, out_pitch: int) -> "StripeF32":
+        h = C.c_void_p()
+        self._chk(lib.sarpro_hip_stripe_begin_polop(self._h, int(op), _vp(d_a), _vp(d_b), int(bool(u16_in)), rows_total, cols, row0,
+                                                    rows_local, in_pitch, int(strategy), int(bit_depth), _vp(d_out), out_pitch, C.byref(h)))
+        return StripeF32(self, h)
+
+    def stripe_run_f32(self, d_in: int, rows_total: int, cols: int, row0: int, rows_local: int, in_pitch: int, strategy, bit_depth,
+                       d_out: int, out_pitch: int) -> Stats:
+        """One row stripe of an f32 band, reductions over the library's RCCL communicator."""
+        st = Stats()
+        self._chk(lib.sarpro_hip_stripe_run_f32(self._h, _vp(d_in), rows_total, cols, row0, rows_local, in_pitch, int(strategy),
+                                                int(bit_depth), _vp(d_out), out_pitch, C.byref(st)))
+        return st
+
+    def stripe_run_polop(self, op, d_a: int, d_b: int, u16_in: bool, rows_total: int, cols: int, row0: int, rows_local: int,
+                         in_pitch: int, strategy, bit_depth, d_out: int, out_pitch: int) -> Stats:
+        st = Stats()
+        self._chk(lib.sarpro_hip_stripe_run_polop(self._h, int(op), _vp(d_a), _vp(d_b), int(bool(u16_in)), rows_total, cols, row0,
+                                                  rows_local, in_pitch, int(strategy), int(bit_depth), _vp(d_out), out_pitch, C.byref(st)))
+        return st
+
     @staticmethod
     def _as_reader(r, cols):
         """(fn, user, keepalive) of a row reader given as a Python callable or as a (fn_ptr, user_ptr) pair"""
@@ -424,6 +453,54 @@ class Stripe:
         if self._h:
             lib.sarpro_hip_stripe_end(self._h)
             self._h = None
+
+
+class StripeF32:
+    """sarpro_hip_stripe_f32: phases of one row stripe of the f32 flavour; the caller merges between phases."""
+
+    def __init__(self, ctx: Context, h):
+        self.ctx, self._h = ctx, h
+
+    def phase1(self) -> F32Partial:
+        p = F32Partial()
+        self.ctx._chk(lib.sarpro_hip_stripe_f32_phase1(self._h, C.byref(p)))
+        return p
+
+    def phase2(self, merged: F32Partial):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx._chk(lib.sarpro_hip_stripe_f32_phase2(self._h, C.byref(merged), C.byref(p), C.byref(n)))
+        return (p.value or 0), n.value
+
+    def _phase(self, fn):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx._chk(fn(self._h, C.byref(p), C.byref(n)))
+        return (p.value or 0), n.value
+
+    def phase3(self):
+        return self._phase(lib.sarpro_hip_stripe_f32_phase3)
+
+    def phase4(self):
+        return self._phase(lib.sarpro_hip_stripe_f32_phase4)
+
+    def phase5(self) -> Stats:
+        st = Stats()
+        self.ctx._chk(lib.sarpro_hip_stripe_f32_phase5(self._h, C.byref(st)))
+        return st
+
+    def end(self):
+        if self._h:
+            lib.sarpro_hip_stripe_f32_end(self._h)
+            self._h = None
+
+
+def host_f32_merge_partials(parts) -> F32Partial:
+    """Merge of the stripes' partials in rank order (count, moments: sum; min / max)."""
+    arr = (F32Partial * len(parts))(*parts)
+    out = F32Partial()
+    rc = lib.sarpro_hip_host_f32_merge_partials(arr, len(parts), C.byref(out))
+    if rc:
+        raise SarproHipError(rc, "host_f32_merge_partials")
+    return out
 
 
 def comm_unique_id() -> bytes:

@@ -77,7 +77,7 @@ extern "C" int sarpro_hip_comm_init(sarpro_hip_ctx *ctx, int nranks, int rank, c
         ctx->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
         return SARPRO_HIP_ERR_RCCL;
     }
-    ctx->comm = comm;
+    ctx->comm = comm; ctx->comm_nranks = nranks; ctx->comm_rank = rank;
     return SARPRO_HIP_OK;
 }
 

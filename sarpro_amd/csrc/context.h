@@ -136,4 +136,5 @@ struct sarpro_hip_ctx {
     // RCCL (lazy)
     void *rccl_lib = nullptr;
     void *comm = nullptr;
+    int comm_nranks = 0, comm_rank = 0;
 };

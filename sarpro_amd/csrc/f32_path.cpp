@@ -56,6 +56,12 @@ struct F32Band {
     sarpro_hip_stats stats{};
     bool want_moments = true;   // mean / std of dB: reported statistics and the Adaptive strategy only
     F32Pol pol;                 // op >= 0: the samples are op(a, b) of two rasters, computed inside every kernel (d_in unused)
+    size_t rows_total = 0, row0 = 0; // the scene this raster is a row stripe of (rows_total = 0: the raster is the scene)
+    sarpro_hip_f32_partial local{}, global{};
+    bool u8o = true, clahe = false, vec = false, empty = false;
+    float t_valid = 0.f;
+    double mean = 0.0, std_db = 0.0, min_db = 0.0, max_db = 0.0;
+    StripePlan *plan = nullptr;
     uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
 };
 
@@ -86,7 +92,7 @@ int rescale_in_place(F32Band &B, const uint64_t *level_hist) {
     }
     std::memset(B.final_hist, 0, sizeof(B.final_hist));
     for (int i = 0; i < 256; ++i) B.final_hist[resc[i]] += level_hist[i];
-    if (!identity) {
+    if (!identity && B.rows && B.cols) {
         uint8_t *stage = ctx->h_upload.as<uint8_t>();
         std::memcpy(stage, resc, 256);
         uint8_t *d_map = ctx->f32ws.as<uint8_t>() + kOffMap;
@@ -97,85 +103,127 @@ int rescale_in_place(F32Band &B, const uint64_t *level_hist) {
     return SARPRO_HIP_OK;
 }
 
-int f32_band_run(F32Band &B) {
+// The band runs in five phases; between them sit the three reductions of a row-striped scene (SURVEY 8e row 1:
+// autoscale.rs:35-117 needs count / min / max of the WHOLE scene before it can bin, the bins before it can select the
+// window; autoscale.rs:572-608 needs whole-tile histograms).  One rank: f32_band_run runs them back to back.
+//   a  prepass                 -> B.local   (count, min, max, dB moments)        merge: sum / min / max
+//   b  4096-bin histogram      -> d_hist    (u64[4096], device)                  merge: sum
+//   c  window; CLAHE tile bins -> d_tile_bins (u64[64*256], device; CLAHE only)  merge: sum
+//   d  level / CLAHE apply     -> d_level_hist (u64[256], device; u8 only)       merge: sum
+//   e  u8 rescale in place (autoscale.rs:348-364), final synchronisation
+int f32_phase_a(F32Band &B) {
     sarpro_hip_ctx *ctx = B.ctx;
-    const bool u8o = B.tamed || B.bit_depth == SARPRO_BITDEPTH_U8;
-    const bool clahe = B.strategy == SARPRO_STRATEGY_CLAHE && !B.tamed;
+    B.u8o = B.tamed || B.bit_depth == SARPRO_BITDEPTH_U8;
+    B.clahe = B.strategy == SARPRO_STRATEGY_CLAHE && !B.tamed;
+    if (B.rows_total == 0) { B.rows_total = B.rows; B.row0 = 0; }
     if ((B.pol.op < 0 ? B.in_pitch : B.pol.pitch) < B.cols || B.out_pitch < B.cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
-    if (B.rows > 0x7FFFFFFFull || B.cols > 0x7FFFFFFFull) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "raster too large");
-    if (clahe && !clahe_shape_ok(B.rows, B.cols))
+    if (B.rows_total > 0x7FFFFFFFull || B.cols > 0x7FFFFFFFull) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "raster too large");
+    if (B.row0 + B.rows > B.rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "stripe outside the scene");
+    if (B.clahe && !clahe_shape_ok(B.rows_total, B.cols))
         return fail(ctx, SARPRO_HIP_ERR_UNSUPPORTED_SHAPE,
                     "CLAHE tile arithmetic underflows for this shape (reference panics: autoscale.rs:250,254)");
     std::memset(&B.stats, 0, sizeof(B.stats));
     std::memset(B.final_hist, 0, sizeof(B.final_hist));
-    if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
+    std::memset(&B.local, 0, sizeof(B.local));
+    B.local.min_v = INFINITY; B.local.max_v = -INFINITY;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, ctx->f32ws.reserve(kWsBytes));
     HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
     HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
+    B.vec = B.pol.op < 0 ? (B.in_pitch % 4 == 0 && aligned16(B.d_in))
+                         : (B.pol.pitch % 4 == 0 && aligned16(B.pol.a) && aligned16(B.pol.b));
+    B.t_valid = valid_threshold_f32();
+    if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     const uint32_t rows = (uint32_t)B.rows, cols = (uint32_t)B.cols;
-    const bool vec = B.pol.op < 0 ? (B.in_pitch % 4 == 0 && aligned16(B.d_in))
-                                  : (B.pol.pitch % 4 == 0 && aligned16(B.pol.a) && aligned16(B.pol.b));
-    const float t_valid = valid_threshold_f32();
-    const size_t esz = u8o ? 1 : 2;
-
-    // ---- pass a: count / min / max (+ dB moments when somebody reads them) ----
-    const int pgrid = f32_prepass_grid(rows, cols, vec);
+    const int pgrid = f32_prepass_grid(rows, cols, B.vec);
     F32Partial *d_part = reinterpret_cast<F32Partial *>(ws + kOffPartials);
     const bool moments = B.want_moments || (B.strategy == SARPRO_STRATEGY_ADAPTIVE && !B.tamed);
     {
         KernelTimer t(ctx, "f32_prepass");
-        HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, t_valid, vec, moments, d_part, pgrid, ctx->stream, B.pol));
+        HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, B.t_valid, B.vec, moments, d_part, pgrid, ctx->stream, B.pol));
     }
     F32Partial *h_part = ctx->h_small.as<F32Partial>();
     HIPCHK(ctx, hipMemcpyAsync(h_part, d_part, sizeof(F32Partial) * (size_t)pgrid, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t count = 0;
-    double sum = 0.0, sumsq = 0.0;
-    float minv = INFINITY, maxv = -INFINITY;
     for (int i = 0; i < pgrid; ++i) {
-        count += h_part[i].count; sum += h_part[i].sum; sumsq += h_part[i].sumsq;
-        minv = std::fmin(minv, h_part[i].minv); maxv = std::fmax(maxv, h_part[i].maxv);
+        B.local.count += h_part[i].count; B.local.sum_db += h_part[i].sum; B.local.sumsq_db += h_part[i].sumsq;
+        B.local.min_v = std::fmin(B.local.min_v, h_part[i].minv); B.local.max_v = std::fmax(B.local.max_v, h_part[i].maxv);
     }
-    if (count == 0) { // autoscale.rs:376-378 / 466-468 / 716-718: zero raster
-        HIPCHK(ctx, hipMemset2DAsync(B.d_out, B.out_pitch * esz, 0, B.cols * esz, B.rows, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        B.final_hist[0] = (uint64_t)B.rows * B.cols;
+    return SARPRO_HIP_OK;
+}
+
+// B.global holds the merged partial.  Leaves the local 4096-bin histogram in d_hist (zeros where the scene has none).
+int f32_phase_b(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    const sarpro_hip_f32_partial &G = B.global;
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws + kOffHist4096);
+    HIPCHK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * 4096, ctx->stream));
+    B.empty = G.count == 0;
+    if (B.empty) return SARPRO_HIP_OK; // autoscale.rs:376-378 / 466-468 / 716-718: zero raster
+    if (std::isinf(G.max_v)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "non-finite (+inf) sample: the reference's statistics are undefined for it");
+    B.mean = G.sum_db / (double)G.count;
+    const double var = G.sumsq_db / (double)G.count - B.mean * B.mean;
+    B.std_db = G.count > 1 ? std::sqrt(std::fmax(var, 0.0)) : 0.0;
+    B.min_db = db_of_f32(G.min_v); B.max_db = db_of_f32(G.max_v);
+    if (!(std::fabs(B.max_db - B.min_db) < 2.220446049250313e-16) && B.rows && B.cols) {
+        float *thr = ctx->h_upload.as<float>();
+        build_bin4096_thresholds(B.min_db, B.max_db, thr);
+        float *d_thr = reinterpret_cast<float *>(ws + kOffThr4096);
+        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 4096, hipMemcpyHostToDevice, ctx->stream));
+        KernelTimer t(ctx, "f32_hist4096");
+        HIPCHK(ctx, launch_f32_hist4096(B.d_in, B.in_pitch, (uint32_t)B.rows, (uint32_t)B.cols, B.t_valid, B.vec, d_thr, d_hist,
+                                        step_estimate(B.min_db, B.max_db - B.min_db, 4096.0, 0.0), ctx->stream, B.pol));
+    }
+    return SARPRO_HIP_OK;
+}
+
+// d_hist holds the merged bins.  CLAHE: leaves the local tile histograms in d_tile_bins.
+int f32_phase_c(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    unsigned long long *d_tile_bins = reinterpret_cast<unsigned long long *>(ws + kOffTileBins);
+    unsigned long long *d_level_hist = reinterpret_cast<unsigned long long *>(ws + kOffLevelHist);
+    if (B.clahe) HIPCHK(ctx, hipMemsetAsync(d_tile_bins, 0, sizeof(uint64_t) * 64 * 256, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_level_hist, 0, sizeof(uint64_t) * 256, ctx->stream));
+    if (B.empty) return SARPRO_HIP_OK;
+    uint64_t *h_hist = ctx->h_small.as<uint64_t>();
+    HIPCHK(ctx, hipMemcpyAsync(h_hist, ws + kOffHist4096, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    RETCHK(stats_from_bins4096(B.global.count, B.min_db, B.max_db, B.mean, B.std_db, h_hist, &B.stats));
+    RETCHK(select_window(&B.stats, B.strategy, B.tamed));
+    if (!B.clahe || B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
+    RETCHK(get_plan(ctx, B.rows_total, B.cols, B.row0, B.rows, B.vec ? 4 : 1, &B.plan));
+    float *thr = ctx->h_upload.as<float>();
+    build_clahe_bin_thresholds(B.stats, thr);
+    float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
+    HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
+    if (B.plan->hist_rects_tiled.empty()) return SARPRO_HIP_OK;
+    F32TileHistArgs ta{};
+    ta.in = B.d_in; ta.pitch = B.in_pitch; ta.rects = B.plan->d_hist_rects_tiled.as<Rect>();
+    ta.t_valid = B.t_valid; ta.thr = d_thr; ta.tile_bins = d_tile_bins;
+    ta.pol = B.pol;
+    ta.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
+    KernelTimer t(ctx, "f32_tile_hist");
+    HIPCHK(ctx, launch_f32_tile_hist(ta, (int)B.plan->hist_rects_tiled.size(), B.vec, ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+// CLAHE: d_tile_bins holds the merged tile histograms.  Writes the stripe's levels; u8: local level histogram in d_level_hist.
+int f32_phase_d(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    const bool u8o = B.u8o;
+    const size_t esz = u8o ? 1 : 2;
+    const uint32_t rows = (uint32_t)B.rows, cols = (uint32_t)B.cols;
+    unsigned long long *d_level_hist = reinterpret_cast<unsigned long long *>(ws + kOffLevelHist);
+    if (B.empty) {
+        if (B.rows && B.cols) HIPCHK(ctx, hipMemset2DAsync(B.d_out, B.out_pitch * esz, 0, B.cols * esz, B.rows, ctx->stream));
         return SARPRO_HIP_OK;
     }
-    if (std::isinf(maxv)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "non-finite (+inf) sample: the reference's statistics are undefined for it");
-    const double mean = sum / (double)count;
-    const double var = sumsq / (double)count - mean * mean;
-    const double std_db = count > 1 ? std::sqrt(std::fmax(var, 0.0)) : 0.0;
-    const double min_db = db_of_f32(minv), max_db = db_of_f32(maxv);
-
-    // ---- pass b: 4096-bin histogram -> percentiles (autoscale.rs:102-159) ----
-    uint64_t *h_hist = ctx->h_small.as<uint64_t>();
-    std::memset(h_hist, 0, sizeof(uint64_t) * 4096);
-    if (!(std::fabs(max_db - min_db) < 2.220446049250313e-16)) {
-        float *thr = ctx->h_upload.as<float>();
-        build_bin4096_thresholds(min_db, max_db, thr);
-        float *d_thr = reinterpret_cast<float *>(ws + kOffThr4096);
-        unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws + kOffHist4096);
-        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 4096, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * 4096, ctx->stream));
-        {
-            KernelTimer t(ctx, "f32_hist4096");
-            HIPCHK(ctx, launch_f32_hist4096(B.d_in, B.in_pitch, rows, cols, t_valid, vec, d_thr, d_hist,
-                                            step_estimate(min_db, max_db - min_db, 4096.0, 0.0), ctx->stream, B.pol));
-        }
-        HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    RETCHK(stats_from_bins4096(count, min_db, max_db, mean, std_db, h_hist, &B.stats));
-    RETCHK(select_window(&B.stats, B.strategy, B.tamed));
-
-    unsigned long long *d_level_hist = reinterpret_cast<unsigned long long *>(ws + kOffLevelHist);
-    if (u8o) HIPCHK(ctx, hipMemsetAsync(d_level_hist, 0, sizeof(uint64_t) * 256, ctx->stream));
-
-    if (!clahe) {
-        // ---- pass c: level map by threshold search ----
+    if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
+    if (!B.clahe) {
         const int nlevels = u8o ? 255 : 65535;
         float *thr = ctx->h_upload.as<float>();
         build_level_thresholds(B.stats, nlevels, thr);
@@ -191,49 +239,44 @@ int f32_band_run(F32Band &B) {
             a.f64_levels = 1;
         }
         a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
-        a.rows = rows; a.cols = cols; a.t_valid = t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
+        a.rows = rows; a.cols = cols; a.t_valid = B.t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
         a.pol = B.pol;
         KernelTimer t(ctx, "f32_level");
-        HIPCHK(ctx, launch_f32_level(a, vec, !u8o, ctx->stream));
-    } else {
-        // ---- pass d: CLAHE tile histograms -> CDFs; pass e: apply ----
-        StripePlan *plan = nullptr;
-        RETCHK(get_plan(ctx, B.rows, B.cols, 0, B.rows, vec ? 4 : 1, &plan));
-        float *thr = ctx->h_upload.as<float>();
-        build_clahe_bin_thresholds(B.stats, thr);
-        float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
-        unsigned long long *d_tile_bins = reinterpret_cast<unsigned long long *>(ws + kOffTileBins);
-        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_tile_bins, 0, sizeof(uint64_t) * 64 * 256, ctx->stream));
-        F32TileHistArgs ta{};
-        ta.in = B.d_in; ta.pitch = B.in_pitch; ta.rects = plan->d_hist_rects_tiled.as<Rect>();
-        ta.t_valid = t_valid; ta.thr = d_thr; ta.tile_bins = d_tile_bins;
-        ta.pol = B.pol;
-        ta.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
-        {
-            KernelTimer t(ctx, "f32_tile_hist");
-            HIPCHK(ctx, launch_f32_tile_hist(ta, (int)plan->hist_rects_tiled.size(), vec, ctx->stream));
-        }
-        uint64_t *h_tb = ctx->h_small.as<uint64_t>();
-        HIPCHK(ctx, hipMemcpyAsync(h_tb, d_tile_bins, sizeof(uint64_t) * 64 * 256, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        double *h_cdfs = reinterpret_cast<double *>(ctx->h_upload.as<uint8_t>() + 4096);
-        RETCHK(clahe_cdfs(h_tb, B.rows, B.cols, h_cdfs));
-        double *d_cdfs = reinterpret_cast<double *>(ws + kOffCdfs);
-        HIPCHK(ctx, hipMemcpyAsync(d_cdfs, h_cdfs, sizeof(double) * 64 * 256, hipMemcpyHostToDevice, ctx->stream));
-        F32ClaheApplyArgs a{};
-        a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
-        a.rects = plan->d_apply_rects.as<Rect>(); a.cdfs = d_cdfs; a.t_valid = t_valid; a.thr = d_thr;
-        a.row_w = plan->d_row_w.as<RowWeight>(); a.col_w = plan->d_col_w.as<RowWeight>();
-        a.level_hist = d_level_hist; a.max_val = u8o ? 255.0 : 65535.0;
-        a.est = ta.est;
-        a.pol = B.pol;
-        KernelTimer t(ctx, "f32_clahe_apply");
-        HIPCHK(ctx, launch_f32_clahe_apply(a, (int)plan->apply_rects.size(), vec, !u8o, ctx->stream));
+        HIPCHK(ctx, launch_f32_level(a, B.vec, !u8o, ctx->stream));
+        return SARPRO_HIP_OK;
     }
-    if (u8o) {
+    uint64_t *h_tb = ctx->h_small.as<uint64_t>();
+    HIPCHK(ctx, hipMemcpyAsync(h_tb, ws + kOffTileBins, sizeof(uint64_t) * 64 * 256, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (B.plan->apply_rects.empty()) return SARPRO_HIP_OK;
+    double *h_cdfs = reinterpret_cast<double *>(ctx->h_upload.as<uint8_t>() + 4096);
+    RETCHK(clahe_cdfs(h_tb, B.rows_total, B.cols, h_cdfs));
+    double *d_cdfs = reinterpret_cast<double *>(ws + kOffCdfs);
+    HIPCHK(ctx, hipMemcpyAsync(d_cdfs, h_cdfs, sizeof(double) * 64 * 256, hipMemcpyHostToDevice, ctx->stream));
+    F32ClaheApplyArgs a{};
+    a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
+    a.rects = B.plan->d_apply_rects.as<Rect>(); a.cdfs = d_cdfs; a.t_valid = B.t_valid; a.thr = reinterpret_cast<float *>(ws + kOffThrLevel);
+    a.row_w = B.plan->d_row_w.as<RowWeight>() + B.row0; // the table is indexed by the scene's row, the kernel by the stripe's
+    a.col_w = B.plan->d_col_w.as<RowWeight>();
+    a.level_hist = d_level_hist; a.max_val = u8o ? 255.0 : 65535.0;
+    a.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
+    a.pol = B.pol;
+    KernelTimer t(ctx, "f32_clahe_apply");
+    HIPCHK(ctx, launch_f32_clahe_apply(a, (int)B.plan->apply_rects.size(), B.vec, !u8o, ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+// u8: d_level_hist holds the merged histogram of the pre-rescale levels.
+int f32_phase_e(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    if (B.empty) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        B.final_hist[0] = (uint64_t)B.rows_total * B.cols;
+        return SARPRO_HIP_OK;
+    }
+    if (B.u8o) {
         uint64_t *h_lh = ctx->h_small.as<uint64_t>();
-        HIPCHK(ctx, hipMemcpyAsync(h_lh, d_level_hist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_lh, ctx->f32ws.as<uint8_t>() + kOffLevelHist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         uint64_t lh[256];
         std::memcpy(lh, h_lh, sizeof(lh));
@@ -241,6 +284,17 @@ int f32_band_run(F32Band &B) {
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SARPRO_HIP_OK;
+}
+
+int f32_band_run(F32Band &B) {
+    B.rows_total = B.rows; B.row0 = 0;
+    RETCHK(f32_phase_a(B));
+    if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
+    B.global = B.local;
+    RETCHK(f32_phase_b(B));
+    RETCHK(f32_phase_c(B));
+    RETCHK(f32_phase_d(B));
+    return f32_phase_e(B);
 }
 
 } // namespace
@@ -294,6 +348,165 @@ extern "C" int sarpro_hip_polop_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, int 
                                                        sarpro_hip_stats *stats_out) {
     if (ctx) timing_reset(ctx);
     return polop_band_dev(ctx, op, d_a, d_b, 1, rows, cols, in_pitch, strategy, bit_depth, d_out, out_pitch, stats_out);
+}
+
+// ---------------------------------------------------------------------------------------
+// Row stripes of the f32 flavour (autoscale.rs:35-117 needs the scene's count / min / max before it can
+// bin and the scene's bins before it can select the window).  One open f32 stripe per context: the phases keep their
+// intermediate buffers in the context's workspace.
+struct sarpro_hip_stripe_f32 {
+    F32Band B;
+    int phase = 0;
+};
+
+static int stripe_f32_begin(sarpro_hip_ctx *ctx, const float *d_in, int op, const void *d_a, const void *d_b, int elem_u16, size_t rows_total,
+                            size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int bit_depth, void *d_out,
+                            size_t out_pitch, sarpro_hip_stripe_f32 **out) {
+    if (!ctx || !out) return SARPRO_HIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
+    if (op >= 0 && (op < SARPRO_OP_SUM || op > SARPRO_OP_LOGRATIO)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad polarisation operation");
+    if (rows_local * cols && (!d_out || (op < 0 ? !d_in : (!d_a || !d_b)))) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (row0 + rows_local > rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "stripe outside the scene");
+    sarpro_hip_stripe_f32 *s = new sarpro_hip_stripe_f32();
+    F32Band &B = s->B;
+    B.ctx = ctx; B.d_in = d_in; B.rows = rows_local; B.cols = cols; B.in_pitch = in_pitch;
+    B.rows_total = rows_total; B.row0 = row0;
+    if (op >= 0) { B.pol.a = d_a; B.pol.b = d_b; B.pol.pitch = in_pitch; B.pol.op = op; B.pol.u16 = elem_u16; }
+    B.strategy = strategy; B.bit_depth = bit_depth; B.d_out = d_out; B.out_pitch = out_pitch;
+    B.want_moments = true;
+    timing_reset(ctx);
+    *out = s;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_begin_f32(sarpro_hip_ctx *ctx, const float *d_in, size_t rows_total, size_t cols, size_t row0,
+                                           size_t rows_local, size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
+                                           sarpro_hip_stripe_f32 **out) {
+    return stripe_f32_begin(ctx, d_in, -1, nullptr, nullptr, 0, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out, out_pitch, out);
+}
+
+extern "C" int sarpro_hip_stripe_begin_polop(sarpro_hip_ctx *ctx, int op, const void *d_a, const void *d_b, int elem_u16, size_t rows_total,
+                                             size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int bit_depth,
+                                             void *d_out, size_t out_pitch, sarpro_hip_stripe_f32 **out) {
+    if (op < 0) return ctx ? fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad polarisation operation") : SARPRO_HIP_ERR_INVALID_ARG;
+    return stripe_f32_begin(ctx, nullptr, op, d_a, d_b, elem_u16 ? 1 : 0, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out,
+                            out_pitch, out);
+}
+
+extern "C" int sarpro_hip_stripe_f32_phase1(sarpro_hip_stripe_f32 *s, sarpro_hip_f32_partial *local_out) {
+    if (!s || !local_out || s->phase != 0) return SARPRO_HIP_ERR_INVALID_ARG;
+    RETCHK(f32_phase_a(s->B));
+    *local_out = s->B.local;
+    s->phase = 1;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_host_f32_merge_partials(const sarpro_hip_f32_partial *parts, size_t n, sarpro_hip_f32_partial *out) {
+    if ((!parts && n) || !out) return SARPRO_HIP_ERR_INVALID_ARG;
+    sarpro_hip_f32_partial g{};
+    g.min_v = INFINITY; g.max_v = -INFINITY;
+    for (size_t i = 0; i < n; ++i) { // rank order: the f64 sums are reproducible for a given stripe plan
+        g.count += parts[i].count; g.sum_db += parts[i].sum_db; g.sumsq_db += parts[i].sumsq_db;
+        g.min_v = std::fmin(g.min_v, parts[i].min_v); g.max_v = std::fmax(g.max_v, parts[i].max_v);
+    }
+    *out = g;
+    return SARPRO_HIP_OK;
+}
+
+static int stripe_f32_buf(sarpro_hip_stripe_f32 *s, size_t off, size_t n, bool present, uint64_t **d_buf, size_t *count) {
+    HIPCHK(s->B.ctx, hipStreamSynchronize(s->B.ctx->stream)); // the buffer is complete when the phase returns
+    *d_buf = present ? reinterpret_cast<uint64_t *>(s->B.ctx->f32ws.as<uint8_t>() + off) : nullptr;
+    *count = present ? n : 0;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_f32_phase2(sarpro_hip_stripe_f32 *s, const sarpro_hip_f32_partial *global, uint64_t **d_buf, size_t *count) {
+    if (!s || !global || !d_buf || !count || s->phase != 1) return SARPRO_HIP_ERR_INVALID_ARG;
+    s->B.global = *global;
+    RETCHK(f32_phase_b(s->B));
+    s->phase = 2;
+    return stripe_f32_buf(s, kOffHist4096, 4096, true, d_buf, count);
+}
+
+extern "C" int sarpro_hip_stripe_f32_phase3(sarpro_hip_stripe_f32 *s, uint64_t **d_buf, size_t *count) {
+    if (!s || !d_buf || !count || s->phase != 2) return SARPRO_HIP_ERR_INVALID_ARG;
+    RETCHK(f32_phase_c(s->B));
+    s->phase = 3;
+    return stripe_f32_buf(s, kOffTileBins, 64 * 256, s->B.clahe, d_buf, count);
+}
+
+extern "C" int sarpro_hip_stripe_f32_phase4(sarpro_hip_stripe_f32 *s, uint64_t **d_buf, size_t *count) {
+    if (!s || !d_buf || !count || s->phase != 3) return SARPRO_HIP_ERR_INVALID_ARG;
+    RETCHK(f32_phase_d(s->B));
+    s->phase = 4;
+    return stripe_f32_buf(s, kOffLevelHist, 256, s->B.u8o, d_buf, count);
+}
+
+extern "C" int sarpro_hip_stripe_f32_phase5(sarpro_hip_stripe_f32 *s, sarpro_hip_stats *stats_out) {
+    if (!s || s->phase != 4) return SARPRO_HIP_ERR_INVALID_ARG;
+    RETCHK(f32_phase_e(s->B));
+    if (stats_out) *stats_out = s->B.stats;
+    s->phase = 5;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" void sarpro_hip_stripe_f32_end(sarpro_hip_stripe_f32 *s) { delete s; }
+
+// the stripe in one call per rank, reductions over the library's communicator
+static int stripe_f32_run(sarpro_hip_stripe_f32 *s, sarpro_hip_stats *stats_out) {
+    F32Band &B = s->B;
+    sarpro_hip_ctx *ctx = B.ctx;
+    if (!ctx->comm) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "communicator not initialised");
+    const int n = ctx->comm_nranks, me = ctx->comm_rank;
+    if (n > 1024) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "more than 1024 ranks");
+    RETCHK(f32_phase_a(B));
+    // all-gather of the 32-byte partials as an all-reduce(sum) of a buffer that is zero outside the rank's own slot: RCCL adds
+    // the words as u64, x + 0 + ... + 0 is exact whatever bit pattern x is
+    static_assert(sizeof(sarpro_hip_f32_partial) == 32, "partial = 4 words");
+    uint64_t *d_g = reinterpret_cast<uint64_t *>(ctx->f32ws.as<uint8_t>() + kOffPartials);
+    uint64_t *h_g = ctx->h_small.as<uint64_t>();
+    HIPCHK(ctx, hipMemsetAsync(d_g, 0, 32 * (size_t)n, ctx->stream));
+    std::memcpy(h_g, &B.local, 32);
+    HIPCHK(ctx, hipMemcpyAsync(d_g + 4 * me, h_g, 32, hipMemcpyHostToDevice, ctx->stream));
+    RETCHK(comm_allreduce_sum_u64_async(ctx, d_g, 4 * (size_t)n));
+    HIPCHK(ctx, hipMemcpyAsync(h_g, d_g, 32 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<sarpro_hip_f32_partial> parts((size_t)n);
+    std::memcpy(parts.data(), h_g, 32 * (size_t)n);
+    RETCHK(sarpro_hip_host_f32_merge_partials(parts.data(), parts.size(), &B.global));
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    RETCHK(f32_phase_b(B));
+    RETCHK(comm_allreduce_sum_u64_async(ctx, reinterpret_cast<uint64_t *>(ws + kOffHist4096), 4096));
+    RETCHK(f32_phase_c(B));
+    if (B.clahe) RETCHK(comm_allreduce_sum_u64_async(ctx, reinterpret_cast<uint64_t *>(ws + kOffTileBins), 64 * 256));
+    RETCHK(f32_phase_d(B));
+    if (B.u8o) RETCHK(comm_allreduce_sum_u64_async(ctx, reinterpret_cast<uint64_t *>(ws + kOffLevelHist), 256));
+    RETCHK(f32_phase_e(B));
+    if (stats_out) *stats_out = B.stats;
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_run_f32(sarpro_hip_ctx *ctx, const float *d_in, size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                                         size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
+                                         sarpro_hip_stats *stats_out) {
+    sarpro_hip_stripe_f32 *s = nullptr;
+    RETCHK(sarpro_hip_stripe_begin_f32(ctx, d_in, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out, out_pitch, &s));
+    int rc = stripe_f32_run(s, stats_out);
+    delete s;
+    return rc;
+}
+
+extern "C" int sarpro_hip_stripe_run_polop(sarpro_hip_ctx *ctx, int op, const void *d_a, const void *d_b, int elem_u16, size_t rows_total,
+                                           size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int bit_depth,
+                                           void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out) {
+    sarpro_hip_stripe_f32 *s = nullptr;
+    RETCHK(sarpro_hip_stripe_begin_polop(ctx, op, d_a, d_b, elem_u16, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out,
+                                         out_pitch, &s));
+    int rc = stripe_f32_run(s, stats_out);
+    delete s;
+    return rc;
 }
 
 static int host_polop_band(sarpro_hip_ctx *ctx, int op, const void *a, const void *b, int elem_u16, size_t rows, size_t cols, int strategy,

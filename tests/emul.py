@@ -118,53 +118,69 @@ def _steps(thr: np.ndarray, v: np.ndarray) -> np.ndarray:
     return np.searchsorted(thr[1:], v, side="right")
 
 
-def f32_levels(x: np.ndarray, strategy: St, u8: bool, tamed: int = 0):
-    """Levels of an f32 band through the product's threshold tables (numpy search = kernel)."""
+def f32_levels(x: np.ndarray, strategy: St, u8: bool, tamed: int = 0, rows_total=None, row0=0, reduce=None, gather=None):
+    """Levels of an f32 band (or of a row stripe of it) through the product's threshold tables (numpy search = kernel).
+    Stripes: `gather(partial) -> [partials of all ranks]` where the GPU path gathers the 32-byte partials, `reduce(hist)`
+    where it all-reduces a u64 histogram (sarpro_hip_stripe_f32_phase1..4)."""
     import oracle  # only for the dB moments (mean/std), which the device computes with its own log10
+    reduce = reduce or (lambda a: a)
+    gather = gather or (lambda p: [p])
     x = np.ascontiguousarray(x, np.float32)
+    rows_total = rows_total or x.shape[0]
+    cols = x.shape[1]
     tv = np.float32(S.host_f32_valid_threshold())
     valid = x >= tv  # NaN -> False
-    n = int(valid.sum())
+    db_all, _ = oracle.db_mask(x) if x.size else (np.zeros(x.shape), None)
+    dbv = db_all[valid]
+    local = S.F32Partial(int(valid.sum()), float(dbv.sum()), float((dbv * dbv).sum()),
+                         float(x[valid].min()) if valid.any() else float("inf"), float(x[valid].max()) if valid.any() else float("-inf"))
+    g = S.host_f32_merge_partials(gather(local))
+    n = int(g.count)
     if n == 0:
         return np.zeros(x.shape, np.uint16), None
-    vmin, vmax = x[valid].min(), x[valid].max()
-    db_min = 10.0 * np.log10(np.float64(vmin))
-    db_max = 10.0 * np.log10(np.float64(vmax))
-    db_all, _ = oracle.db_mask(x)
-    dbv = db_all[valid]
-    assert db_min == dbv.min() and db_max == dbv.max()
-    mean, std = float(dbv.mean()), float(dbv.std())
+    db_min = 10.0 * np.log10(np.float64(np.float32(g.min_v)))
+    db_max = 10.0 * np.log10(np.float64(np.float32(g.max_v)))
+    if rows_total == x.shape[0]:
+        assert db_min == dbv.min() and db_max == dbv.max()
+        mean, std = float(dbv.mean()), float(dbv.std())
+    else:
+        mean = g.sum_db / n
+        std = float(np.sqrt(max(g.sumsq_db / n - mean * mean, 0.0))) if n > 1 else 0.0
     hist = np.zeros(4096, np.uint64)
     if not abs(db_max - db_min) < np.finfo(np.float64).eps:
         thr = S.host_f32_bin4096_thresholds(float(db_min), float(db_max))
         hist = np.bincount(_steps(thr, x[valid]), minlength=4096).astype(np.uint64)
-    st = S.host_stats_from_bins4096(n, float(db_min), float(db_max), mean, std, hist)
+    st = S.host_stats_from_bins4096(n, float(db_min), float(db_max), mean, std, reduce(hist))
     S.host_window(st, strategy, tamed)
     if strategy == St.Clahe and not tamed:
         bins = _steps(S.host_f32_clahe_bin_thresholds(st), x).astype(np.int64)
-        dn_like = np.where(valid, 1, 0).astype(np.uint16)  # validity carrier for the shared helpers
-        rows, cols = x.shape
-        th_, tw_ = -(-rows // 8), -(-cols // 8)
+        th_, tw_ = -(-rows_total // 8), -(-cols // 8)
         tile = np.zeros((64, 256), np.uint64)
         for ty in range(8):
+            r0, r1 = max(ty * th_, row0) - row0, min((ty + 1) * th_, rows_total, row0 + x.shape[0]) - row0
+            if r1 <= r0:
+                continue
             for tx in range(8):
-                sl = (slice(ty * th_, min((ty + 1) * th_, rows)), slice(tx * tw_, min((tx + 1) * tw_, cols)))
+                sl = (slice(r0, r1), slice(tx * tw_, min((tx + 1) * tw_, cols)))
                 tile[ty * 8 + tx] = np.bincount(bins[sl][valid[sl]].ravel(), minlength=256)
-        cdfs = S.host_clahe_cdfs(tile, rows, cols)
+        cdfs = S.host_clahe_cdfs(reduce(tile), rows_total, cols)
         # reuse the u16 blend helper: feed it "bins" through an identity-like table
         lut = np.arange(65536, dtype=np.int64) % 256
         fake = np.where(valid, bins, 0).astype(np.uint16)
-        lv = clahe_apply(np.where(valid, fake + 256 * 1, 0).astype(np.uint16), lut.astype(np.uint8), cdfs, rows, cols,
-                         255.0 if u8 else 65535.0)
+        lv = clahe_apply(np.where(valid, fake + 256 * 1, 0).astype(np.uint16), lut.astype(np.uint8), cdfs, rows_total, cols,
+                         255.0 if u8 else 65535.0, row0)
         return np.where(valid, lv, 0).astype(np.uint16), st
     thr = S.host_f32_level_thresholds(st, Bd.U8 if (u8 or tamed) else Bd.U16)
     lv = _steps(thr, x)
     return np.where(valid, lv, 0).astype(np.uint16), st
 
 
-def f32_pipeline(x: np.ndarray, bit_depth: Bd, strategy: St):
-    lv, st = f32_levels(x, strategy, bit_depth == Bd.U8)
-    if bit_depth == Bd.U16:
+def f32_pipeline(x: np.ndarray, bit_depth: Bd, strategy: St, rows_total=None, row0=0, reduce=None, gather=None):
+    lv, st = f32_levels(x, strategy, bit_depth == Bd.U8, 0, rows_total, row0, reduce, gather)
+    if bit_depth == Bd.U16 or st is None:
         return lv, st
-    resc = S.host_u8_rescale_lut(int(lv.min()), int(lv.max()))
+    reduce = reduce or (lambda a: a)
+    lh = reduce(np.bincount(lv.ravel(), minlength=256).astype(np.uint64))  # the level histogram the GPU path all-reduces
+    nz = np.nonzero(lh)[0]
+    resc = S.host_u8_rescale_lut(int(nz[0]), int(nz[-1]))
     return resc[lv], st
