@@ -129,6 +129,8 @@ def main():
             if not name.startswith("host:"):
                 wtimes[name] = wtimes.get(name, 0.0) + ms
     dom_warm = max(wtimes, key=wtimes.get) if wtimes else None
+    if dom_warm is None:  # --warmup 0: no measurement to choose by; the kernel that dominates this strategy's chain in every profile
+        dom_warm = ("clahe_fused_rgb" if args.fused else "clahe_apply_u8_spec") if strategy == AutoscaleStrategy.Clahe else "lut_compose_u16"
     if dom_warm:
         ctx.time_only(dom_warm)
     dtimes: list[float] = []  # the dominant kernel's launches inside the timed region

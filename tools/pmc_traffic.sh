@@ -10,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 import csv, sys, collections, json
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"].split("(")[0].split("::")[-1]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].split("::")[-1]
     acc[k] += float(r["Counter_Value"]); n[k] += 1
 out = {k: {"mean": acc[k] / n[k], "dispatches": n[k]} for k in acc}
 json.dump({"counter": sys.argv[2], "per_kernel": out}, open(sys.argv[3], "w"), indent=1)

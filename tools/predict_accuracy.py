@@ -12,7 +12,7 @@ rows = cols = side
 pitch = (cols + 63) // 64 * 64
 q = synth.q_tables()
 out = []
-with S.Context(0, timing=True) as c:
+with S.Context(0, timing=True, fused_clahe=True) as c:
     d = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
     rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
     for seed_off in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
