@@ -367,6 +367,10 @@ int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, cons
                               size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
                               uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out);
 
+/* Self-test: the division the u16 pol-op kernels use (the Newton core of the IEEE division without its rescaling frame) against
+ * the compiler's IEEE division over ALL 2^32 pairs of u16 values, ratio and normalised difference.  *mismatches_out must be 0. */
+int sarpro_hip_selftest_polop_division(sarpro_hip_ctx *ctx, uint64_t *mismatches_out);
+
 /* ---- row stripes of the f32 flavour (a calibrated f32 band, or a polarisation operation of two bands computed on the
  * fly): autoscale.rs:35-117 needs the scene's count / min / max before it can bin, and the scene's 4096 bins before it can
  * select the window, so the protocol has one more reduction than the u16 one.  One open f32 stripe per context. ---- */

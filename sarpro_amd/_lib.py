@@ -76,6 +76,7 @@ SYMBOLS = [
     "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_dualpol_synrgb_resized_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
     "sarpro_hip_tiff_pair_reader", "sarpro_hip_tiff_create", "sarpro_hip_tiff_write_rows", "sarpro_hip_tiff_row_sink",
     "sarpro_hip_tiff_finish", "sarpro_hip_tiff_last_error", "sarpro_hip_host_update_geotransform",
+    "sarpro_hip_selftest_polop_division",
     "sarpro_hip_stripe_begin_f32", "sarpro_hip_stripe_begin_polop", "sarpro_hip_stripe_f32_phase1", "sarpro_hip_stripe_f32_phase2",
     "sarpro_hip_stripe_f32_phase3", "sarpro_hip_stripe_f32_phase4", "sarpro_hip_stripe_f32_phase5", "sarpro_hip_stripe_f32_end",
     "sarpro_hip_stripe_run_f32", "sarpro_hip_stripe_run_polop", "sarpro_hip_host_f32_merge_partials",
@@ -172,6 +173,7 @@ _proto("sarpro_hip_stripe_phase2", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
 _proto("sarpro_hip_stripe_phase3", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
 _proto("sarpro_hip_stripe_phase4", _i, _vp, _vp, _sz, _S)
 _proto("sarpro_hip_stripe_end", None, _vp)
+_proto("sarpro_hip_selftest_polop_division", _i, _vp, C.POINTER(C.c_uint64))
 _proto("sarpro_hip_stripe_begin_f32", _i, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, C.POINTER(_vp))
 _proto("sarpro_hip_stripe_begin_polop", _i, _vp, _i, _vp, _vp, _i, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, C.POINTER(_vp))
 _proto("sarpro_hip_stripe_f32_phase1", _i, _vp, C.POINTER(F32Partial))

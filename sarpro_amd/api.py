@@ -119,7 +119,8 @@ class Context:
         else:
             x = np.ascontiguousarray(processed, np.float32)
             fn = lib.sarpro_hip_autoscale_band_f32
-        self._chk(fn(self._h, _vp(x), rows, cols, int(strategy), int(bit_depth), _vp(out8), _vp(out16), C.byref(st)))
+        # stats_out = NULL lets the f32 flavour skip the dB moments and the eleven-percentile histogram (zone route)
+        self._chk(fn(self._h, _vp(x), rows, cols, int(strategy), int(bit_depth), _vp(out8), _vp(out16), C.byref(st) if want_stats else None))
         res = (out8, None) if bit_depth == BitDepth.U8 else (np.empty(0, np.uint8), out16)
         return res + (st,) if want_stats else res
 
@@ -138,9 +139,16 @@ class Context:
         else:
             fn, dt = lib.sarpro_hip_polop_autoscale_band_f32, np.float32
         x, y = np.ascontiguousarray(a, dt), np.ascontiguousarray(b, dt)
-        self._chk(fn(self._h, int(op), _vp(x), _vp(y), rows, cols, int(strategy), int(bit_depth), _vp(out8), _vp(out16), C.byref(st)))
+        self._chk(fn(self._h, int(op), _vp(x), _vp(y), rows, cols, int(strategy), int(bit_depth), _vp(out8), _vp(out16),
+                     C.byref(st) if want_stats else None))
         res = (out8, None) if bit_depth == BitDepth.U8 else (np.empty(0, np.uint8), out16)
         return res + (st,) if want_stats else res
+
+    def selftest_polop_division(self) -> int:
+        """Pairs of u16 values (of all 2^32) for which the u16 pol-op kernels' division differs from the IEEE division: must be 0."""
+        n = C.c_uint64()
+        self._chk(lib.sarpro_hip_selftest_polop_division(self._h, C.byref(n)))
+        return n.value
 
     def dev_polop_autoscale_band(self, op, d_a: int, d_b: int, u16_in: bool, rows: int, cols: int, in_pitch: int, strategy, bit_depth,
                                  d_out: int, out_pitch: int, want_stats: bool = True) -> Stats | None:

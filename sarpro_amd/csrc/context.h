@@ -106,6 +106,7 @@ struct sarpro_hip_ctx {
     sarpro::DevBuf stage_out[3];
     sarpro::DevBuf qtab;                         // synthetic scene tables
     sarpro::DevBuf f32ws;                        // f32-path workspace
+    sarpro::DevBuf f32zone;                      // f32 zone route: samples kept by the min / max pass (a few per cent of the scene)
     uint32_t resize_key[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // (in, out, elem, precision) of the cached coefficient tables
     sarpro::DevBuf resize_tmp, resize_coef[2], resized[2]; // resize path: intermediate image, coefficient tables, resized bands
     sarpro::DevBuf chain_consts;                 // device-resident chain: dB table | suppressed lut_r/g per floor | blue pairs

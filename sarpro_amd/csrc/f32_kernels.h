@@ -47,8 +47,15 @@ struct F32LevelArgs {
     double low, high, range, gamma, max_val; // range = max(high - low, 1)
     float t_first, t_last;
     int f64_levels;
+    // f64_levels == 2: no 65535-entry table at all -- a sample within 1e-6 of a level boundary is QUEUED (row, column, bits) and
+    // the host settles it with the reference's own arithmetic (glibc); thr is then unused.  *uq_count > uq_cap: overflow.
+    uint32_t *uq_count;
+    uint4 *uq_entries;
+    uint32_t uq_cap;
     F32Pol pol;
 };
+// out[row * pitch + col] = level for n patches (row, col, level, -)
+hipError_t launch_patch_u16(uint16_t *out, size_t pitch, const uint4 *d_patches, uint32_t n, hipStream_t s);
 
 struct F32TileHistArgs {
     const float *in;
@@ -75,6 +82,61 @@ struct F32ClaheApplyArgs {
     F32StepEstimate est;
     F32Pol pol;
 };
+
+// ---- percentiles without the 4096-bin sweep (f32_path.cpp: zone route) ----
+// A row sample locates each percentile the strategy reads to within a few buckets of the float's leading 15 bits; the
+// min / max pass then also counts the valid samples at or above every zone bound and appends the samples INSIDE a zone to a
+// side buffer.  With the scene's min / max known, the few 4096-bin thresholds that fall inside a zone are counted against that
+// buffer: the bin of the percentile, the count below it and the count in it come out exact (autoscale.rs:120-140).
+constexpr int kMaxZones = 6;
+constexpr int kMaxProbes = 2 * kMaxZones;
+constexpr int kSampleKeys = 32768; // key = bits >> 16 of a positive f32: 8 exponent + 7 mantissa bits
+constexpr int kSubKeys = 512;      // the next 9 mantissa bits: sub-bucket of a probed key
+struct F32ZoneWork { // device memory, written by the zone kernels
+    uint32_t ns, kmin, kmax, nprobe;       // sample size, lowest / highest populated key
+    uint32_t probe_key[kMaxProbes];        // key whose bucket holds the probe rank
+    uint32_t probe_base[kMaxProbes];       // sampled values below that bucket
+    uint32_t probe_rank[kMaxProbes];
+    int32_t nz;                            // zones selected (0: the route steps aside)
+    float bounds[2 * kMaxZones];           // lo_0 < hi_0 < lo_1 < hi_1 ...: zone j = [lo_j, hi_j); unused entries +inf
+    float mass_est;                        // estimated share of the valid samples inside the zones
+};
+struct F32ZoneSelectArgs {
+    F32ZoneWork *work;
+    const uint32_t *key_hist;    // [kSampleKeys]
+    uint32_t *sub_hist;          // [kMaxProbes][kSubKeys]
+    double pcts[kMaxZones];      // the percentiles the strategy reads
+    int npcts;
+    float t_valid;
+    float max_mass;              // zones heavier than this share of the samples: nz = 0
+    float sample_fraction;       // sampled rows / rows (1: the "sample" is the scene, the probe ranks are exact)
+};
+struct F32ZoneArgs {
+    const float *in;
+    size_t pitch;
+    uint32_t rows, cols;
+    float t_valid;
+    F32Pol pol;
+    F32Partial *partials;            // [grid]
+    const F32ZoneWork *work;         // nz, bounds
+    unsigned long long *ge_counts;   // [grid][2 * kMaxZones]: valid samples >= bounds[k], per workgroup
+    float *zone_buf;                 // wave v of workgroup w appends to [w * cap + v * cap / 4, + cap / 4): cap % 4 == 0
+    uint32_t cap;
+    uint32_t *zone_n;                // [grid * 4]: samples each wave found inside zones (> cap / 4: overflow, the route is abandoned)
+};
+// rows r = stride/2, stride/2 + stride, ...: the samples (pol-op applied) stored row by row in `sample` (nsrows x sample_pitch) and
+// the histogram of their leading bits
+hipError_t launch_f32_sample_keys(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, uint32_t row_stride,
+                                  float *d_sample, uint32_t sample_pitch, uint32_t *d_key_hist /* zeroed */, hipStream_t s,
+                                  const F32Pol &pol = F32Pol());
+hipError_t launch_selftest_div_small_ints(unsigned long long *d_mismatches /* zeroed */, hipStream_t s);
+hipError_t launch_f32_zone_pick(const F32ZoneSelectArgs &a, hipStream_t s);
+hipError_t launch_f32_sample_sub(const float *d_sample, uint64_t n, float t_valid, const F32ZoneWork *work, uint32_t *d_sub_hist /* zeroed */, hipStream_t s);
+hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s);
+hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int nz_max, int grid, hipStream_t s);
+// counts[i] += zone samples x with thr[i] <= x < thr[i + 1], i = 0 .. nthr (thr[0] = -inf implied below thr[1]; thr sorted, nthr <= 255)
+hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, uint32_t cap, int nregions, const float *d_thr, int nthr,
+                                 unsigned long long *d_counts /* [256], zeroed */, hipStream_t s);
 
 int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec);
 // moments = false: count / min / max only (no per-sample f64 log10: the pass is then memory-bound)

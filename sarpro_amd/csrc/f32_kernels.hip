@@ -42,14 +42,34 @@ __device__ inline uint32_t est_search(const float *thr, float v, const F32StepEs
 }
 
 // ops.rs:4-44, IEEE f32 (hipcc's default correctly rounded divide); the same function as kernels.hip k_polop_f32
+// num / den for operands that are integers of magnitude < 2^18 (u16 DN, their sums and differences), den != 0: the Newton
+// core of the compiler's IEEE division (LLVM's f32 fdiv expansion) without its v_div_scale / v_div_fmas / v_div_fixup frame.
+// That frame rescales operands whose exponents are extreme and patches inf / nan / zero denominators; for these operands it
+// is the identity, so the quotient is the correctly rounded one, bit for bit -- checked against `/` over ALL 2^32 pairs of
+// u16 values, for the ratio and for the normalised difference (tests/test_gpu_polop_fused.py).
+__device__ inline float div_small_ints(float num, float den) {
+    float r = __builtin_amdgcn_rcpf(den);
+    const float e0 = __builtin_fmaf(-den, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    float q = num * r;
+    const float e1 = __builtin_fmaf(-den, q, num);
+    q = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-den, q, num);
+    return __builtin_fmaf(e2, r, q);
+}
+
+template <bool INTS = false>
 __device__ inline float pol_one(int op, float x, float y) {
-    switch (op) {
-    case SARPRO_OP_SUM: return x + y;
-    case SARPRO_OP_DIFF: return x - y;
-    case SARPRO_OP_RATIO:
-    case SARPRO_OP_LOGRATIO: return fabsf(y) > 1e-10f ? x / y : 0.0f;
-    default: { const float d = x + y; return fabsf(d) > 1e-10f ? (x - y) / d : 0.0f; }
-    }
+    // straight-line in the (uniform) operation: one guarded division whatever it is, so that the divisions of a vector's four
+    // elements interleave instead of sitting behind a chain of scalar branches each
+    const bool nd = op == SARPRO_OP_NDIFF;
+    const float s = x + y, d = x - y;
+    const float num = nd ? d : x, den = nd ? s : y;
+    const bool ok = fabsf(den) > 1e-10f;
+    const float dsafe = ok ? den : 1.0f;       // unconditional division: the compiler would otherwise put each behind its own branch
+    const float q0 = INTS ? div_small_ints(num, dsafe) : num / dsafe;
+    const float q = ok ? q0 : 0.0f;
+    return op == SARPRO_OP_SUM ? s : (op == SARPRO_OP_DIFF ? d : q);
 }
 
 template <int VEC> struct F32Vec;
@@ -74,6 +94,38 @@ template <> struct F32Vec<4> {
         o.v = make_float4(pol_one(p.op, x.x, y.x), pol_one(p.op, x.y, y.y), pol_one(p.op, x.z, y.z), pol_one(p.op, x.w, y.w));
         return o;
     }
+    // The same in two steps -- the loads alone, then the arithmetic -- so that a loop can issue the NEXT item's loads before it
+    // works on the current one (one item in flight per wave leaves HBM idle: bytes in flight / latency is the bandwidth).
+    struct Raw { uint4 a; uint2 b, c; };
+    __device__ static Raw load_raw(const float *in, size_t pitch, const F32Pol &p, size_t r, size_t col) {
+        Raw w;
+        w.a = make_uint4(0, 0, 0, 0); w.b = make_uint2(0, 0); w.c = make_uint2(0, 0);
+        if (p.op < 0) w.a = *reinterpret_cast<const uint4 *>(in + r * pitch + col);
+        else if (p.u16) {
+            w.b = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p.a) + r * p.pitch + col);
+            w.c = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p.b) + r * p.pitch + col);
+        } else {
+            w.a = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p.a) + r * p.pitch + col);
+            const uint4 y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p.b) + r * p.pitch + col);
+            w.b = make_uint2(y.x, y.y); w.c = make_uint2(y.z, y.w);
+        }
+        return w;
+    }
+    __device__ static F32Vec make(const Raw &w, const F32Pol &p) {
+        F32Vec o;
+        if (p.op < 0) { o.v = make_float4(__uint_as_float(w.a.x), __uint_as_float(w.a.y), __uint_as_float(w.a.z), __uint_as_float(w.a.w)); return o; }
+        float4 x, y;
+        if (p.u16) {
+            x = make_float4((float)(w.b.x & 0xFFFFu), (float)(w.b.x >> 16), (float)(w.b.y & 0xFFFFu), (float)(w.b.y >> 16));
+            y = make_float4((float)(w.c.x & 0xFFFFu), (float)(w.c.x >> 16), (float)(w.c.y & 0xFFFFu), (float)(w.c.y >> 16));
+        } else {
+            x = make_float4(__uint_as_float(w.a.x), __uint_as_float(w.a.y), __uint_as_float(w.a.z), __uint_as_float(w.a.w));
+            y = make_float4(__uint_as_float(w.b.x), __uint_as_float(w.b.y), __uint_as_float(w.c.x), __uint_as_float(w.c.y));
+        }
+        if (p.u16) o.v = make_float4(pol_one<true>(p.op, x.x, y.x), pol_one<true>(p.op, x.y, y.y), pol_one<true>(p.op, x.z, y.z), pol_one<true>(p.op, x.w, y.w));
+        else o.v = make_float4(pol_one(p.op, x.x, y.x), pol_one(p.op, x.y, y.y), pol_one(p.op, x.z, y.z), pol_one(p.op, x.w, y.w));
+        return o;
+    }
 };
 template <> struct F32Vec<1> {
     float v;
@@ -86,6 +138,48 @@ template <> struct F32Vec<1> {
         o.v = p.u16 ? pol_one(p.op, (float)reinterpret_cast<const uint16_t *>(p.a)[i], (float)reinterpret_cast<const uint16_t *>(p.b)[i])
                     : pol_one(p.op, reinterpret_cast<const float *>(p.a)[i], reinterpret_cast<const float *>(p.b)[i]);
         return o;
+    }
+    struct Raw { float x, y; };
+    __device__ static Raw load_raw(const float *in, size_t pitch, const F32Pol &p, size_t r, size_t col) {
+        Raw w{0.0f, 0.0f};
+        if (p.op < 0) { w.x = in[r * pitch + col]; return w; }
+        const size_t i = r * p.pitch + col;
+        if (p.u16) { w.x = (float)reinterpret_cast<const uint16_t *>(p.a)[i]; w.y = (float)reinterpret_cast<const uint16_t *>(p.b)[i]; }
+        else { w.x = reinterpret_cast<const float *>(p.a)[i]; w.y = reinterpret_cast<const float *>(p.b)[i]; }
+        return w;
+    }
+    __device__ static F32Vec make(const Raw &w, const F32Pol &p) {
+        F32Vec o;
+        o.v = p.op < 0 ? w.x : pol_one(p.op, w.x, w.y);
+        return o;
+    }
+};
+
+// Walk of the grid-stride kernels over (row, vector column) items: no division per item, the next item's loads issued before the
+// current item is worked on.
+template <int VEC>
+struct StrideWalk {
+    uint64_t idx, total, step;
+    uint32_t r, vc, vpr, step_r, step_c;
+    typename F32Vec<VEC>::Raw cur;
+    __device__ StrideWalk(uint32_t rows, uint32_t cols, const float *in, size_t pitch, const F32Pol &pol) {
+        vpr = (cols + VEC - 1) / VEC;
+        total = (uint64_t)rows * vpr;
+        step = (uint64_t)gridDim.x * blockDim.x;
+        step_r = (uint32_t)(step / vpr); step_c = (uint32_t)(step % vpr);
+        idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        r = (uint32_t)(idx / vpr); vc = (uint32_t)(idx % vpr);
+        if (idx < total) cur = F32Vec<VEC>::load_raw(in, pitch, pol, r, (size_t)vc * VEC);
+    }
+    __device__ bool live() const { return idx < total; }
+    // returns the current item's samples and its (row, column); advances, prefetching the item after it
+    __device__ F32Vec<VEC> next(const float *in, size_t pitch, const F32Pol &pol, uint32_t *row, uint32_t *col) {
+        *row = r; *col = vc * VEC;
+        const typename F32Vec<VEC>::Raw mine = cur;
+        idx += step; r += step_r; vc += step_c;
+        if (vc >= vpr) { vc -= vpr; ++r; }
+        if (idx < total) cur = F32Vec<VEC>::load_raw(in, pitch, pol, r, (size_t)vc * VEC);
+        return F32Vec<VEC>::make(mine, pol);
     }
 };
 
@@ -128,8 +222,6 @@ __device__ inline double db_of_f32_fast(float x, const double *logc, const doubl
 template <int VEC, bool MOMENTS>
 __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict__ in, size_t pitch, uint32_t rows,
                                                         uint32_t cols, float t_valid, F32Partial *__restrict__ out, F32Pol pol) {
-    const uint32_t vpr = (cols + VEC - 1) / VEC;
-    const uint64_t total = (uint64_t)rows * vpr;
     unsigned long long cnt = 0;
     double sum = 0.0, sumsq = 0.0;
     float mn = INFINITY, mx = -INFINITY;
@@ -141,10 +233,10 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
         invc[threadIdx.x] = 1.0 / c;
         __syncthreads();
     }
-    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t r = (uint32_t)(idx / vpr);
-        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
-        const F32Vec<VEC> v = F32Vec<VEC>::fetch(in, pitch, pol, r, col);
+    StrideWalk<VEC> walk(rows, cols, in, pitch, pol);
+    while (walk.live()) {
+        uint32_t r, col;
+        const F32Vec<VEC> v = walk.next(in, pitch, pol, &r, &col);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float x = v.get(j);
@@ -176,6 +268,301 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
+// a'. zone route (f32_kernels.h): row sample of the float's leading bits; min / max pass that also counts the samples at or
+//     above each zone bound and keeps the samples inside a zone; count of the kept samples against a few thresholds.
+// ------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_f32_sample_keys(const float *__restrict__ in, size_t pitch, uint32_t rows, uint32_t cols,
+                                                            float t_valid, uint32_t row_stride, float *__restrict__ sample,
+                                                            uint32_t sample_pitch, uint32_t *__restrict__ g_hist, F32Pol pol) {
+    extern __shared__ uint32_t keys[]; // [kSampleKeys]
+    for (int i = threadIdx.x; i < kSampleKeys; i += kBlock) keys[i] = 0;
+    __syncthreads();
+    const uint32_t vpr = (cols + VEC - 1) / VEC;
+    const uint32_t nsrows = (rows + row_stride - 1) / row_stride;
+    for (uint32_t sr = blockIdx.x; sr < nsrows; sr += gridDim.x) {
+        const uint32_t r = min(sr * row_stride + row_stride / 2, rows - 1); // mid-phase rows
+        float *dst = sample + (size_t)sr * sample_pitch;
+        for (uint32_t vc = threadIdx.x; vc < vpr; vc += kBlock) {
+            const uint32_t col = vc * VEC;
+            const F32Vec<VEC> v = F32Vec<VEC>::fetch(in, pitch, pol, r, col);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float x = v.get(j);
+                if (!(col + j < cols && x >= t_valid)) x = 0.0f; // invalid: below every threshold
+                else atomicAdd(&keys[__float_as_uint(x) >> 16], 1u);
+                dst[col + j] = x; // sample_pitch covers vpr * VEC
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSampleKeys; i += kBlock)
+        if (keys[i]) atomicAdd(&g_hist[i], keys[i]);
+}
+
+// one workgroup of 1024: prefix sums over the key histogram, the bucket and base count of every probe rank
+__global__ __launch_bounds__(1024) void k_f32_zone_pick(F32ZoneSelectArgs a) {
+    __shared__ uint32_t incl[1024];
+    __shared__ uint32_t s_kmin, s_kmax, s_rank[kMaxProbes];
+    const int t = threadIdx.x;
+    constexpr int per = kSampleKeys / 1024;
+    uint32_t sum = 0, lo = 0xFFFFFFFFu, hi = 0;
+    for (int k = 0; k < per; ++k) {
+        const uint32_t h = a.key_hist[t * per + k];
+        sum += h;
+        if (h) { lo = min(lo, (uint32_t)(t * per + k)); hi = max(hi, (uint32_t)(t * per + k)); }
+    }
+    if (t == 0) { s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
+    incl[t] = sum;
+    __syncthreads();
+    if (lo != 0xFFFFFFFFu) { atomicMin(&s_kmin, lo); atomicMax(&s_kmax, hi); }
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = t >= d ? incl[t - d] : 0;
+        __syncthreads();
+        incl[t] += v;
+        __syncthreads();
+    }
+    const uint32_t ns = incl[1023];
+    if (t == 0) {
+        // rank error of a row sample: 6 sigma of a simple random sample of that size (finite-population corrected), never
+        // below 0.2 % (rows are clusters: neighbouring samples are correlated); a zone that still misses costs the 4096-bin sweep
+        const double f = (double)a.sample_fraction;
+        const double delta = f >= 1.0 ? 0.0 : fmax(0.002, 6.0 * sqrt((1.0 - f) / (double)max(ns, 1u)));
+        for (int i = 0; i < a.npcts; ++i) {
+            const double n = (double)ns;
+            s_rank[2 * i] = (uint32_t)floor(fmax(a.pcts[i] - delta, 0.0) * n);
+            s_rank[2 * i + 1] = (uint32_t)fmin(ceil(fmin(a.pcts[i] + delta, 1.0) * n), n - 1.0);
+        }
+        a.work->ns = ns; a.work->kmin = s_kmin; a.work->kmax = s_kmax; a.work->nprobe = 2 * a.npcts;
+        a.work->nz = 0;
+    }
+    __syncthreads();
+    if (ns == 0) return;
+    const uint32_t excl = incl[t] - sum;
+    for (int i = 0; i < 2 * a.npcts; ++i) {
+        const uint32_t r = s_rank[i];
+        if (excl <= r && r < incl[t]) {
+            uint32_t c = excl;
+            for (int k = 0; k < per; ++k) {
+                const uint32_t h = a.key_hist[t * per + k];
+                if (r < c + h) { a.work->probe_key[i] = t * per + k; a.work->probe_base[i] = c; a.work->probe_rank[i] = r; break; }
+                c += h;
+            }
+        }
+    }
+}
+
+// the stored sample again: sub-bucket histograms of the probed keys
+__global__ __launch_bounds__(kBlock) void k_f32_sample_sub(const float *__restrict__ sample, uint64_t n, float t_valid,
+                                                           const F32ZoneWork *__restrict__ work, uint32_t *__restrict__ g_sub) {
+    __shared__ uint32_t sub[kMaxProbes * kSubKeys];
+    __shared__ uint32_t pk[kMaxProbes];
+    for (int i = threadIdx.x; i < kMaxProbes * kSubKeys; i += kBlock) sub[i] = 0;
+    const int np = (int)work->nprobe;
+    if ((int)threadIdx.x < kMaxProbes) pk[threadIdx.x] = (int)threadIdx.x < np ? work->probe_key[threadIdx.x] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const float x = sample[i];
+        if (!(x >= t_valid)) continue;
+        const uint32_t bits = __float_as_uint(x), key = bits >> 16;
+#pragma unroll
+        for (int p = 0; p < kMaxProbes; ++p)
+            if (key == pk[p]) atomicAdd(&sub[p * kSubKeys + ((bits >> 7) & (kSubKeys - 1))], 1u); // equal probe keys: each keeps its own copy
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kMaxProbes * kSubKeys; i += kBlock)
+        if (sub[i]) atomicAdd(&g_sub[i], sub[i]);
+}
+
+// one wave: the value at every probe rank to 2^-16, then the zones
+__global__ __launch_bounds__(64) void k_f32_zone_finalize(F32ZoneSelectArgs a) {
+    __shared__ uint32_t edge[kMaxProbes]; // bit pattern: lower edge of the probe's sub-bucket (even probes), upper edge (odd probes)
+    F32ZoneWork *w = a.work;
+    const int t = threadIdx.x;
+    const int np = (int)w->nprobe;
+    if (w->ns < 20000u || w->kmax >= 0x7F80u) {
+        if (t == 0) w->nz = 0;
+        if (t < 2 * kMaxZones) w->bounds[t] = INFINITY;
+        return;
+    }
+    if (t < np) {
+        uint32_t c = w->probe_base[t], sb = kSubKeys - 1;
+        const uint32_t r = w->probe_rank[t];
+        for (int k = 0; k < kSubKeys; ++k) {
+            const uint32_t h = a.sub_hist[t * kSubKeys + k];
+            if (r < c + h) { sb = k; break; }
+            c += h;
+        }
+        const uint32_t base = (w->probe_key[t] << 16) | (sb << 7);
+        edge[t] = (t & 1) ? base + (1u << 7) : base;
+    }
+    __syncthreads();
+    __shared__ float zl[kMaxZones], zh[kMaxZones];
+    __shared__ int s_m;
+    if (t == 0) {
+        // a 4096-bin of the (estimated) span, in relative value; the zones are widened by 2.5 of them on either side
+        const double lo_all = (double)__uint_as_float(w->kmin << 16), hi_all = (double)__uint_as_float((w->kmax + 1) << 16);
+        const double span_db = 10.0 * log10(hi_all / lo_all);
+        const double widen = pow(10.0, 2.5 * (span_db / 4096.0) / 10.0);
+        int nz = 0;
+        for (int q = 0; q < a.npcts; ++q) {
+            float lo = (float)((double)__uint_as_float(edge[2 * q]) / widen);
+            float hi = (float)((double)__uint_as_float(edge[2 * q + 1]) * widen);
+            lo = __uint_as_float(__float_as_uint(lo) - 1u); // rounding of the two conversions: one step outwards
+            hi = __uint_as_float(__float_as_uint(hi) + 1u);
+            if (!(lo > a.t_valid)) lo = a.t_valid;
+            if (!(hi < 3.0e38f)) hi = INFINITY;
+            int i = nz++;
+            while (i > 0 && zl[i - 1] > lo) { zl[i] = zl[i - 1]; zh[i] = zh[i - 1]; --i; }
+            zl[i] = lo; zh[i] = hi;
+        }
+        int m = 0;
+        for (int i = 0; i < nz; ++i) {
+            if (m && zl[i] <= zh[m - 1]) zh[m - 1] = fmaxf(zh[m - 1], zh[i]);
+            else { zl[m] = zl[i]; zh[m] = zh[i]; ++m; }
+        }
+        s_m = m;
+    }
+    __syncthreads();
+    const int m = s_m;
+    // share of the sample inside the zones, edge buckets weighted by their overlap (the wave's lanes take buckets in turn)
+    double mass = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const uint32_t b0 = __float_as_uint(zl[j]), b1 = isinf(zh[j]) ? 0x7F800000u : __float_as_uint(zh[j]);
+        for (uint32_t k = (b0 >> 16) + t; k <= min(b1 >> 16, (uint32_t)kSampleKeys - 1); k += 64) {
+            const double s0 = fmax((double)b0, (double)(k << 16)), s1 = fmin((double)b1, (double)((k + 1) << 16));
+            if (s1 > s0) mass += (double)a.key_hist[k] * (s1 - s0) / 65536.0;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) mass += __shfl_down(mass, d);
+    if (t != 0) return;
+    mass /= (double)w->ns;
+    w->mass_est = (float)mass;
+    for (int k = 0; k < 2 * kMaxZones; ++k) w->bounds[k] = INFINITY;
+    w->nz = (float)(1.3 * mass + 0.004) <= a.max_mass ? m : 0;
+    if (w->nz > 0)
+        for (int j = 0; j < m; ++j) { w->bounds[2 * j] = zl[j]; w->bounds[2 * j + 1] = zh[j]; } // else the min / max pass keeps nothing
+}
+
+// NZ = number of zones (template: only the live bounds are compared).  Counts are kept per wave in scalar registers
+// (v_cmp -> s_bcnt1): one VALU instruction per bound and sample.
+template <int VEC, int NZ>
+__global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
+    // Valid samples are positive floats: they order like their bit patterns read as signed integers, an invalid one is replaced
+    // by -1.0f (a negative integer, below every bound).  Integer compares have no NaN twin, min / max are VOP2.
+    int bd[2 * NZ];
+#pragma unroll
+    for (int k = 0; k < 2 * NZ; ++k) bd[k] = __float_as_int(a.work->bounds[k]);
+    // wave-uniform counters (a wave sees < 2^32 samples: total / waves of the grid)
+    uint32_t cnt = 0, ge[2 * NZ];
+#pragma unroll
+    for (int k = 0; k < 2 * NZ; ++k) ge[k] = 0;
+    int mn = 0x7F800000, mx = (int)0x80000000;
+    __shared__ unsigned long long gsum[2 * kMaxZones + 1];
+    __shared__ float ring[kWavesPerBlock][128]; // kept samples on their way out: flushed 64 at a time, one coalesced store
+    if (threadIdx.x <= 2 * kMaxZones) gsum[threadIdx.x] = 0;
+    __syncthreads();
+    // every WAVE appends to its own quarter of the workgroup's region: the cursor is a scalar, no atomics
+    const uint32_t wcap = a.cap / kWavesPerBlock;
+    float *mine = a.zone_buf + (size_t)blockIdx.x * a.cap + (size_t)wave_id() * wcap;
+    float *myring = ring[wave_id()];
+    uint32_t cursor = 0, flushed = 0;
+    StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.pitch, a.pol);
+    while (walk.live()) {
+        uint32_t r, col;
+        const F32Vec<VEC> v = walk.next(a.in, a.pitch, a.pol, &r, &col);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float x = v.get(j);
+            if (!(col + j < a.cols && x >= a.t_valid)) x = -1.0f; // NaN included
+            const int xi = __float_as_int(x);
+            cnt += (uint32_t)__popcll(__ballot(xi >= 0));
+            mn = min(mn, xi >= 0 ? xi : 0x7F800000);
+            mx = max(mx, xi);
+            bool inz = false;
+#pragma unroll
+            for (int z = 0; z < NZ; ++z) {
+                const bool g0 = xi >= bd[2 * z], g1 = xi >= bd[2 * z + 1];
+                ge[2 * z] += (uint32_t)__popcll(__ballot(g0));
+                ge[2 * z + 1] += (uint32_t)__popcll(__ballot(g1));
+                inz |= g0 != g1; // g1 implies g0
+            }
+            const unsigned long long zm = __ballot(inz);
+            if (zm) {
+                const uint32_t pos = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(zm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zm, 0u));
+                if (inz) myring[pos & 127u] = x;
+                cursor += (uint32_t)__popcll(zm);
+                if (cursor - flushed >= 64u) { // the wave's own LDS writes are visible to it in program order
+                    const uint32_t p = flushed + (uint32_t)lane_id();
+                    if (p < wcap) mine[p] = myring[p & 127u];
+                    flushed += 64u;
+                }
+            }
+        }
+    }
+    {
+        const uint32_t p = flushed + (uint32_t)lane_id();
+        if (p < cursor && p < wcap) mine[p] = myring[p & 127u];
+    }
+    // the lane with the smallest item index stays in the loop longest: lane 0 of every wave holds the wave's totals
+    __shared__ F32Partial part[kBlock];
+    part[threadIdx.x] = F32Partial{0, 0.0, 0.0, mn == 0x7F800000 ? INFINITY : __int_as_float(mn), mx < 0 ? -INFINITY : __int_as_float(mx)};
+    if (lane_id() == 0) {
+        atomicAdd(&gsum[2 * kMaxZones], (unsigned long long)cnt);
+#pragma unroll
+        for (int k = 0; k < 2 * NZ; ++k) atomicAdd(&gsum[k], (unsigned long long)ge[k]);
+        a.zone_n[blockIdx.x * kWavesPerBlock + wave_id()] = cursor;
+    }
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            F32Partial x = part[threadIdx.x], y = part[threadIdx.x + s];
+            x.minv = fminf(x.minv, y.minv); x.maxv = fmaxf(x.maxv, y.maxv);
+            part[threadIdx.x] = x;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        F32Partial p = part[0];
+        p.count = gsum[2 * kMaxZones];
+        a.partials[blockIdx.x] = p;
+    }
+    if (threadIdx.x < 2 * kMaxZones) a.ge_counts[(size_t)blockIdx.x * 2 * kMaxZones + threadIdx.x] = gsum[threadIdx.x];
+}
+
+// self-test of div_small_ints: every pair (a, b) of u16 values, the ratio a / b (b != 0) and the normalised difference
+// (a - b) / (a + b) (a + b != 0) against the compiler's IEEE division; counts the pairs that differ
+__global__ __launch_bounds__(256) void k_selftest_div_small_ints(unsigned long long *mismatches) {
+    const uint32_t a = blockIdx.x;          // 65536 blocks
+    uint32_t bad = 0;
+    for (uint32_t b = threadIdx.x; b < 65536u; b += 256) {
+        const float x = (float)a, y = (float)b;
+        if (b != 0 && __float_as_uint(div_small_ints(x, y)) != __float_as_uint(x / y)) ++bad;
+        const float s = x + y, d = x - y;
+        if (s != 0.0f && __float_as_uint(div_small_ints(d, s)) != __float_as_uint(d / s)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+__global__ __launch_bounds__(kBlock) void k_f32_zone_count(const float *__restrict__ zone_buf, const uint32_t *__restrict__ zone_n, uint32_t cap,
+                                                           int nregions, const float *__restrict__ g_thr, int nthr,
+                                                           unsigned long long *__restrict__ g_counts) {
+    __shared__ float thr[256 + 1];
+    __shared__ uint32_t hist[256];
+    thr[threadIdx.x] = (threadIdx.x >= 1 && (int)threadIdx.x <= nthr) ? g_thr[threadIdx.x] : (threadIdx.x ? INFINITY : -INFINITY);
+    if (threadIdx.x == 0) thr[256] = INFINITY;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int w = blockIdx.x; w < nregions; w += gridDim.x) {
+        const uint32_t n = min(zone_n[w], cap);
+        const float *src = zone_buf + (size_t)w * cap;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hist[step_search<255>(thr, src[i])], 1u);
+    }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&g_counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------
 // b. 4096-bin statistics histogram (autoscale.rs:108-117) by threshold search.
 // ------------------------------------------------------------------------------------
 template <int VEC>
@@ -187,12 +574,10 @@ __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict
     for (int i = threadIdx.x; i < 4096; i += kBlock) { thr[i] = i ? g_thr[i] : -INFINITY; hist[i] = 0; }
     if (threadIdx.x == 0) thr[4096] = INFINITY;
     __syncthreads();
-    const uint32_t vpr = (cols + VEC - 1) / VEC;
-    const uint64_t total = (uint64_t)rows * vpr;
-    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t r = (uint32_t)(idx / vpr);
-        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
-        const F32Vec<VEC> v = F32Vec<VEC>::fetch(in, pitch, pol, r, col);
+    StrideWalk<VEC> walk(rows, cols, in, pitch, pol);
+    while (walk.live()) {
+        uint32_t r, col;
+        const F32Vec<VEC> v = walk.next(in, pitch, pol, &r, &col);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float x = v.get(j);
@@ -222,14 +607,13 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
         invc[threadIdx.x] = 1.0 / c;
     }
     __syncthreads();
-    const uint32_t vpr = (a.cols + VEC - 1) / VEC;
-    const uint64_t total = (uint64_t)a.rows * vpr;
     const bool vec_store = a.out_pitch % VEC == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     uint32_t zeros = 0;
-    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t r = (uint32_t)(idx / vpr);
-        const uint32_t col = (uint32_t)(idx - (uint64_t)r * vpr) * VEC;
-        const F32Vec<VEC> v = F32Vec<VEC>::fetch(a.in, a.in_pitch, a.pol, r, col);
+    StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.in_pitch, a.pol);
+    while (walk.live()) {
+        uint32_t r, col;
+        const F32Vec<VEC> v = walk.next(a.in, a.in_pitch, a.pol, &r, &col);
+        const uint32_t r_row = r;
         uint32_t lvs[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -244,7 +628,13 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
                         const double t = (fmin(fmax(db, a.low), a.high) - a.low) / a.range;
                         const double y = fmin(fmax((a.gamma == 1.0 ? t : pow(t, a.gamma)) * a.max_val, 0.0), a.max_val);
                         const double r = rint(y);
-                        lv = (fabs(y - r) < 1e-6 || !(y == y)) ? step_search<65535>(a.thr, x) : (uint32_t)y;
+                        if (fabs(y - r) < 1e-6 || !(y == y)) {
+                            if (a.f64_levels == 2) {
+                                const uint32_t q = atomicAdd(a.uq_count, 1u);
+                                if (q < a.uq_cap) a.uq_entries[q] = make_uint4(r_row, col + j, __float_as_uint(x), 0u);
+                                lv = (uint32_t)y; // provisional: the host patches it
+                            } else lv = step_search<65535>(a.thr, x);
+                        } else lv = (uint32_t)y;
                     }
                 } else if (a.est.use) lv = OUT16 ? est_search<65535>(a.thr, x, a.est) : est_search<255>(thr, x, a.est);
                 else lv = OUT16 ? step_search<65535>(a.thr, x) : step_search<255>(thr, x);
@@ -275,8 +665,13 @@ __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
     const Rect rc = a.rects[blockIdx.x];
     const int col = rc.cstart + lane_id() * VEC;
     if (col < rc.c1 && col + VEC > rc.c0) {
-        for (int r = rc.r0 + wave_id(); r < rc.r1; r += kWavesPerBlock) {
-            const F32Vec<VEC> v = F32Vec<VEC>::fetch(a.in, a.pitch, a.pol, r, col);
+        int r = rc.r0 + wave_id();
+        typename F32Vec<VEC>::Raw cur{};
+        if (r < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r, col);
+        for (; r < rc.r1; r += kWavesPerBlock) {
+            const typename F32Vec<VEC>::Raw mine = cur;
+            if (r + kWavesPerBlock < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r + kWavesPerBlock, col); // next row in flight
+            const F32Vec<VEC> v = F32Vec<VEC>::make(mine, a.pol);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int c = col + j;
@@ -322,8 +717,13 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
         omdx[j] = w.omd;
     }
     if (lane_on) {
-        for (int r = rc.r0 + wave_id(); r < rc.r1; r += kWavesPerBlock) {
-            const F32Vec<VEC> v = F32Vec<VEC>::fetch(a.in, a.in_pitch, a.pol, r, col);
+        int r = rc.r0 + wave_id();
+        typename F32Vec<VEC>::Raw cur{};
+        if (r < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r, col);
+        for (; r < rc.r1; r += kWavesPerBlock) {
+            const typename F32Vec<VEC>::Raw mine = cur;
+            if (r + kWavesPerBlock < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r + kWavesPerBlock, col); // next row in flight
+            const F32Vec<VEC> v = F32Vec<VEC>::make(mine, a.pol);
             const RowWeight rw = a.row_w[r];
             uint32_t lvs[VEC];
 #pragma unroll
@@ -384,6 +784,69 @@ inline int stream_grid(uint64_t items, int per_cu = 8) {
 
 } // namespace
 
+hipError_t launch_f32_sample_keys(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, uint32_t row_stride,
+                                  float *d_sample, uint32_t sample_pitch, uint32_t *d_key_hist, hipStream_t s, const F32Pol &pol) {
+    const size_t lds = sizeof(uint32_t) * kSampleKeys;
+    const uint32_t nsrows = (rows + row_stride - 1) / row_stride;
+    const int grid = (int)std::min<uint32_t>(nsrows, 256u);
+    hipError_t e;
+    if (vec) {
+        if ((e = opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_f32_sample_keys<4>))) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_f32_sample_keys<4>), dim3(grid), dim3(kBlock), lds, s, in, pitch, rows, cols, t_valid, row_stride, d_sample, sample_pitch,
+                           d_key_hist, pol);
+    } else {
+        if ((e = opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_f32_sample_keys<1>))) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_f32_sample_keys<1>), dim3(grid), dim3(kBlock), lds, s, in, pitch, rows, cols, t_valid, row_stride, d_sample, sample_pitch,
+                           d_key_hist, pol);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_div_small_ints(unsigned long long *d_mismatches, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_div_small_ints, dim3(65536), dim3(256), 0, s, d_mismatches);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_zone_pick(const F32ZoneSelectArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_f32_zone_pick, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_sample_sub(const float *d_sample, uint64_t n, float t_valid, const F32ZoneWork *work, uint32_t *d_sub_hist, hipStream_t s) {
+    hipLaunchKernelGGL(k_f32_sample_sub, dim3(stream_grid(n, 4)), dim3(kBlock), 0, s, d_sample, n, t_valid, work, d_sub_hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_f32_zone_finalize, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int VEC>
+static void launch_prepass_zones_nz(const F32ZoneArgs &a, int nz, int grid, hipStream_t s) {
+    switch (nz) {
+    case 1: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 1>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 2>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 3>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 4>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 5>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, kMaxZones>), dim3(grid), dim3(kBlock), 0, s, a); break;
+    }
+}
+
+// nz_max: an upper bound of the number of zones the selection can produce (the number of percentiles): unused bounds are +inf
+hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int nz_max, int grid, hipStream_t s) {
+    if (vec) launch_prepass_zones_nz<4>(a, nz_max, grid, s);
+    else launch_prepass_zones_nz<1>(a, nz_max, grid, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, uint32_t cap, int nregions, const float *d_thr, int nthr,
+                                 unsigned long long *d_counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_f32_zone_count, dim3(std::min(nregions, 1024)), dim3(kBlock), 0, s, zone_buf, zone_n, cap, nregions, d_thr, nthr, d_counts);
+    return hipGetLastError();
+}
+
 int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec) {
     const int V = vec ? 4 : 1;
     return stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4);
@@ -407,6 +870,19 @@ hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uin
     dim3 grid(stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4));
     if (vec) hipLaunchKernelGGL(k_f32_hist4096<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est, pol);
     else hipLaunchKernelGGL(k_f32_hist4096<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est, pol);
+    return hipGetLastError();
+}
+
+namespace {
+__global__ void k_patch_u16(uint16_t *out, size_t pitch, const uint4 *patches, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[(size_t)patches[i].x * pitch + patches[i].y] = (uint16_t)patches[i].z;
+}
+} // namespace
+
+hipError_t launch_patch_u16(uint16_t *out, size_t pitch, const uint4 *d_patches, uint32_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_patch_u16, dim3((n + 255) / 256), dim3(256), 0, s, out, pitch, d_patches, n);
     return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 // binary search.  No CPU fallback: all rasters come from the kernels in f32_kernels.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -44,7 +45,14 @@ constexpr size_t kOffTileBins = kOffThrLevel + 256 * 1024 + 4096;    // 128 KiB 
 constexpr size_t kOffLevelHist = kOffTileBins + 128 * 1024;          // 2 KiB
 constexpr size_t kOffCdfs = kOffLevelHist + 4 * 1024;                // 128 KiB
 constexpr size_t kOffMap = kOffCdfs + 128 * 1024;                    // 256 B
-constexpr size_t kWsBytes = kOffMap + 4096;
+constexpr size_t kOffKeyHist = kOffMap + 4096;                       // zone route: 128 KiB sample histogram of the float's leading bits
+constexpr size_t kOffZoneGe = kOffKeyHist + 128 * 1024;              // 2048 x 12 x 8 B
+constexpr size_t kOffZoneN = kOffZoneGe + 2048 * 2 * kMaxZones * 8;  // 2048 x 4 B
+constexpr size_t kOffZoneThr = kOffZoneN + 2048 * 4 * 4;             // 257 x 4 B (zone_n: one count per wave)
+constexpr size_t kOffZoneCounts = kOffZoneThr + 2048;                // 256 x 8 B
+constexpr size_t kOffSubHist = kOffZoneCounts + 4096;                // kMaxProbes x kSubKeys x 4 B
+constexpr size_t kOffZoneWork = kOffSubHist + kMaxProbes * kSubKeys * 4;
+constexpr size_t kWsBytes = kOffZoneWork + 4096;
 
 struct F32Band {
     sarpro_hip_ctx *ctx = nullptr;
@@ -62,6 +70,13 @@ struct F32Band {
     float t_valid = 0.f;
     double mean = 0.0, std_db = 0.0, min_db = 0.0, max_db = 0.0;
     StripePlan *plan = nullptr;
+    // zone route (percentiles without the 4096-bin sweep): zones chosen from a row sample, resolved after the min / max pass
+    bool allow_zones = false, use_zones = false, have_stats = false;
+    int nz = 0, znp = 0, zgrid = 0;
+    float zlo[kMaxZones], zhi[kMaxZones];
+    uint32_t zcap = 0;
+    uint64_t zge[2 * kMaxZones];
+    const char *zone_note = "";
     uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
 };
 
@@ -103,6 +118,231 @@ int rescale_in_place(F32Band &B, const uint64_t *level_hist) {
     return SARPRO_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Zone route.  The 4096-bin histogram of autoscale.rs:102-117 exists to invert a handful of percentiles
+// (autoscale.rs:120-140), and each inversion reads three numbers: the bin the target rank falls in, the count below that bin
+// and the count in it.  A row sample (every ~32nd row, histogram of the float's leading 15 bits) says where each percentile
+// lies to within a few of those buckets; the min / max pass counts the valid samples at or above each zone bound and keeps
+// the samples inside the zones (a few per cent of the scene); once min / max are known the 4096-bin thresholds that fall
+// inside a zone are counted against the kept samples.  Counts are exact, so the percentile is the reference's or -- when a
+// zone missed its percentile, a workgroup's share of the side buffer overflowed, or the scene is small / degenerate -- the
+// route is abandoned and the 4096-bin sweep runs as before.  Not used when the caller wants the full statistics
+// (all eleven percentiles, dB moments) or for the Adaptive strategy, which reads most of them.
+int needed_percentiles(int strategy, int tamed, double *p) {
+    auto put = [&](std::initializer_list<double> v) { int n = 0; for (double x : v) p[n++] = x; return n; };
+    if (tamed == kTamedCopol) return put({0.02, 0.05, 0.99});       // autoscale.rs:721-729
+    if (tamed == kTamedCrosspol) return put({0.05, 0.99});
+    switch (strategy) {
+    case SARPRO_STRATEGY_STANDARD: return put({0.5, 0.25, 0.75, 0.02, 0.98});
+    case SARPRO_STRATEGY_ROBUST: return put({0.25, 0.75, 0.01, 0.99});
+    case SARPRO_STRATEGY_EQUALIZED:
+    case SARPRO_STRATEGY_CLAHE: return put({0.01, 0.99});
+    case SARPRO_STRATEGY_TAMED: return put({0.25, 0.99});
+    case SARPRO_STRATEGY_DEFAULT: return put({0.05, 0.95});
+    default: return 0; // Adaptive: skew, tail heaviness and five more
+    }
+}
+
+void set_percentile(sarpro_hip_stats &s, double p, double v) {
+    if (p == 0.5) s.median_db = v; else if (p == 0.01) s.p01 = v; else if (p == 0.02) s.p02 = v; else if (p == 0.05) s.p05 = v;
+    else if (p == 0.10) s.p10 = v; else if (p == 0.25) s.p25 = v; else if (p == 0.75) s.p75 = v; else if (p == 0.90) s.p90 = v;
+    else if (p == 0.95) s.p95 = v; else if (p == 0.98) s.p98 = v; else if (p == 0.99) s.p99 = v;
+}
+
+inline float f32_from_bits(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
+inline uint32_t bits_of_f32(float f) { uint32_t b; std::memcpy(&b, &f, 4); return b; }
+
+// sample pass -> zones, all on the device (no host turn before the min / max pass): the sampled rows are stored (pol-op
+// applied) and histogrammed by their leading 15 bits; one workgroup finds the bucket of every probe rank (each percentile
+// -/+ delta); a second pass over the stored sample resolves those buckets to 2^-16; one wave builds the zones -- probe values
+// widened by 2.5 bins of the estimated span, merged, given up when they would hold more than kZoneMaxMass of the samples.
+constexpr float kZoneMaxMass = 0.10f;
+int f32_zone_presample(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    B.use_zones = false;
+    const char *env = getenv("SARPRO_HIP_F32_ZONES");
+    if (env && !std::strcmp(env, "0")) return SARPRO_HIP_OK;
+    const bool forced = env && (!std::strcmp(env, "force") || !std::strcmp(env, "tiny"));
+    double pcts[8];
+    const int np = needed_percentiles(B.strategy, B.tamed, pcts);
+    const uint64_t px = (uint64_t)B.rows * B.cols;
+    if (np == 0 || np > kMaxZones || B.want_moments || B.rows_total != B.rows || (!forced && px < (4ull << 20)) || B.rows < 64 || B.cols < 64)
+        return SARPRO_HIP_OK;
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    uint32_t *d_keys = reinterpret_cast<uint32_t *>(ws + kOffKeyHist);
+    uint32_t *d_sub = reinterpret_cast<uint32_t *>(ws + kOffSubHist);
+    F32ZoneWork *d_work = reinterpret_cast<F32ZoneWork *>(ws + kOffZoneWork);
+    const uint32_t stride = (uint32_t)std::max<uint64_t>(1, B.rows / 640);
+    const uint32_t nsrows = ((uint32_t)B.rows + stride - 1) / stride;
+    const uint32_t spitch = ((uint32_t)B.cols + 3) / 4 * 4;
+    B.zgrid = f32_prepass_grid((uint32_t)B.rows, (uint32_t)B.cols, B.vec);
+    const double share = (double)px / (double)B.zgrid;
+    B.zcap = (uint32_t)std::max(1024.0, share * (double)kZoneMaxMass) / 4 * 4; // a quarter per wave
+    if (env && !std::strcmp(env, "tiny")) B.zcap = 0; // test switch: no room at all, the first kept sample overflows
+    // one buffer: the stored sample now, the kept samples of the min / max pass afterwards
+    HIPCHK(ctx, ctx->f32zone.reserve(std::max((size_t)B.zgrid * B.zcap, (size_t)nsrows * spitch) * sizeof(float)));
+    HIPCHK(ctx, hipMemsetAsync(d_keys, 0, sizeof(uint32_t) * kSampleKeys, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_sub, 0, sizeof(uint32_t) * kMaxProbes * kSubKeys, ctx->stream));
+    F32ZoneSelectArgs sa{};
+    sa.work = d_work; sa.key_hist = d_keys; sa.sub_hist = d_sub; sa.npcts = np; sa.t_valid = B.t_valid; sa.max_mass = kZoneMaxMass;
+    for (int i = 0; i < np; ++i) sa.pcts[i] = pcts[i];
+    sa.sample_fraction = stride == 1 ? 1.0f : (float)nsrows / (float)B.rows;
+    {
+        KernelTimer t(ctx, "f32_sample_keys");
+        HIPCHK(ctx, launch_f32_sample_keys(B.d_in, B.in_pitch, (uint32_t)B.rows, (uint32_t)B.cols, B.t_valid, B.vec, stride, ctx->f32zone.as<float>(),
+                                           spitch, d_keys, ctx->stream, B.pol));
+    }
+    {
+        KernelTimer t(ctx, "f32_zone_select");
+        HIPCHK(ctx, launch_f32_zone_pick(sa, ctx->stream));
+        HIPCHK(ctx, launch_f32_sample_sub(ctx->f32zone.as<float>(), (uint64_t)nsrows * spitch, B.t_valid, d_work, d_sub, ctx->stream));
+        HIPCHK(ctx, launch_f32_zone_finalize(sa, ctx->stream));
+    }
+    B.znp = np;
+    B.use_zones = true;
+    return SARPRO_HIP_OK;
+}
+
+// the min / max pass of the zone route: B.local, B.zge, overflow check
+int f32_zone_prepass(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    const int grid = B.zgrid;
+    F32ZoneArgs a{};
+    a.in = B.d_in; a.pitch = B.in_pitch; a.rows = (uint32_t)B.rows; a.cols = (uint32_t)B.cols; a.t_valid = B.t_valid; a.pol = B.pol;
+    a.partials = reinterpret_cast<F32Partial *>(ws + kOffPartials);
+    a.work = reinterpret_cast<const F32ZoneWork *>(ws + kOffZoneWork);
+    a.ge_counts = reinterpret_cast<unsigned long long *>(ws + kOffZoneGe);
+    a.zone_buf = ctx->f32zone.as<float>();
+    a.cap = B.zcap;
+    a.zone_n = reinterpret_cast<uint32_t *>(ws + kOffZoneN);
+    {
+        KernelTimer t(ctx, "f32_prepass_zones");
+        HIPCHK(ctx, launch_f32_prepass_zones(a, B.vec, B.znp, grid, ctx->stream));
+    }
+    uint8_t *h = ctx->h_small.as<uint8_t>();
+    F32Partial *h_part = reinterpret_cast<F32Partial *>(h);
+    uint64_t *h_ge = reinterpret_cast<uint64_t *>(h + sizeof(F32Partial) * 2048);
+    uint32_t *h_n = reinterpret_cast<uint32_t *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8);
+    HIPCHK(ctx, hipMemcpyAsync(h_part, a.partials, sizeof(F32Partial) * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_ge, a.ge_counts, sizeof(uint64_t) * 2 * kMaxZones * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_n, a.zone_n, sizeof(uint32_t) * 4 * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+    F32ZoneWork *h_work = reinterpret_cast<F32ZoneWork *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8 + 2048 * 4 * 4);
+    HIPCHK(ctx, hipMemcpyAsync(h_work, a.work, sizeof(F32ZoneWork), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    B.nz = std::min(std::max(h_work->nz, 0), kMaxZones);
+    for (int i = 0; i < B.nz; ++i) { B.zlo[i] = h_work->bounds[2 * i]; B.zhi[i] = h_work->bounds[2 * i + 1]; }
+    if (B.nz == 0) { B.use_zones = false; B.zone_note = "no zones (sample too small, or zones too heavy)"; }
+    if (getenv("SARPRO_HIP_F32_ZONES_DEBUG")) {
+        std::fprintf(stderr, "[zones] ns=%u kmin=%#x kmax=%#x nprobe=%u nz=%d mass_est=%.4f cap=%u grid=%d\n", h_work->ns, h_work->kmin, h_work->kmax,
+                     h_work->nprobe, h_work->nz, (double)h_work->mass_est, B.zcap, B.zgrid);
+        for (unsigned i = 0; i < h_work->nprobe && i < (unsigned)kMaxProbes; ++i)
+            std::fprintf(stderr, "[zones]   probe %u: rank %u key %#x base %u\n", i, h_work->probe_rank[i], h_work->probe_key[i], h_work->probe_base[i]);
+        for (int i = 0; i < 2 * kMaxZones; i += 2) std::fprintf(stderr, "[zones]   zone %d: [%g, %g)\n", i / 2, (double)h_work->bounds[i], (double)h_work->bounds[i + 1]);
+    }
+    std::memset(B.zge, 0, sizeof(B.zge));
+    bool overflow = false;
+    for (int i = 0; i < grid; ++i) {
+        B.local.count += h_part[i].count;
+        B.local.min_v = std::fmin(B.local.min_v, h_part[i].minv); B.local.max_v = std::fmax(B.local.max_v, h_part[i].maxv);
+        for (int k = 0; k < 2 * kMaxZones; ++k) B.zge[k] += h_ge[(size_t)i * 2 * kMaxZones + k];
+        for (int w = 0; w < 4; ++w) overflow |= h_n[4 * i + w] > B.zcap / 4;
+    }
+    if (overflow) { B.use_zones = false; B.zone_note = "side buffer overflow"; }
+    return SARPRO_HIP_OK;
+}
+
+// min / max known: count the kept samples against the 4096-bin thresholds inside the zones -> the strategy's percentiles
+int f32_zone_resolve(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    uint8_t *ws = ctx->f32ws.as<uint8_t>();
+    const sarpro_hip_f32_partial &G = B.global;
+    B.have_stats = false;
+    if (G.count == 0 || std::isinf(G.max_v)) return SARPRO_HIP_OK; // the ordinary route reports these
+    const double min_db = db_of_f32(G.min_v), max_db = db_of_f32(G.max_v);
+    if (std::fabs(max_db - min_db) < 2.220446049250313e-16) return SARPRO_HIP_OK;
+    struct Zr { int b_lo, b_hi, s, e; } zr[kMaxZones];
+    float tt[257];
+    int kk[257]; // bin index k of tt[i] when it is a threshold, -1 for a zone bound
+    int n = 0;
+    tt[0] = -INFINITY; kk[0] = -1;
+    for (int j = 0; j < B.nz; ++j) {
+        const float hi_in = std::isinf(B.zhi[j]) ? G.max_v : std::nextafterf(B.zhi[j], 0.0f);
+        zr[j].b_lo = bin4096_of_f32(std::fmax(B.zlo[j], G.min_v), min_db, max_db);
+        zr[j].b_hi = bin4096_of_f32(std::fmin(hi_in, G.max_v), min_db, max_db);
+        if (B.zlo[j] > G.max_v || hi_in < G.min_v) zr[j].b_hi = zr[j].b_lo; // zone outside the data: no thresholds
+        const int nt = zr[j].b_hi - zr[j].b_lo;
+        if (n + nt + 2 > 255) { B.zone_note = "too many thresholds"; return SARPRO_HIP_OK; }
+        zr[j].s = ++n; tt[n] = B.zlo[j]; kk[n] = -1;
+        if (nt > 0) {
+            build_bin4096_thresholds_range(min_db, max_db, zr[j].b_lo + 1, zr[j].b_hi, tt + n + 1);
+            for (int t = 0; t < nt; ++t) kk[n + 1 + t] = zr[j].b_lo + 1 + t;
+            n += nt;
+        }
+        zr[j].e = ++n; tt[n] = B.zhi[j]; kk[n] = -1;
+    }
+    for (int i = 2; i <= n; ++i)
+        if (!(tt[i] >= tt[i - 1])) { B.zone_note = "threshold order"; return SARPRO_HIP_OK; }
+    float *h_thr = ctx->h_upload.as<float>();
+    std::memcpy(h_thr, tt, sizeof(float) * (size_t)(n + 1));
+    float *d_thr = reinterpret_cast<float *>(ws + kOffZoneThr);
+    unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(ws + kOffZoneCounts);
+    HIPCHK(ctx, hipMemcpyAsync(d_thr, h_thr, sizeof(float) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * 256, ctx->stream));
+    {
+        KernelTimer t(ctx, "f32_zone_count");
+        HIPCHK(ctx, launch_f32_zone_count(ctx->f32zone.as<float>(), reinterpret_cast<uint32_t *>(ws + kOffZoneN), B.zcap / 4, B.zgrid * 4, d_thr, n, d_counts,
+                                          ctx->stream));
+    }
+    uint64_t *h_counts = ctx->h_small.as<uint64_t>();
+    HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // cum[i] = valid samples below tt[i], for every i inside a zone
+    uint64_t cum[257];
+    const uint64_t N = G.count;
+    for (int j = 0; j < B.nz; ++j) {
+        uint64_t c = N - B.zge[2 * j];
+        for (int i = zr[j].s; i <= zr[j].e; ++i) { cum[i] = c; c += h_counts[i]; }
+        if (cum[zr[j].e] != N - B.zge[2 * j + 1]) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
+    }
+    sarpro_hip_stats st{};
+    st.valid_count = N; st.min_db = min_db; st.max_db = max_db;
+    double pcts[8];
+    const int np = needed_percentiles(B.strategy, B.tamed, pcts);
+    for (int q = 0; q < np; ++q) {
+        const uint64_t target = percentile_target(N, pcts[q]);
+        bool done = false;
+        for (int j = 0; j < B.nz && !done; ++j) {
+            if (!(cum[zr[j].s] <= target && target < cum[zr[j].e])) continue;
+            // the bin b with cum(thr_b) <= target < cum(thr_{b+1}): both thresholds must lie inside the zone
+            for (int i = zr[j].s + 1; i < zr[j].e; ++i) {
+                if (cum[i] > target) { // tt[i] = thr_{b+1}
+                    const int b = kk[i] - 1;
+                    uint64_t below;
+                    if (i - 1 > zr[j].s) below = cum[i - 1];                      // tt[i-1] = thr_b
+                    else if (cum[zr[j].s] == 0) below = 0;                          // nothing below the zone at all
+                    else break;                                                     // thr_b lies below the zone
+                    st.valid_count = N;
+                    set_percentile(st, pcts[q], percentile_from_bin(min_db, max_db, b, target, below, cum[i] - below));
+                    done = true;
+                    break;
+                }
+            }
+            if (!done && zr[j].e - 1 > zr[j].s && cum[zr[j].e] == N && kk[zr[j].e - 1] == 4095) { // last bin, open above
+                const uint64_t below = cum[zr[j].e - 1];
+                set_percentile(st, pcts[q], percentile_from_bin(min_db, max_db, 4095, target, below, N - below));
+                done = true;
+            }
+        }
+        if (!done) { B.zone_note = "percentile outside its zone"; return SARPRO_HIP_OK; }
+    }
+    B.min_db = min_db; B.max_db = max_db; B.mean = 0.0; B.std_db = 0.0;
+    B.stats = st;
+    RETCHK(select_window(&B.stats, B.strategy, B.tamed));
+    B.have_stats = true;
+    return SARPRO_HIP_OK;
+}
+
 // The band runs in five phases; between them sit the three reductions of a row-striped scene (SURVEY 8e row 1:
 // autoscale.rs:35-117 needs count / min / max of the WHOLE scene before it can bin, the bins before it can select the
 // window; autoscale.rs:572-608 needs whole-tile histograms).  One rank: f32_band_run runs them back to back.
@@ -128,7 +368,7 @@ int f32_phase_a(F32Band &B) {
     B.local.min_v = INFINITY; B.local.max_v = -INFINITY;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, ctx->f32ws.reserve(kWsBytes));
-    HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
+    HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands + 64 * 1024 + 65536 * 16));
     HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
     B.vec = B.pol.op < 0 ? (B.in_pitch % 4 == 0 && aligned16(B.d_in))
                          : (B.pol.pitch % 4 == 0 && aligned16(B.pol.a) && aligned16(B.pol.b));
@@ -136,6 +376,9 @@ int f32_phase_a(F32Band &B) {
     if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     const uint32_t rows = (uint32_t)B.rows, cols = (uint32_t)B.cols;
+    B.use_zones = B.have_stats = false;
+    if (B.allow_zones) RETCHK(f32_zone_presample(B));
+    if (B.use_zones) return f32_zone_prepass(B);
     const int pgrid = f32_prepass_grid(rows, cols, B.vec);
     F32Partial *d_part = reinterpret_cast<F32Partial *>(ws + kOffPartials);
     const bool moments = B.want_moments || (B.strategy == SARPRO_STRATEGY_ADAPTIVE && !B.tamed);
@@ -188,11 +431,13 @@ int f32_phase_c(F32Band &B) {
     if (B.clahe) HIPCHK(ctx, hipMemsetAsync(d_tile_bins, 0, sizeof(uint64_t) * 64 * 256, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_level_hist, 0, sizeof(uint64_t) * 256, ctx->stream));
     if (B.empty) return SARPRO_HIP_OK;
-    uint64_t *h_hist = ctx->h_small.as<uint64_t>();
-    HIPCHK(ctx, hipMemcpyAsync(h_hist, ws + kOffHist4096, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    RETCHK(stats_from_bins4096(B.global.count, B.min_db, B.max_db, B.mean, B.std_db, h_hist, &B.stats));
-    RETCHK(select_window(&B.stats, B.strategy, B.tamed));
+    if (!B.have_stats) {
+        uint64_t *h_hist = ctx->h_small.as<uint64_t>();
+        HIPCHK(ctx, hipMemcpyAsync(h_hist, ws + kOffHist4096, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        RETCHK(stats_from_bins4096(B.global.count, B.min_db, B.max_db, B.mean, B.std_db, h_hist, &B.stats));
+        RETCHK(select_window(&B.stats, B.strategy, B.tamed));
+    }
     if (!B.clahe || B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
     RETCHK(get_plan(ctx, B.rows_total, B.cols, B.row0, B.rows, B.vec ? 4 : 1, &B.plan));
     float *thr = ctx->h_upload.as<float>();
@@ -226,21 +471,60 @@ int f32_phase_d(F32Band &B) {
     if (!B.clahe) {
         const int nlevels = u8o ? 255 : 65535;
         float *thr = ctx->h_upload.as<float>();
-        build_level_thresholds(B.stats, nlevels, thr);
         float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
-        thr[nlevels + 1] = INFINITY; // sentinel read by the estimate's verification
-        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * (size_t)(nlevels + 2), hipMemcpyHostToDevice, ctx->stream));
         F32LevelArgs a{};
         a.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), (double)nlevels, 0.0, B.stats.gamma);
-        if (!u8o && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE")) { // 65535 levels: f64 evaluation, thresholds only near a boundary
-            a.low = B.stats.low_clip; a.high = B.stats.high_clip; a.range = std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0);
-            a.gamma = B.stats.gamma; a.max_val = (double)nlevels;
-            a.t_first = thr[1]; a.t_last = thr[nlevels];
-            a.f64_levels = 1;
-        }
         a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
         a.rows = rows; a.cols = cols; a.t_valid = B.t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
         a.pol = B.pol;
+        const bool f64_levels = !u8o && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
+        if (f64_levels) { // 65535 levels: f64 evaluation on the device, the reference's own arithmetic only near a level boundary
+            a.low = B.stats.low_clip; a.high = B.stats.high_clip; a.range = std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0);
+            a.gamma = B.stats.gamma; a.max_val = (double)nlevels;
+        }
+        // Without the 65535-entry table (1-2 ms of glibc per call): the samples within 1e-6 of a boundary -- a few hundred of
+        // 4e8 -- are queued and settled here, with level_of_db.  SARPRO_HIP_F32_LEVEL_TABLE=1 (or a queue that overflows) builds
+        // the table and lets the kernel search it instead.
+        constexpr uint32_t kUqCap = 65536;
+        bool queued = f64_levels && !getenv("SARPRO_HIP_F32_LEVEL_TABLE");
+        if (queued) {
+            HIPCHK(ctx, ctx->f32zone.reserve((size_t)kUqCap * sizeof(uint4)));
+            a.uq_count = reinterpret_cast<uint32_t *>(ws + kOffZoneCounts);
+            a.uq_entries = ctx->f32zone.as<uint4>();
+            a.uq_cap = kUqCap;
+            a.t_first = level_threshold_one(B.stats, nlevels, 1); a.t_last = level_threshold_one(B.stats, nlevels, nlevels);
+            a.f64_levels = 2;
+            HIPCHK(ctx, hipMemsetAsync(a.uq_count, 0, 4, ctx->stream));
+            {
+                KernelTimer t(ctx, "f32_level");
+                HIPCHK(ctx, launch_f32_level(a, B.vec, true, ctx->stream));
+            }
+            uint32_t *h_n = ctx->h_small.as<uint32_t>();
+            HIPCHK(ctx, hipMemcpyAsync(h_n, a.uq_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t n = *h_n;
+            if (n <= kUqCap) {
+                if (n) {
+                    uint32_t *h_e = ctx->h_small.as<uint32_t>() + 4; // 16-byte aligned; reserved in phase a
+                    HIPCHK(ctx, hipMemcpyAsync(h_e, a.uq_entries, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    for (uint32_t i = 0; i < n; ++i) {
+                        float x;
+                        std::memcpy(&x, &h_e[4 * i + 2], 4);
+                        h_e[4 * i + 2] = level_of_db(db_of_f32(x), B.stats.low_clip, B.stats.high_clip, B.stats.gamma, (double)nlevels);
+                    }
+                    HIPCHK(ctx, hipMemcpyAsync(a.uq_entries, h_e, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+                    KernelTimer t(ctx, "f32_level_patch");
+                    HIPCHK(ctx, launch_patch_u16(reinterpret_cast<uint16_t *>(B.d_out), B.out_pitch, a.uq_entries, n, ctx->stream));
+                }
+                return SARPRO_HIP_OK;
+            }
+            queued = false; // overflow: the table route redoes the raster
+        }
+        build_level_thresholds(B.stats, nlevels, thr);
+        thr[nlevels + 1] = INFINITY; // sentinel read by the estimate's verification
+        HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * (size_t)(nlevels + 2), hipMemcpyHostToDevice, ctx->stream));
+        if (f64_levels) { a.t_first = thr[1]; a.t_last = thr[nlevels]; a.f64_levels = 1; }
         KernelTimer t(ctx, "f32_level");
         HIPCHK(ctx, launch_f32_level(a, B.vec, !u8o, ctx->stream));
         return SARPRO_HIP_OK;
@@ -288,10 +572,14 @@ int f32_phase_e(F32Band &B) {
 
 int f32_band_run(F32Band &B) {
     B.rows_total = B.rows; B.row0 = 0;
+    B.allow_zones = true;
     RETCHK(f32_phase_a(B));
     if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
     B.global = B.local;
-    RETCHK(f32_phase_b(B));
+    if (B.use_zones) RETCHK(f32_zone_resolve(B));
+    if (getenv("SARPRO_HIP_F32_ZONES_DEBUG")) std::fprintf(stderr, "[zones] answered=%d note='%s'\n", (int)B.have_stats, B.zone_note);
+    if (B.have_stats) { B.empty = false; }
+    else RETCHK(f32_phase_b(B));
     RETCHK(f32_phase_c(B));
     RETCHK(f32_phase_d(B));
     return f32_phase_e(B);
@@ -507,6 +795,22 @@ extern "C" int sarpro_hip_stripe_run_polop(sarpro_hip_ctx *ctx, int op, const vo
     int rc = stripe_f32_run(s, stats_out);
     delete s;
     return rc;
+}
+
+// Self-test of the division the u16 pol-op kernels use (f32_kernels.hip div_small_ints): all 2^32 pairs of u16 values against the
+// compiler's IEEE division.  *mismatches_out = 0 is the proof the fused pol-op rests on.
+extern "C" int sarpro_hip_selftest_polop_division(sarpro_hip_ctx *ctx, uint64_t *mismatches_out) {
+    if (!ctx || !mismatches_out) return SARPRO_HIP_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->f32ws.reserve(kWsBytes));
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->f32ws.as<uint8_t>() + kOffZoneCounts);
+    HIPCHK(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    HIPCHK(ctx, launch_selftest_div_small_ints(d, ctx->stream));
+    unsigned long long h = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches_out = h;
+    return SARPRO_HIP_OK;
 }
 
 static int host_polop_band(sarpro_hip_ctx *ctx, int op, const void *a, const void *b, int elem_u16, size_t rows, size_t cols, int strategy,

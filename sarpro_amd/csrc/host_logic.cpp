@@ -666,11 +666,61 @@ void build_bin4096_thresholds(double min_db, double max_db, float *thr) {
     step_thresholds(idx, [=](int k) { return min_db + span * ((double)k / kStatBins); }, kStatBins - 1, thr);
 }
 
+// the same index function and thresholds for a few bins only (the zone route of f32_path.cpp)
+int bin4096_of_f32(float x, double min_db, double max_db) {
+    const double span = max_db - min_db, inv_span = 1.0 / span;
+    double t = clampd((db_of_f32(x) - min_db) * inv_span, 0.0, 1.0);
+    uint64_t i = as_u64(t * (double)kStatBins);
+    return (int)(i >= (uint64_t)kStatBins ? kStatBins - 1 : i);
+}
+
+void build_bin4096_thresholds_range(double min_db, double max_db, int k0, int k1, float *thr_out) {
+    const double span = max_db - min_db;
+    const uint32_t lo0 = f32_to_bits(valid_threshold_f32());
+    const int top = bin4096_of_f32(bits_to_f32(kMaxFiniteBits), min_db, max_db);
+    uint32_t lo = lo0;
+    for (int k = k0; k <= k1; ++k) {
+        if (k > top) { thr_out[k - k0] = INFINITY; continue; }
+        const double gv = std::pow(10.0, (min_db + span * ((double)k / kStatBins)) / 10.0);
+        const uint32_t guess = (gv > 0.0 && gv < 3.0e38) ? f32_to_bits((float)gv) : lo;
+        const uint32_t b = find_first_bits([&](uint32_t x) { return bin4096_of_f32(bits_to_f32(x), min_db, max_db) >= k; }, lo, kMaxFiniteBits, guess);
+        thr_out[k - k0] = bits_to_f32(b);
+        lo = b;
+    }
+}
+
+// autoscale.rs:120-140 from the three numbers it reads: the bin the target rank falls in, the count below the bin, the count in it
+double percentile_from_bin(double min_db, double max_db, int bin, uint64_t target, uint64_t cum_below, uint64_t in_bin) {
+    const double span = max_db - min_db;
+    const uint64_t within = target >= cum_below ? target - cum_below : 0;
+    const double frac = in_bin > 0 ? (double)within / (double)in_bin : 0.0;
+    const double bin_width = span / (double)kStatBins;
+    const double bin_start = min_db + (double)bin * bin_width;
+    return bin_start + frac * bin_width;
+}
+
+uint64_t percentile_target(uint64_t n, double p) {
+    uint64_t target = as_u64(std::floor(p * (double)n));
+    return target >= n ? n - 1 : target;
+}
+
 void build_level_thresholds(const sarpro_hip_stats &s, int nlevels, float *thr) {
     const double lo = s.low_clip, hi = s.high_clip, g = s.gamma, max_val = (double)nlevels;
     const double range = std::fmax(hi - lo, 1.0);
     auto lvl = [=](double db) -> int64_t { return (int64_t)level_of_db(db, lo, hi, g, max_val); };
     step_thresholds(lvl, [=](int k) { return lo + range * std::pow((double)k / max_val, 1.0 / g); }, nlevels, thr);
+}
+
+// one entry of that table: the smallest f32 whose level is >= k
+float level_threshold_one(const sarpro_hip_stats &s, int nlevels, int k) {
+    const double lo = s.low_clip, hi = s.high_clip, g = s.gamma, max_val = (double)nlevels;
+    const double range = std::fmax(hi - lo, 1.0);
+    auto lvl = [=](double db) -> int64_t { return (int64_t)level_of_db(db, lo, hi, g, max_val); };
+    if ((int64_t)k > lvl(db_of_f32(bits_to_f32(kMaxFiniteBits)))) return INFINITY;
+    const double gv = std::pow(10.0, (lo + range * std::pow((double)k / max_val, 1.0 / g)) / 10.0);
+    const uint32_t lo0 = f32_to_bits(valid_threshold_f32());
+    const uint32_t guess = (gv > 0.0 && gv < 3.0e38) ? f32_to_bits((float)gv) : lo0;
+    return bits_to_f32(find_first_bits([&](uint32_t x) { return lvl(db_of_f32(bits_to_f32(x))) >= (int64_t)k; }, lo0, kMaxFiniteBits, guess));
 }
 
 void build_clahe_bin_thresholds(const sarpro_hip_stats &s, float *thr) {

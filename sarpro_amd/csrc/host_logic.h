@@ -94,6 +94,10 @@ const double *gamma_level_thresholds_u8();
 // log10/pow; the device only compares v against thresholds (no device libm in any decision).
 // ---------------------------------------------------------------------------------------
 namespace sarpro {
+int bin4096_of_f32(float x, double min_db, double max_db);                                             // autoscale.rs:113-115
+void build_bin4096_thresholds_range(double min_db, double max_db, int k0, int k1, float *thr_out);     // thresholds k0 .. k1 (1 <= k <= 4095)
+double percentile_from_bin(double min_db, double max_db, int bin, uint64_t target, uint64_t cum_below, uint64_t in_bin); // autoscale.rs:120-140
+uint64_t percentile_target(uint64_t n, double p);                                                      // autoscale.rs:121-122
 double db_of_f32(float v);        // pipeline.rs:19-20
 float valid_threshold_f32();      // smallest f32 v with db_of_f32(v) > -50 (pipeline.rs:22)
 // thr[k], k = 1..4095: smallest valid f32 whose 4096-bin index (autoscale.rs:113-115) is >= k;
@@ -101,6 +105,7 @@ float valid_threshold_f32();      // smallest f32 v with db_of_f32(v) > -50 (pip
 void build_bin4096_thresholds(double min_db, double max_db, float *thr4096);
 // thr[k], k = 1..nlevels: smallest valid f32 whose level (autoscale.rs:440-442) is >= k.
 void build_level_thresholds(const sarpro_hip_stats &s, int nlevels /*255 or 65535*/, float *thr);
+float level_threshold_one(const sarpro_hip_stats &s, int nlevels, int k); // thr[k] of that table alone
 // thr[k], k = 1..255: smallest valid f32 whose CLAHE bin (autoscale.rs:585-586, 262-265) is >= k.
 void build_clahe_bin_thresholds(const sarpro_hip_stats &s, float *thr256);
 } // namespace sarpro

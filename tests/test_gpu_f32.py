@@ -7,6 +7,7 @@ import f32data
 import oracle
 from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, SarproHipError, synth
 from sarpro_amd import _lib
+import sarpro_amd as S
 
 pytestmark = pytest.mark.gpu
 
@@ -97,3 +98,22 @@ def test_f32_degenerate_and_errors(ctx):
     with pytest.raises(SarproHipError) as ei:
         ctx.process_scalar_data_pipeline(np.ones((9, 64), np.float32), Bd.U8, St.Clahe)
     assert ei.value.code == _lib.ERR_UNSUPPORTED_SHAPE
+
+
+@pytest.mark.parametrize("strategy", [St.Robust, St.Standard, St.Adaptive, St.Default])
+def test_u16_levels_without_the_table_equal_the_table_route(strategy, monkeypatch):
+    """65535 levels: by default the samples within 1e-6 of a level boundary are queued and settled on the host with the
+    reference's own arithmetic (no 65535-entry table); SARPRO_HIP_F32_LEVEL_TABLE=1 builds the table and searches it.  Same
+    raster, and the oracle's.  A boundary-heavy raster (few distinct values, each ON a level boundary of some window) too."""
+    import f32data
+    rng = np.random.default_rng(8)
+    for x in (f32data.ratio_scene(320, 410), f32data.nasty_scene(200, 333),
+              rng.choice(np.float32([0.001, 0.01, 0.1, 1.0, 10.0, 100.0]), (256, 256))):
+        rc, ref = oracle.pipeline(x, int(Bd.U16), int(strategy))
+        assert rc == 0
+        with S.Context(0, timing=True) as c:
+            monkeypatch.delenv("SARPRO_HIP_F32_LEVEL_TABLE", raising=False)
+            a = c.process_scalar_data_pipeline(x, Bd.U16, strategy)[1]
+            monkeypatch.setenv("SARPRO_HIP_F32_LEVEL_TABLE", "1")
+            b = c.process_scalar_data_pipeline(x, Bd.U16, strategy)[1]
+        assert np.array_equal(a, ref) and np.array_equal(b, ref)

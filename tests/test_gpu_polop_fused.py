@@ -69,3 +69,9 @@ def test_fused_polop_dev_equals_unfused_route(ctx, op, strategy):
             got = torch.zeros((rows, pitch), dtype=dt, device="cuda")
             ctx.dev_polop_autoscale_band(op, src[0].data_ptr(), src[1].data_ptr(), u16_in, rows, cols, pitch, strategy, bd, got.data_ptr(), pitch)
             assert torch.equal(got[:, :cols], want[:, :cols]), (bd, u16_in)
+
+
+def test_fast_division_of_the_u16_kernels_is_the_ieee_division_for_every_pair(ctx):
+    """ops.rs:10-33 on u16 DN: the kernels divide with the Newton core of the IEEE division (no rescaling frame).  All 2^32 pairs,
+    a / b and (a - b) / (a + b), against the compiler's correctly rounded division: no pair may differ."""
+    assert ctx.selftest_polop_division() == 0
