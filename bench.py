@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--sync-steps", action="store_true", help="one host round trip per scene instead of stream-ordered enqueue")
     ap.add_argument("--cpu-sample", type=int, default=7000, help="side of the square CPU-baseline sample scene")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (end-to-end over PCIe, BASELINE configs 2 and 3)")
+    ap.add_argument("--pitch-align", type=int, default=64, help="row pitch of the resident rasters, rounded up to this many elements")
     ap.add_argument("--fused", action="store_true", help="dual-pol CLAHE through the one-sweep fused pass (SARPRO_HIP_CTX_FUSED_CLAHE)")
     args = ap.parse_args()
 
@@ -76,7 +77,7 @@ def main():
 
     strategy = {s.name.lower(): s for s in AutoscaleStrategy}[args.strategy.lower()]
     rows, cols = args.rows, args.cols
-    pitch = (cols + 63) // 64 * 64
+    pitch = (cols + args.pitch_align - 1) // args.pitch_align * args.pitch_align
     # scenes are enqueued back to back on the library's stream (SARPRO_HIP_CTX_ASYNC_DEV); --sync-steps: one host round trip per scene
     use_async = not args.sync_steps and not (args.mode == "stripe" and world > 1)
     ctx = sarpro_amd.Context(local_rank, timing=True, async_dev=use_async, fused_clahe=args.fused)

@@ -572,7 +572,15 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     a.rects = (tiled ? J.plan->d_hist_rects_tiled : J.plan->d_hist_rects_flat).as<Rect>() + first;
     a.lds_bins = 8192;
     const int nrects = last - first;
-    if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_LINEAR_HIST")) {
+    if (J.vec && tiled && J.nbands == 2 && J.plan->fused_grid > 0 && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_PIECE_HIST")) {
+        // whole tiled pass, both bands: persistent workgroups on the fused pass's pieces (fused_kernels.hip k_dn_hist_pieces)
+        DnHistPiecesArgs pa{};
+        for (int b = 0; b < 2; ++b) { pa.in[b] = a.in[b]; pa.tile_hist[b] = a.tile_hist[b]; }
+        pa.pitch = a.pitch; pa.items = J.plan->d_fused_items.as<FusedItem>(); pa.wg_first = J.plan->d_fused_first.as<int32_t>();
+        pa.lds_bins = a.lds_bins;
+        KernelTimer t(ctx, "dn_hist_u16");
+        HIPCHK(ctx, launch_dn_hist_pieces(pa, J.plan->fused_grid, ctx->stream));
+    } else if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_LINEAR_HIST")) {
         KernelTimer t(ctx, "dn_hist_u16"); // whole untiled pass in one go: the in-order sweep
         HIPCHK(ctx, launch_dn_hist_u16_linear(a, (uint32_t)J.rows_local, (uint32_t)J.cols, J.nbands, ctx->stream));
     } else if (nrects > 0) {

@@ -101,6 +101,16 @@ struct FusedTablesArgs { // predicted floor -> compose tables (identity rescale)
     uint32_t force;
 };
 
+struct DnHistPiecesArgs { // per-tile DN histograms of both bands over the fused pass's pieces (k_dn_hist_pieces)
+    const uint16_t *in[kMaxBands];
+    uint32_t *tile_hist[kMaxBands]; // [64][65536], zeroed by the caller
+    size_t pitch;                   // elements, % 4 == 0
+    const FusedItem *items;
+    const int32_t *wg_first;        // [grid + 1]
+    uint32_t lds_bins;              // DN < lds_bins are privatised in LDS
+};
+hipError_t launch_dn_hist_pieces(const DnHistPiecesArgs &a, int grid, hipStream_t s);
+
 hipError_t fused_configure(); // once per device: dynamic LDS opt-in of the fused kernels
 hipError_t launch_fused_prep(const FusedPrepArgs &a, hipStream_t s);
 hipError_t launch_fused_predict(const FusedPredictArgs &a, hipStream_t s);
