@@ -468,9 +468,14 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     float *myring = ring[wave_id()];
     uint32_t cursor = 0, flushed = 0;
     StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.pitch, a.pol);
-    while (walk.live()) {
-        uint32_t r, col;
-        const F32Vec<VEC> v = walk.next(a.in, a.pitch, a.pol, &r, &col);
+    // A wave-uniform trip count (lane 0 holds the wave's smallest item index, so it runs longest): with a divergent loop exit
+    // the compiler keeps the wave-level counters in vector registers and pays vector adds for them.
+    const uint64_t first = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u);
+    const uint32_t nit = __builtin_amdgcn_readfirstlane(first < walk.total ? (uint32_t)((walk.total - first + walk.step - 1) / walk.step) : 0u);
+    for (uint32_t it = 0; it < nit; ++it) {
+        uint32_t r = 0, col = 0xFFFFFFF0u; // a lane past its last item: every sample fails the column test
+        F32Vec<VEC> v{};
+        if (walk.live()) v = walk.next(a.in, a.pitch, a.pol, &r, &col);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float x = v.get(j);
@@ -614,6 +619,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
         uint32_t r, col;
         const F32Vec<VEC> v = walk.next(a.in, a.in_pitch, a.pol, &r, &col);
         const uint32_t r_row = r;
+        const double inv_range = 1.0 / a.range;
         uint32_t lvs[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -625,7 +631,8 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
                     else if (x < a.t_first) lv = 0u;
                     else {
                         const double db = db_of_f32_fast(x, logc, invc); // within ~1e-14 of glibc's value: far inside the 1e-6 margin below
-                        const double t = (fmin(fmax(db, a.low), a.high) - a.low) / a.range;
+                        // a multiplication where the reference divides by `range`: a relative 1e-16, 1e-11 levels, far inside the margin
+                        const double t = (fmin(fmax(db, a.low), a.high) - a.low) * inv_range;
                         const double y = fmin(fmax((a.gamma == 1.0 ? t : pow(t, a.gamma)) * a.max_val, 0.0), a.max_val);
                         const double r = rint(y);
                         if (fabs(y - r) < 1e-6 || !(y == y)) {
