@@ -232,7 +232,7 @@ class Context:
             fn, dt = lib.sarpro_hip_dualpol_synrgb_f32, np.float32
         b1 = np.ascontiguousarray(band1, dt)
         b2 = np.ascontiguousarray(band2, dt)
-        self._chk(fn(self._h, _vp(b1), _vp(b2), rows, cols, int(strategy), int(mode), _vp(rgb), _vp(u1), _vp(u2), st))
+        self._chk(fn(self._h, _vp(b1), _vp(b2), rows, cols, int(strategy), int(mode), _vp(rgb), _vp(u1), _vp(u2), st if want_stats else None))
         out = (rgb,)
         if want_u8:
             out += (u1, u2)

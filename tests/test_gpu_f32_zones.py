@@ -114,3 +114,18 @@ def test_zone_route_default_on_for_large_rasters_and_equal_to_the_sweep(monkeypa
                 assert ("f32_zone_count" in names(c)) == (env is None), (strategy, names(c))
                 outs.append(o[:, :cols].clone())
             assert torch.equal(outs[0], outs[1]), strategy
+
+
+@pytest.mark.parametrize("strategy", [St.Tamed, St.Clahe, St.Robust])
+def test_zone_route_inside_the_dual_pol_f32_product(strategy, monkeypatch):
+    """save.rs:317-367 for f32 bands: both pipelines (and, for Tamed, the band-specific re-autoscale of autoscale.rs:710-741,
+    whose windows read p02 / p05 / p99) take the zone route; the RGB is the oracle's."""
+    monkeypatch.setenv("SARPRO_HIP_F32_ZONES", "force")
+    rows, cols = 333, 417
+    b = [f32data.resampled_scene(rows, cols, k) for k in (0, 1)]
+    rc, ref, _, _ = oracle.dualpol_synrgb(b[0], b[1], int(strategy))
+    assert rc == 0
+    with S.Context(0, timing=True) as c:
+        rgb = c.dualpol_synrgb(b[0], b[1], strategy)
+        assert np.array_equal(rgb, ref)
+        assert "f32_prepass_zones" in names(c)
