@@ -454,9 +454,10 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
 #pragma unroll
     for (int k = 0; k < 2 * NZ; ++k) bd[k] = __float_as_int(a.work->bounds[k]);
     // wave-uniform counters (a wave sees < 2^32 samples: total / waves of the grid)
-    uint32_t cnt = 0, ge[2 * NZ];
+    // (only the LOWER bound of a zone is counted: the zone's own population comes out of the count kernel)
+    uint32_t cnt = 0, ge[NZ];
 #pragma unroll
-    for (int k = 0; k < 2 * NZ; ++k) ge[k] = 0;
+    for (int k = 0; k < NZ; ++k) ge[k] = 0;
     int mn = 0x7F800000, mx = (int)0x80000000;
     __shared__ unsigned long long gsum[2 * kMaxZones + 1];
     __shared__ float ring[kWavesPerBlock][128]; // kept samples on their way out: flushed 64 at a time, one coalesced store
@@ -488,8 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
 #pragma unroll
             for (int z = 0; z < NZ; ++z) {
                 const bool g0 = xi >= bd[2 * z], g1 = xi >= bd[2 * z + 1];
-                ge[2 * z] += (uint32_t)__popcll(__ballot(g0));
-                ge[2 * z + 1] += (uint32_t)__popcll(__ballot(g1));
+                ge[z] += (uint32_t)__popcll(__ballot(g0));
                 inz |= g0 != g1; // g1 implies g0
             }
             const unsigned long long zm = __ballot(inz);
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     if (lane_id() == 0) {
         atomicAdd(&gsum[2 * kMaxZones], (unsigned long long)cnt);
 #pragma unroll
-        for (int k = 0; k < 2 * NZ; ++k) atomicAdd(&gsum[k], (unsigned long long)ge[k]);
+        for (int k = 0; k < NZ; ++k) atomicAdd(&gsum[2 * k], (unsigned long long)ge[k]);
         a.zone_n[blockIdx.x * kWavesPerBlock + wave_id()] = cursor;
     }
     __syncthreads();

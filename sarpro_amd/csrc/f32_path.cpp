@@ -76,6 +76,8 @@ struct F32Band {
     float zlo[kMaxZones], zhi[kMaxZones];
     uint32_t zcap = 0;
     uint64_t zge[2 * kMaxZones];
+    std::vector<uint32_t> zone_kept_store;
+    const uint32_t *zone_kept = nullptr; // per-wave kept counts of the min / max pass
     const char *zone_note = "";
     uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
 };
@@ -248,6 +250,8 @@ int f32_zone_prepass(F32Band &B) {
         for (int k = 0; k < 2 * kMaxZones; ++k) B.zge[k] += h_ge[(size_t)i * 2 * kMaxZones + k];
         for (int w = 0; w < 4; ++w) overflow |= h_n[4 * i + w] > B.zcap / 4;
     }
+    B.zone_kept_store.assign(h_n, h_n + 4 * (size_t)grid);
+    B.zone_kept = B.zone_kept_store.data();
     if (overflow) { B.use_zones = false; B.zone_note = "side buffer overflow"; }
     return SARPRO_HIP_OK;
 }
@@ -303,7 +307,13 @@ int f32_zone_resolve(F32Band &B) {
     for (int j = 0; j < B.nz; ++j) {
         uint64_t c = N - B.zge[2 * j];
         for (int i = zr[j].s; i <= zr[j].e; ++i) { cum[i] = c; c += h_counts[i]; }
-        if (cum[zr[j].e] != N - B.zge[2 * j + 1]) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
+        if (cum[zr[j].e] > N) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
+    }
+    { // every kept sample lies in exactly one interval of one zone
+        uint64_t kept = 0, counted = 0;
+        for (int j = 0; j < B.nz; ++j) counted += cum[zr[j].e] - cum[zr[j].s];
+        for (int i = 0; i < 4 * B.zgrid; ++i) kept += B.zone_kept ? B.zone_kept[i] : 0;
+        if (B.zone_kept && kept != counted) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
     }
     sarpro_hip_stats st{};
     st.valid_count = N; st.min_db = min_db; st.max_db = max_db;
