@@ -271,19 +271,20 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
 // a'. zone route (f32_kernels.h): row sample of the float's leading bits; min / max pass that also counts the samples at or
 //     above each zone bound and keeps the samples inside a zone; count of the kept samples against a few thresholds.
 // ------------------------------------------------------------------------------------
+constexpr int kSampleBlock = 1024; // 128 KiB of LDS per workgroup: one per CU, so make it a full one
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_f32_sample_keys(const float *__restrict__ in, size_t pitch, uint32_t rows, uint32_t cols,
+__global__ __launch_bounds__(kSampleBlock) void k_f32_sample_keys(const float *__restrict__ in, size_t pitch, uint32_t rows, uint32_t cols,
                                                             float t_valid, uint32_t row_stride, float *__restrict__ sample,
                                                             uint32_t sample_pitch, uint32_t *__restrict__ g_hist, F32Pol pol) {
     extern __shared__ uint32_t keys[]; // [kSampleKeys]
-    for (int i = threadIdx.x; i < kSampleKeys; i += kBlock) keys[i] = 0;
+    for (int i = threadIdx.x; i < kSampleKeys; i += kSampleBlock) keys[i] = 0;
     __syncthreads();
     const uint32_t vpr = (cols + VEC - 1) / VEC;
     const uint32_t nsrows = (rows + row_stride - 1) / row_stride;
     for (uint32_t sr = blockIdx.x; sr < nsrows; sr += gridDim.x) {
         const uint32_t r = min(sr * row_stride + row_stride / 2, rows - 1); // mid-phase rows
         float *dst = sample + (size_t)sr * sample_pitch;
-        for (uint32_t vc = threadIdx.x; vc < vpr; vc += kBlock) {
+        for (uint32_t vc = threadIdx.x; vc < vpr; vc += kSampleBlock) {
             const uint32_t col = vc * VEC;
             const F32Vec<VEC> v = F32Vec<VEC>::fetch(in, pitch, pol, r, col);
 #pragma unroll
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_sample_keys(const float *__restr
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kSampleKeys; i += kBlock)
+    for (int i = threadIdx.x; i < kSampleKeys; i += kSampleBlock)
         if (keys[i]) atomicAdd(&g_hist[i], keys[i]);
 }
 
@@ -357,14 +358,19 @@ __global__ __launch_bounds__(kBlock) void k_f32_sample_sub(const float *__restri
                                                            const F32ZoneWork *__restrict__ work, uint32_t *__restrict__ g_sub) {
     __shared__ uint32_t sub[kMaxProbes * kSubKeys];
     __shared__ uint32_t pk[kMaxProbes];
+    __shared__ uint32_t probed[kSampleKeys / 32]; // bit k: key k is probed (most samples are not in a probed bucket)
     for (int i = threadIdx.x; i < kMaxProbes * kSubKeys; i += kBlock) sub[i] = 0;
+    for (int i = threadIdx.x; i < kSampleKeys / 32; i += kBlock) probed[i] = 0;
     const int np = (int)work->nprobe;
     if ((int)threadIdx.x < kMaxProbes) pk[threadIdx.x] = (int)threadIdx.x < np ? work->probe_key[threadIdx.x] : 0xFFFFFFFFu;
+    __syncthreads();
+    if ((int)threadIdx.x < np) atomicOr(&probed[(pk[threadIdx.x] & (kSampleKeys - 1)) >> 5], 1u << (pk[threadIdx.x] & 31u));
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const float x = sample[i];
         if (!(x >= t_valid)) continue;
         const uint32_t bits = __float_as_uint(x), key = bits >> 16;
+        if (key >= (uint32_t)kSampleKeys || !((probed[key >> 5] >> (key & 31u)) & 1u)) continue;
 #pragma unroll
         for (int p = 0; p < kMaxProbes; ++p)
             if (key == pk[p]) atomicAdd(&sub[p * kSubKeys + ((bits >> 7) & (kSubKeys - 1))], 1u); // equal probe keys: each keeps its own copy
@@ -385,11 +391,14 @@ __global__ __launch_bounds__(64) void k_f32_zone_finalize(F32ZoneSelectArgs a) {
         if (t < 2 * kMaxZones) w->bounds[t] = INFINITY;
         return;
     }
+    __shared__ uint32_t subl[kMaxProbes * kSubKeys];
+    for (int i = t; i < np * kSubKeys; i += 64) subl[i] = a.sub_hist[i];
+    __syncthreads();
     if (t < np) {
         uint32_t c = w->probe_base[t], sb = kSubKeys - 1;
         const uint32_t r = w->probe_rank[t];
         for (int k = 0; k < kSubKeys; ++k) {
-            const uint32_t h = a.sub_hist[t * kSubKeys + k];
+            const uint32_t h = subl[t * kSubKeys + k];
             if (r < c + h) { sb = k; break; }
             c += h;
         }
@@ -799,11 +808,11 @@ hipError_t launch_f32_sample_keys(const float *in, size_t pitch, uint32_t rows, 
     hipError_t e;
     if (vec) {
         if ((e = opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_f32_sample_keys<4>))) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_f32_sample_keys<4>), dim3(grid), dim3(kBlock), lds, s, in, pitch, rows, cols, t_valid, row_stride, d_sample, sample_pitch,
+        hipLaunchKernelGGL((k_f32_sample_keys<4>), dim3(grid), dim3(kSampleBlock), lds, s, in, pitch, rows, cols, t_valid, row_stride, d_sample, sample_pitch,
                            d_key_hist, pol);
     } else {
         if ((e = opt_in_dynamic_lds(reinterpret_cast<const void *>(&k_f32_sample_keys<1>))) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_f32_sample_keys<1>), dim3(grid), dim3(kBlock), lds, s, in, pitch, rows, cols, t_valid, row_stride, d_sample, sample_pitch,
+        hipLaunchKernelGGL((k_f32_sample_keys<1>), dim3(grid), dim3(kSampleBlock), lds, s, in, pitch, rows, cols, t_valid, row_stride, d_sample, sample_pitch,
                            d_key_hist, pol);
     }
     return hipGetLastError();
