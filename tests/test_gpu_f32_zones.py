@@ -92,9 +92,11 @@ def test_zone_route_with_the_pol_op_computed_on_the_fly(op, strategy, monkeypatc
         assert "f32_prepass_zones" in names(c)
 
 
-def test_zone_route_default_on_for_large_rasters_and_equal_to_the_sweep(monkeypatch):
-    """No switch: a 3000 x 3000 raster (> 4 MP) takes the route by itself; its raster equals the 4096-bin route's."""
-    rows, cols, pitch = 3000, 3000, 3008
+@pytest.mark.parametrize("side", [3000, 20000])
+def test_zone_route_default_on_for_large_rasters_and_equal_to_the_sweep(side, monkeypatch):
+    """No switch: a raster above 4 MP takes the route by itself -- a row SAMPLE places the zones there (every 4th row at 3000^2,
+    every 31st at BASELINE.json's 20000^2) -- and its raster equals the 4096-bin route's, pixel for pixel."""
+    rows, cols, pitch = side, side, (side + 63) // 64 * 64
     q = synth.q_tables()
     with S.Context(0, timing=True) as c:
         d = [torch.zeros((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
