@@ -238,7 +238,7 @@ def pmc_traffic_gb(kernel, local_px):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r2_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied), scaled
     to this run's pixel count.  None when the kernel has no committed measurement."""
-    names = {"clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_u16_interior",
+    names = {"clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_pieces",
              "compose_u8": "k_compose_u8", "lut_apply_u16": "k_lut_apply_u16", "lut_compose_u16": "k_lut_compose_u16"}
     try:
         with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:

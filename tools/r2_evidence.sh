@@ -21,6 +21,11 @@ python3 tools/predict_accuracy.py > $O/predict_accuracy.txt 2>&1
 python3 tools/time_strategies.py > $O/time_strategies.txt 2>&1
 timeout 600 python3 tools/soak_spec_vs_exact.py 6 > $O/soak_spec_vs_exact.txt 2>&1
 timeout 600 python3 tools/soak_routes.py 2 > $O/soak_routes.txt 2>&1
+python3 tools/time_f32_routes.py > $O/time_f32_routes.txt 2>&1
+timeout 900 python3 tools/soak_zones.py 300 > $O/soak_zones_300.txt 2>&1
+bash tools/pitch_sweep.sh > $O/pitch_sweep.txt 2>&1
+bash tools/pmc_f32.sh $O/pmc_f32 > $O/pmc_f32.txt 2>&1
+cd $R
 [ -x build/stream_bench ] && ./build/stream_bench > $O/stream_bench.txt 2>&1
 [ -x build/instr_bench ] && ./build/instr_bench > $O/instr_bench.txt 2>&1
 # 5. timeline of the f32 flavour (config 3(ii))
