@@ -17,6 +17,7 @@ struct F32Partial { // one per block of the pre-pass
 struct F32StepEstimate {
     float inv_x0, scale, bias; // t = log2(x * inv_x0) * scale (the clipped window maps to 0..1), step = t^gamma * nsteps + bias
     float gamma, nsteps;
+    float a_mul, b_add;        // gamma == 1: step = log2(x) * a_mul + b_add, the same expression folded (one v_log, one fma, one clamp)
     int use;
 };
 

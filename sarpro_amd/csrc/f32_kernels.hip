@@ -33,9 +33,14 @@ __device__ inline uint32_t step_search(const float *thr, float v) {
 // thr[k] <= v < thr[k + 1] (ascending table), whatever produced k; otherwise the binary search decides.
 template <int N>
 __device__ inline uint32_t est_search(const float *thr, float v, const F32StepEstimate &e) {
-    float t = fminf(fmaxf(__builtin_amdgcn_logf(v * e.inv_x0) * e.scale, 0.0f), 1.0f); // log2; NaN -> 0
-    if (e.gamma != 1.0f) t = __builtin_amdgcn_exp2f(e.gamma * __builtin_amdgcn_logf(t)); // t^gamma (t = 0: exp2(-inf) = 0)
-    const uint32_t k = (uint32_t)fminf(fmaxf(t * e.nsteps + e.bias, 0.0f), (float)N);
+    uint32_t k;
+    if (e.gamma == 1.0f) { // the common case, folded: the estimate only has to be right often, the two reads below decide
+        k = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_logf(v), e.a_mul, e.b_add), 0.0f, (float)N); // NaN -> 0
+    } else {
+        float t = fminf(fmaxf(__builtin_amdgcn_logf(v * e.inv_x0) * e.scale, 0.0f), 1.0f); // log2; NaN -> 0
+        t = __builtin_amdgcn_exp2f(e.gamma * __builtin_amdgcn_logf(t)); // t^gamma (t = 0: exp2(-inf) = 0)
+        k = (uint32_t)fminf(fmaxf(t * e.nsteps + e.bias, 0.0f), (float)N);
+    }
     const float t0 = thr[k], t1 = thr[k + 1];
     if (t0 <= v && v < t1) return k;
     return step_search<N>(thr, v);

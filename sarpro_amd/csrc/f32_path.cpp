@@ -87,7 +87,8 @@ F32StepEstimate step_estimate(double low_db, double range_db, double nsteps, dou
     F32StepEstimate e{};
     const double inv_x0 = std::pow(10.0, -low_db / 10.0), scale = 3.010299956639812 / range_db; // 10 log10(2)
     e.inv_x0 = (float)inv_x0; e.scale = (float)scale; e.bias = (float)bias; e.gamma = (float)gamma; e.nsteps = (float)nsteps;
-    e.use = std::isfinite(e.inv_x0) && e.inv_x0 > 1e-30f && std::isfinite(e.scale) && e.scale * e.nsteps < 3.0e6f &&
+    e.a_mul = (float)(scale * nsteps); e.b_add = (float)(std::log2(inv_x0) * scale * nsteps + bias);
+    e.use = std::isfinite(e.inv_x0) && e.inv_x0 > 1e-30f && std::isfinite(e.scale) && e.scale * e.nsteps < 3.0e6f && std::isfinite(e.b_add) &&
             !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
     return e;
 }
