@@ -63,6 +63,15 @@ __device__ inline float div_small_ints(float num, float den) {
     return __builtin_fmaf(e2, r, q);
 }
 
+// ops.rs:10-19 / 22-33 / 35-44: num / den where |den| > 1e-10, else 0
+template <bool INTS>
+__device__ inline float ratio_one(float num, float den) {
+    const bool ok = fabsf(den) > 1e-10f;
+    const float dsafe = ok ? den : 1.0f; // unconditional division: the compiler would otherwise put each behind its own branch
+    const float q = INTS ? div_small_ints(num, dsafe) : num / dsafe;
+    return ok ? q : 0.0f;
+}
+
 template <bool INTS = false>
 __device__ inline float pol_one(int op, float x, float y) {
     // straight-line in the (uniform) operation: one guarded division whatever it is, so that the divisions of a vector's four
@@ -127,8 +136,16 @@ template <> struct F32Vec<4> {
             x = make_float4(__uint_as_float(w.a.x), __uint_as_float(w.a.y), __uint_as_float(w.a.z), __uint_as_float(w.a.w));
             y = make_float4(__uint_as_float(w.b.x), __uint_as_float(w.b.y), __uint_as_float(w.c.x), __uint_as_float(w.c.y));
         }
-        if (p.u16) o.v = make_float4(pol_one<true>(p.op, x.x, y.x), pol_one<true>(p.op, x.y, y.y), pol_one<true>(p.op, x.z, y.z), pol_one<true>(p.op, x.w, y.w));
-        else o.v = make_float4(pol_one(p.op, x.x, y.x), pol_one(p.op, x.y, y.y), pol_one(p.op, x.z, y.z), pol_one(p.op, x.w, y.w));
+        // one uniform branch per VECTOR on the kind of operation, then four straight-line elements (pol_one's selects on the
+        // operation cost six instructions per element when it is not known at compile time)
+        if (p.op == SARPRO_OP_RATIO || p.op == SARPRO_OP_LOGRATIO) {
+            if (p.u16) o.v = make_float4(ratio_one<true>(x.x, y.x), ratio_one<true>(x.y, y.y), ratio_one<true>(x.z, y.z), ratio_one<true>(x.w, y.w));
+            else o.v = make_float4(ratio_one<false>(x.x, y.x), ratio_one<false>(x.y, y.y), ratio_one<false>(x.z, y.z), ratio_one<false>(x.w, y.w));
+        } else if (p.op == SARPRO_OP_NDIFF) {
+            if (p.u16) o.v = make_float4(ratio_one<true>(x.x - y.x, x.x + y.x), ratio_one<true>(x.y - y.y, x.y + y.y), ratio_one<true>(x.z - y.z, x.z + y.z), ratio_one<true>(x.w - y.w, x.w + y.w));
+            else o.v = make_float4(ratio_one<false>(x.x - y.x, x.x + y.x), ratio_one<false>(x.y - y.y, x.y + y.y), ratio_one<false>(x.z - y.z, x.z + y.z), ratio_one<false>(x.w - y.w, x.w + y.w));
+        } else if (p.op == SARPRO_OP_SUM) o.v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        else o.v = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
         return o;
     }
 };
