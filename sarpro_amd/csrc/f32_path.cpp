@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 
+#include "chain_kernels.h"
 #include "f32_kernels.h"
 #include "internal.h"
 
@@ -540,14 +541,20 @@ int f32_phase_d(F32Band &B) {
         HIPCHK(ctx, launch_f32_level(a, B.vec, !u8o, ctx->stream));
         return SARPRO_HIP_OK;
     }
-    uint64_t *h_tb = ctx->h_small.as<uint64_t>();
-    HIPCHK(ctx, hipMemcpyAsync(h_tb, ws + kOffTileBins, sizeof(uint64_t) * 64 * 256, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (B.plan->apply_rects.empty()) return SARPRO_HIP_OK;
-    double *h_cdfs = reinterpret_cast<double *>(ctx->h_upload.as<uint8_t>() + 4096);
-    RETCHK(clahe_cdfs(h_tb, B.rows_total, B.cols, h_cdfs));
     double *d_cdfs = reinterpret_cast<double *>(ws + kOffCdfs);
-    HIPCHK(ctx, hipMemcpyAsync(d_cdfs, h_cdfs, sizeof(double) * 64 * 256, hipMemcpyHostToDevice, ctx->stream));
+    if (getenv("SARPRO_HIP_F32_HOST_CDFS")) { // the host twin of the kernel below (cross-check switch)
+        uint64_t *h_tb = ctx->h_small.as<uint64_t>();
+        HIPCHK(ctx, hipMemcpyAsync(h_tb, ws + kOffTileBins, sizeof(uint64_t) * 64 * 256, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        double *h_cdfs = reinterpret_cast<double *>(ctx->h_upload.as<uint8_t>() + 4096);
+        RETCHK(clahe_cdfs(h_tb, B.rows_total, B.cols, h_cdfs));
+        HIPCHK(ctx, hipMemcpyAsync(d_cdfs, h_cdfs, sizeof(double) * 64 * 256, hipMemcpyHostToDevice, ctx->stream));
+    } else { // clip / redistribute / CDF per tile on the device (chain_kernels.hip, the u16 chain's kernel): no host turn
+        KernelTimer t(ctx, "chain_cdfs");
+        HIPCHK(ctx, launch_chain_cdfs(reinterpret_cast<const unsigned long long *>(ws + kOffTileBins), d_cdfs, (uint32_t)B.rows_total, (uint32_t)B.cols, 1,
+                                      ctx->stream));
+    }
     F32ClaheApplyArgs a{};
     a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
     a.rects = B.plan->d_apply_rects.as<Rect>(); a.cdfs = d_cdfs; a.t_valid = B.t_valid; a.thr = reinterpret_cast<float *>(ws + kOffThrLevel);

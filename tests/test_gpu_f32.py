@@ -117,3 +117,17 @@ def test_u16_levels_without_the_table_equal_the_table_route(strategy, monkeypatc
             monkeypatch.setenv("SARPRO_HIP_F32_LEVEL_TABLE", "1")
             b = c.process_scalar_data_pipeline(x, Bd.U16, strategy)[1]
         assert np.array_equal(a, ref) and np.array_equal(b, ref)
+
+
+def test_clahe_cdfs_on_the_device_equal_the_host_twin(monkeypatch):
+    """The f32 flavour's CLAHE CDFs come from the u16 chain's kernel (no host turn); SARPRO_HIP_F32_HOST_CDFS=1 is the host twin."""
+    import f32data
+    x = f32data.ratio_scene(333, 417)
+    rc, ref = oracle.pipeline(x, int(Bd.U16), int(St.Clahe))
+    with S.Context(0, timing=True) as c:
+        a = c.process_scalar_data_pipeline(x, Bd.U16, St.Clahe)[1]
+        assert "chain_cdfs" in [n for n, _ in c.last_kernel_times()]
+        monkeypatch.setenv("SARPRO_HIP_F32_HOST_CDFS", "1")
+        b = c.process_scalar_data_pipeline(x, Bd.U16, St.Clahe)[1]
+        assert "chain_cdfs" not in [n for n, _ in c.last_kernel_times()]
+    assert np.array_equal(a, ref) and np.array_equal(b, ref)
