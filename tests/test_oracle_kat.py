@@ -197,3 +197,30 @@ def test_scale_u16_to_u8_worked_by_hand():
     (half away from zero), 3 -> round(1.02) = 1, 251 -> round(253.98) = 254."""
     v = np.array([2, 252, 127, 3, 251], np.uint16)
     assert oracle.scale_u16_to_u8(v).tolist() == [0, 255, 128, 1, 254]
+
+
+def test_clahe_blend_geometry_worked_by_hand():
+    """autoscale.rs:305-334 on a 64 x 64 raster (tile_h = tile_w = ceil(64 / 8) = 8).  Tile indices and weights below are worked by
+    hand from `rf = r / tile_h - 0.5`, `ty = max(floor(rf), 0)`, `dy = rf - ty`, `ty1 = min(ty + 1, 7)` (same in x); the CDF values
+    themselves are taken from the oracle's own table, so this pins the GEOMETRY of the blend, not the CDFs (those have their own
+    hand-worked tests above)."""
+    rng = np.random.default_rng(4)
+    norm = rng.random((64, 64))
+    mask = np.ones((64, 64), np.uint8)
+    rc, out, cdfs = oracle.clahe(norm, mask, want_cdfs=True)
+    assert rc == 0
+    #        (r,  c):  (ty0, ty1, dy,      tx0, tx1, dx)
+    hand = {(0, 0):    (0, 1, -0.5,        0, 1, -0.5),      # rf = -0.5 -> floor -1 -> clamped to tile 0: dy = -0.5 (extrapolation)
+            (3, 12):   (0, 1, -0.125,      1, 2, 0.0),       # rf = 3/8 - 0.5 = -0.125; cf = 12/8 - 0.5 = 1.0 exactly
+            (4, 4):    (0, 1, 0.0,         0, 1, 0.0),       # tile centre: the tile's own CDF
+            (20, 35):  (2, 3, 0.0,         3, 4, 0.875),     # rf = 2.0; cf = 35/8 - 0.5 = 3.875
+            (37, 9):   (4, 5, 0.125,       0, 1, 0.625),     # rf = 4.125; cf = 0.625
+            (60, 61):  (7, 7, 0.0,         7, 7, 0.125),     # rf = 7.0, cf = 7.125: last half tile, both neighbours are tile 7 (flat)
+            (63, 0):   (7, 7, 0.375,       0, 1, -0.5)}      # rf = 7.375 (flat in y), cf = -0.5 (extrapolated in x)
+    for (r, c), (ty0, ty1, dy, tx0, tx1, dx) in hand.items():
+        b = int(np.floor(min(max(norm[r, c], 0.0), 1.0) * 255.0 + 0.5))  # f64::round of a non-negative value
+        c00, c01 = cdfs[ty0 * 8 + tx0, b], cdfs[ty0 * 8 + tx1, b]
+        c10, c11 = cdfs[ty1 * 8 + tx0, b], cdfs[ty1 * 8 + tx1, b]
+        top = c00 * (1.0 - dx) + c01 * dx
+        bottom = c10 * (1.0 - dx) + c11 * dx
+        assert out[r, c] == top * (1.0 - dy) + bottom * dy, (r, c)
