@@ -37,7 +37,7 @@ def _order_library_behind_torch(request):
 
     import sarpro_amd
     saved = {}
-    for cls in (sarpro_amd.Context, getattr(sarpro_amd.api, "Stripe", None)):
+    for cls in (sarpro_amd.Context, getattr(sarpro_amd.api, "Stripe", None), getattr(sarpro_amd.api, "StripeF32", None)):
         if cls is None:
             continue
         for name, fn in list(vars(cls).items()):
