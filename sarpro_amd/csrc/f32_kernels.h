@@ -92,7 +92,8 @@ struct F32ClaheApplyArgs {
 constexpr int kMaxZones = 6;
 constexpr int kMaxProbes = 2 * kMaxZones;
 constexpr int kSampleKeys = 32768; // key = bits >> 16 of a positive f32: 8 exponent + 7 mantissa bits
-constexpr int kSubKeys = 512;      // the next 9 mantissa bits: sub-bucket of a probed key
+constexpr int kSubKeys = 512;
+constexpr int kZoneMaxThr = 1023;  // thresholds (zone bounds included) the count kernel takes: 2^m - 1      // the next 9 mantissa bits: sub-bucket of a probed key
 struct F32ZoneWork { // device memory, written by the zone kernels
     uint32_t ns, kmin, kmax, nprobe;       // sample size, lowest / highest populated key
     uint32_t probe_key[kMaxProbes];        // key whose bucket holds the probe rank
@@ -135,9 +136,9 @@ hipError_t launch_f32_zone_pick(const F32ZoneSelectArgs &a, hipStream_t s);
 hipError_t launch_f32_sample_sub(const float *d_sample, uint64_t n, float t_valid, const F32ZoneWork *work, uint32_t *d_sub_hist /* zeroed */, hipStream_t s);
 hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s);
 hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int nz_max, int grid, hipStream_t s);
-// counts[i] += zone samples x with thr[i] <= x < thr[i + 1], i = 0 .. nthr (thr[0] = -inf implied below thr[1]; thr sorted, nthr <= 255)
+// counts[i] += zone samples x with thr[i] <= x < thr[i + 1], i = 0 .. nthr (thr[0] = -inf implied below thr[1]; thr sorted, nthr <= kZoneMaxThr)
 hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, uint32_t cap, int nregions, const float *d_thr, int nthr,
-                                 unsigned long long *d_counts /* [256], zeroed */, hipStream_t s);
+                                 unsigned long long *d_counts /* [kZoneMaxThr + 1], zeroed */, hipStream_t s);
 
 int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec);
 // moments = false: count / min / max only (no per-sample f64 log10: the pass is then memory-bound)

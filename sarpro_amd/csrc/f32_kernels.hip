@@ -583,19 +583,19 @@ __global__ __launch_bounds__(256) void k_selftest_div_small_ints(unsigned long l
 __global__ __launch_bounds__(kBlock) void k_f32_zone_count(const float *__restrict__ zone_buf, const uint32_t *__restrict__ zone_n, uint32_t cap,
                                                            int nregions, const float *__restrict__ g_thr, int nthr,
                                                            unsigned long long *__restrict__ g_counts) {
-    __shared__ float thr[256 + 1];
-    __shared__ uint32_t hist[256];
-    thr[threadIdx.x] = (threadIdx.x >= 1 && (int)threadIdx.x <= nthr) ? g_thr[threadIdx.x] : (threadIdx.x ? INFINITY : -INFINITY);
-    if (threadIdx.x == 0) thr[256] = INFINITY;
-    hist[threadIdx.x] = 0;
+    __shared__ float thr[kZoneMaxThr + 2];
+    __shared__ uint32_t hist[kZoneMaxThr + 1];
+    for (int i = threadIdx.x; i <= kZoneMaxThr + 1; i += kBlock) thr[i] = (i >= 1 && i <= nthr) ? g_thr[i] : (i ? INFINITY : -INFINITY);
+    for (int i = threadIdx.x; i <= kZoneMaxThr; i += kBlock) hist[i] = 0;
     __syncthreads();
     for (int w = blockIdx.x; w < nregions; w += gridDim.x) {
         const uint32_t n = min(zone_n[w], cap);
         const float *src = zone_buf + (size_t)w * cap;
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hist[step_search<255>(thr, src[i])], 1u);
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hist[step_search<kZoneMaxThr>(thr, src[i])], 1u);
     }
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&g_counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    for (int i = threadIdx.x; i <= kZoneMaxThr; i += kBlock)
+        if (hist[i]) atomicAdd(&g_counts[i], (unsigned long long)hist[i]);
 }
 
 // ------------------------------------------------------------------------------------

@@ -49,9 +49,9 @@ constexpr size_t kOffMap = kOffCdfs + 128 * 1024;                    // 256 B
 constexpr size_t kOffKeyHist = kOffMap + 4096;                       // zone route: 128 KiB sample histogram of the float's leading bits
 constexpr size_t kOffZoneGe = kOffKeyHist + 128 * 1024;              // 2048 x 12 x 8 B
 constexpr size_t kOffZoneN = kOffZoneGe + 2048 * 2 * kMaxZones * 8;  // 2048 x 4 B
-constexpr size_t kOffZoneThr = kOffZoneN + 2048 * 4 * 4;             // 257 x 4 B (zone_n: one count per wave)
-constexpr size_t kOffZoneCounts = kOffZoneThr + 2048;                // 256 x 8 B
-constexpr size_t kOffSubHist = kOffZoneCounts + 4096;                // kMaxProbes x kSubKeys x 4 B
+constexpr size_t kOffZoneThr = kOffZoneN + 2048 * 4 * 4;             // (kZoneMaxThr + 2) x 4 B (zone_n: one count per wave)
+constexpr size_t kOffZoneCounts = kOffZoneThr + 8192;                // (kZoneMaxThr + 1) x 8 B
+constexpr size_t kOffSubHist = kOffZoneCounts + 16384;               // kMaxProbes x kSubKeys x 4 B
 constexpr size_t kOffZoneWork = kOffSubHist + kMaxProbes * kSubKeys * 4;
 constexpr size_t kWsBytes = kOffZoneWork + 4096;
 
@@ -166,11 +166,10 @@ int f32_zone_presample(F32Band &B) {
     B.use_zones = false;
     const char *env = getenv("SARPRO_HIP_F32_ZONES");
     if (env && !std::strcmp(env, "0")) return SARPRO_HIP_OK;
-    const bool forced = env && (!std::strcmp(env, "force") || !std::strcmp(env, "tiny"));
     double pcts[8];
     const int np = needed_percentiles(B.strategy, B.tamed, pcts);
     const uint64_t px = (uint64_t)B.rows * B.cols;
-    if (np == 0 || np > kMaxZones || B.want_moments || B.rows_total != B.rows || (!forced && px < (4ull << 20)) || B.rows < 64 || B.cols < 64)
+    if (np == 0 || np > kMaxZones || B.want_moments || B.rows_total != B.rows || B.rows < 64 || B.cols < 64)
         return SARPRO_HIP_OK;
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     uint32_t *d_keys = reinterpret_cast<uint32_t *>(ws + kOffKeyHist);
@@ -268,8 +267,8 @@ int f32_zone_resolve(F32Band &B) {
     const double min_db = db_of_f32(G.min_v), max_db = db_of_f32(G.max_v);
     if (std::fabs(max_db - min_db) < 2.220446049250313e-16) return SARPRO_HIP_OK;
     struct Zr { int b_lo, b_hi, s, e; } zr[kMaxZones];
-    float tt[257];
-    int kk[257]; // bin index k of tt[i] when it is a threshold, -1 for a zone bound
+    float tt[kZoneMaxThr + 2];
+    int kk[kZoneMaxThr + 2]; // bin index k of tt[i] when it is a threshold, -1 for a zone bound
     int n = 0;
     tt[0] = -INFINITY; kk[0] = -1;
     for (int j = 0; j < B.nz; ++j) {
@@ -278,7 +277,7 @@ int f32_zone_resolve(F32Band &B) {
         zr[j].b_hi = bin4096_of_f32(std::fmin(hi_in, G.max_v), min_db, max_db);
         if (B.zlo[j] > G.max_v || hi_in < G.min_v) zr[j].b_hi = zr[j].b_lo; // zone outside the data: no thresholds
         const int nt = zr[j].b_hi - zr[j].b_lo;
-        if (n + nt + 2 > 255) { B.zone_note = "too many thresholds"; return SARPRO_HIP_OK; }
+        if (n + nt + 2 > kZoneMaxThr) { B.zone_note = "too many thresholds"; return SARPRO_HIP_OK; }
         zr[j].s = ++n; tt[n] = B.zlo[j]; kk[n] = -1;
         if (nt > 0) {
             build_bin4096_thresholds_range(min_db, max_db, zr[j].b_lo + 1, zr[j].b_hi, tt + n + 1);
@@ -294,17 +293,17 @@ int f32_zone_resolve(F32Band &B) {
     float *d_thr = reinterpret_cast<float *>(ws + kOffZoneThr);
     unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(ws + kOffZoneCounts);
     HIPCHK(ctx, hipMemcpyAsync(d_thr, h_thr, sizeof(float) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * 256, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * (kZoneMaxThr + 1), ctx->stream));
     {
         KernelTimer t(ctx, "f32_zone_count");
         HIPCHK(ctx, launch_f32_zone_count(ctx->f32zone.as<float>(), reinterpret_cast<uint32_t *>(ws + kOffZoneN), B.zcap / 4, B.zgrid * 4, d_thr, n, d_counts,
                                           ctx->stream));
     }
     uint64_t *h_counts = ctx->h_small.as<uint64_t>();
-    HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(uint64_t) * (kZoneMaxThr + 1), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     // cum[i] = valid samples below tt[i], for every i inside a zone
-    uint64_t cum[257];
+    uint64_t cum[kZoneMaxThr + 2];
     const uint64_t N = G.count;
     for (int j = 0; j < B.nz; ++j) {
         uint64_t c = N - B.zge[2 * j];

@@ -94,8 +94,8 @@ def test_zone_route_with_the_pol_op_computed_on_the_fly(op, strategy, monkeypatc
 
 @pytest.mark.parametrize("side", [3000, 20000])
 def test_zone_route_default_on_for_large_rasters_and_equal_to_the_sweep(side, monkeypatch):
-    """No switch: a raster above 4 MP takes the route by itself -- a row SAMPLE places the zones there (every 4th row at 3000^2,
-    every 31st at BASELINE.json's 20000^2) -- and its raster equals the 4096-bin route's, pixel for pixel."""
+    """No switch: the route is the default -- a row SAMPLE places the zones (every 4th row at 3000^2, every 31st at
+    BASELINE.json's 20000^2) -- and its raster equals the 4096-bin route's, pixel for pixel."""
     rows, cols, pitch = side, side, (side + 63) // 64 * 64
     q = synth.q_tables()
     with S.Context(0, timing=True) as c:
