@@ -122,6 +122,7 @@ def test_u16_levels_without_the_table_equal_the_table_route(strategy, monkeypatc
 def test_clahe_cdfs_on_the_device_equal_the_host_twin(monkeypatch):
     """The f32 flavour's CLAHE CDFs come from the u16 chain's kernel (no host turn); SARPRO_HIP_F32_HOST_CDFS=1 is the host twin."""
     import f32data
+    monkeypatch.delenv("SARPRO_HIP_F32_HOST_CDFS", raising=False)
     x = f32data.ratio_scene(333, 417)
     rc, ref = oracle.pipeline(x, int(Bd.U16), int(St.Clahe))
     with S.Context(0, timing=True) as c:
