@@ -224,3 +224,42 @@ def test_clahe_blend_geometry_worked_by_hand():
         top = c00 * (1.0 - dx) + c01 * dx
         bottom = c10 * (1.0 - dx) + c11 * dx
         assert out[r, c] == top * (1.0 - dy) + bottom * dy, (r, c)
+
+
+def test_standard_window_narrow_dynamic_range_arm_worked_by_hand():
+    """autoscale.rs:404-413, the `dynamic_range < 15` arm of the Standard strategy.  Ten valid samples: six of 1.0 (0 dB), four of
+    10.0 (10 dB).  min = 0, max = 10 dB, dynamic range 10 < 15 -> range = max(20, 0.8 * 10) = 20, gamma = 1.1, window =
+    median -/+ 10, then clamped to [min, max] = [0, 10].  Median (autoscale.rs:120-140): target = floor(0.5 * 10) = 5 < 6 = the count
+    of bin 0 -> bin 0, frac = 5 / 6, bin width 10 / 4096 -> median = (5/6) * (10/4096).  Levels: ((0 - 0) / 10)^1.1 * 255 = 0 and
+    ((10 - 0) / 10)^1.1 * 255 = 255; both 0 and 255 occur, so scale_u16_to_u8 is the identity."""
+    x = np.array([[1.0, 10.0, 1.0, 10.0, 1.0], [1.0, 10.0, 1.0, 10.0, 1.0]], np.float32)
+    rc, out, st = oracle.pipeline(x, 0, 0, want_stats=True)  # U8, Standard
+    assert rc == 0
+    assert st.valid_count == 10 and st.min_db == 0.0 and st.max_db == 10.0
+    assert st.median_db == (5.0 / 6.0) * (10.0 / 4096.0)
+    assert st.low_clip == 0.0 and st.high_clip == 10.0 and st.gamma == 1.1
+    assert out.tolist() == [[0, 255, 0, 255, 0], [0, 255, 0, 255, 0]]
+
+
+def test_robust_window_worked_by_hand():
+    """autoscale.rs:492-499.  100 valid samples: value 10^(k/10) (k dB) for k = 0 .. 99, one each, so min = 0, max = 99 dB, span 99,
+    bin of k dB = floor(k / 99 * 4096).  Percentile p: target = floor(100 p); every occupied bin holds one sample, so the bin of
+    rank `target` is the bin of k = target with frac = 0: value = bin_start = floor(k/99*4096) * (99/4096).
+    p25 -> k = 25, p75 -> k = 75, p01 -> k = 1, p99 -> k = 99 (capped at n - 1 = 99).  iqr = p75 - p25; Robust window =
+    max(p25 - 2.5 iqr, p01, min) .. min(p75 + 2.5 iqr, p99, max) = p01 .. p99 here (2.5 iqr = 125 dB reaches beyond both)."""
+    k = np.arange(100, dtype=np.float64)
+    x = (10.0 ** (k / 10.0)).astype(np.float32).reshape(10, 10)
+    rc, out, st = oracle.pipeline(x, 1, 1, want_stats=True)  # U16, Robust
+    assert rc == 0 and st.valid_count == 100
+    # the f32 samples are not exactly 10^(k/10): take min / max as the oracle reports them, then redo the arithmetic by hand
+    span = st.max_db - st.min_db
+    db, _ = oracle.db_mask(x)
+    dbs = np.sort(db.ravel())
+    def pct(p):
+        target = min(int(np.floor(p * 100)), 99)
+        b = min(int(np.clip((dbs[target] - st.min_db) * (1.0 / span), 0.0, 1.0) * 4096.0), 4095)
+        return st.min_db + b * (span / 4096.0) + 0.0 * (span / 4096.0)
+    assert st.p25 == pct(0.25) and st.p75 == pct(0.75) and st.p01 == pct(0.01) and st.p99 == pct(0.99)
+    assert abs(st.p25 - 25.0) < 0.03 and abs(st.p75 - 75.0) < 0.03  # one bin is 99/4096 = 0.024 dB
+    assert st.low_clip == st.p01 and st.high_clip == st.p99 and st.gamma == 1.0
+    assert out[0, 0] == 0 and out[9, 9] == 65535
