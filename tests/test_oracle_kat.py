@@ -263,3 +263,25 @@ def test_robust_window_worked_by_hand():
     assert abs(st.p25 - 25.0) < 0.03 and abs(st.p75 - 75.0) < 0.03  # one bin is 99/4096 = 0.024 dB
     assert st.low_clip == st.p01 and st.high_clip == st.p99 and st.gamma == 1.0
     assert out[0, 0] == 0 and out[9, 9] == 65535
+
+
+def test_tamed_synrgb_windows_worked_by_hand():
+    """autoscale.rs:710-742 on the 100-sample ladder of the test above (one sample per dB, 0 .. 99): co-pol window low = min(p02, p05)
+    = p02 (the k = 2 sample's bin start), cross-pol low = p05 (k = 5), high = p99 (k = 99) for both; level = ((clamp(db) - low) /
+    max(high - low, 1) * 255) truncated, no scale_u16_to_u8 afterwards.  Samples at or below the low cut map to 0, the top one to 255,
+    and the co-pol raster is everywhere >= the cross-pol raster (its window starts lower)."""
+    k = np.arange(100, dtype=np.float64)
+    x = (10.0 ** (k / 10.0)).astype(np.float32).reshape(10, 10)
+    db, _ = oracle.db_mask(x)
+    d = db.ravel()
+    span = d.max() - d.min()
+    def bin_start(kk):
+        b = min(int(np.clip((d[kk] - d.min()) * (1.0 / span), 0.0, 1.0) * 4096.0), 4095)
+        return d.min() + b * (span / 4096.0)
+    for is_copol, klow in ((True, 2), (False, 5)):
+        out = oracle.tamed_synrgb_u8(x, is_copol).ravel()
+        low, high = bin_start(klow), bin_start(99)
+        want = np.array([int(min(max((min(max(v, low), high) - low) / max(high - low, 1.0) * 255.0, 0.0), 255.0)) for v in d], np.uint8)
+        assert np.array_equal(out, want), is_copol
+        assert out[: klow + 1].max() == 0 and out[klow + 1] > 0 and out[99] == 255
+    assert np.all(oracle.tamed_synrgb_u8(x, True) >= oracle.tamed_synrgb_u8(x, False))
