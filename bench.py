@@ -51,7 +51,6 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=7000, help="side of the square CPU-baseline sample scene")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (end-to-end over PCIe, BASELINE configs 2 and 3)")
     ap.add_argument("--pitch-align", type=int, default=64, help="row pitch of the resident rasters, rounded up to this many elements")
-    ap.add_argument("--fused", action="store_true", help="dual-pol CLAHE through the one-sweep fused pass (SARPRO_HIP_CTX_FUSED_CLAHE)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -80,7 +79,7 @@ def main():
     pitch = (cols + args.pitch_align - 1) // args.pitch_align * args.pitch_align
     # scenes are enqueued back to back on the library's stream (SARPRO_HIP_CTX_ASYNC_DEV); --sync-steps: one host round trip per scene
     use_async = not args.sync_steps and not (args.mode == "stripe" and world > 1)
-    ctx = sarpro_amd.Context(local_rank, timing=True, async_dev=use_async, fused_clahe=args.fused)
+    ctx = sarpro_amd.Context(local_rank, timing=True, async_dev=use_async)
     q = synth.q_tables()
 
     if args.mode == "stripe" and world > 1:
@@ -131,7 +130,7 @@ def main():
                 wtimes[name] = wtimes.get(name, 0.0) + ms
     dom_warm = max(wtimes, key=wtimes.get) if wtimes else None
     if dom_warm is None:  # --warmup 0: no measurement to choose by; the kernel that dominates this strategy's chain in every profile
-        dom_warm = ("clahe_fused_rgb" if args.fused else "clahe_apply_u8_spec") if strategy == AutoscaleStrategy.Clahe else "lut_compose_u16"
+        dom_warm = "clahe_apply_u8_spec" if strategy == AutoscaleStrategy.Clahe else "lut_compose_u16"
     if dom_warm:
         ctx.time_only(dom_warm)
     dtimes: list[float] = []  # the dominant kernel's launches inside the timed region
@@ -172,7 +171,7 @@ def main():
             per_launch[dom] = float(np.mean(dtimes))
             launches[dom] = len(dtimes) / args.steps
         # algorithmic bytes per pixel PER LAUNCH (both bands), DESIGN.md section 4
-        alg_bpp = {"dn_hist_u16": 4.0, "clahe_fused_rgb": 7.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0, "lut_compose_u16": 7.0}
+        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0, "lut_compose_u16": 7.0}
         roofline = None
         if dom:
             local_px = rows_local * cols

@@ -97,10 +97,6 @@ typedef struct sarpro_hip_ctx sarpro_hip_ctx;
  * idle for the ~30 us a host round trip per scene costs.  Every other call stays synchronous.  The reference's
  * functions are synchronous: this is an opt-in for callers that keep rasters in HBM. */
 #define SARPRO_HIP_CTX_ASYNC_DEV 2u
-/* Dual-pol CLAHE -> synRGB of a whole scene through the fused pass (csrc/fused_kernels.hip): both DN rasters in, RGB out in
- * one sweep, 11 instead of 15 B/px of HBM traffic per scene, same raster.  Off by default: on MI355X the pass is bound by
- * instruction issue, not by HBM, and a scene takes ~10 % longer than through the apply + compose passes. */
-#define SARPRO_HIP_CTX_FUSED_CLAHE 4u
 int sarpro_hip_ctx_create(int device, unsigned flags, sarpro_hip_ctx **ctx_out);
 void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx);
 const char *sarpro_hip_last_error(const sarpro_hip_ctx *ctx); /* ctx may be NULL: last ctx_create error */
@@ -271,21 +267,22 @@ int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **names_out, fl
  * dozen kernels timed one by one runs ~6 % slower than untimed, timed on its dominant kernel only ~0.5 %. */
 int sarpro_hip_ctx_time_only(sarpro_hip_ctx *ctx, const char *kernel_name);
 
-/* Diagnostics of the last fused CLAHE pass of this context (dual-pol CLAHE -> synRGB of a whole scene takes it: both DN
- * rasters in, RGB out, with a predicted synRGB floor that the pass verifies; csrc/fused_kernels.hip).  Synchronises the
- * context's stream.  spec_ok: the speculative pass ran; verdict 0: its RGB stood, 1: the prediction was refuted and
- * the exact passes ran (also when spec_ok is 0); the raster is the reference's either way. */
+/* Diagnostics of the last speculative CLAHE chain of this context.  A whole dual-pol u8 scene (>= 32 MP) counts its level
+ * histogram on sampled rows only; from the sample the chain PROVES that the u8 rescale of autoscale.rs:348-364 is the
+ * identity (levels 0 and 255 occur) and PREDICTS the suppressed-synRGB floor (synthetic_rgb.rs:99-113), composes with the
+ * prediction, and verifies it exactly inside the compose pass (csrc/chain_kernels.hip, k_chain_predict).  Synchronises the
+ * context's stream.  spec_ok: the proof held and the speculative composition ran; verdict 0: its RGB stood, 1: refuted (or
+ * never ran) and the exact recount + composition ran; the raster is the reference's either way. */
 typedef struct {
-    uint32_t spec_ok, direct, verdict;
-    int32_t floor_pred;
-    uint64_t n_lt[2];      /* band-pixels with level < floor_pred, < floor_pred + 1 (speculative pass) */
-    uint64_t queued[4];    /* uncertain pixels queued per pass (sample, speculative, histogram, final) */
-    uint32_t overflowed[4];/* workgroups whose queue overflowed per pass (their share was redone exactly) */
-    uint64_t dbg[8];       /* builds with -DFUSED_DIAG: origin of the queued pixels (interior / extrapolating cells, ...) */
-    double cum_est[2];     /* the sample's estimate of n_lt[0], n_lt[1] (invalid pixels included) */
-    uint64_t total_px;     /* pixels per band */
-} sarpro_hip_fused_report;
-int sarpro_hip_ctx_fused_report(sarpro_hip_ctx *ctx, sarpro_hip_fused_report *out);
+    uint32_t spec_ok, verdict;
+    int32_t floor_pred;       /* predicted floor before the +3 cushion; 37 stands for "37 or more" (the cushion caps at 40) */
+    uint32_t pad;
+    uint64_t n_lt[2];         /* band-pixels with level < floor_pred, < floor_pred + 1 (exact, counted by the compose pass) */
+    uint64_t target;          /* synthetic_rgb.rs:99-100 */
+    double est_lt[2];         /* the sample's estimate of n_lt */
+    uint64_t sample_valid[2]; /* valid pixels on the sampled rows, per band */
+} sarpro_hip_spec_report;
+int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_report *out);
 
 /* ================= row-stripe (multi-GPU) protocol ================= */
 /* One scene split into row stripes, one per rank.  Each phase

@@ -123,7 +123,7 @@ impl Drop for RasterCore {
 impl RasterCore {
     pub fn new(device: i32) -> Result<Self> { Self::with_flags(device, 0) }
 
-    /// flags: `sys::SARPRO_HIP_CTX_TIMING | SARPRO_HIP_CTX_ASYNC_DEV | SARPRO_HIP_CTX_FUSED_CLAHE`
+    /// flags: `sys::SARPRO_HIP_CTX_TIMING | SARPRO_HIP_CTX_ASYNC_DEV`
     pub fn with_flags(device: i32, flags: c_uint) -> Result<Self> {
         let mut ctx = std::ptr::null_mut();
         let rc = unsafe { sys::sarpro_hip_ctx_create(device as c_int, flags, &mut ctx) };

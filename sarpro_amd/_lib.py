@@ -70,7 +70,7 @@ SYMBOLS = [
     "sarpro_hip_polop_autoscale_band_f32", "sarpro_hip_polop_autoscale_band_u16", "sarpro_hip_polop_autoscale_band_f32_dev", "sarpro_hip_polop_autoscale_band_u16_dev",
     "sarpro_hip_dualpol_synrgb_u16_dev", "sarpro_hip_polop_f32_dev", "sarpro_hip_synrgb_u8_dev",
     "sarpro_hip_last_kernel_times",
-    "sarpro_hip_ctx_time_only", "sarpro_hip_ctx_fused_report",
+    "sarpro_hip_ctx_time_only", "sarpro_hip_ctx_spec_report",
     "sarpro_hip_stripe_begin_u16", "sarpro_hip_stripe_phase1", "sarpro_hip_stripe_phase2",
     "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end", "sarpro_hip_stripe_run_u16",
     "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_dualpol_synrgb_resized_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
@@ -161,12 +161,12 @@ _proto("sarpro_hip_last_kernel_times", _i, _vp, C.POINTER(C.c_char_p), C.POINTER
 _proto("sarpro_hip_ctx_time_only", _i, _vp, C.c_char_p)
 
 
-class FusedReport(C.Structure):
-    _fields_ = [("spec_ok", C.c_uint32), ("direct", C.c_uint32), ("verdict", C.c_uint32), ("floor_pred", C.c_int32),
-                ("n_lt", C.c_uint64 * 2), ("queued", C.c_uint64 * 4), ("overflowed", C.c_uint32 * 4), ("dbg", C.c_uint64 * 8), ("cum_est", C.c_double * 2), ("total_px", C.c_uint64)]
+class SpecReport(C.Structure):
+    _fields_ = [("spec_ok", C.c_uint32), ("verdict", C.c_uint32), ("floor_pred", C.c_int32), ("pad", C.c_uint32),
+                ("n_lt", C.c_uint64 * 2), ("target", C.c_uint64), ("est_lt", C.c_double * 2), ("sample_valid", C.c_uint64 * 2)]
 
 
-_proto("sarpro_hip_ctx_fused_report", _i, _vp, C.POINTER(FusedReport))
+_proto("sarpro_hip_ctx_spec_report", _i, _vp, C.POINTER(SpecReport))
 _proto("sarpro_hip_stripe_begin_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, C.POINTER(_vp))
 _proto("sarpro_hip_stripe_phase1", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
 _proto("sarpro_hip_stripe_phase2", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))

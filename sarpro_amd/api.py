@@ -45,11 +45,10 @@ def _vp(a):
 class Context:
     """One sarpro_hip_ctx: a device, a stream, a grow-only workspace.  One per host thread."""
 
-    def __init__(self, device: int = 0, timing: bool = False, async_dev: bool = False, fused_clahe: bool = False):
+    def __init__(self, device: int = 0, timing: bool = False, async_dev: bool = False):
         h = C.c_void_p()
         # async_dev: SARPRO_HIP_CTX_ASYNC_DEV -- dev_dualpol_synrgb_u16 returns once enqueued; call synchronize()
-        # fused_clahe: SARPRO_HIP_CTX_FUSED_CLAHE -- dual-pol CLAHE -> synRGB through the one-sweep fused pass (same raster)
-        rc = lib.sarpro_hip_ctx_create(device, (1 if timing else 0) | (2 if async_dev else 0) | (4 if fused_clahe else 0), C.byref(h))
+        rc = lib.sarpro_hip_ctx_create(device, (1 if timing else 0) | (2 if async_dev else 0), C.byref(h))
         if rc != _lib.OK:
             raise SarproHipError(rc, (lib.sarpro_hip_last_error(None) or b"").decode())
         self._h = h
@@ -89,13 +88,13 @@ class Context:
         n = lib.sarpro_hip_last_kernel_times(self._h, names, ms, 1024)
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
 
-    def fused_report(self) -> dict:
-        """Diagnostics of the last fused CLAHE pass (sarpro_hip_ctx_fused_report); synchronises the stream."""
-        from ._lib import FusedReport
-        r = FusedReport()
-        self._chk(lib.sarpro_hip_ctx_fused_report(self._h, C.byref(r)))
-        return {"spec_ok": int(r.spec_ok), "direct": int(r.direct), "verdict": int(r.verdict), "floor_pred": int(r.floor_pred),
-                "n_lt": [int(x) for x in r.n_lt], "queued": [int(x) for x in r.queued], "overflowed": [int(x) for x in r.overflowed], "cum_est": [float(x) for x in r.cum_est], "total_px": int(r.total_px)}
+    def spec_report(self) -> dict:
+        """Diagnostics of the last speculative CLAHE chain (sarpro_hip_ctx_spec_report); synchronises the stream."""
+        from ._lib import SpecReport
+        r = SpecReport()
+        self._chk(lib.sarpro_hip_ctx_spec_report(self._h, C.byref(r)))
+        return {"spec_ok": int(r.spec_ok), "verdict": int(r.verdict), "floor_pred": int(r.floor_pred), "n_lt": [int(x) for x in r.n_lt],
+                "target": int(r.target), "est_lt": [float(x) for x in r.est_lt], "sample_valid": [int(x) for x in r.sample_valid]}
 
     def time_only(self, kernel_name=None):
         """Bracket only this kernel with events (None: every kernel); see sarpro_hip_ctx_time_only."""

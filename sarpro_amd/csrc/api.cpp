@@ -156,37 +156,18 @@ extern "C" int sarpro_hip_ctx_time_only(sarpro_hip_ctx *ctx, const char *kernel_
     return SARPRO_HIP_OK;
 }
 
-extern "C" int sarpro_hip_ctx_fused_report(sarpro_hip_ctx *ctx, sarpro_hip_fused_report *out) {
+extern "C" int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_report *out) {
     if (!ctx || !out) return SARPRO_HIP_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
-    if (!ctx->fused_state.p) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no fused CLAHE pass has run on this context");
-    std::vector<unsigned char> buf(sizeof(sarpro::FusedState));
+    if (!ctx->spec_state.p) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no speculative CLAHE chain has run on this context");
+    sarpro::ChainSpecState st;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(buf.data(), ctx->fused_state.p, buf.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const sarpro::FusedState *fs = reinterpret_cast<const sarpro::FusedState *>(buf.data());
-    if (getenv("SARPRO_HIP_FUSED_DIAG_DUMP")) { fprintf(stderr, "[fused diag] queued per workgroup (speculative pass):"); for (int k = 0; k < 256; ++k) fprintf(stderr, " %u", fs->qcount[1][k] & 0x7FFFFFFFu); fprintf(stderr, "\n"); }
-    out->spec_ok = fs->spec_ok; out->direct = fs->direct; out->verdict = fs->verdict; out->floor_pred = fs->floor_pred;
-    out->n_lt[0] = fs->n_lt[0]; out->n_lt[1] = fs->n_lt[1];
-    for (int k = 0; k < 8; ++k) out->dbg[k] = fs->dbg[k];
-    {
-        out->total_px = fs->total_px;
-        double inv = 0.0; // k_fused_predict adds the invalid pixels (level 0 in both bands) to its estimate
-        std::vector<unsigned char> sb(2 * sizeof(sarpro::ChainBandState));
-        if (ctx->chain_state.p && hipMemcpy(sb.data(), ctx->chain_state.p, sb.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-            const sarpro::ChainBandState *st = reinterpret_cast<const sarpro::ChainBandState *>(sb.data());
-            for (int b = 0; b < 2; ++b) inv += (double)out->total_px - (double)st[b].stats.valid_count;
-        }
-        const int f = fs->floor_pred;
-        out->cum_est[0] = (f >= 1 && f <= 31) ? fs->cum_est[f - 1] + inv : 0.0;
-        out->cum_est[1] = (f >= 0 && f <= 30) ? fs->cum_est[f] + inv : 0.0;
-    }
-    if (getenv("SARPRO_HIP_FUSED_DIAG_DUMP")) for (uint32_t k = 0; k < std::min(fs->dbg_n, 64u); ++k) { const uint32_t *o = fs->dbg_samples[k]; { float f[5]; memcpy(f, o + 2, 20); fprintf(stderr, "[fused diag] r %u c %u entry %.6f %.6f %.6f %.6f dy %.6f addr %u\n", o[0], o[1], f[0], f[1], f[2], f[3], f[4], o[7]); } }
-    for (int m = 0; m < 4; ++m)
-        for (int k = 0; k < sarpro::kFusedMaxGrid; ++k) {
-            const uint32_t q = fs->qcount[m][k];
-            if (q & 0x80000000u) out->overflowed[m] += 1; else out->queued[m] += q;
-        }
+    HIPCHK(ctx, hipMemcpy(&st, ctx->spec_state.p, sizeof(st), hipMemcpyDeviceToHost));
+    out->spec_ok = st.spec_ok; out->verdict = st.verdict; out->floor_pred = st.floor_pred;
+    out->n_lt[0] = st.n_lt[0]; out->n_lt[1] = st.n_lt[1]; out->target = st.target;
+    out->est_lt[0] = st.est_lt[0]; out->est_lt[1] = st.est_lt[1];
+    out->sample_valid[0] = st.sample_valid[0]; out->sample_valid[1] = st.sample_valid[1];
     return SARPRO_HIP_OK;
 }
 
@@ -216,11 +197,23 @@ extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **na
 // ---------------------------------------------------------------------------------------
 namespace sarpro {
 
+// Column strips of the vector kernels start on a multiple of this many pixels (read when a plan is built): with 64, the 1-KiB
+// row segment a wave reads (64 lanes x 8 u16) is 128-byte aligned and covers 8 memory lines instead of 9, the 512 bytes of
+// levels it writes cover 4.5 instead of 5.  Cells and tiles start at multiples of tile_w / 2 (1250 px on the headline scene),
+// so with the vector width alone (8) nearly every segment straddled a line at both ends: +13 % of HBM traffic on the apply
+// pass by the PMC counters (profiles/r2_traffic.json).  The leading lanes of a cell's first strip are masked instead.
+static size_t strip_align(int vecw) {
+    if (vecw != 8 && vecw != 4) return (size_t)vecw;
+    size_t a = 64;
+    if (const char *e = getenv("SARPRO_HIP_STRIP_ALIGN")) a = (size_t)std::max(1, atoi(e));
+    return std::max<size_t>(vecw, a / vecw * vecw);
+}
+
 static void push_strips(std::vector<Rect> &out, const StripePlan &P, size_t lo, size_t hi, size_t c0, size_t c1,
                         const int ids[4], size_t chunk_rows, int vecw, int flags = 0) {
     if (lo >= hi || c0 >= c1) return;
-    const size_t strip = 64 * (size_t)vecw;
-    for (size_t cs = c0 / vecw * vecw; cs < c1; cs += strip) {
+    const size_t strip = 64 * (size_t)vecw, align = strip_align(vecw);
+    for (size_t cs = c0 / align * align; cs < c1; cs += strip) {
         Rect r{};
         r.c0 = (int32_t)std::max(c0, cs);
         r.c1 = (int32_t)std::min(c1, cs + strip);
@@ -260,12 +253,12 @@ static int upload_vec(sarpro_hip_ctx *ctx, DevBuf &d, const void *src, size_t by
     return SARPRO_HIP_OK;
 }
 
-// Fused CLAHE pass: the scene as strips of 1, 2, 4, 8 or 16 wave columns (256 px each) inside one interpolation cell,
-// cut into row ranges so that each of the `grid` persistent workgroups gets the same cost (rows x wave columns, the
-// ragged last column included).  Cell-major order: a workgroup's pieces are neighbours, it restages its tables rarely.
-static void build_fused_pieces(StripePlan *P, int grid) {
+// Pieces of a whole scene for persistent workgroups (piece_kernels.hip): strips of 1, 2, 4, 8 or 16 wave columns (256 px each)
+// inside one interpolation cell, cut into row ranges so that each of the `grid` workgroups gets the same cost (rows x wave
+// columns, the ragged last column included).  Cell-major order: a workgroup's pieces are neighbours.
+static void build_pieces(StripePlan *P, int grid) {
     const ClaheGeometry &g = P->geom;
-    struct Strip { FusedItem it; double cost_per_row; };
+    struct Strip { PieceItem it; double cost_per_row; };
     std::vector<Strip> strips;
     double total = 0.0;
     // cells = ranges of constant (t0, t1), cut again where the weight changes sign -- the first half tile extrapolates (d < 0,
@@ -291,11 +284,10 @@ static void build_fused_pieces(StripePlan *P, int grid) {
             if (c0 >= c1) continue;
             const RowWeight &cw = g.col_w[c0];
             const bool neg = rw.d < 0.0 || cw.d < 0.0; // constant sign inside the cut cell
-            const size_t cstart = c0 / 4 * 4;
+            const size_t cstart = c0 / strip_align(4) * strip_align(4);
             size_t nch = (c1 - cstart + 255) / 256, off = 0;
             while (nch > 0) {
                 int lg = 4;
-                if (const char *e = getenv("SARPRO_HIP_FUSED_MAXG")) lg = std::min(4, std::max(0, atoi(e))); // experiment: widest strip = 2^lg wave columns
                 while ((size_t(1) << lg) > nch) --lg;
                 const size_t gw = size_t(1) << lg;
                 Strip st{};
@@ -315,9 +307,9 @@ static void build_fused_pieces(StripePlan *P, int grid) {
             }
         }
     }
-    P->fused_grid = grid;
-    P->fused_items.clear();
-    P->fused_first.assign((size_t)grid + 1, 0);
+    P->piece_grid = grid;
+    P->piece_items.clear();
+    P->piece_first.assign((size_t)grid + 1, 0);
     const double share = total / (double)grid;
     double acc = 0.0;
     int k = 0;
@@ -332,26 +324,16 @@ static void build_fused_pieces(StripePlan *P, int grid) {
                 rows = std::max(gy, (rows + gy - 1) / gy * gy); // whole steps of the 16 waves
                 take = std::min(take, rows);
             }
-            FusedItem it = st.it;
+            PieceItem it = st.it;
             it.r0 = r; it.r1 = r + take;
-            P->fused_items.push_back(it);
-            P->fused_first[(size_t)k + 1] = (int32_t)P->fused_items.size();
+            P->piece_items.push_back(it);
+            P->piece_first[(size_t)k + 1] = (int32_t)P->piece_items.size();
             acc += st.cost_per_row * (double)take;
             r += take;
             if (k < grid - 1 && acc >= share * (double)(k + 1) - 1e-9) ++k;
         }
     }
-    for (int i = 1; i <= grid; ++i) P->fused_first[(size_t)i] = std::max(P->fused_first[(size_t)i], P->fused_first[(size_t)i - 1]);
-    P->fused_qoff.assign((size_t)grid + 1, 0u);
-    for (int w = 0; w < grid; ++w) {
-        double need = 0.0;
-        for (int i = P->fused_first[(size_t)w]; i < P->fused_first[(size_t)w + 1]; ++i) {
-            const FusedItem &it = P->fused_items[(size_t)i];
-            need += (double)(it.r1 - it.r0) * (double)(it.c1 - it.c0) * ((it.flags & 1) ? kFusedQueueRateEdge : kFusedQueueRateInner);
-        }
-        const uint32_t cap = (uint32_t)std::min(need + (double)kFusedQueueMin, 16.0e6);
-        P->fused_qoff[(size_t)w + 1] = P->fused_qoff[(size_t)w] + (cap + 63u) / 64u * 64u;
-    }
+    for (int i = 1; i <= grid; ++i) P->piece_first[(size_t)i] = std::max(P->piece_first[(size_t)i], P->piece_first[(size_t)i - 1]);
 }
 
 int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,
@@ -372,7 +354,8 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     build_clahe_geometry(rows_total, cols, &P->geom);
     const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
     const size_t target_items = 4096;
-    const size_t chunk_rows = std::min<size_t>(256, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 256 rows: taller apply items measured slower (320: +3 %, 625: +10 %, a whole 1250-row cell: +30 % -- the resident workgroups drift apart and lose the sweep's DRAM locality), 96..234 rows all the same
+    size_t chunk_rows = std::min<size_t>(256, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 256 rows: taller apply items measured slower (320: +3 %, 625: +10 %, a whole 1250-row cell: +30 % -- the resident workgroups drift apart and lose the sweep's DRAM locality), 96..234 rows all the same
+    if (const char *e = getenv("SARPRO_HIP_CHUNK_ROWS")) chunk_rows = (size_t)std::max(8, atoi(e)); // experiments
     const ClaheGeometry &g = P->geom;
     const bool split = false; // edge lanes are masked inside the vector kernels; no separate sliver items
     for (size_t ty = 0; ty < (size_t)kTiles; ++ty) {
@@ -430,30 +413,10 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
         sweep_order(P->hist_rects_flat);
         sweep_order(P->apply_rects);
     }
-    if (vecw == 8 && row0 == 0 && rows_local == rows_total && ctx->cu_count > 0) build_fused_pieces(P, std::min(ctx->cu_count, kFusedMaxGrid));
+    if (vecw == 8 && row0 == 0 && rows_local == rows_total && ctx->cu_count > 0) build_pieces(P, std::min(ctx->cu_count, kPieceMaxGrid));
     int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
-    if (!rc) rc = upload_vec(ctx, P->d_fused_items, P->fused_items.data(), P->fused_items.size() * sizeof(FusedItem));
-    if (!rc) rc = upload_vec(ctx, P->d_fused_first, P->fused_first.data(), P->fused_first.size() * sizeof(int32_t));
-    if (!rc) rc = upload_vec(ctx, P->d_fused_qoff, P->fused_qoff.data(), P->fused_qoff.size() * sizeof(uint32_t));
-    if (!rc && P->fused_grid > 0) {
-        // f32 row weights; the last mantissa bit carries the level of a saturated pixel in this row of an extrapolating
-        // cell (fused_kernels.hip header): 1 <=> fl(fl(1 - dy) + dy) >= 1.0 <=> level 255, 0 <=> level 254
-        std::vector<float> wf(g.row_w.size());
-        for (size_t i = 0; i < wf.size(); ++i) {
-            const double dy = g.row_w[i].d;
-            const volatile double t1 = 1.0 - dy;
-            const volatile double o = t1 + dy;
-            uint32_t bits;
-            const float f = (float)dy;
-            memcpy(&bits, &f, 4);
-            bits = (bits & ~1u) | (o >= 1.0 ? 1u : 0u);
-            memcpy(&wf[i], &bits, 4);
-        }
-        rc = upload_vec(ctx, P->d_row_wf, wf.data(), wf.size() * sizeof(float));
-        wf.resize(g.col_w.size());
-        for (size_t i = 0; i < wf.size(); ++i) wf[i] = (float)g.col_w[i].d;
-        if (!rc) rc = upload_vec(ctx, P->d_col_wf, wf.data(), wf.size() * sizeof(float));
-    }
+    if (!rc) rc = upload_vec(ctx, P->d_piece_items, P->piece_items.data(), P->piece_items.size() * sizeof(PieceItem));
+    if (!rc) rc = upload_vec(ctx, P->d_piece_first, P->piece_first.data(), P->piece_first.size() * sizeof(int32_t));
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_tiled, P->hist_sliver_tiled.data(), P->hist_sliver_tiled.size() * sizeof(Rect));
@@ -572,14 +535,14 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     a.rects = (tiled ? J.plan->d_hist_rects_tiled : J.plan->d_hist_rects_flat).as<Rect>() + first;
     a.lds_bins = 8192;
     const int nrects = last - first;
-    if (J.vec && tiled && J.nbands == 2 && J.plan->fused_grid > 0 && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_PIECE_HIST")) {
-        // whole tiled pass, both bands: persistent workgroups on the fused pass's pieces (fused_kernels.hip k_dn_hist_pieces)
+    if (J.vec && tiled && J.nbands == 2 && J.plan->piece_grid > 0 && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_PIECE_HIST")) {
+        // whole tiled pass, both bands: persistent workgroups on balanced pieces (piece_kernels.hip k_dn_hist_pieces)
         DnHistPiecesArgs pa{};
         for (int b = 0; b < 2; ++b) { pa.in[b] = a.in[b]; pa.tile_hist[b] = a.tile_hist[b]; }
-        pa.pitch = a.pitch; pa.items = J.plan->d_fused_items.as<FusedItem>(); pa.wg_first = J.plan->d_fused_first.as<int32_t>();
+        pa.pitch = a.pitch; pa.items = J.plan->d_piece_items.as<PieceItem>(); pa.wg_first = J.plan->d_piece_first.as<int32_t>();
         pa.lds_bins = a.lds_bins;
         KernelTimer t(ctx, "dn_hist_u16");
-        HIPCHK(ctx, launch_dn_hist_pieces(pa, J.plan->fused_grid, ctx->stream));
+        HIPCHK(ctx, launch_dn_hist_pieces(pa, J.plan->piece_grid, ctx->stream));
     } else if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_LINEAR_HIST")) {
         KernelTimer t(ctx, "dn_hist_u16"); // whole untiled pass in one go: the in-order sweep
         HIPCHK(ctx, launch_dn_hist_u16_linear(a, (uint32_t)J.rows_local, (uint32_t)J.cols, J.nbands, ctx->stream));
@@ -986,117 +949,16 @@ static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_
     return SARPRO_HIP_OK;
 }
 
-// The fused CLAHE pass (fused_kernels.hip) after the CDFs: sample -> predicted floor and tables -> speculative pass
-// (DN, DN -> RGB, counts that prove the prediction) -> fixup of the queued pixels + verification; then, gated on the
-// device by the verdict, the exact passes: level histograms -> k_chain_finish -> final pass.  Nothing here synchronises.
-static uint32_t fused_force_flags() {
-    const char *e = getenv("SARPRO_HIP_FUSED_FORCE");
-    if (!e) return 0u;
+// Scenes below this size keep the exact partial histogram: their chain is launch-bound, the gated kernels would cost more than
+// the sampled histogram saves.  SARPRO_HIP_SAMPLED_HIST_MIN_PX overrides (the tests run the speculative chain on small rasters).
+constexpr size_t kSampledHistMinPx = 32u << 20;
+static uint32_t spec_force_flags() { // SARPRO_HIP_SPEC_FORCE=mispredict,nospec: every rare branch of the speculative chain is testable
+    const char *e = getenv("SARPRO_HIP_SPEC_FORCE");
     uint32_t f = 0;
-    if (strstr(e, "nospec")) f |= kFusedForceNoSpec;
-    if (strstr(e, "mispredict")) f |= kFusedForceMispredict;
-    if (strstr(e, "twolevel")) f |= kFusedForceTwoLevel;
-    if (strstr(e, "tinyqueue")) f |= kFusedForceTinyQueue;
+    if (!e) return f;
+    if (strstr(e, "mispredict")) f |= kSpecForceMispredict;
+    if (strstr(e, "nospec")) f |= kSpecForceNoSpec;
     return f;
-}
-
-static int job_run_fused(U16Job &J, uint8_t *d_rgb, size_t rgb_pitch_px) {
-    sarpro_hip_ctx *ctx = J.ctx;
-    const bool dbg = getenv("SARPRO_HIP_FUSED_DEBUG_SYNC") != nullptr; // diagnostics: synchronise and report after every launch
-#define FUSED_DBG(what) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[fused] %s: %s\n", what, hipGetErrorString(e_)); } } while (0)
-    StripePlan *P = J.plan;
-    const int grid = P->fused_grid;
-    if (!ctx->fused_ready) { HIPCHK(ctx, fused_configure()); ctx->fused_ready = true; }
-    HIPCHK(ctx, ctx->fused_state.reserve(sizeof(FusedState)));
-    HIPCHK(ctx, ctx->fused_queue.reserve(sizeof(uint4) * std::max<size_t>(P->fused_qoff.back(), 64)));
-    if (!ctx->fused_hist3.p) { // zeroed once: its last reader (k_fused_predict) leaves it zeroed
-        HIPCHK(ctx, ctx->fused_hist3.reserve(sizeof(uint32_t) * kFusedHist3Words));
-        HIPCHK(ctx, hipMemsetAsync(ctx->fused_hist3.p, 0, sizeof(uint32_t) * kFusedHist3Words, ctx->stream));
-    }
-    HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
-    uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
-    ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
-    const unsigned long long total_px = (unsigned long long)J.rows_total * J.cols;
-    const uint32_t force = fused_force_flags();
-    FusedArgs a{};
-    for (int b = 0; b < 2; ++b) {
-        a.in[b] = J.d_in[b];
-        a.cdfs[b] = ctx->cdfs.as<double>() + (size_t)b * 64 * 256;
-        a.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
-    }
-    a.in_pitch = J.in_pitch;
-    a.rgb = d_rgb; a.rgb_pitch_px = rgb_pitch_px;
-    a.items = P->d_fused_items.as<FusedItem>();
-    a.wg_first = P->d_fused_first.as<int32_t>();
-    a.state = d_state;
-    a.row_w = P->d_row_w.as<RowWeight>(); a.col_w = P->d_col_w.as<RowWeight>();
-    a.row_wf = P->d_row_wf.as<float>(); a.col_wf = P->d_col_wf.as<float>();
-    a.row_off = (int32_t)J.row0;
-    a.fs = ctx->fused_state.as<FusedState>();
-    a.tables = ctx->tables.as<uint8_t>();
-    a.queue = ctx->fused_queue.as<uint4>();
-    a.qoff = P->d_fused_qoff.as<uint32_t>();
-    a.hist3 = ctx->fused_hist3.as<uint32_t>();
-    a.dump = ctx->spec_dump.as<uint8_t>();
-    a.level_hist = ctx->level_hist.as<unsigned long long>();
-    // sample pass: every 32nd step of a full-size scene, denser on small rasters (a step is 1..16 rows)
-    a.sample_stride = (uint32_t)std::min<size_t>(32, std::max<size_t>(1, J.rows_total / 600));
-    if (const char *e = getenv("SARPRO_HIP_FUSED_SAMPLE")) a.sample_stride = (uint32_t)std::max(1, atoi(e));
-    a.force = force;
-    {
-        KernelTimer t(ctx, "fused_prep");
-        FusedPrepArgs pa{};
-        pa.fs = a.fs; pa.state = d_state; pa.tile_bins = ctx->tile_bins.as<unsigned long long>(); pa.cdfs = ctx->cdfs.as<double>();
-        pa.total_px = total_px; pa.force = force;
-        HIPCHK(ctx, launch_fused_prep(pa, ctx->stream)); FUSED_DBG("launch_fused_prep(pa, ctx->stream)");
-    }
-    {
-        KernelTimer t(ctx, "fused_sample");
-        HIPCHK(ctx, launch_fused_main(a, kFusedSample, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedSample, grid, ctx->stream)");
-    }
-    {
-        KernelTimer t(ctx, "fused_predict");
-        FusedPredictArgs pa{};
-        pa.fs = a.fs; pa.state = d_state; pa.tile_bins = ctx->tile_bins.as<unsigned long long>(); pa.hist3 = a.hist3; pa.total_px = total_px; pa.force = force;
-        HIPCHK(ctx, launch_fused_predict(pa, ctx->stream)); FUSED_DBG("launch_fused_predict");
-    }
-    {
-        KernelTimer t(ctx, "fused_tables");
-        FusedTablesArgs ta{};
-        ta.fs = a.fs; ta.tables = ctx->tables.as<uint8_t>(); ta.supp_rg = consts + kChainOffSupp; ta.blue_pair_supp = consts + kChainOffBlue;
-        ta.force = force;
-        HIPCHK(ctx, launch_fused_tables_predict(ta, ctx->stream)); FUSED_DBG("launch_fused_tables_predict(ta, ctx->stream)");
-    }
-    {
-        KernelTimer t(ctx, "clahe_fused_rgb");
-        HIPCHK(ctx, launch_fused_main(a, kFusedSpec, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedSpec, grid, ctx->stream)");
-    }
-    {
-        KernelTimer t(ctx, "fused_fixup");
-        HIPCHK(ctx, launch_fused_fixup(a, kFusedSpec, grid, total_px, ctx->stream)); FUSED_DBG("launch_fused_fixup(a, kFusedSpec, grid, total_px, ctx->stream)");
-    }
-    {   // exact passes: skipped on the device unless the preconditions failed or the prediction was refuted
-        KernelTimer t(ctx, "fused_exact_passes");
-        HIPCHK(ctx, launch_fused_main(a, kFusedHist, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedHist, grid, ctx->stream)");
-        HIPCHK(ctx, launch_fused_fixup(a, kFusedHist, grid, total_px, ctx->stream)); FUSED_DBG("launch_fused_fixup(a, kFusedHist, grid, total_px, ctx->stream)");
-        ChainFinishArgs fa{};
-        fa.level_hist = ctx->level_hist.as<unsigned long long>();
-        fa.total_px = total_px;
-        fa.nbands = 2;
-        fa.resc_out = state + kStateOffResc;
-        fa.identity_out = state + kStateOffIdent;
-        fa.tables = ctx->tables.as<uint8_t>();
-        fa.supp_rg = consts + kChainOffSupp;
-        fa.blue_pair_supp = consts + kChainOffBlue;
-        fa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
-        fa.suppressed = 1;
-        fa.gate = a.fs;
-        HIPCHK(ctx, launch_chain_finish(fa, ctx->stream)); FUSED_DBG("launch_chain_finish(fa, ctx->stream)");
-        HIPCHK(ctx, launch_fused_main(a, kFusedFinal, grid, ctx->stream)); FUSED_DBG("launch_fused_main(a, kFusedFinal, grid, ctx->stream)");
-        HIPCHK(ctx, launch_fused_fixup(a, kFusedFinal, grid, total_px, ctx->stream)); FUSED_DBG("launch_fused_fixup(a, kFusedFinal, grid, total_px, ctx->stream)");
-    }
-#undef FUSED_DBG
-    return SARPRO_HIP_OK;
 }
 
 static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
@@ -1107,11 +969,29 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
     HIPCHK(ctx, ctx->tile_bins.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands));
     HIPCHK(ctx, ctx->cdfs.reserve(sizeof(double) * 64 * 256 * kMaxBands));
-    HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
+    HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands * 2)); // [0, 2): the apply pass's histogram; [2, 4): the gated recount
     HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
     HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
     uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
     ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
+    // Dual-pol u8 scene on one device: the level histogram is counted on sampled rows only and the composition is speculative
+    // (k_chain_predict); SARPRO_HIP_NO_SAMPLED_HIST=1 keeps the partial histogram of every row and the unconditional tail.
+    const bool exact_only = getenv("SARPRO_HIP_NO_SPEC") != nullptr; // cross-check: every pixel through the exact f64 blend
+    const size_t rgb_pitch_ok = rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb);
+    bool sampled = J.synrgb && J.nbands == 2 && J.u8_out() && !J.reduce && !exact_only && !getenv("SARPRO_HIP_FULL_LEVEL_HIST") &&
+                   !getenv("SARPRO_HIP_NO_SAMPLED_HIST") && d_rgb && rgb_pitch_ok && J.row0 == 0 && J.rows_local == J.rows_total;
+    uint32_t sample_stride = 9;
+    if (sampled) {
+        size_t min_px = kSampledHistMinPx;
+        if (const char *e = getenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX")) min_px = (size_t)strtoull(e, nullptr, 10);
+        if (const char *e = getenv("SARPRO_HIP_SAMPLE_STRIDE")) sample_stride = (uint32_t)std::max(5, atoi(e));
+        if ((size_t)J.rows_total * J.cols < min_px) sampled = false;
+    }
+    ChainSpecState *d_spec = nullptr;
+    if (sampled) {
+        HIPCHK(ctx, ctx->spec_state.reserve(sizeof(ChainSpecState)));
+        d_spec = ctx->spec_state.as<ChainSpecState>();
+    }
 
     RETCHK(job_phase1(J)); // per-tile DN histograms -> ctx->ghist
     RETCHK(chain_reduce(J, ctx->ghist.p, 65536 * (size_t)J.nbands, "allreduce_dn_hist"));
@@ -1123,6 +1003,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         sa.binlut = ctx->luts.as<uint8_t>();
         sa.binlut_stride = 131072;
         sa.level_hist = ctx->level_hist.as<unsigned long long>(); // cleared here for the apply kernel (one fill kernel less)
+        sa.sample_valid = d_spec ? d_spec->sample_valid : nullptr;
         KernelTimer t(ctx, "chain_stats");
         RETCHK(chain_stats_scratch(ctx, &sa));
         HIPCHK(ctx, launch_chain_stats(sa, J.nbands, ctx->stream));
@@ -1144,15 +1025,6 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         KernelTimer t(ctx, "chain_cdfs");
         HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
                                       J.nbands, ctx->stream));
-    }
-    // dual-pol RGB of a whole scene, opt-in (SARPRO_HIP_CTX_FUSED_CLAHE / SARPRO_HIP_FUSED_CLAHE=1): the fused pass, 7 B/px and no
-    // level rasters.  Measured on MI355X it is instruction-issue bound and ~10 % SLOWER per scene than the apply + compose passes
-    // below, which therefore stay the default; it moves 11 instead of 15 B/px over HBM.
-    if (J.synrgb && J.nbands == 2 && !J.reduce && !d_out[0] && !d_out[1] && d_rgb && rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb) &&
-        J.plan->fused_grid > 0 && ((ctx->flags & SARPRO_HIP_CTX_FUSED_CLAHE) || getenv("SARPRO_HIP_FUSED_CLAHE")) && !getenv("SARPRO_HIP_NO_SPEC") &&
-        !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) {
-        RETCHK(job_run_fused(J, d_rgb, rgb_pitch_px));
-        return chain_tail(J, stats_out, d_state);
     }
     // apply: levels into the internal rasters (dual-pol) or straight into the caller's raster (single band)
     const bool direct = !J.synrgb;
@@ -1198,8 +1070,12 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     // (the level histogram was cleared by the statistics kernels)
     // whole scene on this device: levels >= 64 are only counted in bulk (chain_kernels.hip k_level_hist_guard); a row
     // stripe keeps the full histogram, which is what the ranks sum
-    const bool exact_only = getenv("SARPRO_HIP_NO_SPEC") != nullptr; // cross-check: every pixel through the exact f64 blend
-    a.partial_hist = (!J.reduce && !exact_only && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;
+    a.hist_mode = sampled ? 2u : (!J.reduce && !exact_only && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;
+    if (sampled) {
+        a.sample_stride = sample_stride;
+        a.sample_phase = sample_stride / 2; // mid-phase: the row weights of the sampled rows average to those of all rows
+        a.sample_valid = d_spec->sample_valid;
+    }
     if (exact_only) {
         KernelTimer t(ctx, "clahe_apply_u16");
         HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, true, false, ctx->stream));
@@ -1209,7 +1085,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         KernelTimer t(ctx, "clahe_apply_u8_spec");
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), J.nbands, ctx->stream));
     }
-    if (a.partial_hist) {
+    if (a.hist_mode == 1) {
         KernelTimer t(ctx, "level_hist_guard");
         HIPCHK(ctx, ctx->hist_flags.reserve(sizeof(uint32_t) * kMaxBands));
         HIPCHK(ctx, launch_level_hist_guard(ctx->level_hist.as<unsigned long long>(), (unsigned long long)J.rows_total * J.cols, J.nbands,
@@ -1221,9 +1097,52 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         HIPCHK(ctx, launch_level_hist_if_flagged(ra, J.nbands, ctx->stream));
     }
     RETCHK(chain_reduce(J, ctx->level_hist.p, 256 * kMaxBands, "allreduce_level_hist"));
+    ComposeArgs c{};
+    int cvec = 1;
+    if (J.synrgb) {
+        c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch;
+        c.rgb = d_rgb; c.rgb_pitch_px = rgb_pitch_px; c.rows = rows; c.cols = cols;
+        c.tables = ctx->tables.as<uint8_t>();
+        cvec = (c.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(c.b1) && ptr_aligned16(c.b2) && ptr_aligned16(d_rgb)) ? 16 : 1;
+    }
+    unsigned long long *final_hist = ctx->level_hist.as<unsigned long long>();
+    if (sampled) { // identity proof + predicted floor + tables -> speculative composition (counts and verdict) -> gated exact recount
+        if (cvec != 16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "sampled level histogram without the vector compose pass");
+        ChainPredictArgs pa{};
+        pa.sample_hist = ctx->level_hist.as<unsigned long long>();
+        pa.exact_hist = final_hist = ctx->level_hist.as<unsigned long long>() + 256 * kMaxBands;
+        pa.spec = d_spec;
+        pa.state = d_state;
+        pa.total_px = (unsigned long long)J.rows_total * J.cols;
+        pa.resc_out = state + kStateOffResc;
+        pa.identity_out = state + kStateOffIdent;
+        pa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        pa.tables = ctx->tables.as<uint8_t>();
+        pa.supp_rg = consts + kChainOffSupp;
+        pa.blue_pair_supp = consts + kChainOffBlue;
+        pa.force = spec_force_flags();
+        {
+            KernelTimer t(ctx, "chain_predict");
+            HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
+        }
+        c.spec = d_spec;
+        c.speculative = 1;
+        {
+            KernelTimer t(ctx, "compose_u8");
+            HIPCHK(ctx, launch_compose_u8(c, 16, ctx->stream));
+        }
+        c.speculative = 0; // the composition below is the gated fallback
+        KernelTimer t(ctx, "spec_fallback_recount");
+        LevelRecountArgs ra{};
+        for (int b = 0; b < J.nbands; ++b) ra.levels[b] = reinterpret_cast<const uint8_t *>(a.out[b]);
+        ra.pitch = a.out_pitch; ra.rows = (uint32_t)J.rows_local; ra.cols = cols;
+        ra.level_hist = final_hist; ra.gate = d_spec;
+        HIPCHK(ctx, launch_level_hist_if_flagged(ra, J.nbands, ctx->stream));
+    }
     {
         ChainFinishArgs fa{};
-        fa.level_hist = ctx->level_hist.as<unsigned long long>();
+        fa.level_hist = final_hist;
+        fa.gate = d_spec;
         fa.total_px = (unsigned long long)J.rows_total * J.cols;
         fa.nbands = J.nbands;
         fa.resc_out = state + kStateOffResc;
@@ -1237,13 +1156,8 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         HIPCHK(ctx, launch_chain_finish(fa, ctx->stream));
     }
     if (J.synrgb) {
-        ComposeArgs c{};
-        c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch;
-        c.rgb = d_rgb; c.rgb_pitch_px = rgb_pitch_px; c.rows = rows; c.cols = cols;
-        c.tables = ctx->tables.as<uint8_t>();
-        const int cvec = (c.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(c.b1) && ptr_aligned16(c.b2) && ptr_aligned16(d_rgb)) ? 16 : 1;
         {
-            KernelTimer t(ctx, "compose_u8");
+            KernelTimer t(ctx, sampled ? "spec_fallback_compose" : "compose_u8");
             HIPCHK(ctx, launch_compose_u8(c, cvec, ctx->stream));
         }
         for (int b = 0; b < 2; ++b) // optional per-band u8 rasters: levels through the band's rescale

@@ -4,8 +4,6 @@
 
 namespace sarpro {
 
-struct FusedState; // fused_kernels.h
-
 struct ChainBandState { // lives in device memory, one per band
     sarpro_hip_stats stats;
     uint32_t win_hi;    // first DN whose dB value reached the high clip (the bin table is constant above)
@@ -31,7 +29,8 @@ struct ChainStatsArgs {
     int strategy;
     int tamed_kind[kMaxBands];       // 0 / 1 copol / 2 crosspol (autoscale.rs:721-727)
     unsigned long long total_px;     // pixels per band (level 0 also counts the invalid ones)
-    unsigned long long *level_hist;  // [nbands][256], levels mode only
+    unsigned long long *level_hist;  // [nbands][256]: cleared by kernel A (levels mode: filled by kernel C; CLAHE: by the apply kernel)
+    unsigned long long *sample_valid;// [nbands] or null: cleared by kernel A (CLAHE chain with a sampled level histogram)
     const double *gamma_thr;         // [3][256]: x-thresholds of trunc(pow(x, g) * 255) for g = 0.8, 0.9, 1.1 (host-built)
     ChainStatsPartial *partials;     // scratch [nbands][kChainStatsParts]
     unsigned long long *bins4096;    // scratch [nbands][4096]
@@ -56,7 +55,7 @@ struct ChainFinishArgs {
     size_t dn_table_stride;
     const uint8_t *default_rg;            // [512] default lut_r | lut_g (synthetic_rgb.rs:22-29)
     const uint8_t *blue_pair_default;     // [256][256]
-    const FusedState *gate;               // fused CLAHE chain: run only when its exact passes run (null: always)
+    const ChainSpecState *gate;           // speculative CLAHE chain: run only when the verdict refuted the speculation (null: always)
 };
 
 hipError_t launch_chain_stats(const ChainStatsArgs &a, int nbands, hipStream_t s);
@@ -73,7 +72,23 @@ struct LevelRecountArgs {
     uint32_t rows, cols;
     unsigned long long *level_hist;    // [nbands][256]
     const uint32_t *flags;             // [nbands], written by k_level_hist_guard
+    const ChainSpecState *gate;        // set: flags are ignored, every band is recounted iff gate->verdict != 0
 };
+// CLAHE chain with a sampled level histogram: identity proof + predicted floor + compose tables (k_chain_predict)
+struct ChainPredictArgs {
+    const unsigned long long *sample_hist; // [2][256] partial level histogram of the sampled rows (bin 0 implied)
+    unsigned long long *exact_hist;        // [2][256] cleared here: the gated recount adds into it
+    ChainSpecState *spec;
+    const ChainBandState *state;           // stats.valid_count per band
+    unsigned long long total_px;           // pixels per band
+    uint8_t *resc_out, *identity_out;      // [2][256] identity maps, [2] ones (they stand iff the verdict accepts)
+    int *floor_out;
+    uint8_t *tables;                       // compose tables R2|G2|B2
+    const uint8_t *supp_rg;                // [41][512]
+    const uint8_t *blue_pair_supp;         // [256][256]
+    uint32_t force;                        // kSpecForce*
+};
+hipError_t launch_chain_predict(const ChainPredictArgs &a, hipStream_t s);
 hipError_t launch_level_hist_if_flagged(const LevelRecountArgs &a, int nbands, hipStream_t s);
 // dst = map[src] unless skip_flag && *skip_flag (device byte) is non-zero and src == dst
 hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, uint32_t rows,

@@ -9,7 +9,6 @@
 // tables of the suppressed synRGB LUTs (one per possible floor) and the blue pair tables are
 // constant tables built once on the host with glibc and uploaded at context creation.
 #include "chain_kernels.h"
-#include "fused_kernels.h"
 
 #include <cfloat>
 
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_a(ChainStatsArgs a) 
     if (part == 0) { // scratch of the next two kernels
         for (int i = t; i < kStatBins; i += kPartBlock) a.bins4096[(size_t)band * kStatBins + i] = 0ull;
         if (a.level_hist) a.level_hist[(size_t)band * 256 + t] = 0ull; // levels mode: filled by kernel C; CLAHE: by the apply kernel
-        if (t == 0) { a.state[band].win_hi = 65535u; a.state[band].uncertain = 0u; }
+        if (t == 0) { a.state[band].win_hi = 65535u; a.state[band].uncertain = 0u; if (a.sample_valid) a.sample_valid[band] = 0ull; }
     }
     unsigned long long cnt = 0;
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
@@ -464,7 +463,7 @@ __global__ __launch_bounds__(256) void k_chain_cdfs(const unsigned long long *__
 // (tiny) maps and builds its slice of the 65536-entry blue table; block 0 also publishes the maps.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a) {
-    if (a.gate && a.gate->spec_ok != 0 && a.gate->verdict == 0) return; // the speculative fused pass already wrote the final RGB
+    if (a.gate && a.gate->verdict == 0) return; // the speculative composition stands (k_chain_predict): nothing to finish
     __shared__ unsigned long long lh[2][256];
     __shared__ uint8_t resc[2][256];
     __shared__ unsigned long long combined[256];
@@ -560,6 +559,95 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Speculation on the two global quantities that stand between the CLAHE blend and the composition (dual-pol u8 scene on one
+// device).  The apply pass counted its level histogram on SAMPLED rows only (kernels.hip, HIST == 2: the per-pixel LDS atomics
+// were 15 % of the dominant kernel), so the histogram is an estimate.  This kernel turns it into
+//   * a PROOF that the u8 rescale of autoscale.rs:348-364 is the identity: a level that occurs in the sample occurs in the
+//     raster; with level 0 (any invalid pixel of the scene, or a sampled valid one) and level 255 present in both bands,
+//     min = 0 and max = 255;
+//   * a PREDICTION F of the suppressed-synRGB floor (synthetic_rgb.rs:99-113): per band the invalid pixels (level 0, their
+//     number is exact: pixels - valid) plus the sampled valid pixels' level counts scaled by valid / sampled valid;
+// and builds the compose tables for (identity, F).  The compose pass then counts the band-pixels below F and F + 1 exactly
+// while it composes and accepts or refutes F (kernels.hip, k_compose_u8<16, true>); refuted, or without the proof, the gated
+// exact kernels run: level recount -> k_chain_finish -> composition.  The raster is the reference's either way; the
+// prediction only decides which kernels produce it.  Every block computes the (tiny) prediction and builds its slice of the
+// blue table; block 0 publishes the state.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs a) {
+    __shared__ double est[2][64];
+    __shared__ int s_ok[2], s_fwc;
+    const int t = threadIdx.x, wb = t >> 6, ln = t & 63;
+    if (wb < 2) {
+        const unsigned long long *sh = a.sample_hist + (size_t)wb * 256;
+        unsigned long long v[4], others = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = sh[ln * 4 + k]; if (ln * 4 + k) others += v[k]; }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) others += __shfl_xor(others, m, 64);
+        const unsigned long long sv = a.spec->sample_valid[wb], valid = a.state[wb].stats.valid_count;
+        const unsigned long long invalid = a.total_px - valid;
+        const bool consistent = sv >= others && sv > 0;
+        const unsigned long long s0v = consistent ? sv - others : 0ull; // sampled valid pixels at level 0
+        const bool has255 = __builtin_amdgcn_ballot_w64(ln == 63 && v[3] != 0ull) != 0ull;
+        const bool has0 = invalid > 0ull || s0v > 0ull;
+        const double scale = consistent ? (double)valid / (double)sv : 0.0;
+        if (ln < 16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int l = ln * 4 + k;
+                est[wb][l] = l ? scale * (double)v[k] : (double)invalid + scale * (double)s0v;
+            }
+        }
+        if (ln == 0) s_ok[wb] = (consistent && has0 && has255) ? 1 : 0;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t total = (uint32_t)(a.total_px + a.total_px);
+        const double tc = round((double)total * 0.05);
+        const uint32_t target = tc >= 4294967295.0 ? 4294967295u : (uint32_t)tc;
+        double cum = 0.0, lt0 = 0.0, lt1 = 0.0;
+        int f = kSpecFloorCap;
+        for (int i = 0; i < kSpecFloorCap; ++i) {
+            cum += est[0][i] + est[1][i];
+            if (cum >= (double)target) { f = i; break; }
+        }
+        bool ok = s_ok[0] && s_ok[1];
+        if (a.force & kSpecForceNoSpec) ok = false;
+        if (a.force & kSpecForceMispredict) f = f < kSpecFloorCap ? f + 1 : kSpecFloorCap - 1;
+        for (int i = 0; i <= f && i < 64; ++i) { if (i < f) lt0 += est[0][i] + est[1][i]; lt1 += est[0][i] + est[1][i]; }
+        s_fwc = f + 3 < 40 ? f + 3 : 40;
+        if (blockIdx.x == 0) {
+            ChainSpecState *sp = a.spec;
+            sp->spec_ok = ok ? 1u : 0u;
+            sp->verdict = 1u; // until the speculative composition has verified the floor
+            sp->floor_pred = f;
+            sp->done = 0u;
+            sp->n_lt[0] = 0ull; sp->n_lt[1] = 0ull;
+            sp->target = target;
+            sp->est_lt[0] = lt0; sp->est_lt[1] = lt1;
+            sp->force = a.force;
+            if (a.floor_out) *a.floor_out = s_fwc; // stands iff the verdict accepts; k_chain_finish rewrites it otherwise
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (t < 512) { a.exact_hist[t] = 0ull; if (a.resc_out) a.resc_out[t] = (uint8_t)(t & 255); }
+        if (t < 2 && a.identity_out) a.identity_out[t] = 1;
+    }
+    __syncthreads();
+    const int fwc = s_fwc;
+    const uint8_t *lut_r = a.supp_rg + (size_t)fwc * 512, *lut_g = lut_r + 256;
+    uint8_t *R2 = a.tables, *G2 = a.tables + 256, *B2 = a.tables + 512;
+    if (blockIdx.x == 0 && t < 256) {
+        R2[t] = t <= fwc ? 0 : lut_r[t];
+        G2[t] = t <= fwc ? 0 : lut_g[t];
+    }
+    for (int i = blockIdx.x * kStatsBlock + t; i < 65536; i += gridDim.x * kStatsBlock) {
+        const int r1 = i >> 8, r2 = i & 255;
+        B2[i] = (r1 <= fwc && r2 <= fwc) ? 0 : a.blue_pair_supp[((size_t)lut_r[r1] << 8) | lut_g[r2]];
+    }
+}
+
 // In-place u8 remap with the map in device memory (per-band u8 outputs of the chain).
 __global__ __launch_bounds__(256) void k_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst,
                                                      size_t dst_pitch, uint32_t rows, uint32_t cols,
@@ -615,7 +703,7 @@ __global__ __launch_bounds__(256) void k_level_hist_guard(unsigned long long *le
 
 __global__ __launch_bounds__(256) void k_level_hist_if_flagged(LevelRecountArgs a) {
     const int band = blockIdx.y;
-    if (!a.flags[band]) return;
+    if (a.gate ? a.gate->verdict == 0 : !a.flags[band]) return;
     const uint8_t *__restrict__ in = a.levels[band];
     const size_t pitch = a.pitch;
     const uint32_t rows = a.rows, cols = a.cols;
@@ -648,6 +736,10 @@ hipError_t launch_chain_cdfs(const unsigned long long *tile_bins, double *cdfs, 
 }
 hipError_t launch_chain_finish(const ChainFinishArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_finish, dim3((a.nbands == 2 && a.tables) || a.levels_mode ? 64 : 1), dim3(kStatsBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_chain_predict(const ChainPredictArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_predict, dim3(64), dim3(kStatsBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, uint32_t rows,

@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "kernels.h"
-#include "fused_kernels.h"
+#include "piece_kernels.h"
 
 namespace sarpro {
 
@@ -61,15 +61,14 @@ struct StripePlan {
     std::vector<Rect> apply_rects, apply_sliver;           // interpolation-cell items
     DevBuf d_hist_rects_tiled, d_hist_rects_flat, d_apply_rects, d_row_w, d_col_w;
     DevBuf d_hist_sliver_tiled, d_hist_sliver_flat, d_apply_sliver;
-    // fused CLAHE pass (whole scene, vecw == 8): every workgroup's pieces, balanced by cost
-    std::vector<FusedItem> fused_items;
-    std::vector<int32_t> fused_first; // [fused_grid + 1]
-    std::vector<uint32_t> fused_qoff; // [fused_grid + 1]: each workgroup's slice of the queue of uncertain pixels
-    int fused_grid = 0;
-    DevBuf d_fused_items, d_fused_first, d_fused_qoff, d_row_wf, d_col_wf; // ... and the blend weights rounded to f32
+    // whole scene, vecw == 8: every persistent workgroup's pieces, balanced by cost (piece_kernels.hip)
+    std::vector<PieceItem> piece_items;
+    std::vector<int32_t> piece_first; // [piece_grid + 1]
+    int piece_grid = 0;
+    DevBuf d_piece_items, d_piece_first;
     int refs = 0; // open stripe handles that hold this plan (the cache never evicts those)
     void release_all() {
-        d_fused_items.release(); d_fused_first.release(); d_fused_qoff.release(); d_row_wf.release(); d_col_wf.release();
+        d_piece_items.release(); d_piece_first.release();
         d_hist_rects_tiled.release(); d_hist_rects_flat.release(); d_apply_rects.release();
         d_hist_sliver_tiled.release(); d_hist_sliver_flat.release(); d_apply_sliver.release();
         d_row_w.release(); d_col_w.release();
@@ -98,9 +97,8 @@ struct sarpro_hip_ctx {
     sarpro::DevBuf spec_dump;                    // kSpecDumpBytes: write-only scratch of the speculative apply kernel
     sarpro::DevBuf hist_flags;                   // u32 [2]: band whose partial level histogram had to be recounted
     sarpro::DevBuf tables;                       // compose tables 66048 B
-    sarpro::DevBuf fused_state, fused_queue, fused_hist3; // fused CLAHE pass: FusedState | per-workgroup queues of uncertain pixels | sample strata
-    int cu_count = 0;                            // compute units of the device (grid of the persistent fused pass)
-    bool fused_ready = false;                    // dynamic-LDS opt-in of the fused kernels done for this device
+    sarpro::DevBuf spec_state;                   // ChainSpecState of the speculative CLAHE chain (chain_kernels.h)
+    int cu_count = 0;                            // compute units of the device (grid of the persistent piece kernels)
     sarpro::DevBuf levels[sarpro::kMaxBands];    // u8 level rasters (intermediate)
     sarpro::DevBuf stage_in[sarpro::kMaxBands];  // host API staging
     sarpro::DevBuf stage_out[3];

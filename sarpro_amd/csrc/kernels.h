@@ -48,7 +48,10 @@ struct ClaheApplyArgs {
     double max_val;                         // 255.0 or 65535.0
     const struct ChainBandState *dev_state;  // chain mode: win_hi is read from device memory (null: use win_hi[])
     uint32_t lut_cap;                       // speculative kernel: LDS capacity of the offset table (entries)
-    uint32_t partial_hist;                  // speculative kernel: levels >= 64 are only counted in bulk (see k_level_hist_guard)
+    uint32_t hist_mode;                     // speculative kernel: 0 full level histogram, 1 levels >= 64 only counted in bulk (see
+                                            // k_level_hist_guard), 2 the bulk form on sampled rows only (see k_chain_predict)
+    uint32_t sample_stride, sample_phase;   // hist_mode 2: row r is sampled iff (row_off + r) % sample_stride == sample_phase; stride > 4
+    unsigned long long *sample_valid;       // hist_mode 2: [nbands] valid (DN != 0) pixels on the sampled rows, added to
     uint8_t *dump;                          // speculative kernel: kSpecDumpBytes of scratch that edge lanes' full-width stores go to
 };
 
@@ -71,7 +74,28 @@ struct ComposeArgs {
     size_t in_pitch, rgb_pitch_px; // elements / pixels
     uint32_t rows, cols;
     const uint8_t *tables;         // R2[256] | G2[256] | B2[65536]
+    struct ChainSpecState *spec;   // CLAHE chain with a predicted floor (chain_kernels.h), else null
+    int speculative;               // 1: the speculative composition (runs iff spec->spec_ok, counts, decides spec->verdict);
+                                   // 0 with spec set: the fallback composition (runs iff spec->verdict != 0)
 };
+
+// State of the CLAHE chain's speculation on the synRGB floor (device memory, one per context).  k_chain_predict writes it
+// after the apply pass, the speculative compose pass adds its counts and the verdict, the gated exact kernels read it.
+constexpr int kSpecFloorCap = 37; // synthetic_rgb.rs:110-113: floor + 3 is capped at 40, so every floor >= 37 is the same floor
+struct ChainSpecState {
+    uint32_t spec_ok;              // both bands hold level 0 and level 255 (=> the u8 rescale is the identity) and a floor was predicted
+    uint32_t verdict;              // 0: the speculative RGB is final; 1: refuted (or never composed): the exact kernels run
+    int32_t floor_pred;            // predicted floor F (before the +3 cushion), kSpecFloorCap = "at least that"
+    uint32_t done;                 // workgroups of the speculative compose pass that have added their counts
+    unsigned long long n_lt[2];    // band-pixels with level < F, < F + 1, counted by the speculative compose pass
+    unsigned long long target;     // synthetic_rgb.rs:99-100
+    unsigned long long sample_valid[2]; // valid pixels on the sampled rows, per band (apply pass)
+    double est_lt[2];              // the sample's estimate of n_lt (diagnostics)
+    uint32_t force;                // test switches (kSpecForce*)
+    uint32_t pad;
+};
+constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it
+constexpr uint32_t kSpecForceNoSpec = 2u;     // "level 0 or 255 missing": no speculative composition at all
 
 constexpr size_t kSpecDumpBytes = 256 * 1024;
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);

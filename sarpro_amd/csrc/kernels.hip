@@ -28,6 +28,11 @@ template <int VEC> struct U16Vec;
 template <> struct U16Vec<8> {
     uint4 v;
     __device__ static U16Vec load(const uint16_t *p) { U16Vec r; r.v = *reinterpret_cast<const uint4 *>(p); return r; }
+    __device__ static U16Vec load_stream(const uint16_t *p) { // read-once data: non-temporal
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+        U16Vec r; r.v = make_uint4(t.x, t.y, t.z, t.w); return r;
+    }
     __device__ uint32_t get(int j) const {
         uint32_t w = j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w));
         return (j & 1) ? (w >> 16) : (w & 0xFFFFu);
@@ -484,8 +489,8 @@ struct SpecLds { // byte offsets into dynamic LDS
     static constexpr uint32_t cdf64 = 0;                      // [257][4] double
     static constexpr uint32_t cdf32 = 257 * 32 + 224;         // kCdfCopies interleaved copies of [257] float4 (256-B aligned)
     static constexpr uint32_t colw = cdf32 + kCdf32Bytes;     // [512] double: exact dx of the strip's columns
-    static constexpr uint32_t hist = colw + 512 * 8;          // [256 + 64] u32
-    static constexpr uint32_t lut = hist + (256 + 64) * 4;    // [lut_cap] u16
+    static constexpr uint32_t hist = colw + 512 * 8;          // [256 + 64 + 4] u32: level bins | per-lane dummy words | [320] valid samples counted
+    static constexpr uint32_t lut = hist + (256 + 64 + 4) * 4; // [lut_cap] u16
 };
 // The row weights stay in global memory: one wave-uniform load per row, prefetched with the row.
 // (1 - dx) and (1 - dy) are recomputed as 1.0 - d: the reference's own expression (autoscale.rs:327-329)
@@ -506,14 +511,37 @@ __device__ __forceinline__ double to_sgpr(double x) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-template <bool LUT_LDS, bool PARTIAL_HIST>
+#ifndef SARPRO_LUT_GLOBAL_N
+#define SARPRO_LUT_GLOBAL_N 0
+#endif
+#if SARPRO_LUT_GLOBAL_N > 0
+__device__ uint16_t g_offlut_dev[2 * 65536]; // experiment: DN -> LDS byte offset of the CDF entry, in global memory
+__global__ void k_build_offlut(const uint8_t *b0, const uint8_t *b1) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * 65536) { const uint32_t d = i & 65535; const uint8_t *b = (i >> 16) ? b1 : b0; g_offlut_dev[i] = (uint16_t)(SpecLds::cdf32 + cdf32_offset(d ? (uint32_t)b[d] : 256u)); }
+}
+#endif
+// HIST: 0 = every level of every pixel counted, 1 = partial (levels < kPartialHistLevels one by one, the rest in bulk), 2 = the
+// partial form on SAMPLED rows only (row % sample_stride == sample_phase): the histogram is then an estimate that the chain
+// uses to PREDICT the synRGB floor, which the compose pass verifies exactly (chain_kernels.hip, k_chain_predict); together
+// with the levels the sampled rows count their valid (DN != 0) pixels, the stratum the estimate is scaled by.
+#ifdef SARPRO_NT_LOAD
+#define SPEC_LOAD(p) U16Vec<VEC>::load_stream(p)
+#else
+#define SPEC_LOAD(p) U16Vec<VEC>::load(p)
+#endif
+template <bool LUT_LDS, int HIST>
 __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const Rect &rc, int band, unsigned char *lds,
                                                 uint32_t win_hi) {
     constexpr int VEC = 8;
     const uint16_t *__restrict__ in = a.in[band];
     const uint8_t *__restrict__ glut = a.binlut[band];
     const RowWeight *__restrict__ row_w = a.row_w + a.row_off;
+#ifdef SARPRO_ABL_NO_HIST // timing ablation: no level histogram at all (the chain's raster is garbage)
+    const bool count_levels = false;
+#else
     const bool count_levels = a.level_hist[band] != nullptr;
+#endif
     const int col = rc.cstart + lane_id() * VEC;
     const bool full = col >= rc.c0 && col + VEC <= rc.c1;
     // edge lanes: samples outside the item are computed like the others (whatever DN the row holds there), then their
@@ -533,9 +561,21 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
     const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner; // pad[0] bit 0: extrapolating cell
     const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
     const uint32_t win_hi2 = win_hi | (win_hi << 16);
+    constexpr bool PARTIAL_HIST = HIST != 0;
     uint32_t lane_max = 0u, lane_high = 0u; // PARTIAL_HIST: this lane's highest level and its count of levels >= kPartialHistLevels
+    uint32_t lane_valid = 0u;               // HIST == 2: this lane's kept samples with DN != 0 on the sampled rows
 
-    auto process_row = [&](int r, const U16Vec<VEC> &v, const double dy_v) { // dy: wave-uniform
+    auto process_row = [&](int r, const U16Vec<VEC> &v, const double dy_v, const bool sampled) { // dy, sampled: wave-uniform
+        // (counted first: the row's samples are then dead after the offset lookups, not held across the blend)
+        if (HIST == 2 && count_levels && sampled) { // valid samples of this row: non-zero halfwords, kept ones only
+            const uint32_t w[4] = {v.v.x, v.v.y, v.v.z, v.v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t nz = (((w[k] & 0x7FFF7FFFu) + 0x7FFF7FFFu) | w[k]) & 0x80008000u; // bit 15 / 31: halfword != 0
+                const uint32_t kb = keep[k >> 1] >> (16 * (k & 1));                               // the two keep bytes of these samples
+                lane_valid += (uint32_t)__builtin_popcount(nz & (((kb & 0x80u) << 8) | ((kb & 0x8000u) << 16)));
+            }
+        }
         const double dy = to_sgpr(dy_v), omdy = to_sgpr(1.0 - dy);
         const float wy1 = to_sgpr((float)omdy * 255.0f), wy2 = to_sgpr((float)dy * 255.0f);
         uint32_t off[VEC];
@@ -552,8 +592,18 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 uint32_t a0, a1;
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(1u), "v"(cw));
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(1u), "v"(cw));
+#if defined(SARPRO_ABL_NOLOOKUP) // timing ablation (garbage raster): no DN -> offset lookup, the gather address straight from the DN bits
+                off[2 * k] = SpecLds::cdf32 + ((a0 << 3) & 0xFF0u);
+                off[2 * k + 1] = SpecLds::cdf32 + ((a1 << 3) & 0xFF0u);
+#elif SARPRO_LUT_GLOBAL_N > 0 // experiment: the first N of a lane's 8 offset lookups through the vector L1 instead of LDS
+                off[2 * k] = (2 * k < SARPRO_LUT_GLOBAL_N) ? (uint32_t)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(g_offlut_dev + band * 65536) + a0)
+                                                          : (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a0);
+                off[2 * k + 1] = (2 * k + 1 < SARPRO_LUT_GLOBAL_N) ? (uint32_t)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(g_offlut_dev + band * 65536) + a1)
+                                                                  : (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a1);
+#else
                 off[2 * k] = (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a0);
                 off[2 * k + 1] = (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a1);
+#endif
             }
         } else {
 #pragma unroll
@@ -562,6 +612,10 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 off[j] = SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u);
             }
         }
+#ifdef SARPRO_ABL_NOCONFLICT // timing ablation (garbage raster): every lane of a 16-lane group gathers from its own 16-B slot class
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) off[j] = SpecLds::cdf32 + (((off[j] - SpecLds::cdf32) & 0xF00u) | (((uint32_t)lane_id() & 15u) << 4));
+#endif
         constexpr int kAhead = 2; // CDF gathers issued ahead of their use (3 in flight; measured: 1 -> 2 -1.4 %, 4 no better)
         v4f cq[VEC];
 #pragma unroll
@@ -581,7 +635,11 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
             pb[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(yb, j & 3, pb[j >> 2]);
         }
         const uint32_t d0 = pk[0] ^ pb[0], d1 = pk[1] ^ pb[1];
+#ifdef SARPRO_ABL_NOEXACT // timing ablation (garbage raster): no exact path
+        if (false) {
+#else
         if (d0 | d1) { // rare: some pixel of this lane lies within the margin of an integer -> exact path
+#endif
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 if (((j < 4 ? d0 : d1) >> (8 * (j & 3))) & 0xFFu) { // reference op order (autoscale.rs:327-329, 602)
@@ -599,7 +657,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         }
         pk[0] &= keep[0];
         pk[1] &= keep[1];
-        if (count_levels) { // level 0 (incl. masked edge samples) is not counted: bin 0 = pixels - others
+        if (count_levels && (HIST != 2 || sampled)) { // level 0 (incl. masked edge samples) is not counted: bin 0 = pixels - others
             // one predicated ds_add_u32 per pixel, EXEC narrowed to the lanes that count (a shared bin 0 would serialise
             // the no-data wedge); written out because the compiler wraps each predicated atomic in a branch
             const uint32_t one = 1u, two = 2u, zero = 0u, lim = kPartialHistLevels;
@@ -647,7 +705,11 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         // Every lane issues the 8-byte store, edge lanes into the scratch line: a store inside a divergent branch sits
         // behind an `execz` skip, the waitcnt pass then sees a path through the row without a store and makes the next
         // row wait for vmcnt(0) -- i.e. for this row's store to be acknowledged -- before it may use its prefetched data.
+#ifdef SARPRO_NT_STORE
+        { typedef uint32_t v2u __attribute__((ext_vector_type(2))); v2u t; t.x = pk[0]; t.y = pk[1]; __builtin_nontemporal_store(t, reinterpret_cast<v2u *>(full ? o8 : dump)); }
+#else
         *reinterpret_cast<uint2 *>(full ? o8 : dump) = make_uint2(pk[0], pk[1]);
+#endif
         if (!full) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
@@ -659,35 +721,66 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         const int step = kWavesPerBlock;
         const uint16_t *p = in + col;
         int r = __builtin_amdgcn_readfirstlane(rc.r0 + wave_id());
+        // HIST == 2: row r is sampled iff (row_off + r) % stride == phase; kept as a scalar residue that advances with r
+        const int stride = (int)a.sample_stride, phase = (int)a.sample_phase;
+        int smod = HIST == 2 ? __builtin_amdgcn_readfirstlane((a.row_off + r) % stride) : 0;
         // the next row is always loaded (clamped to the item's last row: at worst one redundant load), so the
         // load is unconditional and the compiler can wait with vmcnt(1) -- a conditional prefetch made it wait
         // vmcnt(0) right after issuing it, i.e. no overlap at all inside a wave
+#ifdef SARPRO_PREFETCH2 // experiment: two rows in flight behind the one being processed
         if (r < rc.r1) {
-            U16Vec<VEC> cur = U16Vec<VEC>::load(p + (size_t)r * a.in_pitch);
+            const int lastr = rc.r1 - 1;
+            U16Vec<VEC> cur = SPEC_LOAD(p + (size_t)r * a.in_pitch);
+            double dy = row_w[r].d;
+            int r1n = min(r + step, lastr);
+            U16Vec<VEC> n1 = SPEC_LOAD(p + (size_t)r1n * a.in_pitch);
+            double dy1 = row_w[r1n].d;
+            for (; r < rc.r1; r += step) {
+                const int rn = min(r + 2 * step, lastr);
+                const U16Vec<VEC> n2 = SPEC_LOAD(p + (size_t)rn * a.in_pitch);
+                const double dy2 = row_w[rn].d;
+                process_row(r, cur, dy, smod == phase);
+                cur = n1; dy = dy1; n1 = n2; dy1 = dy2;
+                if (HIST == 2) { smod += step; if (smod >= stride) smod -= stride; }
+            }
+        }
+#else
+        if (r < rc.r1) {
+            U16Vec<VEC> cur = SPEC_LOAD(p + (size_t)r * a.in_pitch);
             double dy = row_w[r].d; // exact dy of the row, wave-uniform, prefetched like the row itself
             { // first row peeled: the loop is then entered with the same operations in flight as on its back edge
                 const int rn = min(r + step, rc.r1 - 1);
-                const U16Vec<VEC> nxt = U16Vec<VEC>::load(p + (size_t)rn * a.in_pitch);
+                const U16Vec<VEC> nxt = SPEC_LOAD(p + (size_t)rn * a.in_pitch);
                 const double dyn = row_w[rn].d;
-                process_row(r, cur, dy);
+                process_row(r, cur, dy, smod == phase);
                 cur = nxt;
                 dy = dyn;
                 r += step;
+                if (HIST == 2) { smod += step; if (smod >= stride) smod -= stride; }
             }
             for (; r < rc.r1; r += step) {
                 const int rn = min(r + step, rc.r1 - 1);
-                const U16Vec<VEC> nxt = U16Vec<VEC>::load(p + (size_t)rn * a.in_pitch);
+                const U16Vec<VEC> nxt = SPEC_LOAD(p + (size_t)rn * a.in_pitch);
                 const double dyn = row_w[rn].d;
-                process_row(r, cur, dy);
+                process_row(r, cur, dy, smod == phase);
                 cur = nxt;
                 dy = dyn;
+                if (HIST == 2) { smod += step; if (smod >= stride) smod -= stride; }
             }
         }
+#endif
     }
     if (PARTIAL_HIST && count_levels && lane_high) // lane_high > 0 implies lane_max >= kPartialHistLevels
         atomicAdd(reinterpret_cast<uint32_t *>(lds + SpecLds::hist) + lane_max, lane_high);
+    if (HIST == 2 && count_levels) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) lane_valid += __shfl_xor(lane_valid, m, 64);
+        if (lane_id() == 0 && lane_valid) atomicAdd(reinterpret_cast<uint32_t *>(lds + SpecLds::hist) + 320, lane_valid);
+    }
 }
 
+// one kernel per histogram mode (known on the host): each gets the registers ITS row loop needs, not the maximum of all three
+template <int HIST>
 __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const Rect rc = a.rects[blockIdx.x];
@@ -730,7 +823,7 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             for (uint32_t cc = 0; cc < kCdfCopies; ++cc)
                 *reinterpret_cast<float4 *>(lds + SpecLds::cdf32 + cdf32_offset(256) + cc * 16) = make_float4(kz, kz, 0.0f, 0.0f);
         }
-        for (int i = b; i < 256 + 64; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
+        for (int i = b; i < 256 + 64 + 4; i += kBlock) reinterpret_cast<uint32_t *>(lds + SpecLds::hist)[i] = 0;
         for (int i = b; i < 512; i += kBlock) { // exact column weights of this strip, for the f64 path
             const int c2 = rc.cstart + i;
             *reinterpret_cast<double *>(lds + SpecLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
@@ -740,17 +833,16 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u));
     }
     __syncthreads();
-    if (a.partial_hist) {
-        if (lut_lds) clahe_spec_rows<true, true>(a, rc, band, lds, win_hi);
-        else clahe_spec_rows<false, true>(a, rc, band, lds, win_hi);
-    } else {
-        if (lut_lds) clahe_spec_rows<true, false>(a, rc, band, lds, win_hi);
-        else clahe_spec_rows<false, false>(a, rc, band, lds, win_hi);
-    }
+    if (lut_lds) clahe_spec_rows<true, HIST>(a, rc, band, lds, win_hi);
+    else clahe_spec_rows<false, HIST>(a, rc, band, lds, win_hi);
     if (ghist) {
         __syncthreads();
         const uint32_t n = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[threadIdx.x];
         if (n && threadIdx.x) atomicAdd(&ghist[threadIdx.x], (unsigned long long)n); // bin 0 restored on the host
+        if (HIST == 2 && threadIdx.x == 0) {
+            const uint32_t nv = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[320];
+            if (nv) atomicAdd(&a.sample_valid[band], (unsigned long long)nv);
+        }
     }
 }
 
@@ -822,9 +914,27 @@ constexpr int kComposeBlock = 1024; // 66 KiB of tables per block -> 2 blocks (3
 constexpr int kComposeTableBytes = 512 + 65536;
 constexpr int kComposeStageBytes = (kComposeBlock / kWave) * 3072; // per-wave 3 KiB transpose stage (VEC = 16)
 
-template <int VEC>
+// SPEC (the CLAHE chain's speculative composition, chain_kernels.hip k_chain_predict): the tables were built for a PREDICTED
+// floor F; while composing, the pass counts the band-pixels (both level rasters) with level >= F and >= F + 1, SWAR on the
+// packed level bytes it has loaded anyway -- the pass is HBM-bound, the ~64 VALU operations per 16 pixels are free -- and the
+// workgroup that finishes last turns the counts into the verdict:  cum(F-1) < target <= cum(F)  <=>  F is the floor of
+// synthetic_rgb.rs:99-113.  Gating: SPEC runs iff spec_ok; the plain form with a.spec set runs iff the verdict refuted the
+// speculative RGB (or it never ran).
+__device__ __forceinline__ uint32_t swar_ge_bytes(uint32_t xo, uint32_t xa, uint32_t t4) {
+    // bytes of x that are >= t (t <= 127): xo = x | 0x80808080, xa = x & 0x80808080; no borrow crosses a byte since every byte of xo >= 0x80 >= t
+    return (uint32_t)__builtin_popcount(((xo - t4) & 0x80808080u) | xa);
+}
+
+template <int VEC, bool SPEC>
 __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    if (SPEC) { if (!a.spec->spec_ok) return; }
+    else if (a.spec && a.spec->verdict == 0) return; // fallback composition: the speculative RGB stands
+    uint32_t t4[2] = {0u, 0u}, n_ge[2] = {0u, 0u}, n_px = 0u; // SPEC: thresholds F, F + 1 in every byte; this lane's counts
+    if (SPEC) {
+        const uint32_t f = (uint32_t)a.spec->floor_pred;
+        t4[0] = f * 0x01010101u; t4[1] = (f + 1u) * 0x01010101u;
+    }
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
@@ -858,6 +968,15 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
                 const uint4 q1 = *reinterpret_cast<const uint4 *>(a.b1 + (size_t)r * a.in_pitch + col);
                 const uint4 q2 = *reinterpret_cast<const uint4 *>(a.b2 + (size_t)r * a.in_pitch + col);
                 const uint32_t w1[4] = {q1.x, q1.y, q1.z, q1.w}, w2[4] = {q2.x, q2.y, q2.z, q2.w};
+                if (SPEC) {
+                    n_px += 32u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t xo1 = w1[g] | 0x80808080u, xa1 = w1[g] & 0x80808080u, xo2 = w2[g] | 0x80808080u, xa2 = w2[g] & 0x80808080u;
+                        n_ge[0] += swar_ge_bytes(xo1, xa1, t4[0]) + swar_ge_bytes(xo2, xa2, t4[0]);
+                        n_ge[1] += swar_ge_bytes(xo1, xa1, t4[1]) + swar_ge_bytes(xo2, xa2, t4[1]);
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) { // 4 px -> 12 bytes -> 3 dwords
                     uint32_t px[4][3];
@@ -887,6 +1006,11 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
                 for (uint32_t j = 0; col + j < a.cols; ++j) {
                     const uint32_t v1 = p1[j], v2 = p2[j];
                     po[3 * j + 0] = R2[v1]; po[3 * j + 1] = G2[v2]; po[3 * j + 2] = B2[(v1 << 8) | v2];
+                    if (SPEC) {
+                        n_px += 2u;
+                        n_ge[0] += (v1 >= (t4[0] & 0xFFu)) + (v2 >= (t4[0] & 0xFFu));
+                        n_ge[1] += (v1 >= (t4[1] & 0xFFu)) + (v2 >= (t4[1] & 0xFFu));
+                    }
                 }
             }
         }
@@ -899,6 +1023,33 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
             for (int j = 0; j < VEC && col + j < a.cols; ++j) {
                 const uint32_t v1 = p1[j], v2 = p2[j];
                 po[3 * j + 0] = R2[v1]; po[3 * j + 1] = G2[v2]; po[3 * j + 2] = B2[(v1 << 8) | v2];
+            }
+        }
+    }
+    if (SPEC) { // counts -> workgroup -> device; the workgroup that arrives last decides
+        uint32_t lt0 = n_px - n_ge[0], lt1 = n_px - n_ge[1];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { lt0 += __shfl_xor(lt0, m, 64); lt1 += __shfl_xor(lt1, m, 64); }
+        // scratch in the table area (static __shared__ beside the opted-in 160 KiB of dynamic LDS is refused at launch); the
+        // barrier makes sure no wave still reads the tables
+        uint32_t *s_lt = reinterpret_cast<uint32_t *>(lds_raw);
+        __syncthreads();
+        if (threadIdx.x == 0) { s_lt[0] = 0u; s_lt[1] = 0u; }
+        __syncthreads();
+        if (lane == 0) { atomicAdd(&s_lt[0], lt0); atomicAdd(&s_lt[1], lt1); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ChainSpecState *sp = a.spec;
+            atomicAdd(&sp->n_lt[0], (unsigned long long)s_lt[0]);
+            atomicAdd(&sp->n_lt[1], (unsigned long long)s_lt[1]);
+            __threadfence();
+            if (atomicAdd(&sp->done, 1u) == gridDim.x - 1u) {
+                __threadfence();
+                const unsigned long long c0 = atomicAdd(&sp->n_lt[0], 0ull), c1 = atomicAdd(&sp->n_lt[1], 0ull), target = sp->target;
+                // floor_pred < kSpecFloorCap: F is the floor iff cum(F-1) < target <= cum(F); == kSpecFloorCap stands for "at least
+                // that" (the +3 cushion is capped at 40 either way): true iff cum(kSpecFloorCap - 1) < target
+                const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
+                sp->verdict = ok ? 0u : 1u;
             }
         }
     }
@@ -1173,7 +1324,12 @@ hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, 
 #define SARPRO_LDS_PAD 0
 #endif
     const size_t lds = SpecLds::lut + (((size_t)a.lut_cap) * 2 + 15 & ~(size_t)15) + SARPRO_LDS_PAD;
-    hipLaunchKernelGGL(k_clahe_apply_u8_spec, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+#if SARPRO_LUT_GLOBAL_N > 0
+    hipLaunchKernelGGL(k_build_offlut, dim3(512), dim3(256), 0, s, a.binlut[0], a.binlut[nbands > 1 ? 1 : 0]);
+#endif
+    if (a.hist_mode == 2) hipLaunchKernelGGL(k_clahe_apply_u8_spec<2>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+    else if (a.hist_mode == 1) hipLaunchKernelGGL(k_clahe_apply_u8_spec<1>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+    else hipLaunchKernelGGL(k_clahe_apply_u8_spec<0>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1225,11 +1381,15 @@ hipError_t opt_in_dynamic_lds(const void *kernel) {
 
 hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s) {
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
-    if (hipError_t e = opt_in_dynamic_lds(vec == 16 ? reinterpret_cast<const void *>(k_compose_u8<16>) : reinterpret_cast<const void *>(k_compose_u8<1>))) return e; // ~115 KiB
+    if (a.speculative && (vec != 16 || !a.spec)) return hipErrorInvalidValue;
+    const void *fn = a.speculative ? reinterpret_cast<const void *>(k_compose_u8<16, true>)
+                     : vec == 16   ? reinterpret_cast<const void *>(k_compose_u8<16, false>) : reinterpret_cast<const void *>(k_compose_u8<1, false>);
+    if (hipError_t e = opt_in_dynamic_lds(fn)) return e; // ~115 KiB
     const uint64_t items = (uint64_t)a.rows * ((a.cols + vec - 1) / vec);
     dim3 grid(stream_grid(items, kComposeBlock, 2));
-    if (vec == 16) hipLaunchKernelGGL(k_compose_u8<16>, grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
-    else hipLaunchKernelGGL(k_compose_u8<1>, grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
+    if (a.speculative) hipLaunchKernelGGL((k_compose_u8<16, true>), grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
+    else if (vec == 16) hipLaunchKernelGGL((k_compose_u8<16, false>), grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
+    else hipLaunchKernelGGL((k_compose_u8<1, false>), grid, dim3(kComposeBlock), kComposeTableBytes + kComposeStageBytes, s, a);
     return hipGetLastError();
 }
 

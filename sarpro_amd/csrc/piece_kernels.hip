@@ -1,0 +1,119 @@
+// piece_kernels.hip -- per-tile DN histograms of a whole dual-pol scene on gfx950, walked as cost-balanced "pieces" by
+// persistent 1024-thread workgroups (the first pass of the CLAHE chain: autoscale.rs:259-268 needs the per-tile counts,
+// autoscale.rs:35-160 their sum).  Round 2's one-sweep CLAHE -> RGB pass lived on the same traversal; it measured slower
+// than apply + compose (DESIGN.md section 6b keeps the numbers) and was removed in round 3.
+#include "piece_kernels.h"
+
+namespace sarpro {
+
+namespace {
+
+constexpr int kPBlock = 1024, kPWaves = 16;
+// LDS atomics through the address-space-3 pointer (the HIP overloads take generic pointers)
+#define LDS_ADD(off, v) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)(off)), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+__device__ __forceinline__ int p_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int p_lane() { return (int)(threadIdx.x & 63); }
+
+// ------------------------------------------------------------------------------------
+// The per-tile DN histograms of BOTH bands over balanced pieces of the scene: persistent workgroups of 1024 threads, each on its
+// static share of the scene (strips of 2^k wave columns x row ranges inside one tile), reading the two rasters at the rate the
+// piece traversal streams them (tools/stream_bench.hip: 5.6-6.2 TB/s against 4.6 for the 256-thread strip items of
+// kernels.hip 1b).  Counting as there: one unconditional ds_add_u32 per pixel -- DN in [1, W) to its bin, DN = 0 and the
+// bright tail to a per-lane dummy word, tail pixels to the tile's global histogram -- and DN = 0 is not accumulated at all
+// (bin 0 is what is left of the tile, restored by the consumer).  The LDS histograms are published when the tile changes.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(lds); // band b: [b * (W + 64), + W) bins, then 64 dummy words
+    const uint32_t W = a.lds_bins, S = W + 64u;
+    const int first = a.wg_first[blockIdx.x], last = a.wg_first[blockIdx.x + 1];
+    if (first >= last) return;
+    for (uint32_t i = threadIdx.x; i < 2u * S; i += kPBlock) h[i] = 0u;
+    __syncthreads();
+    const int wave = p_wave(), lane = p_lane();
+    const uint32_t dummy[2] = {(W + (uint32_t)lane) * 4u, (S + W + (uint32_t)lane) * 4u};
+    int cur_tile = -1;
+    auto publish = [&]() { // all threads, between barriers
+        if (cur_tile < 0) return;
+        for (int b = 0; b < 2; ++b) {
+            uint32_t *g = a.tile_hist[b] + (size_t)cur_tile * 65536u;
+            for (uint32_t i = threadIdx.x + 1; i < W; i += kPBlock) {
+                const uint32_t n = h[b * S + i];
+                if (n) { atomicAdd(&g[i], n); h[b * S + i] = 0u; }
+            }
+        }
+    };
+    for (int it = first; it < last; ++it) {
+        const PieceItem I = a.items[it];
+        if (I.tile != cur_tile) {
+            __syncthreads();
+            publish();
+            cur_tile = I.tile;
+            __syncthreads();
+        }
+        const int gx = 1 << I.gx_log2, gy = kPWaves >> I.gx_log2;
+        const int wx = wave & (gx - 1), wy = wave >> I.gx_log2;
+        const int col = I.cstart + (wx * 64 + lane) * 4;
+        if (col >= I.c1 || col + 4 <= I.c0) continue;
+        // samples outside the piece's columns become DN = 0 (never counted)
+        uint32_t m[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (col + j >= I.c0 && col + j < I.c1) m[j >> 1] |= 0xFFFFu << (16 * (j & 1));
+        uint32_t *const gt[2] = {a.tile_hist[0] + (size_t)I.tile * 65536u, a.tile_hist[1] + (size_t)I.tile * 65536u};
+        auto consume = [&](int b, uint2 w) {
+            const uint32_t ww[2] = {w.x & m[0], w.y & m[1]};
+            uint32_t big = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t d = (j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu);
+                const bool in_lds = d - 1u < W - 1u; // 1 <= d < W
+                big |= (d >= W ? 1u : 0u) << j;
+                const uint32_t off = in_lds ? (b ? S * 4u : 0u) + d * 4u : dummy[b];
+#ifdef PIECE_HIST_NO_ATOMICS // timing experiment: the traversal and the address arithmetic without the LDS atomics
+                big += off;
+#else
+                LDS_ADD(off, 1u);
+#endif
+            }
+#ifdef PIECE_HIST_NO_ATOMICS
+            if (big == 0xFFFFFFFFu) atomicAdd(&gt[b][0], 1u);
+#else
+            if (big) { // bright tail: rare
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((big >> j) & 1u) atomicAdd(&gt[b][(j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu)], 1u);
+            }
+#endif
+        };
+        const uint16_t *__restrict__ p1 = a.in[0] + col, *__restrict__ p2 = a.in[1] + col;
+        int r = I.r0 + wy;
+        if (r < I.r1) { // two rows in flight per wave: the next row's loads are issued before this row is counted
+            const int lastr = I.r1 - 1;
+            uint2 n1 = *reinterpret_cast<const uint2 *>(p1 + (size_t)r * a.pitch), n2 = *reinterpret_cast<const uint2 *>(p2 + (size_t)r * a.pitch);
+            for (; r < I.r1; r += gy) {
+                const uint2 c1 = n1, c2 = n2;
+                const int rn = min(r + gy, lastr);
+                n1 = *reinterpret_cast<const uint2 *>(p1 + (size_t)rn * a.pitch);
+                n2 = *reinterpret_cast<const uint2 *>(p2 + (size_t)rn * a.pitch);
+                consume(0, c1);
+                consume(1, c2);
+            }
+        }
+    }
+    __syncthreads();
+    publish();
+}
+
+} // namespace
+
+hipError_t launch_dn_hist_pieces(const DnHistPiecesArgs &a, int grid, hipStream_t s) {
+    if (grid <= 0 || grid > kPieceMaxGrid) return hipErrorInvalidValue;
+    const size_t lds = 2 * ((size_t)a.lds_bins + 64) * sizeof(uint32_t);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_dn_hist_pieces))) return e;
+    hipLaunchKernelGGL(k_dn_hist_pieces, dim3(grid), dim3(kPBlock), lds, s, a);
+    return hipGetLastError();
+}
+
+} // namespace sarpro

@@ -1,0 +1,148 @@
+"""GPU parity of the speculative CLAHE chain (whole dual-pol u8 scene on one device).
+
+The apply pass counts its level histogram on sampled rows only; k_chain_predict proves from the sample that the u8 rescale
+(autoscale.rs:348-364) is the identity and predicts the suppressed-synRGB floor (synthetic_rgb.rs:99-113); the compose pass
+composes with the prediction and verifies it exactly; refuted (or unproven), the gated recount -> finish -> compose run.
+Whatever the route, the raster must be the oracle's, bit for bit.  SARPRO_HIP_SAMPLED_HIST_MIN_PX=0 takes the route on the
+small rasters the oracle can check (the product only takes it from 32 MP on); SARPRO_HIP_SPEC_FORCE forces the rare branches.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from sarpro_amd import AutoscaleStrategy as St, SyntheticRgbMode as Mode
+from sarpro_amd import synth
+import sarpro_amd as S
+
+pytestmark = pytest.mark.gpu
+
+
+def run(c, b1, b2):
+    rgb, u1, u2 = c.dualpol_synrgb(b1, b2, St.Clahe, want_u8=True)
+    names = [n for n, _ in c.last_kernel_times()]
+    return rgb, u1, u2, names
+
+
+def ref(b1, b2):
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1.astype(np.float32), b2.astype(np.float32), int(St.Clahe))
+    assert rc == 0
+    return rrgb, r1, r2
+
+
+@pytest.mark.parametrize("shape", [(264, 512), (512, 640), (1000, 777), (300, 4100), (2000, 1500)])
+@pytest.mark.parametrize("seed", [0, 5])
+def test_speculative_chain_matches_oracle(shape, seed, monkeypatch):
+    rows, cols = shape
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    b1, b2 = synth.scene_u16(rows, cols, 0, seed=synth.SEED_SCENE_A + seed), synth.scene_u16(rows, cols, 1, seed=synth.SEED_SCENE_A + seed)
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, u1, u2, names = run(c, b1, b2)
+        rep = c.spec_report()
+    assert "chain_predict" in names and "level_hist_guard" not in names
+    assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), rep
+    if rep["spec_ok"] and rep["verdict"] == 0:  # an accepted floor is the reference's floor: the counts bracket the target
+        f = rep["floor_pred"]
+        assert f == 37 or rep["n_lt"][0] < rep["target"] <= rep["n_lt"][1]
+        lv = np.concatenate([r1.ravel(), r2.ravel()])
+        assert rep["n_lt"][0] == int((lv < f).sum()) and (f == 37 or rep["n_lt"][1] == int((lv <= f).sum()))
+
+
+@pytest.mark.parametrize("force", ["mispredict", "nospec", "mispredict,nospec"])
+def test_speculative_chain_forced_fallbacks(force, monkeypatch):
+    """A floor that is wrong by one must be refuted by the compose pass's counts; without the identity proof no speculative
+    composition may run at all.  Both end in the exact kernels and the oracle's raster."""
+    rows, cols = 700, 1100
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
+    b1, b2 = synth.scene_u16(rows, cols, 0), synth.scene_u16(rows, cols, 1)
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, u1, u2, _ = run(c, b1, b2)  # unforced first: the state of an accepted scene must not leak into the next
+        assert np.array_equal(rgb, rrgb)
+        monkeypatch.setenv("SARPRO_HIP_SPEC_FORCE", force)
+        rgb, u1, u2, names = run(c, b1, b2)
+        rep = c.spec_report()
+        assert rep["verdict"] == 1 and rep["spec_ok"] == (0 if "nospec" in force else 1), rep
+        assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), rep
+        monkeypatch.delenv("SARPRO_HIP_SPEC_FORCE")
+        rgb, u1, u2, _ = run(c, b1, b2)  # and back
+        assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb)
+
+
+@pytest.mark.parametrize("kind", ["two_values", "high_plateau", "constant", "no_invalid", "all_invalid_band", "bright_only"])
+def test_rasters_whose_sample_lacks_level_0_or_255(kind, monkeypatch):
+    """No identity proof (a band without level 0 or without level 255) => spec_ok = 0 and the exact kernels decide the rescale."""
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    rng = np.random.default_rng(11)
+    rows, cols = 264, 512
+    lacks = True
+    if kind == "two_values":      # two populated bins: levels ~127 and 255 only
+        b1 = rng.choice(np.array([120, 4000], np.uint16), size=(rows, cols))
+        b2 = rng.choice(np.array([300, 900], np.uint16), size=(rows, cols))
+    elif kind == "high_plateau":  # 80 % of the pixels in the lowest bin: its CDF foot is already at ~0.8
+        b1 = np.where(rng.random((rows, cols)) < 0.8, 50, rng.integers(51, 6000, (rows, cols))).astype(np.uint16)
+        b2 = np.where(rng.random((rows, cols)) < 0.5, 70, rng.integers(71, 3000, (rows, cols))).astype(np.uint16)
+    elif kind == "constant":
+        b1 = np.full((rows, cols), 777, np.uint16)
+        b2 = np.full((rows, cols), 12, np.uint16)
+    elif kind == "all_invalid_band":
+        b1 = np.zeros((rows, cols), np.uint16)
+        b2 = synth.scene_u16(rows, cols, 1)
+    elif kind == "bright_only":   # wide DN range, no invalid pixel: level 0 only where a tile's first bin is nearly empty
+        b1 = rng.integers(1, 60000, (rows, cols)).astype(np.uint16)
+        b2 = rng.integers(200, 9000, (rows, cols)).astype(np.uint16)
+        lacks = None
+    else:                         # natural scene without its no-data wedge
+        b1, b2 = np.maximum(synth.scene_u16(rows, cols, 0), 1), np.maximum(synth.scene_u16(rows, cols, 1), 1)
+        lacks = None
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, u1, u2, _ = run(c, b1, b2)
+        rep = c.spec_report()
+    assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), (kind, rep)
+    if lacks:
+        assert rep["spec_ok"] == 0 and rep["verdict"] == 1, rep
+
+
+@pytest.mark.parametrize("stride", [5, 7, 9, 13, 64])
+def test_every_sample_stride_gives_the_same_raster(stride, monkeypatch):
+    rows, cols = 900, 1300
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", str(stride))
+    b1, b2 = synth.scene_u16(rows, cols, 0), synth.scene_u16(rows, cols, 1)
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, u1, u2, _ = run(c, b1, b2)
+        rep = c.spec_report()
+    assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), rep
+    nrows = len(range(stride // 2, rows, stride))
+    for k, b in enumerate((b1, b2)):  # the stratum the estimate is scaled by: valid pixels on the sampled rows
+        assert rep["sample_valid"][k] == int((b[stride // 2::stride] != 0).sum()), (k, nrows)
+
+
+def test_sampled_route_equals_partial_and_full_histogram_routes(monkeypatch):
+    """Three routes to the same raster: sampled histogram + speculative composition (default from 32 MP on),
+    SARPRO_HIP_NO_SAMPLED_HIST=1 (partial histogram of every row), SARPRO_HIP_FULL_LEVEL_HIST=1."""
+    rows, cols = 6000, 6016  # 36 MP: the product's own threshold
+    pitch = cols
+    q = synth.q_tables()
+    with S.Context(0, timing=True) as c:
+        band = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+        for b in range(2):
+            c.dev_synth_scene_u16(synth.SEED_SCENE_A + 3, b, q, rows, cols, 0, rows, band[b].data_ptr(), pitch)
+        out = []
+        for env in ({}, {"SARPRO_HIP_NO_SAMPLED_HIST": "1"}, {"SARPRO_HIP_FULL_LEVEL_HIST": "1"}, {"SARPRO_HIP_SPEC_FORCE": "mispredict"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+            c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
+            names = [n for n, _ in c.last_kernel_times()]
+            assert ("chain_predict" in names) == (not env or "SARPRO_HIP_SPEC_FORCE" in env), (env, names)
+            for k in env:
+                monkeypatch.delenv(k)
+            out.append(rgb)
+        assert int(out[0].max().item()) > 0
+        for o in out[1:]:
+            assert torch.equal(out[0], o)

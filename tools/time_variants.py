@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of library builds inside ONE process-per-build on the same box: per-kernel times of the headline chain.
-usage: python tools/time_variants.py lib_a.so lib_b.so ...   (paths relative to sarpro_amd/; '-' = the default build)"""
+usage: python tools/time_variants.py SPEC ...   SPEC = lib[:ENV=VAL[,ENV=VAL...]], lib relative to sarpro_amd/ ('-' = the default build)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -26,10 +26,14 @@ with S.Context(0, timing=True) as c:
                 acc.setdefault(n, []).append(ms)
     print(json.dumps({n: round(sorted(v)[len(v) // 2], 4) for n, v in acc.items()}))
 ''' % ROOT
-for lib in sys.argv[1:]:
+for spec in sys.argv[1:]:
+    lib, _, envs = spec.partition(":")
     env = dict(os.environ)
+    for kv in filter(None, envs.split(",")):
+        k, _, v = kv.partition("=")
+        env[k] = v
     if lib != "-":
         env["SARPRO_HIP_LIB"] = os.path.join(ROOT, "sarpro_amd", lib)
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    print(lib, line[-1] if line else ("FAILED: " + out.stderr[-400:]), flush=True)
+    print(spec, line[-1] if line else ("FAILED: " + out.stderr[-400:]), flush=True)
