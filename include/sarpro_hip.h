@@ -280,7 +280,7 @@ typedef struct {
     uint64_t n_lt[2];         /* band-pixels with level < floor_pred, < floor_pred + 1 (exact, counted by the compose pass) */
     uint64_t target;          /* synthetic_rgb.rs:99-100 */
     double est_lt[2];         /* the sample's estimate of n_lt */
-    uint64_t sample_valid[2]; /* valid pixels on the sampled rows, per band */
+    uint64_t sample_valid[2]; /* per band: valid pixels on the sampled rows, each work item weighted by rows / sampled rows, 4096 = 1.0 */
 } sarpro_hip_spec_report;
 int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_report *out);
 

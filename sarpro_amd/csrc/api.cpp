@@ -284,7 +284,9 @@ static void build_pieces(StripePlan *P, int grid) {
             if (c0 >= c1) continue;
             const RowWeight &cw = g.col_w[c0];
             const bool neg = rw.d < 0.0 || cw.d < 0.0; // constant sign inside the cut cell
-            const size_t cstart = c0 / strip_align(4) * strip_align(4);
+            size_t palign = 4; // (pieces: 64-px alignment measured 5 % SLOWER on the histogram pass, unlike the strips of the apply pass)
+            if (const char *e = getenv("SARPRO_HIP_PIECE_ALIGN")) palign = (size_t)std::max(4, atoi(e) / 4 * 4);
+            const size_t cstart = c0 / palign * palign;
             size_t nch = (c1 - cstart + 255) / 256, off = 0;
             while (nch > 0) {
                 int lg = 4;
@@ -354,7 +356,7 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     build_clahe_geometry(rows_total, cols, &P->geom);
     const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
     const size_t target_items = 4096;
-    size_t chunk_rows = std::min<size_t>(256, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 256 rows: taller apply items measured slower (320: +3 %, 625: +10 %, a whole 1250-row cell: +30 % -- the resident workgroups drift apart and lose the sweep's DRAM locality), 96..234 rows all the same
+    size_t chunk_rows = std::min<size_t>(128, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 128 rows: with line-aligned strips 112..160 rows measured 3-4 % faster than 234 and than 96, 64 rows 12 % slower (per-item table staging), 512 rows 10 % slower (the resident workgroups drift apart and lose the sweep's DRAM locality)
     if (const char *e = getenv("SARPRO_HIP_CHUNK_ROWS")) chunk_rows = (size_t)std::max(8, atoi(e)); // experiments
     const ClaheGeometry &g = P->geom;
     const bool split = false; // edge lanes are masked inside the vector kernels; no separate sliver items
@@ -980,7 +982,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     const size_t rgb_pitch_ok = rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb);
     bool sampled = J.synrgb && J.nbands == 2 && J.u8_out() && !J.reduce && !exact_only && !getenv("SARPRO_HIP_FULL_LEVEL_HIST") &&
                    !getenv("SARPRO_HIP_NO_SAMPLED_HIST") && d_rgb && rgb_pitch_ok && J.row0 == 0 && J.rows_local == J.rows_total;
-    uint32_t sample_stride = 9;
+    uint32_t sample_stride = 17; // sampled rows cost the apply pass ~0.4 % each ninth: 9 -> 17 -> 33 measured 0.540 / 0.535 / 0.529 ms; the estimate's sigma grows with sqrt(stride)
     if (sampled) {
         size_t min_px = kSampledHistMinPx;
         if (const char *e = getenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX")) min_px = (size_t)strtoull(e, nullptr, 10);

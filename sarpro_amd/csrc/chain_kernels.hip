@@ -708,16 +708,31 @@ __global__ __launch_bounds__(256) void k_level_hist_if_flagged(LevelRecountArgs 
     const size_t pitch = a.pitch;
     const uint32_t rows = a.rows, cols = a.cols;
     unsigned long long *__restrict__ hist = a.level_hist + (size_t)band * 256;
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[4][256]; // one histogram per wave: a quarter of the collisions on the crowded levels
+    for (int i = threadIdx.x; i < 1024; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
-    const uint64_t total = (uint64_t)rows * cols;
-    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
-        const uint32_t r = (uint32_t)(idx / cols), c = (uint32_t)(idx - (uint64_t)r * cols);
-        atomicAdd(&h[in[(size_t)r * pitch + c]], 1u);
+    uint32_t *hw = h[threadIdx.x >> 6];
+    if (pitch % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) { // 16 levels per load, a wave reads 1 KiB of a row
+        const uint32_t vpr = (cols + 15) / 16;
+        const uint64_t total = (uint64_t)rows * vpr;
+        for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+            const uint32_t r = (uint32_t)(idx / vpr), c = (uint32_t)(idx - (uint64_t)r * vpr) * 16;
+            const uint4 q = *reinterpret_cast<const uint4 *>(in + (size_t)r * pitch + c);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            const uint32_t nvalid = min(16u, cols - c); // the last vector of a row may reach into the pitch padding
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if ((uint32_t)k < nvalid) atomicAdd(&hw[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+        }
+    } else {
+        const uint64_t total = (uint64_t)rows * cols;
+        for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+            const uint32_t r = (uint32_t)(idx / cols), c = (uint32_t)(idx - (uint64_t)r * cols);
+            atomicAdd(&hw[in[(size_t)r * pitch + c]], 1u);
+        }
     }
     __syncthreads();
-    const uint32_t n = h[threadIdx.x];
+    const uint32_t n = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
     if (n && threadIdx.x) atomicAdd(&hist[threadIdx.x], (unsigned long long)n); // bin 0 stays implied, as the apply kernel leaves it
 }
 

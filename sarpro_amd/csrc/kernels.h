@@ -81,6 +81,7 @@ struct ComposeArgs {
 
 // State of the CLAHE chain's speculation on the synRGB floor (device memory, one per context).  k_chain_predict writes it
 // after the apply pass, the speculative compose pass adds its counts and the verdict, the gated exact kernels read it.
+constexpr unsigned long long kSampleWeightOne = 4096; // fixed-point 1.0 of the sampled histogram's per-item weights
 constexpr int kSpecFloorCap = 37; // synthetic_rgb.rs:110-113: floor + 3 is capped at 40, so every floor >= 37 is the same floor
 struct ChainSpecState {
     uint32_t spec_ok;              // both bands hold level 0 and level 255 (=> the u8 rescale is the identity) and a floor was predicted
@@ -89,7 +90,7 @@ struct ChainSpecState {
     uint32_t done;                 // workgroups of the speculative compose pass that have added their counts
     unsigned long long n_lt[2];    // band-pixels with level < F, < F + 1, counted by the speculative compose pass
     unsigned long long target;     // synthetic_rgb.rs:99-100
-    unsigned long long sample_valid[2]; // valid pixels on the sampled rows, per band (apply pass)
+    unsigned long long sample_valid[2]; // valid pixels on the sampled rows, per band, weighted like the histogram (apply pass)
     double est_lt[2];              // the sample's estimate of n_lt (diagnostics)
     uint32_t force;                // test switches (kSpecForce*)
     uint32_t pad;

@@ -11,6 +11,16 @@ namespace {
 constexpr int kPBlock = 1024, kPWaves = 16;
 // LDS atomics through the address-space-3 pointer (the HIP overloads take generic pointers)
 #define LDS_ADD(off, v) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)(off)), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#ifdef SARPRO_NT_PIECE
+__device__ __forceinline__ uint2 piece_load_nt(const uint16_t *p) {
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    const v2u t = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p));
+    return make_uint2(t.x, t.y);
+}
+#define PIECE_LOAD(p) piece_load_nt(p)
+#else
+#define PIECE_LOAD(p) (*reinterpret_cast<const uint2 *>(p))
+#endif
 __device__ __forceinline__ int p_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int p_lane() { return (int)(threadIdx.x & 63); }
 
@@ -90,12 +100,12 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
         int r = I.r0 + wy;
         if (r < I.r1) { // two rows in flight per wave: the next row's loads are issued before this row is counted
             const int lastr = I.r1 - 1;
-            uint2 n1 = *reinterpret_cast<const uint2 *>(p1 + (size_t)r * a.pitch), n2 = *reinterpret_cast<const uint2 *>(p2 + (size_t)r * a.pitch);
+            uint2 n1 = PIECE_LOAD(p1 + (size_t)r * a.pitch), n2 = PIECE_LOAD(p2 + (size_t)r * a.pitch);
             for (; r < I.r1; r += gy) {
                 const uint2 c1 = n1, c2 = n2;
                 const int rn = min(r + gy, lastr);
-                n1 = *reinterpret_cast<const uint2 *>(p1 + (size_t)rn * a.pitch);
-                n2 = *reinterpret_cast<const uint2 *>(p2 + (size_t)rn * a.pitch);
+                n1 = PIECE_LOAD(p1 + (size_t)rn * a.pitch);
+                n2 = PIECE_LOAD(p2 + (size_t)rn * a.pitch);
                 consume(0, c1);
                 consume(1, c2);
             }
