@@ -935,25 +935,28 @@ constexpr int kComposeTableBytes = 512 + 65536;
 constexpr int kComposeStageBytes = (kComposeBlock / kWave) * 3072; // per-wave 3 KiB transpose stage (VEC = 16)
 
 // SPEC (the CLAHE chain's speculative composition, chain_kernels.hip k_chain_predict): the tables were built for a PREDICTED
-// floor F; while composing, the pass counts the band-pixels (both level rasters) with level >= F and >= F + 1, SWAR on the
-// packed level bytes it has loaded anyway -- the pass is HBM-bound, the ~64 VALU operations per 16 pixels are free -- and the
-// workgroup that finishes last turns the counts into the verdict:  cum(F-1) < target <= cum(F)  <=>  F is the floor of
-// synthetic_rgb.rs:99-113.  Gating: SPEC runs iff spec_ok; the plain form with a.spec set runs iff the verdict refuted the
-// speculative RGB (or it never ran).
-__device__ __forceinline__ uint32_t swar_ge_bytes(uint32_t xo, uint32_t xa, uint32_t t4) {
-    // bytes of x that are >= t (t <= 127): xo = x | 0x80808080, xa = x & 0x80808080; no borrow crosses a byte since every byte of xo >= 0x80 >= t
-    return (uint32_t)__builtin_popcount(((xo - t4) & 0x80808080u) | xa);
-}
+// floor F; while composing, the pass counts the band-pixels (both level rasters) with level >= F and >= F + 1 on the packed
+// level bytes it has loaded anyway, and the workgroup that finishes last turns the counts into the verdict:
+// cum(F-1) < target <= cum(F)  <=>  F is the floor of synthetic_rgb.rs:99-113.  Counting without a compare per byte:
+// with A_T = sum |x - T| over the bytes (one v_sad_u8 per dword and threshold, accumulating),
+//   #{x >= T + 1} = sum min(x, T + 1) - sum min(x, T)   and   sum min(x, T) = (sum x + N T - A_T) / 2
+//   =>  #{x >= T + 1} = (N + A_T - A_(T+1)) / 2,
+// so three accumulators (T = F - 1, F, F + 1) give both counts for 3 instead of 8 VALU operations per dword (a SWAR
+// compare-and-popcount form cost the pass 0.025 ms of its 0.38).  Gating: SPEC runs iff spec_ok; the plain form with a.spec
+// set runs iff the verdict refuted the speculative RGB (or it never ran).
 
 template <int VEC, bool SPEC>
 __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     if (SPEC) { if (!a.spec->spec_ok) return; }
     else if (a.spec && a.spec->verdict == 0) return; // fallback composition: the speculative RGB stands
-    uint32_t t4[2] = {0u, 0u}, n_ge[2] = {0u, 0u}, n_px = 0u; // SPEC: thresholds F, F + 1 in every byte; this lane's counts
+    // SPEC: thresholds F - 1 (F when F = 0: unused), F, F + 1 in every byte; this lane's |x - T| sums over its vectors, its
+    // pixel count, and the direct counts of the ragged row tails
+    uint32_t t4[3] = {0u, 0u, 0u}, sad[3] = {0u, 0u, 0u}, n_ge[2] = {0u, 0u}, n_px = 0u, n_vec_px = 0u;
+    uint32_t fpred = 0u;
     if (SPEC) {
-        const uint32_t f = (uint32_t)a.spec->floor_pred;
-        t4[0] = f * 0x01010101u; t4[1] = (f + 1u) * 0x01010101u;
+        fpred = (uint32_t)a.spec->floor_pred;
+        t4[0] = (fpred ? fpred - 1u : 0u) * 0x01010101u; t4[1] = fpred * 0x01010101u; t4[2] = (fpred + 1u) * 0x01010101u;
     }
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
@@ -976,6 +979,21 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
         // transposed stores stay inside one row
         const uint32_t wpr = (vpr + 63) / 64; // wave-chunks per row
         const uint64_t chunks = (uint64_t)a.rows * wpr;
+        // software pipeline: the wave's NEXT chunk is loaded before this one is looked up and stored (with 16 waves per CU the
+        // loop was exposed to the load latency); the loads are unconditional -- clamped to the last chunk and, past the row's
+        // last full vector, to the end of the pitch -- so that the compiler can count them
+        const uint32_t last_vec_off = a.in_pitch >= 16 ? (uint32_t)a.in_pitch - 16u : 0u;
+        auto chunk_off = [&](uint64_t ch) -> size_t {
+            const uint32_t r = (uint32_t)(ch / wpr);
+            const uint32_t col = ((uint32_t)(ch - (uint64_t)r * wpr) * 64 + lane) * 16;
+            return (size_t)r * a.in_pitch + min(col, last_vec_off);
+        };
+        uint4 n1 = make_uint4(0, 0, 0, 0), n2 = n1;
+        if (wave0 < chunks) {
+            const size_t o0 = chunk_off(wave0);
+            n1 = *reinterpret_cast<const uint4 *>(a.b1 + o0);
+            n2 = *reinterpret_cast<const uint4 *>(a.b2 + o0);
+        }
         for (uint64_t ch = wave0; ch < chunks; ch += nwaves) {
             const uint32_t r = (uint32_t)(ch / wpr);
             const uint32_t v0 = (uint32_t)(ch - (uint64_t)r * wpr) * 64;
@@ -984,25 +1002,27 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
             const bool fullv = col + 16 <= a.cols;
             const uint32_t nfull = (a.cols / 16 > v0) ? min(64u, a.cols / 16 - v0) : 0u; // full vectors in this chunk (prefix)
             uint32_t o[12];
-            if (fullv) {
+            const uint4 q1 = n1, q2 = n2;
+            {
+                const size_t on = chunk_off(min(ch + nwaves, chunks - 1));
 #ifdef SARPRO_NT_LEVELS
                 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v4u t1 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(a.b1 + (size_t)r * a.in_pitch + col));
-                const v4u t2 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(a.b2 + (size_t)r * a.in_pitch + col));
-                const uint4 q1 = make_uint4(t1.x, t1.y, t1.z, t1.w), q2 = make_uint4(t2.x, t2.y, t2.z, t2.w);
+                const v4u t1 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(a.b1 + on));
+                const v4u t2 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(a.b2 + on));
+                n1 = make_uint4(t1.x, t1.y, t1.z, t1.w); n2 = make_uint4(t2.x, t2.y, t2.z, t2.w);
 #else
-                const uint4 q1 = *reinterpret_cast<const uint4 *>(a.b1 + (size_t)r * a.in_pitch + col);
-                const uint4 q2 = *reinterpret_cast<const uint4 *>(a.b2 + (size_t)r * a.in_pitch + col);
+                n1 = *reinterpret_cast<const uint4 *>(a.b1 + on);
+                n2 = *reinterpret_cast<const uint4 *>(a.b2 + on);
 #endif
+            }
+            if (fullv) {
                 const uint32_t w1[4] = {q1.x, q1.y, q1.z, q1.w}, w2[4] = {q2.x, q2.y, q2.z, q2.w};
                 if (SPEC) {
-                    n_px += 32u;
+                    n_vec_px += 32u;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t xo1 = w1[g] | 0x80808080u, xa1 = w1[g] & 0x80808080u, xo2 = w2[g] | 0x80808080u, xa2 = w2[g] & 0x80808080u;
-                        n_ge[0] += swar_ge_bytes(xo1, xa1, t4[0]) + swar_ge_bytes(xo2, xa2, t4[0]);
-                        n_ge[1] += swar_ge_bytes(xo1, xa1, t4[1]) + swar_ge_bytes(xo2, xa2, t4[1]);
-                    }
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) sad[k] = __builtin_amdgcn_sad_u8(w2[g], t4[k], __builtin_amdgcn_sad_u8(w1[g], t4[k], sad[k]));
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) { // 4 px -> 12 bytes -> 3 dwords
@@ -1035,8 +1055,8 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
                     po[3 * j + 0] = R2[v1]; po[3 * j + 1] = G2[v2]; po[3 * j + 2] = B2[(v1 << 8) | v2];
                     if (SPEC) {
                         n_px += 2u;
-                        n_ge[0] += (v1 >= (t4[0] & 0xFFu)) + (v2 >= (t4[0] & 0xFFu));
-                        n_ge[1] += (v1 >= (t4[1] & 0xFFu)) + (v2 >= (t4[1] & 0xFFu));
+                        n_ge[0] += (v1 >= fpred) + (v2 >= fpred);
+                        n_ge[1] += (v1 >= fpred + 1u) + (v2 >= fpred + 1u);
                     }
                 }
             }
@@ -1054,6 +1074,10 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
         }
     }
     if (SPEC) { // counts -> workgroup -> device; the workgroup that arrives last decides
+        // vectors: #{x >= F} = (N + A_(F-1) - A_F) / 2 (all of them when F = 0), #{x >= F + 1} = (N + A_F - A_(F+1)) / 2: exact per lane
+        n_ge[0] += fpred ? (n_vec_px + sad[0] - sad[1]) >> 1 : n_vec_px;
+        n_ge[1] += (n_vec_px + sad[1] - sad[2]) >> 1;
+        n_px += n_vec_px;
         uint32_t lt0 = n_px - n_ge[0], lt1 = n_px - n_ge[1];
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) { lt0 += __shfl_xor(lt0, m, 64); lt1 += __shfl_xor(lt1, m, 64); }
