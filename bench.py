@@ -48,13 +48,21 @@ def main():
     ap.add_argument("--strategy", default="clahe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="one host round trip per scene instead of stream-ordered enqueue")
-    ap.add_argument("--cpu-sample", type=int, default=7000, help="side of the square CPU-baseline sample scene")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (end-to-end over PCIe, BASELINE configs 2 and 3)")
+    ap.add_argument("--cpu-sample", type=int, default=7000, help="side of the square CPU-baseline sample scene (median of 3 runs)")
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the single full-size (metric configuration) run of the CPU baseline (~30 s)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (N = 1: end-to-end over PCIe, BASELINE configs 1-3, resize; "
+                                                               "N > 1: row-stripe mode over RCCL and the PCIe-inclusive leg on all ranks)")
+    ap.add_argument("--secondary-only", action="store_true", help=argparse.SUPPRESS)  # the child process that measures the N = 1 secondary records
     ap.add_argument("--pitch-align", type=int, default=64, help="row pitch of the resident rasters, rounded up to this many elements")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if args.secondary_only:
+        sys.exit(secondary_child(args))
+    # N = 1: the secondary records are measured by a CHILD process, started here -- before this process touches a GPU runtime --
+    # and parked on its stdin until the headline is done (see secondary_start)
+    sec_child = secondary_start(args) if (args.gpus == 1 and not args.no_secondary) else None
 
     import torch
     import torch.distributed as dist
@@ -199,18 +207,35 @@ def main():
                        "enqueue": "stream-ordered, one synchronisation after the K steps" if use_async else "one host round trip per step"},
             "roofline": roofline,
         }
+    else:
+        out = None
+    # ---- everything below is beside the headline: it runs after the timed region, with the headline's rasters freed, and a
+    # failure in it costs its own record, never the line
+    single_ms = elapsed / args.steps * 1e3  # one rank, one whole scene (batch mode): the N = 1 reference of the stripe leg
+    del band, rgb
+    torch.cuda.empty_cache()
+    if world > 1 and not args.no_secondary:
+        sec = {}
+        try:
+            sec = multi_rank_records(torch, dist, dev, rank, world, rows, cols, strategy, single_ms if args.mode == "batch" else None)
+        except Exception as e:
+            sec = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            out["secondary"] = sec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx, q, args.cpu_sample, int(strategy), torch, dev)
-        if world == 1 and not args.no_secondary:
             try:
-                out["secondary"] = secondary_records(ctx, torch, dev, rows, cols)
-            except Exception as e:  # never at the cost of the headline line
-                out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
+                out["cpu_baseline"] = cpu_baseline(ctx, q, args.cpu_sample, int(strategy), torch, dev, rows if not args.no_cpu_full else 0, cols)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    ctx.close()
+    if rank == 0:
+        if sec_child is not None:
+            out["secondary"] = secondary_collect(sec_child)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 def self_launch(args):
@@ -233,6 +258,150 @@ def self_launch(args):
     return proc.returncode
 
 
+def secondary_start(args):
+    """N = 1: the secondary records are measured by a CHILD process (`bench.py --secondary-only`): they allocate pinned host
+    memory and several full-size rasters and run many passes, and an out-of-memory kill or a GPU fault there must not take
+    the headline line with it.  The child is started before this process has loaded a GPU runtime (nothing is ever exec'ed
+    from a process that has), imports its modules, and waits on its stdin for "go" -- sent after the timed region, when the
+    headline's rasters are freed -- so it cannot disturb the headline either."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--secondary-only", "--rows", str(args.rows), "--cols", str(args.cols)]
+    try:
+        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except Exception as e:
+        return e
+
+
+def secondary_collect(child):
+    if isinstance(child, Exception):
+        return {"error": f"{type(child).__name__}: {child}"}
+    try:
+        stdout, stderr = child.communicate("go\n", timeout=1200)
+        lines = [l for l in stdout.splitlines() if l.startswith("{")]
+        if child.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"secondary child exited with {child.returncode}: {stderr[-300:]}"}
+    except Exception as e:
+        try:
+            child.kill()
+        except Exception:
+            pass
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def secondary_child(args):
+    import torch
+    import sarpro_amd  # noqa: F401  (imported while parked: the first import on a fresh box takes a minute)
+    if sys.stdin.readline().strip() != "go":  # the parent went away (or failed) before the headline was done
+        return 0
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    try:
+        out = secondary_records(torch, dev, args.rows, args.cols)
+    except Exception as e:
+        out = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def multi_rank_records(torch, dist, dev, rank, world, rows, cols, strategy, single_ms):
+    """N > 1, in the same processes as the headline (BASELINE.json configs 4 and 5 as the driver's one command sees them):
+      ranks_seen     -- an all-reduce of ones over torch.distributed's RCCL group: the record proves N ranks took part
+      stripe         -- ONE 400 MP scene as N row stripes, sarpro_hip_stripe_run_u16 over the library's own communicator: three
+                        u64 all-reduces inside the chain (DN histograms, CLAHE tile histograms, level histograms)
+      e2e_all_ranks  -- the PCIe-inclusive leg on every rank at once: pinned host bands -> H2D -> chain -> D2H of the RGB raster"""
+    import ctypes as C
+    import sarpro_amd
+    from sarpro_amd import SyntheticRgbMode, synth
+    from sarpro_amd._lib import lib
+    out = {}
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(ones)
+    out["ranks_seen"] = int(ones.item())
+    q = synth.q_tables()
+    pitch = (cols + 63) // 64 * 64
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    # (i) row stripes of one scene
+    try:
+        ctx = sarpro_amd.Context(dev.index, timing=True)
+        uid = [sarpro_amd.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+        r0s, nrs = sarpro_amd.host_stripe_plan(rows, world)
+        row0, rl = r0s[rank], nrs[rank]
+        band = [torch.empty((max(rl, 1), pitch), dtype=torch.int16, device=dev) for _ in range(2)]
+        rgb = torch.empty((max(rl, 1), pitch * 3), dtype=torch.uint8, device=dev)
+        for b in range(2):
+            ctx.dev_synth_scene_u16(synth.SEED_SCENE_A, b, q, rows, cols, row0, rl, band[b].data_ptr(), pitch)
+
+        def stripe():
+            ctx.stripe_run_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, row0, rl, pitch, strategy, SyntheticRgbMode.Default, rgb.data_ptr(), pitch)
+        for _ in range(3):
+            stripe()
+        n = 10
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            stripe()
+        barrier()
+        ms = max_over_ranks((time.perf_counter() - t0) / n * 1e3)
+        kt = dict(ctx.last_kernel_times())  # the last scene's event pairs on this rank
+        ar = {k: round(max_over_ranks(v) * 1e3, 1) for k, v in sorted(kt.items()) if k.startswith("allreduce_")}
+        out["stripe"] = {"what": f"one {rows}x{cols} dual-pol scene as {world} row stripes, sarpro_hip_stripe_run_u16 over the library's RCCL communicator (BASELINE config 4)",
+                         "ms_per_scene": round(ms, 3), "value": round(rows * cols / ms / 1e3, 1), "unit": "Mpix/s", "scaling": "strong",
+                         "speedup_vs_n1": round(single_ms / ms, 2) if single_ms else None, "n1_ms_per_scene": round(single_ms, 3) if single_ms else None,
+                         "allreduce_us_max_over_ranks": ar, "kernels_ms_rank0": {k: round(v, 4) for k, v in kt.items() if not k.startswith("host:")}}
+        del band, rgb
+        ctx.close()
+    except Exception as e:
+        out["stripe"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    # (ii) PCIe-inclusive leg, all ranks at once
+    try:
+        ctx = sarpro_amd.Context(dev.index)
+        dband = torch.empty((rows, pitch), dtype=torch.int16, device=dev)
+        host = []
+        for b in range(2):
+            ctx.dev_synth_scene_u16(synth.SEED_SCENE_A + rank, b, q, rows, cols, 0, rows, dband.data_ptr(), pitch)
+            h = torch.empty((rows, cols), dtype=torch.int16, pin_memory=True)
+            h.copy_(dband[:, :cols])
+            host.append(h)
+        del dband
+        rgb_h = torch.empty((rows, cols, 3), dtype=torch.uint8, pin_memory=True)
+        b1, b2 = (h.numpy().view(np.uint16) for h in host)
+        o = rgb_h.numpy()
+
+        def e2e():
+            rc = lib.sarpro_hip_dualpol_synrgb_u16(ctx._h, b1.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p), rows, cols, int(strategy), 0,
+                                                   o.ctypes.data_as(C.c_void_p), None, None, None)
+            assert rc == 0
+        e2e()
+        n = 3
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            e2e()
+        barrier()
+        ms = max_over_ranks((time.perf_counter() - t0) / n * 1e3)
+        px = rows * cols
+        out["e2e_all_ranks"] = {"what": f"every rank at once: pinned host u16 bands -> H2D -> calibrate + {strategy.name} + synRGB -> D2H of the RGB raster (sarpro_hip_dualpol_synrgb_u16), one scene per rank (BASELINE config 5's transfer pattern)",
+                                "ms_per_scene_max_over_ranks": round(ms, 2), "value": round(world * px / ms / 1e3, 1), "unit": "Mpix/s aggregate",
+                                "pcie_gb_s_aggregate": round(world * (2 * px * 2 + px * 3) / ms / 1e6, 1), "pcie_gb_s_per_rank": round((2 * px * 2 + px * 3) / ms / 1e6, 1)}
+        del host, rgb_h
+        ctx.close()
+    except Exception as e:
+        out["e2e_all_ranks"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def pmc_traffic_gb(kernel, local_px):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r2_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied), scaled
@@ -248,56 +417,79 @@ def pmc_traffic_gb(kernel, local_px):
         return None
 
 
-def cpu_baseline(ctx, q, side, strategy, torch, dev):
-    """Time the CPU oracle on a bounded side x side sample of the same synthetic workload: (i) ONE thread -- the reference's
-    behaviour, its hot path has no threads -- median of 3 runs; (ii) next to it, labelled as NOT the reference's
-    behaviour, a row-parallel variant of the same loops on all host cores (oracle/sarpro_oracle_mt.c, OpenMP).
-    The full 400 MP scene would take ~30 s per single-thread run (x3 runs, twice): the sample keeps the default bench run
-    within minutes; the path is pointwise + histograms, its per-pixel cost does not depend on the scene size."""
+def cpu_baseline(ctx, q, side, strategy, torch, dev, full_rows=0, full_cols=0):
+    """Time the CPU oracle on the same synthetic workload: (i) ONE thread -- the reference's behaviour, its hot path has no
+    threads -- median of 3 runs on a side x side sample, and ONE run on the metric's own configuration
+    (full_rows x full_cols, ~30 s) beside it, so that "the per-pixel cost does not depend on the scene size" is shown, not
+    stated; (ii) next to each, labelled as NOT the reference's behaviour, a row-parallel variant of the same loops on all host
+    cores (oracle/sarpro_oracle_mt.c, OpenMP).  `value` is the full-size single-thread figure when it was measured."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     from sarpro_amd import synth
 
-    pitch = (side + 63) // 64 * 64
-    bands = []
-    for b in range(2):
-        t = torch.empty((side, pitch), dtype=torch.int16, device=dev)
-        ctx.dev_synth_scene_u16(synth.SEED_SCENE_A, b, q, side, side, 0, side, t.data_ptr(), pitch)
-        bands.append(t[:, :side].contiguous().cpu().numpy().view(np.uint16).astype(np.float32))
+    def scene(rows, cols):
+        pitch = (cols + 63) // 64 * 64
+        bands = []
+        for b in range(2):
+            t = torch.empty((rows, pitch), dtype=torch.int16, device=dev)
+            ctx.dev_synth_scene_u16(synth.SEED_SCENE_A, b, q, rows, cols, 0, rows, t.data_ptr(), pitch)
+            bands.append(t[:, :cols].contiguous().cpu().numpy().view(np.uint16).astype(np.float32))
+            del t
+        return bands
+
+    def timed(fn, n):
+        runs, last = [], None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            last = fn()
+            runs.append(time.perf_counter() - t0)
+        return runs, last
+
     oracle.lib()
-    runs = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rc, rgb, _, _ = oracle.dualpol_synrgb(bands[0], bands[1], strategy)
-        runs.append(time.perf_counter() - t0)
-        assert rc == 0
+    bands = scene(side, side)
+    runs, (rc, rgb, _, _) = timed(lambda: oracle.dualpol_synrgb(bands[0], bands[1], strategy), 3)
+    assert rc == 0
     dt = sorted(runs)[1]
     out = {"value": round(side * side / dt / 1e6, 2), "unit": "Mpix/s", "cores": 1, "kind": "port",
            "sample": f"{side}x{side} dual-pol scene (same generator), whole path, median of 3 runs ({', '.join(f'{x:.1f}' for x in runs)} s) on 1 of {os.cpu_count()} host threads",
            "context": "the reference's README quotes ~40 s per 400 MP dual-band native synRGB scene incl. I/O on an M4 Pro (README.md:63); not measured here"}
+    mt = None
     if strategy == 4:  # the row-parallel variant restates the CLAHE path only
         try:
-            oracle.lib_mt()
-            nthr = int(oracle.lib_mt().sarpro_oracle_mt_threads())
-            runs2 = []
-            same = None
-            for _ in range(3):
-                t0 = time.perf_counter()
-                rc2, rgb2 = oracle.dualpol_clahe_synrgb_mt(bands[0], bands[1])
-                runs2.append(time.perf_counter() - t0)
-                assert rc2 == 0
-                same = bool(np.array_equal(rgb2, rgb))
+            mt = oracle.lib_mt()
+            nthr = int(mt.sarpro_oracle_mt_threads())
+            runs2, (rc2, rgb2) = timed(lambda: oracle.dualpol_clahe_synrgb_mt(bands[0], bands[1]), 3)
+            assert rc2 == 0
             dt2 = sorted(runs2)[1]
             out["row_parallel"] = {"value": round(side * side / dt2 / 1e6, 1), "unit": "Mpix/s", "cores": nthr,
                                    "note": f"same loops split over rows with OpenMP on all {nthr} host threads, median of 3 runs "
                                            f"({', '.join(f'{x:.2f}' for x in runs2)} s); NOT the reference's behaviour (its hot path is single-threaded)",
-                                   "raster_equals_single_thread": same}
+                                   "raster_equals_single_thread": bool(np.array_equal(rgb2, rgb))}
         except Exception as e:  # the single-thread figure is the baseline; this one is informative
             out["row_parallel"] = {"error": str(e)}
+            mt = None
+    del bands, rgb
+    if full_rows and full_cols and (full_rows, full_cols) != (side, side):
+        try:  # the metric's configuration itself, once
+            fb = scene(full_rows, full_cols)
+            px = full_rows * full_cols
+            (t1,), (rc, rgbf, _, _) = timed(lambda: oracle.dualpol_synrgb(fb[0], fb[1], strategy), 1)
+            assert rc == 0
+            out["sample_value"] = out["value"]
+            out["value"] = round(px / t1 / 1e6, 2)
+            out["full_size"] = {"value": out["value"], "unit": "Mpix/s", "cores": 1, "seconds": round(t1, 1),
+                                "what": f"{full_rows}x{full_cols} dual-pol scene (the metric's configuration), whole path, one run on 1 host thread"}
+            out["sample"] = f"value: one {full_rows}x{full_cols} run ({t1:.1f} s); sample_value: " + out["sample"]
+            if mt is not None:
+                (t2,), (rc2, rgb2) = timed(lambda: oracle.dualpol_clahe_synrgb_mt(fb[0], fb[1]), 1)
+                out["row_parallel"]["full_size"] = {"value": round(px / t2 / 1e6, 1), "unit": "Mpix/s", "seconds": round(t2, 2),
+                                                    "raster_equals_single_thread": bool(rc2 == 0 and np.array_equal(rgb2, rgbf))}
+        except Exception as e:
+            out["full_size"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
-def secondary_records(ctx_main, torch, dev, rows, cols):
+def secondary_records(torch, dev, rows, cols):
     """Records beside the headline (never `value`): the PCIe-inclusive end-to-end leg (SURVEY 8d timing protocol 2) and the
     other BASELINE.json configurations, device-resident, at full size.  Each is a handful of calls after the timed region."""
     import sarpro_amd
@@ -352,6 +544,33 @@ def secondary_records(ctx_main, torch, dev, rows, cols):
         del host, rgb_h
     except Exception as e:
         out["e2e"] = {"error": str(e)}
+    # BASELINE config 2 as a flow, device-resident (no PCIe): Robust x2 -> Lanczos3 to 2048^2 -> pad -> default synRGB; carries the
+    # resize kernels' own times (resize.rs:32-89: horizontal pass over the u8 level raster, then vertical pass)
+    try:
+        from sarpro_amd import resize_output_dims
+        fc, fr = resize_output_dims(cols, rows, 2048, True)
+        rgb_small = torch.empty((fr * fc * 3,), dtype=torch.uint8, device=dev)
+        ms = timed(lambda: ctx.dev_dualpol_synrgb_resized(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Robust, 2048, True, rgb_small.data_ptr()), n=3, warm=1)
+        kt = {}
+        for k, v in ctx.last_kernel_times():
+            if not k.startswith("host:"):
+                kt[k] = round(kt.get(k, 0.0) + v, 4)
+        out["config2_flow_resident"] = {"what": "dual-pol u16 resident in HBM -> Robust autoscale x2 (u8 level rasters) -> Lanczos3 to 2048^2 -> pad -> default synRGB, RGB stays on the device",
+                                        "ms_per_scene": round(ms, 3), "value": round(px / ms / 1e3, 1), "unit": "Mpix/s", "kernels_ms_summed_over_both_bands": kt}
+        del rgb_small
+    except Exception as e:
+        out["config2_flow_resident"] = {"error": f"{type(e).__name__}: {e}"}
+    # BASELINE config 1 (the reference's own CPU-runnable case): single band 2048 x 2048, f32 samples, Standard, u8 -- latency of one call
+    try:
+        side = 2048
+        f1 = torch.rand((side, side), dtype=torch.float32, device=dev) * 900.0 + 1.0
+        o1 = torch.empty((side, side), dtype=torch.uint8, device=dev)
+        ms = timed(lambda: ctx.dev_autoscale_band_f32(f1.data_ptr(), side, side, side, St.Standard, Bd.U8, o1.data_ptr(), side, want_stats=False), n=20, warm=3)
+        out["config1"] = {"what": "single band 2048x2048 f32 resident in HBM -> Standard autoscale -> u8 (one synchronous call)", "ms_per_call": round(ms, 4),
+                          "value": round(side * side / ms / 1e3, 1), "unit": "Mpix/s", "kernels_ms": kernels()}
+        del f1, o1
+    except Exception as e:
+        out["config1"] = {"error": f"{type(e).__name__}: {e}"}
     # (2) BASELINE config 2, hot path, device-resident: Robust x2 -> default synRGB at full resolution
     rgb = torch.empty((rows, pitch * 3), dtype=torch.uint8, device=dev)
     ms = timed(lambda: ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Robust, Mode.Default, rgb.data_ptr(), pitch))

@@ -198,6 +198,11 @@ int sarpro_hip_resize_image_data_dev(sarpro_hip_ctx *ctx, const void *d_data, si
 int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *band1, const uint16_t *band2, size_t rows,
                                           size_t cols, int strategy, int mode, size_t target_size, int pad,
                                           uint8_t *rgb_out, sarpro_hip_resize_meta *meta);
+/* The same product with both bands and the RGB raster (final_rows * final_cols * 3 bytes, compact) resident in device memory:
+ * nothing crosses PCIe.  in_pitch in elements.  Synchronous. */
+int sarpro_hip_dualpol_synrgb_resized_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows,
+                                              size_t cols, size_t in_pitch, int strategy, int mode, size_t target_size, int pad,
+                                              uint8_t *d_rgb_out, sarpro_hip_resize_meta *meta);
 
 /* save_processed_image (save.rs:23-170) up to the raster its writer receives: pipeline at native
  * resolution -> resize -> pad, on the device.  `out` holds final_rows * final_cols u8 / u16 elements.
@@ -353,6 +358,9 @@ int sarpro_hip_tiff_write_rows(sarpro_hip_tiff_writer *w, size_t row0, size_t nr
 int sarpro_hip_tiff_row_sink(void *user, size_t row0, size_t nrows, const uint8_t *src, size_t src_pitch_bytes);
 int sarpro_hip_tiff_finish(sarpro_hip_tiff_writer *w); /* writes the directory, closes and frees the writer */
 const char *sarpro_hip_tiff_last_error(void);
+/* sysfs cpulist syntax ("0-31,64-95") -> CPU numbers, at most max of them; returns the count, -1 on a syntax error.  The batch
+ * driver binds each worker thread to the CPUs of its GPU's NUMA node with it (csrc/batch.cpp). */
+int sarpro_hip_host_parse_cpulist(const char *s, int *cpus, int max);
 /* the geotransform of a resized / padded product, save.rs:71-81 (pixel size by cols / final_cols, origin by the padding) */
 void sarpro_hip_host_update_geotransform(double gt[6], size_t cols, size_t rows, const sarpro_hip_resize_meta *m);
 

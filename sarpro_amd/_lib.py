@@ -84,11 +84,11 @@ SYMBOLS = [
     "sarpro_hip_comm_destroy",
     "sarpro_hip_host_stats_from_dn_hist", "sarpro_hip_host_window", "sarpro_hip_host_level_lut_u16",
     "sarpro_hip_host_clahe_bin_lut_u16", "sarpro_hip_host_clahe_cdfs", "sarpro_hip_host_u8_rescale_lut",
-    "sarpro_hip_host_synrgb_luts", "sarpro_hip_host_clahe_shape_ok", "sarpro_hip_host_stripe_plan",
+    "sarpro_hip_host_synrgb_luts", "sarpro_hip_host_clahe_shape_ok", "sarpro_hip_host_parse_cpulist", "sarpro_hip_host_stripe_plan",
     "sarpro_hip_host_stats_from_bins4096", "sarpro_hip_host_f32_valid_threshold", "sarpro_hip_host_f32_bin4096_thresholds",
     "sarpro_hip_host_f32_level_thresholds", "sarpro_hip_host_f32_clahe_bin_thresholds",
     "sarpro_hip_resize_output_dims", "sarpro_hip_resize_image_data", "sarpro_hip_resize_image_data_dev",
-    "sarpro_hip_dualpol_synrgb_resized_u16", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
+    "sarpro_hip_dualpol_synrgb_resized_u16", "sarpro_hip_dualpol_synrgb_resized_u16_dev", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
     "sarpro_hip_batch_dualpol_synrgb_resized_u16",
     "sarpro_hip_synth_scene_u16_dev",
 ]
@@ -209,6 +209,8 @@ _proto("sarpro_hip_resize_output_dims", _i, _sz, _sz, _sz, _i, C.POINTER(_sz), C
 _proto("sarpro_hip_resize_image_data", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp, _M)
 _proto("sarpro_hip_resize_image_data_dev", _i, _vp, _vp, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _M)
 _proto("sarpro_hip_dualpol_synrgb_resized_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
+_proto("sarpro_hip_host_parse_cpulist", _i, C.c_char_p, _vp, _i)
+_proto("sarpro_hip_dualpol_synrgb_resized_u16_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_process_band_resized_u16", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_process_band_resized_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_batch_dualpol_synrgb_resized_u16", _i, C.POINTER(_i), _i, C.POINTER(BatchScene), _sz, _i, _i, _sz, _i, _i,

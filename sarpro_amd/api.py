@@ -268,6 +268,15 @@ class Context:
                                                             target_size or 0, int(pad), _vp(rgb), C.byref(m)))
         return rgb, m
 
+    def dev_dualpol_synrgb_resized(self, d_b1: int, d_b2: int, rows: int, cols: int, in_pitch: int, strategy: AutoscaleStrategy,
+                                   target_size: int | None, pad: bool, d_rgb: int, mode: SyntheticRgbMode = SyntheticRgbMode.Default):
+        """dualpol_synrgb_resized with the bands and the compact final_rows x final_cols x 3 RGB raster in device memory."""
+        from ._lib import ResizeMeta
+        m = ResizeMeta()
+        self._chk(lib.sarpro_hip_dualpol_synrgb_resized_u16_dev(self._h, _vp(d_b1), _vp(d_b2), rows, cols, in_pitch, int(strategy), int(mode),
+                                                                target_size or 0, int(pad), _vp(d_rgb), C.byref(m)))
+        return m
+
     def save_processed_image_raster(self, processed: np.ndarray, bit_depth: BitDepth, strategy: AutoscaleStrategy,
                                     target_size: int | None, pad: bool):
         """save_processed_image (save.rs:23-170) up to the raster its writer receives -> (raster, ResizeMeta)."""

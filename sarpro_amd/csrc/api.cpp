@@ -43,7 +43,11 @@ static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
 // ---------------------------------------------------------------------------------------
 namespace sarpro {
 
+TimingHold::TimingHold(sarpro_hip_ctx *c) : ctx(c) { timing_reset(c); ++c->timing_hold; }
+TimingHold::~TimingHold() { --ctx->timing_hold; }
+
 void timing_reset(sarpro_hip_ctx *ctx) {
+    if (ctx->timing_hold > 0) return;
     if (ctx->async_pending && ctx->events_used < 4096) return; // calls enqueued without a synchronisation: their events are read (and dropped) together
     ctx->times.clear();
     ctx->host_times.clear();

@@ -12,9 +12,67 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
+#include <cctype>
+#include <cstdio>
+
 #include "internal.h"
 
 using namespace sarpro;
+
+// "0-31,64-95\n" (sysfs cpulist syntax) -> CPU numbers; returns how many were written (at most max), -1 on a syntax error
+extern "C" int sarpro_hip_host_parse_cpulist(const char *s, int *cpus, int max) {
+    if (!s || (!cpus && max > 0)) return -1;
+    int n = 0;
+    const char *p = s;
+    while (*p) {
+        while (*p == ',' || isspace((unsigned char)*p)) ++p;
+        if (!*p) break;
+        if (!isdigit((unsigned char)*p)) return -1;
+        char *e = nullptr;
+        long a = strtol(p, &e, 10), b = a;
+        p = e;
+        if (*p == '-') {
+            ++p;
+            if (!isdigit((unsigned char)*p)) return -1;
+            b = strtol(p, &e, 10);
+            p = e;
+        }
+        if (b < a) return -1;
+        for (long c = a; c <= b; ++c) { if (n < max) cpus[n] = (int)c; ++n; if (n >= (1 << 20)) return -1; }
+    }
+    return n < max ? n : max;
+}
+
+// A batch worker pulls ~55 GB/s from host memory into its GPU (pinned ring, H2D at PCIe line rate); eight of them on the wrong
+// socket share one inter-socket link.  Bind the calling thread to the CPUs of the NUMA node the GPU hangs off (sysfs:
+// /sys/bus/pci/devices/<bdf>/numa_node, /sys/devices/system/node/node<N>/cpulist) BEFORE its context allocates the pinned
+// ring, so that the ring is first-touched there.  Returns the node, or -1 when the platform says nothing (single node, no
+// sysfs, container without the files): the worker then runs unbound, as before.  SARPRO_HIP_BATCH_NO_NUMA=1 switches it off.
+static int bind_thread_to_device_numa(int dev) {
+    if (getenv("SARPRO_HIP_BATCH_NO_NUMA")) return -1;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) != hipSuccess) return -1;
+    for (char *c = bdf; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    char path[256];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return -1;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    char list[4096] = {0};
+    if (FILE *f = fopen(path, "r")) { const size_t k = fread(list, 1, sizeof(list) - 1, f); list[k] = 0; fclose(f); } else return -1;
+    std::vector<int> cpus(4096);
+    const int n = sarpro_hip_host_parse_cpulist(list, cpus.data(), (int)cpus.size());
+    if (n <= 0) return -1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int i = 0; i < n; ++i) if (cpus[i] >= 0 && cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &set);
+    if (pthread_setaffinity_np(pthread_self(), sizeof(set), &set) != 0) return -1;
+    return node;
+}
 
 #define HIPCHK(ctx, expr)                                                                         \
     do {                                                                                          \
@@ -42,6 +100,7 @@ static int process_band_resized(sarpro_hip_ctx *ctx, const void *in, bool is_f32
     if (rows * cols && (!in || !out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
     const size_t esz = bit_depth == SARPRO_BITDEPTH_U8 ? 1 : 2;
     size_t pitch = 0, fc = 0, fr = 0;
+    TimingHold hold(ctx);
     RETCHK(stage_in_2d(ctx, ctx->stage_in[0], in, rows, cols, is_f32 ? 4 : 2, &pitch));
     HIPCHK(ctx, ctx->stage_out[1].reserve(std::max<size_t>(rows, 1) * pitch * esz));
     // process_scalar_data_pipeline at native resolution (save.rs:52)
@@ -84,6 +143,7 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, i
     std::vector<int> status(nscenes, SARPRO_HIP_OK);
     auto worker = [&](int dev) {
         sarpro_hip_ctx *ctx = nullptr;
+        bind_thread_to_device_numa(dev); // before the context (and its pinned ring) exists
         int rc = sarpro_hip_ctx_create(dev, 0, &ctx);
         if (rc != SARPRO_HIP_OK) { // this worker cannot run; the others take its share
             int expected = SARPRO_HIP_OK;

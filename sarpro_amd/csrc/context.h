@@ -105,7 +105,7 @@ struct sarpro_hip_ctx {
     sarpro::DevBuf qtab;                         // synthetic scene tables
     sarpro::DevBuf f32ws;                        // f32-path workspace
     sarpro::DevBuf f32zone;                      // f32 zone route: samples kept by the min / max pass (a few per cent of the scene)
-    uint32_t resize_key[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // (in, out, elem, precision) of the cached coefficient tables
+    uint32_t resize_key[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}}; // (in, out, elem, precision, window, block span) of the cached coefficient tables
     sarpro::DevBuf resize_tmp, resize_coef[2], resized[2]; // resize path: intermediate image, coefficient tables, resized bands
     sarpro::DevBuf chain_consts;                 // device-resident chain: dB table | suppressed lut_r/g per floor | blue pairs
     sarpro::DevBuf chain_scratch;               // statistics step: per-slice partials | 4096 bins per band
@@ -125,6 +125,7 @@ struct sarpro_hip_ctx {
     // per-kernel timing of the last call
     bool timing = false;
     bool async_dev = false;                      // SARPRO_HIP_CTX_ASYNC_DEV
+    int timing_hold = 0;                         // > 0: timing_reset is a no-op (a composite call holds its steps' event pairs)
     bool async_pending = false;                  // event pairs of enqueued-but-unread calls are kept until read
     std::string time_only;                       // when set, only the kernel of this name is bracketed by events
     std::vector<sarpro::KernelTime> times;

@@ -20,6 +20,13 @@ struct HostTimer {
     ~HostTimer();
 };
 void timing_reset(sarpro_hip_ctx *ctx);
+// A composite entry point (resize flows: several public calls in a row) resets the timers once and holds them, so that
+// last_kernel_times reports every kernel of the composite call and not only those of its last step.
+struct TimingHold {
+    sarpro_hip_ctx *ctx;
+    explicit TimingHold(sarpro_hip_ctx *c);
+    ~TimingHold();
+};
 size_t round_up(size_t x, size_t m);
 int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,
              StripePlan **out);

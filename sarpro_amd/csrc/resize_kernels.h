@@ -14,7 +14,10 @@ struct ResizePassArgs {
     uint32_t max_val;            // 255 or 65535
     const uint32_t *start, *size; // [out_size]
     const int32_t *k;             // [window][out_size]
+    uint32_t window;              // largest tap count
+    uint32_t block_span;          // horizontal pass: max over groups of kResizeHBlock consecutive outputs of start[last] - start[first]
 };
+constexpr uint32_t kResizeHBlock = 256;
 
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s);
 hipError_t launch_resize_v(const ResizePassArgs &a, int elem_size, hipStream_t s);

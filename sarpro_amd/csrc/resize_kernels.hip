@@ -5,10 +5,18 @@
 #include "resize_kernels.h"
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace sarpro {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef SARPRO_RESIZE_H_ROWS
+#define SARPRO_RESIZE_H_ROWS 2
+#endif
+constexpr int kResizeHRows = SARPRO_RESIZE_H_ROWS;  // rows per step of the register-resident horizontal pass
+constexpr int kResizeHVecs = SARPRO_RESIZE_H_ROWS;  // 16-byte vectors a thread stages per step: kResizeHRows * span <= kResizeHVecs * 256 * 16 bytes
 
 // Horizontal pass: one block per source row; the row is staged in LDS, then each thread produces
 // output pixels ox = t, t+256, ... (coefficients tap-major: lanes over ox read consecutive words).
@@ -37,6 +45,153 @@ __global__ __launch_bounds__(kBlock) void k_resize_h(ResizePassArgs a) {
     }
 }
 
+// Horizontal pass, u8, the form the 400 MP -> 2048^2 products take (resize.rs:32-89 on a level raster): a thread OWNS one
+// output column and walks down the rows; its taps never change, so their coefficients live in registers for the whole
+// kernel -- packed the way the pixels arrive.  Per row the block stages the input window of its 256 outputs in LDS (16-byte
+// coalesced loads, double-buffered), and a thread reads the NCHUNK 16-byte chunks that cover its taps.  The i16-range
+// coefficient k of the byte at chunk position p is split into k = 256 hi + lo (hi signed, lo unsigned byte), both stored at byte
+// p of their packed words, zero outside the thread's taps; then
+//     sum px k  =  sum px lo  +  256 (sum (px - 128) hi  +  128 sum hi)
+// is two 4-way byte dot products per dword (v_dot4_u32_u8, v_dot4_i32_i8 on px ^ 0x80) instead of four extracts and four
+// multiply-adds, and every term is an exact integer well inside i32 (|sum px k| < 2^31 is the crate's own guarantee), so the
+// result equals the tap-by-tap i32 sum of the generic kernel bit for bit.  Algorithmic traffic: the band once (1 B/px) in,
+// out_size / in_size of it out.
+template <int NCHUNK>
+__global__ __launch_bounds__(kResizeHBlock) void k_resize_h_u8_dot(ResizePassArgs a, uint32_t rows, uint32_t span_bytes /* LDS bytes per staged row */) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int R = kResizeHRows; // rows per step: one barrier per R rows, R independent sums per thread
+    const uint32_t first = blockIdx.x * kResizeHBlock;
+    const uint32_t ox = first + threadIdx.x;
+    const bool valid = ox < a.out_size;
+    const uint32_t oxc = valid ? ox : a.out_size - 1;
+    const uint32_t x0 = a.start[oxc], n = a.size[oxc];
+    const uint32_t bx0 = a.start[first] & ~15u;   // the block's window starts here (start[] is non-decreasing)
+    const uint32_t xb = x0 & ~15u, lead = x0 - xb; // this thread's first chunk, and where its first tap sits in it
+    uint32_t lo[NCHUNK * 4], hi[NCHUNK * 4];
+    int32_t sumhi = 0;
+#pragma unroll
+    for (int w = 0; w < NCHUNK * 4; ++w) {
+        uint32_t l = 0, h = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int32_t t = (int32_t)(w * 4 + b) - (int32_t)lead;
+            const int32_t k = (valid && t >= 0 && (uint32_t)t < n) ? a.k[(size_t)t * a.out_size + ox] : 0;
+            l |= (uint32_t)(k & 0xFF) << (8 * b);
+            h |= (uint32_t)((k >> 8) & 0xFF) << (8 * b);
+            sumhi += k >> 8;
+        }
+        lo[w] = l; hi[w] = h;
+    }
+    const int32_t base = (a.precision > 0 ? (int32_t)1 << (a.precision - 1) : 0) + 256 * 128 * sumhi;
+    const uint32_t loff = xb - bx0; // byte offset of this thread's first chunk in a staged row
+    const uint8_t *__restrict__ src = reinterpret_cast<const uint8_t *>(a.src);
+    uint8_t *__restrict__ dst = reinterpret_cast<uint8_t *>(a.dst);
+    // staging: the step's R row windows are nvec 16-byte vectors each; thread t carries vectors t, t + 256, ... (kResizeHVecs at most)
+    const uint32_t nvec = span_bytes / 16, ntot = nvec * R;
+    const size_t row_bytes = a.src_pitch; // the window may reach past the row's pitch at the right edge (zero coefficients there): clamped
+    auto fetch = [&](uint32_t r0, uint4 (&q)[kResizeHVecs]) {
+#pragma unroll
+        for (int i = 0; i < kResizeHVecs; ++i) {
+            const uint32_t v = threadIdx.x + (uint32_t)i * kResizeHBlock;
+            q[i] = make_uint4(0, 0, 0, 0);
+            if (v < ntot) {
+                const uint32_t rr = v / nvec, vv = v - rr * nvec;
+                const uint32_t r = min(r0 + rr, rows - 1);
+                const size_t off = (size_t)bx0 + (size_t)vv * 16;
+                const uint8_t *row = src + (size_t)r * row_bytes;
+                if (off < row_bytes) q[i] = *reinterpret_cast<const uint4 *>(row + off); // off and the pitch are multiples of 16: never partial
+            }
+        }
+    };
+    auto put = [&](const uint4 (&q)[kResizeHVecs], unsigned char *buf) {
+#pragma unroll
+        for (int i = 0; i < kResizeHVecs; ++i) {
+            const uint32_t v = threadIdx.x + (uint32_t)i * kResizeHBlock;
+            if (v < ntot) *reinterpret_cast<uint4 *>(buf + (size_t)v * 16) = q[i];
+        }
+    };
+    const uint32_t step = gridDim.y * R;
+    uint32_t r = blockIdx.y * R;
+    if (r >= rows) return;
+    const size_t buf_bytes = (size_t)span_bytes * R;
+    int cur = 0;
+    uint4 q[kResizeHVecs];
+    fetch(r, q);
+    put(q, lds_raw);
+    __syncthreads();
+    for (; r < rows; r += step) {
+        const bool more = r + step < rows;
+        if (more) fetch(r + step, q); // the next step's rows are in flight (registers) while this step is summed
+        const unsigned char *buf = lds_raw + (size_t)cur * buf_bytes + loff;
+        int32_t acc_hi[R];
+        uint32_t acc_lo[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) { acc_hi[j] = 0; acc_lo[j] = 0; }
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint4 px4 = *reinterpret_cast<const uint4 *>(buf + (size_t)j * span_bytes + c * 16);
+                const uint32_t px[4] = {px4.x, px4.y, px4.z, px4.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    acc_lo[j] = __builtin_amdgcn_udot4(px[w], lo[c * 4 + w], acc_lo[j], false);
+                    acc_hi[j] = __builtin_amdgcn_sdot4((int32_t)(px[w] ^ 0x80808080u), (int32_t)hi[c * 4 + w], acc_hi[j], false);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            int32_t o = (base + (int32_t)acc_lo[j] + 256 * acc_hi[j]) >> a.precision;
+            o = o < 0 ? 0 : (o > 255 ? 255 : o);
+            if (valid && r + j < rows) dst[(size_t)(r + j) * a.dst_pitch + ox] = (uint8_t)o;
+        }
+        if (more) put(q, lds_raw + (size_t)(cur ^ 1) * buf_bytes);
+        __syncthreads(); // the next step is staged, and nobody reads `cur` any more
+        cur ^= 1;
+    }
+}
+
+// Vertical pass, u8: a thread owns 8 neighbouring columns of one output row; every tap is one 8-byte load (a wave reads 512
+// contiguous bytes of an intermediate row), the tap's coefficient is block-uniform (scalar).  Exact i32 sums, as the generic
+// kernel's.
+__global__ __launch_bounds__(256) void k_resize_v_u8_x8(ResizePassArgs a) {
+    const uint32_t oy = blockIdx.y;
+    const uint32_t x = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (x >= a.width) return;
+    const uint8_t *__restrict__ src = reinterpret_cast<const uint8_t *>(a.src);
+    const uint32_t y0 = a.start[oy], n = a.size[oy];
+    const int32_t initial = a.precision > 0 ? (int32_t)1 << (a.precision - 1) : 0;
+    int32_t ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss[j] = initial;
+    const bool full = x + 8 <= a.width && a.src_pitch % 8 == 0;
+    for (uint32_t t = 0; t < n; ++t) {
+        const int32_t k = a.k[(size_t)t * a.out_size + oy];
+        const uint8_t *p = src + (size_t)(y0 + t) * a.src_pitch + x;
+        uint32_t w0 = 0, w1 = 0;
+        if (full) { const uint2 q = *reinterpret_cast<const uint2 *>(p); w0 = q.x; w1 = q.y; }
+        else
+            for (uint32_t j = 0; j < 8 && x + j < a.width; ++j) { if (j < 4) w0 |= (uint32_t)p[j] << (8 * j); else w1 |= (uint32_t)p[j] << (8 * (j - 4)); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ss[j] += (int32_t)((w0 >> (8 * j)) & 0xFFu) * k;
+            ss[4 + j] += (int32_t)((w1 >> (8 * j)) & 0xFFu) * k;
+        }
+    }
+    uint8_t *d = reinterpret_cast<uint8_t *>(a.dst) + (size_t)oy * a.dst_pitch + x;
+    uint32_t o0 = 0, o1 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int32_t o = ss[j] >> a.precision;
+        o = o < 0 ? 0 : (o > 255 ? 255 : o);
+        if (j < 4) o0 |= (uint32_t)o << (8 * j); else o1 |= (uint32_t)o << (8 * (j - 4));
+    }
+    if (x + 8 <= a.width && ((reinterpret_cast<uintptr_t>(d) & 7) == 0)) *reinterpret_cast<uint2 *>(d) = make_uint2(o0, o1);
+    else
+        for (uint32_t j = 0; j < 8 && x + j < a.width; ++j) d[j] = (uint8_t)((j < 4 ? o0 >> (8 * j) : o1 >> (8 * (j - 4))) & 0xFFu);
+}
+
 // Vertical pass: thread per output pixel; lanes run along x, so every tap is a coalesced row read.
 template <typename T, typename Acc>
 __global__ __launch_bounds__(kBlock) void k_resize_v(ResizePassArgs a) {
@@ -57,6 +212,31 @@ __global__ __launch_bounds__(kBlock) void k_resize_v(ResizePassArgs a) {
 
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s) {
     if (!rows || !a.out_size) return hipSuccess;
+    if (elem_size == 1 && a.window && !getenv("SARPRO_HIP_RESIZE_GENERIC")) { // the register-resident form where its window fits
+        const uint32_t nchunk = (15 + a.window + 15) / 16;
+        const uint32_t span = (a.block_span + 15 + nchunk * 16 + 15) / 16 * 16; // bytes of a row that one block's 256 outputs read
+        if (nchunk <= 8 && (size_t)span * kResizeHRows <= (size_t)kResizeHVecs * kResizeHBlock * 16 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 &&
+            a.src_pitch % 16 == 0) {
+            const uint32_t gx = (a.out_size + kResizeHBlock - 1) / kResizeHBlock;
+            const uint32_t steps = (rows + kResizeHRows - 1) / kResizeHRows;
+            uint32_t blocks = 2048; // ~2048 blocks, each walks its share of the rows
+            if (const char *e = getenv("SARPRO_HIP_RESIZE_BLOCKS")) blocks = (uint32_t)std::max(1, atoi(e));
+            const uint32_t gy = std::min<uint32_t>(steps, std::max<uint32_t>(1, blocks / gx));
+            const dim3 grid(gx, gy), block(kResizeHBlock);
+            const size_t lds = (size_t)span * kResizeHRows * 2;
+            switch (nchunk) {
+            case 1: hipLaunchKernelGGL(k_resize_h_u8_dot<1>, grid, block, lds, s, a, rows, span); break;
+            case 2: hipLaunchKernelGGL(k_resize_h_u8_dot<2>, grid, block, lds, s, a, rows, span); break;
+            case 3: hipLaunchKernelGGL(k_resize_h_u8_dot<3>, grid, block, lds, s, a, rows, span); break;
+            case 4: hipLaunchKernelGGL(k_resize_h_u8_dot<4>, grid, block, lds, s, a, rows, span); break;
+            case 5: hipLaunchKernelGGL(k_resize_h_u8_dot<5>, grid, block, lds, s, a, rows, span); break;
+            case 6: hipLaunchKernelGGL(k_resize_h_u8_dot<6>, grid, block, lds, s, a, rows, span); break;
+            case 7: hipLaunchKernelGGL(k_resize_h_u8_dot<7>, grid, block, lds, s, a, rows, span); break;
+            default: hipLaunchKernelGGL(k_resize_h_u8_dot<8>, grid, block, lds, s, a, rows, span); break;
+            }
+            return hipGetLastError();
+        }
+    }
     const size_t lds = ((size_t)a.in_size * elem_size + 15) & ~(size_t)15;
     if (lds > kResizeRowLdsMax) {
         if (elem_size == 1) hipLaunchKernelGGL((k_resize_h<uint8_t, int32_t, false>), dim3(rows), dim3(kBlock), 0, s, a);
@@ -74,6 +254,10 @@ hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size
 hipError_t launch_resize_v(const ResizePassArgs &a, int elem_size, hipStream_t s) {
     if (!a.width || !a.out_size) return hipSuccess;
     dim3 grid((a.width + kBlock - 1) / kBlock, a.out_size);
+    if (elem_size == 1 && !getenv("SARPRO_HIP_RESIZE_GENERIC")) {
+        hipLaunchKernelGGL(k_resize_v_u8_x8, dim3((a.width + kBlock * 8 - 1) / (kBlock * 8), a.out_size), dim3(kBlock), 0, s, a);
+        return hipGetLastError();
+    }
     if (elem_size == 1) hipLaunchKernelGGL((k_resize_v<uint8_t, int32_t>), grid, dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((k_resize_v<uint16_t, long long>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();

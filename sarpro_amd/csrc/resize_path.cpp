@@ -53,6 +53,7 @@ int get_coeffs(sarpro_hip_ctx *ctx, int slot, uint32_t in_size, uint32_t out_siz
         a->size = buf.as<uint32_t>() + n;
         a->k = reinterpret_cast<const int32_t *>(buf.as<uint8_t>() + n * 8);
         a->in_size = in_size; a->out_size = out_size; a->precision = (int)key[3];
+        a->window = key[4]; a->block_span = key[5];
         return SARPRO_HIP_OK;
     }
     ResizeCoeffs c;
@@ -71,7 +72,10 @@ int get_coeffs(sarpro_hip_ctx *ctx, int slot, uint32_t in_size, uint32_t out_siz
     a->size = buf.as<uint32_t>() + n;
     a->k = reinterpret_cast<const int32_t *>(buf.as<uint8_t>() + n * 8);
     a->in_size = c.in_size; a->out_size = c.out_size; a->precision = c.precision;
-    key[0] = in_size; key[1] = out_size; key[2] = (uint32_t)elem_size; key[3] = (uint32_t)c.precision;
+    uint32_t span = 0;
+    for (size_t g = 0; g < n; g += kResizeHBlock) span = std::max(span, c.start[std::min(n, g + kResizeHBlock) - 1] - c.start[g]);
+    a->window = c.window; a->block_span = span;
+    key[0] = in_size; key[1] = out_size; key[2] = (uint32_t)elem_size; key[3] = (uint32_t)c.precision; key[4] = c.window; key[5] = span;
     return SARPRO_HIP_OK;
 }
 
@@ -100,7 +104,6 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     if (!do_resize) {
         if (nc && nr)
             HIPCHK(ctx, hipMemcpy2DAsync(dst, out_pitch * elem_size, d_in, in_pitch * elem_size, nc * elem_size, nr, hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return SARPRO_HIP_OK;
     }
     if (!nc || !nr) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "target size collapses a dimension to zero");
@@ -124,8 +127,7 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
         KernelTimer t(ctx, "resize_v");
         HIPCHK(ctx, launch_resize_v(av, elem_size, ctx->stream));
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return SARPRO_HIP_OK;
+    return SARPRO_HIP_OK; // enqueued: the callers synchronise once, after their last step
 }
 
 } // namespace sarpro
@@ -137,7 +139,9 @@ extern "C" int sarpro_hip_resize_image_data_dev(sarpro_hip_ctx *ctx, const void 
     if (bit_depth != SARPRO_BITDEPTH_U8 && bit_depth != SARPRO_BITDEPTH_U16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad bit depth");
     if ((!d_data || !d_out) && cols * rows) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
     timing_reset(ctx);
-    return resize_pad_dev(ctx, d_data, cols, rows, pitch, target_size, bit_depth == SARPRO_BITDEPTH_U8 ? 1 : 2, pad, d_out, out_pitch, meta);
+    RETCHK(resize_pad_dev(ctx, d_data, cols, rows, pitch, target_size, bit_depth == SARPRO_BITDEPTH_U8 ? 1 : 2, pad, d_out, out_pitch, meta));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
 }
 
 extern "C" int sarpro_hip_resize_image_data(sarpro_hip_ctx *ctx, const void *data, size_t cols, size_t rows, size_t target_size,
@@ -165,7 +169,19 @@ extern "C" int sarpro_hip_resize_image_data(sarpro_hip_ctx *ctx, const void *dat
 // the previous chunk and -- across bands -- nothing else overlap; the 2048^2 result is small enough for one copy.
 static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const host_bands[2], sarpro_hip_row_reader reader, void *reader_user,
                                 size_t rows, size_t cols, int strategy, int mode, size_t target_size, int pad, uint8_t *rgb_out,
-                                sarpro_hip_resize_meta *meta);
+                                sarpro_hip_resize_meta *meta, const uint16_t *const dev_bands[2] = nullptr, size_t dev_pitch = 0);
+
+// The same product with the bands and the RGB raster resident in device memory (nothing crosses PCIe): d_rgb_out holds
+// final_rows * final_cols * 3 bytes, compact.  Synchronous like the host form.
+extern "C" int sarpro_hip_dualpol_synrgb_resized_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows,
+                                                         size_t cols, size_t in_pitch, int strategy, int mode, size_t target_size, int pad,
+                                                         uint8_t *d_rgb_out, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (rows * cols && (!d_band1 || !d_band2 || !d_rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (in_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    const uint16_t *none[2] = {nullptr, nullptr}, *dev[2] = {d_band1, d_band2};
+    return dualpol_resized_impl(ctx, none, nullptr, nullptr, rows, cols, strategy, mode, target_size, pad, d_rgb_out, meta, dev, in_pitch);
+}
 
 extern "C" int sarpro_hip_dualpol_synrgb_resized_stream_u16(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *reader_user,
                                                             size_t rows, size_t cols, int strategy, int mode, size_t target_size,
@@ -187,7 +203,7 @@ extern "C" int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const 
 
 static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands[2], sarpro_hip_row_reader reader, void *reader_user,
                                 size_t rows, size_t cols, int strategy, int mode, size_t target_size, int pad, uint8_t *rgb_out,
-                                sarpro_hip_resize_meta *meta) {
+                                sarpro_hip_resize_meta *meta, const uint16_t *const dev_bands[2], size_t dev_pitch) {
     if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
     if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
     size_t fc = 0, fr = 0;
@@ -195,9 +211,15 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
     const size_t r1 = std::max<size_t>(rows, 1);
     const size_t opitch = round_up(std::max<size_t>(fc, 1), 64);
     sarpro_hip_resize_meta m{};
+    TimingHold hold(ctx); // last_kernel_times: every kernel of both bands, the resize passes and the composition
     for (int b = 0; b < 2; ++b) {
         size_t pitch = 0;
-        if (reader) {
+        const uint16_t *d_in = nullptr;
+        if (dev_bands) {
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            pitch = dev_pitch;
+            d_in = dev_bands[b];
+        } else if (reader) {
             pitch = round_up(std::max<size_t>(cols, 1), 64);
             HIPCHK(ctx, hipSetDevice(ctx->device));
             HIPCHK(ctx, ctx->stage_in[0].reserve(r1 * pitch * 2));
@@ -209,7 +231,8 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
         HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * pitch));
         // per-band u8 at native resolution (pipeline.rs:42; Tamed: autoscale.rs:710 with the band's polarisation)
         const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0;
-        RETCHK(band_u8_dev(ctx, ctx->stage_in[0].as<uint16_t>(), rows, cols, pitch, strategy, tamed, ctx->stage_out[0].as<uint8_t>(), pitch));
+        if (!d_in) d_in = ctx->stage_in[0].as<uint16_t>();
+        RETCHK(band_u8_dev(ctx, d_in, rows, cols, pitch, strategy, tamed, ctx->stage_out[0].as<uint8_t>(), pitch));
         HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch));
         RETCHK(resize_pad_dev(ctx, ctx->stage_out[0].p, cols, rows, pitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m));
     }
@@ -223,7 +246,7 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
     HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[2].p, fc, ctx->resized[1].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
     RETCHK(sarpro_hip_synrgb_u8_dev(ctx, mode, strategy, ctx->stage_out[1].as<uint8_t>(), ctx->stage_out[2].as<uint8_t>(), fc * fr,
                                     ctx->stage_out[0].as<uint8_t>()));
-    HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->stage_out[0].p, fc * fr * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->stage_out[0].p, fc * fr * 3, dev_bands ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SARPRO_HIP_OK;
 }

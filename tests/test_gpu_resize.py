@@ -80,3 +80,56 @@ def test_batch_driver_counts_and_continues_on_error(ctx):
     # stop-on-error: one worker, the failing scene first -> nothing else is attempted
     outs, rep, st, rc = S.batch_dualpol_synrgb_resized([0], [bad] + scenes[:2], St.Clahe, 96, True, continue_on_error=False)
     assert rc == S._lib.ERR_UNSUPPORTED_SHAPE and (rep.processed, rep.errors, rep.skipped) == (0, 1, 2)
+
+
+@pytest.mark.parametrize("shape,target", [((300, 4200), 410), ((64, 20000), 2048), ((513, 1030), 77), ((200, 700), 699), ((90, 9000), 200)])
+def test_register_resident_horizontal_pass_equals_generic_kernel_and_oracle(ctx, shape, target, monkeypatch):
+    """u8 rasters take the horizontal pass whose taps live in registers as packed bytes (two 4-way byte dot products per
+    dword); SARPRO_HIP_RESIZE_GENERIC=1 is the tap-by-tap kernel.  Same integers, so the same raster -- and the oracle's."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, shape).astype(np.uint8)
+    a[:, : shape[1] // 7] = 255  # saturated stretch: the largest sums
+    got, _ = ctx.resize_image_data_with_meta(a, target, False)
+    monkeypatch.setenv("SARPRO_HIP_RESIZE_GENERIC", "1")
+    gen, _ = ctx.resize_image_data_with_meta(a, target, False)
+    ref, _ = oracle.resize_image_data_with_meta(a, target, False)
+    assert np.array_equal(got, gen) and np.array_equal(got, ref)
+
+
+def test_400mp_to_2048_resize_is_float_lanczos3_within_one_lsb():
+    """BASELINE configs 2 and 5 at full size: a 20000 x 20000 u8 raster to 2048 x 2048 on the device against a float64 Lanczos3
+    (normalised taps, the published kernel of the crate the reference calls, resize.rs:32-89) evaluated with torch: the two
+    fixed-point passes with their u8 intermediate stay within one level of it -- what test_oracle_kat.py shows for the
+    oracle on a small raster, here for the product at the size the metric is quoted on."""
+    import ctypes as C
+    import torch
+    import sarpro_amd as S
+    from sarpro_amd._lib import lib, ResizeMeta
+    n_in, n_out = 20000, 2048
+    dev = torch.device("cuda")
+    y = torch.arange(n_in, device=dev, dtype=torch.float64)[:, None]
+    x = torch.arange(n_in, device=dev, dtype=torch.float64)[None, :]
+    img = (127.5 + 100.0 * torch.sin(x / 170.0) * torch.cos(y / 230.0) + 20.0 * torch.sin((x + y) / 37.0)).clamp(0, 255).to(torch.uint8)
+
+    def weights(n_in, n_out):  # dense [n_in, n_out] float64: column ox holds the normalised taps of output ox
+        scale = n_in / n_out
+        fs = max(scale, 1.0)
+        c = (torch.arange(n_out, device=dev, dtype=torch.float64) + 0.5) * scale
+        xs = torch.arange(n_in, device=dev, dtype=torch.float64)[:, None]
+        t = (xs - (c[None, :] - 0.5)) / fs
+        lo = torch.clamp(torch.floor(c - 3 * fs), min=0)[None, :]
+        hi = torch.clamp(torch.ceil(c + 3 * fs), max=n_in)[None, :]
+        w = torch.where((t >= -3) & (t < 3) & (xs >= lo) & (xs < hi), torch.sinc(t) * torch.sinc(t / 3), torch.zeros_like(t))
+        return w / w.sum(0, keepdim=True)
+    W = weights(n_in, n_out)
+    ref = W.T @ (img.to(torch.float64) @ W)
+    out = torch.zeros((n_out, n_out), dtype=torch.uint8, device=dev)
+    with S.Context(0, timing=True) as c:
+        m = ResizeMeta()
+        rc = lib.sarpro_hip_resize_image_data_dev(c._h, C.c_void_p(img.data_ptr()), n_in, n_in, n_in, n_out, 0, 0, C.c_void_p(out.data_ptr()), n_out, C.byref(m))
+        assert rc == 0 and (m.final_cols, m.final_rows) == (n_out, n_out)
+        names = [n for n, _ in c.last_kernel_times()]
+        assert "resize_h" in names and "resize_v" in names
+    err = (out.to(torch.float64) - ref).abs().max().item()
+    assert err <= 1.0, err
+    assert int(out.max().item()) > 200 and int(out.min().item()) < 60

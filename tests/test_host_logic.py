@@ -102,3 +102,19 @@ def test_stripe_plan_covers_rows_once():
             assert r0[0] == 0 and sum(nr) == rows
             assert all(r0[k] + nr[k] == (r0[k + 1] if k + 1 < n else rows) for k in range(n))
     assert S.host_stripe_plan(20000, 8)[1] == [2500] * 8  # = CLAHE tile rows of the 400 MP scene
+
+
+def test_parse_cpulist_of_the_batch_workers_numa_binding():
+    """sysfs cpulist syntax -> CPU numbers (csrc/batch.cpp binds each batch worker to its GPU's NUMA node with it)."""
+    import ctypes as C
+    from sarpro_amd._lib import lib
+
+    def parse(s, cap=64):
+        buf = (C.c_int * cap)()
+        n = lib.sarpro_hip_host_parse_cpulist(s.encode(), buf, cap)
+        return n if n < 0 else list(buf[:n])
+    assert parse("0-3,8-9\n") == [0, 1, 2, 3, 8, 9]
+    assert parse("5") == [5]
+    assert parse("") == []
+    assert parse("0-127", cap=4) == [0, 1, 2, 3]  # truncated to the caller's capacity
+    assert parse("3-1") == -1 and parse("a") == -1 and parse("1-") == -1
