@@ -125,6 +125,7 @@ struct sarpro_hip_ctx {
     // per-kernel timing of the last call
     bool timing = false;
     bool async_dev = false;                      // SARPRO_HIP_CTX_ASYNC_DEV
+    bool f32_stripe_open = false;                // an open sarpro_hip_stripe_f32 owns the f32 workspace until its _end
     int timing_hold = 0;                         // > 0: timing_reset is a no-op (a composite call holds its steps' event pairs)
     bool async_pending = false;                  // event pairs of enqueued-but-unread calls are kept until read
     std::string time_only;                       // when set, only the kernel of this name is bracketed by events

@@ -317,6 +317,9 @@ __global__ __launch_bounds__(kSampleBlock) void k_f32_sample_keys(const float *_
                 dst[col + j] = x; // sample_pitch covers vpr * VEC
             }
         }
+        // the scalar form stops at cols: the pad columns up to the sample's pitch (the second pass reads whole rows of it) must
+        // not keep samples of an earlier call
+        for (uint32_t c = vpr * VEC + threadIdx.x; c < sample_pitch; c += kSampleBlock) dst[c] = 0.0f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kSampleKeys; i += kSampleBlock)

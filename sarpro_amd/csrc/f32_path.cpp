@@ -71,6 +71,7 @@ struct F32Band {
     float t_valid = 0.f;
     double mean = 0.0, std_db = 0.0, min_db = 0.0, max_db = 0.0;
     StripePlan *plan = nullptr;
+    bool stripe_handle = false, plan_held = false; // part of an open sarpro_hip_stripe_f32: the plan is reference-held between its phases
     // zone route (percentiles without the 4096-bin sweep): zones chosen from a row sample, resolved after the min / max pass
     bool allow_zones = false, use_zones = false, have_stats = false;
     int nz = 0, znp = 0, zgrid = 0;
@@ -451,6 +452,7 @@ int f32_phase_c(F32Band &B) {
     }
     if (!B.clahe || B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
     RETCHK(get_plan(ctx, B.rows_total, B.cols, B.row0, B.rows, B.vec ? 4 : 1, &B.plan));
+    if (B.stripe_handle && !B.plan_held) { ++B.plan->refs; B.plan_held = true; } // the plan cache never evicts a held plan (dropped in sarpro_hip_stripe_f32_end)
     float *thr = ctx->h_upload.as<float>();
     build_clahe_bin_thresholds(B.stats, thr);
     float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
@@ -588,6 +590,7 @@ int f32_phase_e(F32Band &B) {
 }
 
 int f32_band_run(F32Band &B) {
+    if (B.ctx->f32_stripe_open) return fail(B.ctx, SARPRO_HIP_ERR_INVALID_ARG, "an f32 row stripe is open on this context: its phases share the context's f32 workspace");
     B.rows_total = B.rows; B.row0 = 0;
     B.allow_zones = true;
     RETCHK(f32_phase_a(B));
@@ -674,8 +677,11 @@ static int stripe_f32_begin(sarpro_hip_ctx *ctx, const float *d_in, int op, cons
     if (op >= 0 && (op < SARPRO_OP_SUM || op > SARPRO_OP_LOGRATIO)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad polarisation operation");
     if (rows_local * cols && (!d_out || (op < 0 ? !d_in : (!d_a || !d_b)))) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
     if (row0 + rows_local > rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "stripe outside the scene");
+    if (ctx->f32_stripe_open) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "one open f32 stripe per context (its phases share the context's f32 workspace)");
     sarpro_hip_stripe_f32 *s = new sarpro_hip_stripe_f32();
+    ctx->f32_stripe_open = true;
     F32Band &B = s->B;
+    B.stripe_handle = true;
     B.ctx = ctx; B.d_in = d_in; B.rows = rows_local; B.cols = cols; B.in_pitch = in_pitch;
     B.rows_total = rows_total; B.row0 = row0;
     if (op >= 0) { B.pol.a = d_a; B.pol.b = d_b; B.pol.pitch = in_pitch; B.pol.op = op; B.pol.u16 = elem_u16; }
@@ -757,7 +763,12 @@ extern "C" int sarpro_hip_stripe_f32_phase5(sarpro_hip_stripe_f32 *s, sarpro_hip
     return SARPRO_HIP_OK;
 }
 
-extern "C" void sarpro_hip_stripe_f32_end(sarpro_hip_stripe_f32 *s) { delete s; }
+extern "C" void sarpro_hip_stripe_f32_end(sarpro_hip_stripe_f32 *s) {
+    if (!s) return;
+    if (s->B.plan && s->B.plan_held) --s->B.plan->refs;
+    if (s->B.ctx) s->B.ctx->f32_stripe_open = false;
+    delete s;
+}
 
 // the stripe in one call per rank, reductions over the library's communicator
 static int stripe_f32_run(sarpro_hip_stripe_f32 *s, sarpro_hip_stats *stats_out) {
@@ -766,25 +777,45 @@ static int stripe_f32_run(sarpro_hip_stripe_f32 *s, sarpro_hip_stats *stats_out)
     if (!ctx->comm) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "communicator not initialised");
     const int n = ctx->comm_nranks, me = ctx->comm_rank;
     if (n > 1024) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "more than 1024 ranks");
-    RETCHK(f32_phase_a(B));
+    // A rank that fails locally (bad pitch, a HIP error in its first pass, no plan) must not leave its peers waiting in a
+    // collective: its status travels WITH the first reduction (one more word behind the gathered partials) and in a one-word
+    // reduction after the phase that builds plans and tables; every rank then returns an error together.  A failure between later
+    // collectives (device faults) still needs the communicator torn down by the caller.
+    const int rc_a = f32_phase_a(B);
     // all-gather of the 32-byte partials as an all-reduce(sum) of a buffer that is zero outside the rank's own slot: RCCL adds
     // the words as u64, x + 0 + ... + 0 is exact whatever bit pattern x is
     static_assert(sizeof(sarpro_hip_f32_partial) == 32, "partial = 4 words");
+    HIPCHK(ctx, ctx->f32ws.reserve(kWsBytes)); // (phase a may have failed before it did)
     uint64_t *d_g = reinterpret_cast<uint64_t *>(ctx->f32ws.as<uint8_t>() + kOffPartials);
+    HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
     uint64_t *h_g = ctx->h_small.as<uint64_t>();
-    HIPCHK(ctx, hipMemsetAsync(d_g, 0, 32 * (size_t)n, ctx->stream));
-    std::memcpy(h_g, &B.local, 32);
+    HIPCHK(ctx, hipMemsetAsync(d_g, 0, 32 * (size_t)n + 8, ctx->stream));
+    if (rc_a == SARPRO_HIP_OK) std::memcpy(h_g, &B.local, 32); else std::memset(h_g, 0, 32);
+    h_g[4] = rc_a == SARPRO_HIP_OK ? 0u : 1u;
     HIPCHK(ctx, hipMemcpyAsync(d_g + 4 * me, h_g, 32, hipMemcpyHostToDevice, ctx->stream));
-    RETCHK(comm_allreduce_sum_u64_async(ctx, d_g, 4 * (size_t)n));
-    HIPCHK(ctx, hipMemcpyAsync(h_g, d_g, 32 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_g + 4 * (size_t)n, h_g + 4, 8, hipMemcpyHostToDevice, ctx->stream));
+    RETCHK(comm_allreduce_sum_u64_async(ctx, d_g, 4 * (size_t)n + 1));
+    HIPCHK(ctx, hipMemcpyAsync(h_g, d_g, 32 * (size_t)n + 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (rc_a != SARPRO_HIP_OK) return rc_a;
+    if (h_g[4 * (size_t)n] != 0) return fail(ctx, SARPRO_HIP_ERR_RCCL, "another rank failed in the first pass of the stripe; every rank returns");
     std::vector<sarpro_hip_f32_partial> parts((size_t)n);
     std::memcpy(parts.data(), h_g, 32 * (size_t)n);
     RETCHK(sarpro_hip_host_f32_merge_partials(parts.data(), parts.size(), &B.global));
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     RETCHK(f32_phase_b(B));
     RETCHK(comm_allreduce_sum_u64_async(ctx, reinterpret_cast<uint64_t *>(ws + kOffHist4096), 4096));
-    RETCHK(f32_phase_c(B));
+    {
+        const int rc_c = f32_phase_c(B);
+        h_g[0] = rc_c == SARPRO_HIP_OK ? 0u : 1u;
+        uint64_t *d_s = d_g + 4 * (size_t)n; // (the gathered partials are consumed)
+        HIPCHK(ctx, hipMemcpyAsync(d_s, h_g, 8, hipMemcpyHostToDevice, ctx->stream));
+        RETCHK(comm_allreduce_sum_u64_async(ctx, d_s, 1));
+        HIPCHK(ctx, hipMemcpyAsync(h_g, d_s, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (rc_c != SARPRO_HIP_OK) return rc_c;
+        if (h_g[0] != 0) return fail(ctx, SARPRO_HIP_ERR_RCCL, "another rank failed while building its plan and tables; every rank returns");
+    }
     if (B.clahe) RETCHK(comm_allreduce_sum_u64_async(ctx, reinterpret_cast<uint64_t *>(ws + kOffTileBins), 64 * 256));
     RETCHK(f32_phase_d(B));
     if (B.u8o) RETCHK(comm_allreduce_sum_u64_async(ctx, reinterpret_cast<uint64_t *>(ws + kOffLevelHist), 256));
@@ -799,7 +830,7 @@ extern "C" int sarpro_hip_stripe_run_f32(sarpro_hip_ctx *ctx, const float *d_in,
     sarpro_hip_stripe_f32 *s = nullptr;
     RETCHK(sarpro_hip_stripe_begin_f32(ctx, d_in, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out, out_pitch, &s));
     int rc = stripe_f32_run(s, stats_out);
-    delete s;
+    sarpro_hip_stripe_f32_end(s);
     return rc;
 }
 
@@ -810,7 +841,7 @@ extern "C" int sarpro_hip_stripe_run_polop(sarpro_hip_ctx *ctx, int op, const vo
     RETCHK(sarpro_hip_stripe_begin_polop(ctx, op, d_a, d_b, elem_u16, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out,
                                          out_pitch, &s));
     int rc = stripe_f32_run(s, stats_out);
-    delete s;
+    sarpro_hip_stripe_f32_end(s);
     return rc;
 }
 

@@ -166,7 +166,9 @@ def test_config2_full_size_400mp_clahe_u16_and_log_ratio_band(ctx):
         if st_dev is not None:
             for name in ("valid_count", "p01", "p99", "low_clip", "high_clip"):
                 assert getattr(st, name) == getattr(st_dev, name), name
-        binlut = S.host_clahe_bin_lut_u16(st)
+        from test_gpu_dev import clahe_bin_of_every_dn  # plain-Python restatement of pipeline.rs:18-23 + autoscale.rs:583-591, 261-264
+        binlut = clahe_bin_of_every_dn(st.low_clip, st.high_clip)
+        assert np.array_equal(binlut, S.host_clahe_bin_lut_u16(st))
         bl = torch.from_numpy(binlut.astype(np.int64)).cuda()
         tile_h = np.zeros((64, 256), np.uint64)
         for ty in range(8):

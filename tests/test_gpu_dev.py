@@ -179,6 +179,24 @@ def test_row_stripes_are_bit_identical_to_one_piece(ctx, strategy):
 
 
 # ---------------------------------------------------------------------------- full size
+def clahe_bin_of_every_dn(low_clip: float, high_clip: float) -> np.ndarray:
+    """CLAHE bin of each integer DN, restated from the reference in plain Python (CPython's math.log10 is glibc's log10,
+    SURVEY 8c): pipeline.rs:18-23 (dB of the sample), autoscale.rs:583-591 (clip to the window, normalise by
+    max(high - low, 1)), autoscale.rs:261-264 (clamp to [0, 1], round-half-away(v * 255), clamp to the bins).  DN = 0 is an
+    invalid sample (dB = -100 < -50): it never reaches a bin; entry 0 is left 0."""
+    import math
+    rng = max(high_clip - low_clip, 1.0)
+    out = np.zeros(65536, np.uint8)
+    for dn in range(1, 65536):
+        db = 10.0 * math.log10(max(float(dn), 1e-10))
+        v = (min(max(db, low_clip), high_clip) - low_clip) / rng
+        v = min(max(v, 0.0), 1.0) * 255.0
+        f = math.floor(v)
+        b = int(f) + (1 if v - f >= 0.5 else 0)  # f64::round: half away from zero
+        out[dn] = min(max(b, 0), 255)
+    return out
+
+
 def test_full_size_400mp_parity_by_decomposition(ctx):
     """20000 x 20000 dual-pol CLAHE + synRGB.  The oracle cannot run this in seconds, so every stage
     is re-derived independently at full size: histograms with torch.bincount, CDFs / tables with the
@@ -212,7 +230,8 @@ def test_full_size_400mp_parity_by_decomposition(ctx):
         S.host_window(st, St.Clahe)
         for name in ("valid_count", "min_db", "max_db", "median_db", "p01", "p99", "low_clip", "high_clip"):
             assert getattr(st, name) == getattr(stats[k], name), name
-        binlut = S.host_clahe_bin_lut_u16(st)
+        binlut = clahe_bin_of_every_dn(st.low_clip, st.high_clip)  # numpy / math restatement: nothing of the product on this side
+        assert np.array_equal(binlut, S.host_clahe_bin_lut_u16(st))  # (and the product's host half agrees with it)
         bl = torch.from_numpy(binlut.astype(np.int64)).cuda()
         tile_h = np.zeros((64, 256), np.uint64)
         for ty in range(8):
