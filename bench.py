@@ -138,7 +138,7 @@ def main():
                 wtimes[name] = wtimes.get(name, 0.0) + ms
     dom_warm = max(wtimes, key=wtimes.get) if wtimes else None
     if dom_warm is None:  # --warmup 0: no measurement to choose by; the kernel that dominates this strategy's chain in every profile
-        dom_warm = "clahe_apply_u8_spec" if strategy == AutoscaleStrategy.Clahe else "lut_compose_u16"
+        dom_warm = "clahe_rgb_fused" if strategy == AutoscaleStrategy.Clahe else "lut_compose_u16"
     if dom_warm:
         ctx.time_only(dom_warm)
     dtimes: list[float] = []  # the dominant kernel's launches inside the timed region
@@ -179,7 +179,7 @@ def main():
             per_launch[dom] = float(np.mean(dtimes))
             launches[dom] = len(dtimes) / args.steps
         # algorithmic bytes per pixel PER LAUNCH (both bands), DESIGN.md section 4
-        alg_bpp = {"dn_hist_u16": 4.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0, "lut_compose_u16": 7.0}
+        alg_bpp = {"dn_hist_u16": 4.0, "clahe_rgb_fused": 7.0, "clahe_apply_u8_spec": 6.0, "clahe_apply_u16": 6.0, "compose_u8": 5.0, "lut_apply_u16": 3.0, "lut_compose_u16": 7.0}
         roofline = None
         if dom:
             local_px = rows_local * cols
@@ -406,7 +406,7 @@ def pmc_traffic_gb(kernel, local_px):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r2_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied), scaled
     to this run's pixel count.  None when the kernel has no committed measurement."""
-    names = {"clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_pieces",
+    names = {"clahe_rgb_fused": "k_clahe_rgb_fused", "clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_pieces",
              "compose_u8": "k_compose_u8", "lut_apply_u16": "k_lut_apply_u16", "lut_compose_u16": "k_lut_compose_u16"}
     try:
         with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:

@@ -170,6 +170,16 @@ int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *band1, const
                                   size_t rows, size_t cols, int strategy, int mode,
                                   uint8_t *rgb_out, uint8_t *u8_band1, uint8_t *u8_band2,
                                   sarpro_hip_stats *stats_out);
+/* f32 bands are what the reference's DEFAULT flow hands the raster core: `--size N` resamples on read (sentinel1.rs:1074-1108), so
+ * the bands arrive as non-integer f32.  flags for the f32 dual-pol entry points below:
+ *   SARPRO_HIP_DUALPOL_PLAIN_PIPELINE  api/mod.rs:404-437 (process_safe_to_buffer_with_mode): both bands go through
+ *                                      process_scalar_data_pipeline with the caller's strategy; without it save.rs:324-351 applies:
+ *                                      under Tamed the bands are re-autoscaled band-specifically (autoscale.rs:710-742). */
+#define SARPRO_HIP_DUALPOL_PLAIN_PIPELINE 1u
+/* save.rs:317-367 / api/mod.rs:404-437 with resize -> pad between the per-band autoscale and the composition, host f32 bands in,
+ * final_rows * final_cols * 3 bytes out (sarpro_hip_resize_output_dims); the reference's order, so the suppressed floor sees the
+ * padding.  The resize happens on the u8 level rasters, as in the reference. */
+/* (declared with the resize entry points below: sarpro_hip_dualpol_synrgb_resized_f32 / _f32_dev) */
 
 /* ================= resize + pad (first "next" row) ================= */
 /* Bookkeeping the reference returns next to the raster (resize.rs:98-108). */
@@ -198,6 +208,12 @@ int sarpro_hip_resize_image_data_dev(sarpro_hip_ctx *ctx, const void *d_data, si
 int sarpro_hip_dualpol_synrgb_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *band1, const uint16_t *band2, size_t rows,
                                           size_t cols, int strategy, int mode, size_t target_size, int pad,
                                           uint8_t *rgb_out, sarpro_hip_resize_meta *meta);
+int sarpro_hip_dualpol_synrgb_resized_f32(sarpro_hip_ctx *ctx, const float *band1, const float *band2, size_t rows, size_t cols,
+                                          int strategy, int mode, unsigned flags, size_t target_size, int pad, uint8_t *rgb_out,
+                                          sarpro_hip_resize_meta *meta);
+int sarpro_hip_dualpol_synrgb_resized_f32_dev(sarpro_hip_ctx *ctx, const float *d_band1, const float *d_band2, size_t rows, size_t cols,
+                                              size_t in_pitch, int strategy, int mode, unsigned flags, size_t target_size, int pad,
+                                              uint8_t *d_rgb_out, sarpro_hip_resize_meta *meta);
 /* The same product with both bands and the RGB raster (final_rows * final_cols * 3 bytes, compact) resident in device memory:
  * nothing crosses PCIe.  in_pitch in elements.  Synchronous. */
 int sarpro_hip_dualpol_synrgb_resized_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows,
@@ -235,6 +251,17 @@ int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices
                                                 size_t nscenes, int strategy, int mode, size_t target_size, int pad,
                                                 int continue_on_error, sarpro_hip_batch_report *report);
 
+/* f32 bands (the reference's default, resampled-on-read flow); flags: SARPRO_HIP_DUALPOL_* */
+typedef struct {
+    const float *band1, *band2; /* rows x cols each */
+    size_t rows, cols;
+    uint8_t *rgb_out;           /* final_rows * final_cols * 3 */
+    int *status_out;            /* optional per-scene status */
+} sarpro_hip_batch_scene_f32;
+int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices, const sarpro_hip_batch_scene_f32 *scenes,
+                                                size_t nscenes, int strategy, int mode, unsigned flags, size_t target_size, int pad,
+                                                int continue_on_error, sarpro_hip_batch_report *report);
+
 /* ================= device-pointer entry points ================= */
 /* Same operations on rasters already resident in HBM.  pitch = row stride in elements
  * (>= cols).  The vectorised kernels need base pointers aligned to 16 bytes and
@@ -245,6 +272,10 @@ int sarpro_hip_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in,
 int sarpro_hip_autoscale_band_f32_dev(sarpro_hip_ctx *ctx, const float *d_in, size_t rows,
                                       size_t cols, size_t in_pitch, int strategy, int bit_depth,
                                       void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out);
+/* f32 bands resident in device memory (pitches in elements / pixels); flags: SARPRO_HIP_DUALPOL_*.  Synchronous. */
+int sarpro_hip_dualpol_synrgb_f32_dev(sarpro_hip_ctx *ctx, const float *d_band1, const float *d_band2, size_t rows, size_t cols,
+                                      size_t in_pitch, int strategy, int mode, unsigned flags, uint8_t *d_rgb, size_t rgb_pitch_px,
+                                      uint8_t *d_u8_band1, uint8_t *d_u8_band2, size_t u8_pitch, sarpro_hip_stats *stats_out);
 int sarpro_hip_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1,
                                       const uint16_t *d_band2, size_t rows, size_t cols,
                                       size_t in_pitch, int strategy, int mode, uint8_t *d_rgb,

@@ -10,5 +10,5 @@ from .api import (Context, SarproHipError, Stripe, StripeF32, host_f32_merge_par
                   host_stripe_plan, host_synrgb_luts, host_u8_rescale_lut, host_window,
                   host_f32_valid_threshold, host_f32_bin4096_thresholds, host_f32_level_thresholds,
                   host_f32_clahe_bin_thresholds, host_stats_from_bins4096, resize_output_dims,
-                  batch_dualpol_synrgb_resized, TiffReader, TiffPair, TiffWriter, host_update_geotransform)
+                  batch_dualpol_synrgb_resized, batch_dualpol_synrgb_resized_f32, TiffReader, TiffPair, TiffWriter, host_update_geotransform)
 from ._lib import Stats, F32Partial  # noqa: F401

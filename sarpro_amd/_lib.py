@@ -55,6 +55,11 @@ class BatchScene(C.Structure):
                 ("rgb_out", C.c_void_p), ("status_out", C.POINTER(C.c_int)), ("reader", C.c_void_p), ("reader_user", C.c_void_p)]
 
 
+class BatchSceneF32(C.Structure):
+    _fields_ = [("band1", C.c_void_p), ("band2", C.c_void_p), ("rows", C.c_size_t), ("cols", C.c_size_t),
+                ("rgb_out", C.c_void_p), ("status_out", C.POINTER(C.c_int))]
+
+
 class BatchReport(C.Structure):  # api/mod.rs:453-458
     _fields_ = [("processed", C.c_size_t), ("skipped", C.c_size_t), ("errors", C.c_size_t)]
 
@@ -88,7 +93,8 @@ SYMBOLS = [
     "sarpro_hip_host_stats_from_bins4096", "sarpro_hip_host_f32_valid_threshold", "sarpro_hip_host_f32_bin4096_thresholds",
     "sarpro_hip_host_f32_level_thresholds", "sarpro_hip_host_f32_clahe_bin_thresholds",
     "sarpro_hip_resize_output_dims", "sarpro_hip_resize_image_data", "sarpro_hip_resize_image_data_dev",
-    "sarpro_hip_dualpol_synrgb_resized_u16", "sarpro_hip_dualpol_synrgb_resized_u16_dev", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
+    "sarpro_hip_dualpol_synrgb_resized_u16", "sarpro_hip_dualpol_synrgb_resized_u16_dev", "sarpro_hip_dualpol_synrgb_f32_dev",
+    "sarpro_hip_dualpol_synrgb_resized_f32", "sarpro_hip_dualpol_synrgb_resized_f32_dev", "sarpro_hip_batch_dualpol_synrgb_resized_f32", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
     "sarpro_hip_batch_dualpol_synrgb_resized_u16",
     "sarpro_hip_synth_scene_u16_dev",
 ]
@@ -210,6 +216,11 @@ _proto("sarpro_hip_resize_image_data", _i, _vp, _vp, _sz, _sz, _sz, _i, _i, _vp,
 _proto("sarpro_hip_resize_image_data_dev", _i, _vp, _vp, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _M)
 _proto("sarpro_hip_dualpol_synrgb_resized_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_host_parse_cpulist", _i, C.c_char_p, _vp, _i)
+_u = C.c_uint
+_proto("sarpro_hip_dualpol_synrgb_f32_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _u, _vp, _sz, _vp, _vp, _sz, C.POINTER(Stats))
+_proto("sarpro_hip_dualpol_synrgb_resized_f32", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _u, _sz, _i, _vp, _M)
+_proto("sarpro_hip_dualpol_synrgb_resized_f32_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _u, _sz, _i, _vp, _M)
+_proto("sarpro_hip_batch_dualpol_synrgb_resized_f32", _i, C.POINTER(C.c_int), _i, C.POINTER(BatchSceneF32), _sz, _i, _i, _u, _sz, _i, _i, C.POINTER(BatchReport))
 _proto("sarpro_hip_dualpol_synrgb_resized_u16_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_process_band_resized_u16", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_process_band_resized_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)

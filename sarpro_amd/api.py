@@ -277,6 +277,39 @@ class Context:
                                                                 target_size or 0, int(pad), _vp(d_rgb), C.byref(m)))
         return m
 
+    def dualpol_synrgb_resized_f32(self, band1: np.ndarray, band2: np.ndarray, strategy: AutoscaleStrategy, target_size: int | None, pad: bool,
+                                   mode: SyntheticRgbMode = SyntheticRgbMode.Default, plain_pipeline: bool = False):
+        """f32 bands (resampled on read, the reference's default flow) -> per-band u8 -> resize -> pad -> synRGB.
+        plain_pipeline: api/mod.rs:404-437 (no Tamed re-autoscale); default: save.rs:317-367."""
+        from ._lib import ResizeMeta
+        rows, cols = band1.shape
+        fc, fr = resize_output_dims(cols, rows, target_size, pad)
+        rgb = np.empty((fr, fc, 3), np.uint8)
+        m = ResizeMeta()
+        b1 = np.ascontiguousarray(band1, np.float32)
+        b2 = np.ascontiguousarray(band2, np.float32)
+        self._chk(lib.sarpro_hip_dualpol_synrgb_resized_f32(self._h, _vp(b1), _vp(b2), rows, cols, int(strategy), int(mode), 1 if plain_pipeline else 0,
+                                                            target_size or 0, int(pad), _vp(rgb), C.byref(m)))
+        return rgb, m
+
+    def dev_dualpol_synrgb_f32(self, d_b1: int, d_b2: int, rows: int, cols: int, in_pitch: int, strategy: AutoscaleStrategy, mode: SyntheticRgbMode,
+                               d_rgb: int, rgb_pitch_px: int, d_u8_1: int = 0, d_u8_2: int = 0, u8_pitch: int = 0, plain_pipeline: bool = False,
+                               want_stats: bool = False):
+        st = (Stats * 2)()
+        self._chk(lib.sarpro_hip_dualpol_synrgb_f32_dev(self._h, _vp(d_b1), _vp(d_b2), rows, cols, in_pitch, int(strategy), int(mode),
+                                                        1 if plain_pipeline else 0, _vp(d_rgb), rgb_pitch_px, _vp(d_u8_1) if d_u8_1 else None,
+                                                        _vp(d_u8_2) if d_u8_2 else None, u8_pitch, st if want_stats else None))
+        return [st[0], st[1]] if want_stats else None
+
+    def dev_dualpol_synrgb_resized_f32(self, d_b1: int, d_b2: int, rows: int, cols: int, in_pitch: int, strategy: AutoscaleStrategy,
+                                       target_size: int | None, pad: bool, d_rgb: int, mode: SyntheticRgbMode = SyntheticRgbMode.Default,
+                                       plain_pipeline: bool = False):
+        from ._lib import ResizeMeta
+        m = ResizeMeta()
+        self._chk(lib.sarpro_hip_dualpol_synrgb_resized_f32_dev(self._h, _vp(d_b1), _vp(d_b2), rows, cols, in_pitch, int(strategy), int(mode),
+                                                                1 if plain_pipeline else 0, target_size or 0, int(pad), _vp(d_rgb), C.byref(m)))
+        return m
+
     def save_processed_image_raster(self, processed: np.ndarray, bit_depth: BitDepth, strategy: AutoscaleStrategy,
                                     target_size: int | None, pad: bool):
         """save_processed_image (save.rs:23-170) up to the raster its writer receives -> (raster, ResizeMeta)."""
@@ -683,6 +716,31 @@ def batch_dualpol_synrgb_resized(devices, scenes, strategy, target_size, pad, mo
     rep = BatchReport()
     rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_u16(dev, len(devices), arr, n, int(strategy), int(mode), target_size or 0,
                                                          int(pad), int(continue_on_error), C.byref(rep))
+    st = [stats[i] for i in range(n)]
+    return [o if s == 0 else None for o, s in zip(outs, st)], rep, st, rc
+
+
+def batch_dualpol_synrgb_resized_f32(devices, scenes, strategy, target_size, pad, mode=SyntheticRgbMode.Default, plain_pipeline: bool = False,
+                                     continue_on_error: bool = True):
+    """The batch driver for scenes with f32 bands: scenes = list of (band1_f32, band2_f32).  Returns (RGB arrays or None, BatchReport, statuses, rc)."""
+    from ._lib import BatchReport, BatchSceneF32
+    n = len(scenes)
+    arr = (BatchSceneF32 * max(n, 1))()
+    keep, outs, stats = [], [], (C.c_int * max(n, 1))()
+    for i, (b1, b2) in enumerate(scenes):
+        b1 = np.ascontiguousarray(b1, np.float32)
+        b2 = np.ascontiguousarray(b2, np.float32)
+        rows, cols = b1.shape
+        fc, fr = resize_output_dims(cols, rows, target_size, pad)
+        rgb = np.empty((fr, fc, 3), np.uint8)
+        keep.append((b1, b2))
+        outs.append(rgb)
+        arr[i] = BatchSceneF32(b1.ctypes.data, b2.ctypes.data if b2.shape == b1.shape else None, rows, cols, rgb.ctypes.data,
+                               C.cast(C.byref(stats, i * C.sizeof(C.c_int)), C.POINTER(C.c_int)))
+    dev = (C.c_int * len(devices))(*devices)
+    rep = BatchReport()
+    rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_f32(dev, len(devices), arr, n, int(strategy), int(mode), 1 if plain_pipeline else 0,
+                                                         target_size or 0, int(pad), int(continue_on_error), C.byref(rep))
     st = [stats[i] for i in range(n)]
     return [o if s == 0 else None for o, s in zip(outs, st)], rep, st, rc
 

@@ -206,6 +206,7 @@ namespace sarpro {
 // levels it writes cover 4.5 instead of 5.  Cells and tiles start at multiples of tile_w / 2 (1250 px on the headline scene),
 // so with the vector width alone (8) nearly every segment straddled a line at both ends: +13 % of HBM traffic on the apply
 // pass by the PMC counters (profiles/r2_traffic.json).  The leading lanes of a cell's first strip are masked instead.
+constexpr size_t kRgbItemRows = 256, kSampleItemRows = 1024;
 static size_t strip_align(int vecw) {
     if (vecw != 8 && vecw != 4) return (size_t)vecw;
     size_t a = 64;
@@ -404,6 +405,14 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
             // error margin there
             const bool neg = rw.d < 0.0 || cw.d < 0.0;
             add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw, neg ? 1 : 0);
+            if (vecw == 8 && row0 == 0 && rows_local == rows_total) { // the fused CLAHE -> RGB pass: 16 waves walk an item, so items are taller
+                size_t frows = kRgbItemRows;
+                if (const char *e = getenv("SARPRO_HIP_RGB_ITEM_ROWS")) frows = (size_t)std::max(16, atoi(e)); // experiments
+                add_rects(P->rgb_rects, nullptr, *P, r0, r1, c0, c1, ids, frows, vecw, neg ? 1 : 0);
+                size_t srows = kSampleItemRows;
+                if (const char *e = getenv("SARPRO_HIP_SAMPLE_ITEM_ROWS")) srows = (size_t)std::max(16, atoi(e)); // experiments
+                add_rects(P->sample_rects, nullptr, *P, r0, r1, c0, c1, ids, srows, vecw, neg ? 1 : 0);
+            }
         }
     }
     // launch order = sweep order: consecutive work items cover adjacent column strips of the same row
@@ -418,6 +427,8 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
         sweep_order(P->hist_rects_tiled);
         sweep_order(P->hist_rects_flat);
         sweep_order(P->apply_rects);
+        sweep_order(P->rgb_rects);
+        sweep_order(P->sample_rects);
     }
     if (vecw == 8 && row0 == 0 && rows_local == rows_total && ctx->cu_count > 0) build_pieces(P, std::min(ctx->cu_count, kPieceMaxGrid));
     int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
@@ -425,6 +436,8 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     if (!rc) rc = upload_vec(ctx, P->d_piece_first, P->piece_first.data(), P->piece_first.size() * sizeof(int32_t));
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_rgb_rects, P->rgb_rects.data(), P->rgb_rects.size() * sizeof(Rect));
+    if (!rc) rc = upload_vec(ctx, P->d_sample_rects, P->sample_rects.data(), P->sample_rects.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_tiled, P->hist_sliver_tiled.data(), P->hist_sliver_tiled.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_flat, P->hist_sliver_flat.data(), P->hist_sliver_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_sliver, P->apply_sliver.data(), P->apply_sliver.size() * sizeof(Rect));
@@ -967,6 +980,85 @@ static uint32_t spec_force_flags() { // SARPRO_HIP_SPEC_FORCE=mispredict,nospec:
     return f;
 }
 
+static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_state);
+
+// The fused CLAHE -> RGB route of job_run_chain, from the CDFs on (everything before it is shared with the other routes).
+static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, size_t rgb_pitch_px, uint32_t sample_stride,
+                             sarpro_hip_stats *stats_out) {
+    sarpro_hip_ctx *ctx = J.ctx;
+    uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
+    ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
+    ChainSpecState *d_spec = ctx->spec_state.as<ChainSpecState>();
+    const uint32_t rows = (uint32_t)J.rows_local, cols = (uint32_t)J.cols;
+    RETCHK(ensure_levels(J)); // the fallback's level rasters (allocated once per shape; untouched when the fused RGB stands)
+    HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
+    unsigned long long *sample_hist = ctx->level_hist.as<unsigned long long>(), *exact_hist = sample_hist + 256 * kMaxBands;
+    ClaheApplyArgs a{};
+    for (int b = 0; b < 2; ++b) {
+        a.in[b] = J.d_in[b];
+        a.out[b] = J.d_levels[b];
+        a.cdfs[b] = fa.cdfs[b];
+        a.binlut[b] = fa.binlut[b];
+        a.level_hist[b] = sample_hist + (size_t)b * 256;
+    }
+    a.in_pitch = J.in_pitch; a.out_pitch = J.lvl_pitch;
+    a.row_w = fa.row_w; a.col_w = fa.col_w; a.row_off = fa.row_off;
+    a.max_val = 255.0; a.dev_state = d_state; a.lut_cap = ctx->chain_lut_cap;
+    a.dump = ctx->spec_dump.as<uint8_t>();
+    a.sample_stride = sample_stride; a.sample_phase = sample_stride / 2; a.sample_valid = d_spec->sample_valid;
+    {   // the sampled rows of both bands through the blend: level histogram + valid counts, nothing stored
+        a.hist_mode = 3u;
+        a.rects = J.plan->d_sample_rects.as<Rect>();
+        KernelTimer t(ctx, "clahe_sample");
+        HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->sample_rects.size(), 2, ctx->stream));
+    }
+    {
+        ChainPredictArgs pa{};
+        pa.sample_hist = sample_hist; pa.exact_hist = exact_hist; pa.spec = d_spec; pa.state = d_state;
+        pa.total_px = (unsigned long long)J.rows_total * J.cols;
+        pa.resc_out = state + kStateOffResc; pa.identity_out = state + kStateOffIdent;
+        pa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        pa.tables = ctx->tables.as<uint8_t>();
+        pa.supp_rg = consts + kChainOffSupp; pa.blue_pair_supp = consts + kChainOffBlue;
+        pa.force = spec_force_flags();
+        KernelTimer t(ctx, "chain_predict");
+        HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
+    }
+    {
+        KernelTimer t(ctx, "clahe_rgb_fused");
+        HIPCHK(ctx, launch_clahe_rgb_fused(fa, std::max(ctx->cu_count, 1), ctx->stream));
+    }
+    {   // gated on the verdict: levels of every pixel with the full histogram -> exact tables -> composition
+        KernelTimer t(ctx, "spec_fallback_apply");
+        a.hist_mode = 0u; a.gate = d_spec;
+        a.rects = J.plan->d_apply_rects.as<Rect>();
+        for (int b = 0; b < 2; ++b) a.level_hist[b] = exact_hist + (size_t)b * 256;
+        HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), 2, ctx->stream));
+    }
+    {
+        ChainFinishArgs f{};
+        f.level_hist = exact_hist; f.gate = d_spec;
+        f.total_px = (unsigned long long)J.rows_total * J.cols; f.nbands = 2;
+        f.resc_out = state + kStateOffResc; f.identity_out = state + kStateOffIdent;
+        f.tables = ctx->tables.as<uint8_t>();
+        f.supp_rg = consts + kChainOffSupp; f.blue_pair_supp = consts + kChainOffBlue;
+        f.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        f.suppressed = 1;
+        KernelTimer t(ctx, "chain_finish");
+        HIPCHK(ctx, launch_chain_finish(f, ctx->stream));
+    }
+    {
+        ComposeArgs c{};
+        c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch;
+        c.rgb = d_rgb; c.rgb_pitch_px = rgb_pitch_px; c.rows = rows; c.cols = cols;
+        c.tables = ctx->tables.as<uint8_t>();
+        c.spec = d_spec; c.speculative = 0;
+        KernelTimer t(ctx, "spec_fallback_compose");
+        HIPCHK(ctx, launch_compose_u8(c, 16, ctx->stream));
+    }
+    return chain_tail(J, stats_out, d_state);
+}
+
 static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
                          sarpro_hip_stats *stats_out) {
     sarpro_hip_ctx *ctx = J.ctx;
@@ -1031,6 +1123,22 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         KernelTimer t(ctx, "chain_cdfs");
         HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
                                       J.nbands, ctx->stream));
+    }
+    // Whole dual-pol u8 scene, RGB only: the fused pass (kernels.hip 6a) -- sample-only pass -> identity proof + predicted floor +
+    // tables -> ONE sweep DN, DN -> RGB that verifies the floor; refuted (or unproven, or windows beyond the pass's LDS pool), the
+    // gated apply -> finish -> compose kernels below produce the raster.  SARPRO_HIP_NO_FUSED_RGB=1: the apply + compose route.
+    if (sampled && !d_out[0] && !d_out[1] && !J.plan->rgb_rects.empty() && !getenv("SARPRO_HIP_NO_FUSED_RGB")) {
+        ClaheRgbArgs fa{};
+        for (int b = 0; b < 2; ++b) {
+            fa.in[b] = J.d_in[b];
+            fa.cdfs[b] = ctx->cdfs.as<double>() + (size_t)b * 64 * 256;
+            fa.binlut[b] = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+        }
+        fa.in_pitch = J.in_pitch; fa.rgb = d_rgb; fa.rgb_pitch_px = rgb_pitch_px;
+        fa.rects = J.plan->d_rgb_rects.as<Rect>(); fa.nrects = (int)J.plan->rgb_rects.size();
+        fa.row_w = J.plan->d_row_w.as<RowWeight>(); fa.col_w = J.plan->d_col_w.as<RowWeight>(); fa.row_off = (int32_t)J.row0;
+        fa.dev_state = d_state; fa.spec = d_spec; fa.tables = ctx->tables.as<uint8_t>();
+        if (clahe_rgb_fused_supported(fa)) return job_run_fused_rgb(J, fa, d_rgb, rgb_pitch_px, sample_stride, stats_out);
     }
     // apply: levels into the internal rasters (dual-pol) or straight into the caller's raster (single band)
     const bool direct = !J.synrgb;

@@ -132,10 +132,11 @@ extern "C" int sarpro_hip_process_band_resized_f32(sarpro_hip_ctx *ctx, const fl
     return process_band_resized(ctx, in, true, rows, cols, strategy, bit_depth, target_size, pad, out, meta);
 }
 
-extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, const sarpro_hip_batch_scene *scenes,
-                                                           size_t nscenes, int strategy, int mode, size_t target_size, int pad,
-                                                           int continue_on_error, sarpro_hip_batch_report *report) {
-    if (!devices || ndevices <= 0 || (!scenes && nscenes) || !report) return SARPRO_HIP_ERR_INVALID_ARG;
+// The batch driver proper: one worker thread + context per listed device, scenes dealt dynamically, BatchReport semantics of
+// api/mod.rs:453-458, 518-526.  `run_scene(ctx, i)` processes scene i on the worker's context.
+template <typename RunScene, typename StatusOut>
+static int run_batch(const int *devices, int ndevices, size_t nscenes, int continue_on_error, sarpro_hip_batch_report *report,
+                     RunScene run_scene, StatusOut status_out) {
     std::memset(report, 0, sizeof(*report));
     std::atomic<size_t> next{0}, processed{0}, errors{0};
     std::atomic<bool> stop{false};
@@ -154,10 +155,7 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, i
             if (stop.load()) break;
             const size_t i = next.fetch_add(1);
             if (i >= nscenes) break;
-            const sarpro_hip_batch_scene &sc = scenes[i];
-            if (sc.reader) rc = sarpro_hip_dualpol_synrgb_resized_stream_u16(ctx, sc.reader, sc.reader_user, sc.rows, sc.cols, strategy, mode, target_size, pad, sc.rgb_out, nullptr);
-            else rc = sarpro_hip_dualpol_synrgb_resized_u16(ctx, sc.band1, sc.band2, sc.rows, sc.cols, strategy, mode, target_size, pad,
-                                                       sc.rgb_out, nullptr);
+            rc = run_scene(ctx, i);
             status[i] = rc;
             if (rc == SARPRO_HIP_OK) {
                 processed.fetch_add(1);
@@ -176,9 +174,35 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, i
     report->processed = processed.load();
     report->errors = errors.load();
     report->skipped = nscenes - report->processed - report->errors; // not attempted after a fatal error
-    for (size_t i = 0; i < nscenes && scenes; ++i)
-        if (scenes[i].status_out) *scenes[i].status_out = status[i];
+    for (size_t i = 0; i < nscenes; ++i) status_out(i, status[i]);
     if (report->errors && !continue_on_error) return first_error.load();
     if (report->processed + report->errors == 0 && nscenes) return first_error.load() ? first_error.load() : SARPRO_HIP_ERR_NO_DEVICE;
     return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, const sarpro_hip_batch_scene *scenes,
+                                                           size_t nscenes, int strategy, int mode, size_t target_size, int pad,
+                                                           int continue_on_error, sarpro_hip_batch_report *report) {
+    if (!devices || ndevices <= 0 || (!scenes && nscenes) || !report) return SARPRO_HIP_ERR_INVALID_ARG;
+    return run_batch(devices, ndevices, nscenes, continue_on_error, report,
+                     [&](sarpro_hip_ctx *ctx, size_t i) {
+                         const sarpro_hip_batch_scene &sc = scenes[i];
+                         if (sc.reader) return sarpro_hip_dualpol_synrgb_resized_stream_u16(ctx, sc.reader, sc.reader_user, sc.rows, sc.cols, strategy, mode, target_size, pad, sc.rgb_out, nullptr);
+                         return sarpro_hip_dualpol_synrgb_resized_u16(ctx, sc.band1, sc.band2, sc.rows, sc.cols, strategy, mode, target_size, pad, sc.rgb_out, nullptr);
+                     },
+                     [&](size_t i, int st) { if (scenes[i].status_out) *scenes[i].status_out = st; });
+}
+
+// The same batch for scenes whose bands are f32 (the reference's default flow: resampled on read, sentinel1.rs:1074-1108); flags:
+// SARPRO_HIP_DUALPOL_* (api/mod.rs:404-437 is SARPRO_HIP_DUALPOL_PLAIN_PIPELINE).
+extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices, const sarpro_hip_batch_scene_f32 *scenes,
+                                                           size_t nscenes, int strategy, int mode, unsigned flags, size_t target_size,
+                                                           int pad, int continue_on_error, sarpro_hip_batch_report *report) {
+    if (!devices || ndevices <= 0 || (!scenes && nscenes) || !report) return SARPRO_HIP_ERR_INVALID_ARG;
+    return run_batch(devices, ndevices, nscenes, continue_on_error, report,
+                     [&](sarpro_hip_ctx *ctx, size_t i) {
+                         const sarpro_hip_batch_scene_f32 &sc = scenes[i];
+                         return sarpro_hip_dualpol_synrgb_resized_f32(ctx, sc.band1, sc.band2, sc.rows, sc.cols, strategy, mode, flags, target_size, pad, sc.rgb_out, nullptr);
+                     },
+                     [&](size_t i, int st) { if (scenes[i].status_out) *scenes[i].status_out = st; });
 }

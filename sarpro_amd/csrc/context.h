@@ -59,6 +59,8 @@ struct StripePlan {
     std::vector<Rect> hist_rects_tiled, hist_sliver_tiled; // per-tile DN histogram items
     std::vector<Rect> hist_rects_flat, hist_sliver_flat;   // single-histogram items (non-CLAHE)
     std::vector<Rect> apply_rects, apply_sliver;           // interpolation-cell items
+    std::vector<Rect> rgb_rects, sample_rects;             // whole scene, vecw == 8: taller cell items of the fused CLAHE -> RGB pass (256 rows) and of its sample-only pre-pass (1024 rows)
+    DevBuf d_rgb_rects, d_sample_rects;
     DevBuf d_hist_rects_tiled, d_hist_rects_flat, d_apply_rects, d_row_w, d_col_w;
     DevBuf d_hist_sliver_tiled, d_hist_sliver_flat, d_apply_sliver;
     // whole scene, vecw == 8: every persistent workgroup's pieces, balanced by cost (piece_kernels.hip)
@@ -68,7 +70,7 @@ struct StripePlan {
     DevBuf d_piece_items, d_piece_first;
     int refs = 0; // open stripe handles that hold this plan (the cache never evicts those)
     void release_all() {
-        d_piece_items.release(); d_piece_first.release();
+        d_piece_items.release(); d_piece_first.release(); d_rgb_rects.release(); d_sample_rects.release();
         d_hist_rects_tiled.release(); d_hist_rects_flat.release(); d_apply_rects.release();
         d_hist_sliver_tiled.release(); d_hist_sliver_flat.release(); d_apply_sliver.release();
         d_row_w.release(); d_col_w.release();

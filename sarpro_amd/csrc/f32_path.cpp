@@ -946,33 +946,77 @@ extern "C" int sarpro_hip_db_mask_f32(sarpro_hip_ctx *ctx, const float *in, size
     return SARPRO_HIP_OK;
 }
 
-extern "C" int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *band1, const float *band2, size_t rows,
-                                             size_t cols, int strategy, int mode, uint8_t *rgb_out, uint8_t *u8_band1,
-                                             uint8_t *u8_band2, sarpro_hip_stats *stats_out) {
-    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+// The dual-pol product of f32 bands -- what the reference's DEFAULT flow feeds the raster core: `--size N` resamples on read
+// (sentinel1.rs:1074-1108), so both bands arrive as non-integer f32.  One implementation behind every entry point:
+//   src   host arrays (staged through stage_in[0]) or device rasters with a pitch;
+//   flow  save.rs:317-367 (pipeline(U8) per band; under Tamed the bands are re-autoscaled band-specifically, autoscale.rs:710-742)
+//         or, with SARPRO_HIP_DUALPOL_PLAIN_PIPELINE, api/mod.rs:404-437 (process_safe_to_buffer_with_mode: BOTH bands through
+//         process_scalar_data_pipeline with the caller's strategy, no Tamed re-autoscale);
+//   tail  native resolution (levels -> tables from the combined level histogram -> compose pass), or the resized flow of both
+//         files: per band resize -> pad, then the composition on the final rasters (the suppressed floor sees the padding).
+struct DualF32Src { const float *host[2]; const float *dev[2]; size_t dev_pitch; };
+struct DualF32Out { uint8_t *rgb_host, *rgb_dev; size_t rgb_dev_pitch_px; uint8_t *u8_host[2], *u8_dev[2]; size_t u8_dev_pitch; };
+
+static int dualpol_f32_impl(sarpro_hip_ctx *ctx, const DualF32Src &src, size_t rows, size_t cols, int strategy, int mode, unsigned flags,
+                            bool resized, size_t target_size, int pad, const DualF32Out &out, sarpro_hip_stats *stats_out,
+                            sarpro_hip_resize_meta *meta) {
     if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
     if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
-    if (rows * cols && (!band1 || !band2 || !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
-    timing_reset(ctx);
-    if (rows * cols == 0) return SARPRO_HIP_OK;
-    const float *bands[2] = {band1, band2};
-    size_t pitch = 0;
+    if (flags & ~SARPRO_HIP_DUALPOL_PLAIN_PIPELINE) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "unknown dual-pol flag");
+    TimingHold hold(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t fc = cols, fr = rows;
+    if (resized) RETCHK(sarpro_hip_resize_output_dims(cols, rows, target_size, pad, &fc, &fr));
+    sarpro_hip_resize_meta m{};
+    if (!resized) { m.final_cols = cols; m.final_rows = rows; m.scale_x = m.scale_y = 1.0; }
+    if (rows * cols == 0) { if (meta) *meta = m; return SARPRO_HIP_OK; } // (the resized flow of an empty raster has nothing to compose either)
+    const bool plain = (flags & SARPRO_HIP_DUALPOL_PLAIN_PIPELINE) != 0;
     const size_t r1 = std::max<size_t>(rows, 1);
+    const size_t opitch = round_up(std::max<size_t>(fc, 1), 64);
     uint64_t combined[256];
     std::memset(combined, 0, sizeof(combined));
-    for (int b = 0; b < 2; ++b) { // save.rs:320-351: pipeline(U8), Tamed -> band-specific tamed autoscale
-        RETCHK(stage_in_2d(ctx, ctx->stage_in[0], bands[b], rows, cols, 4, &pitch));
-        HIPCHK(ctx, ctx->levels[b].reserve(r1 * pitch));
+    size_t pitch = 0;
+    for (int b = 0; b < 2; ++b) {
+        const float *d_in = nullptr;
+        if (src.dev[b]) { d_in = src.dev[b]; pitch = src.dev_pitch; }
+        else { RETCHK(stage_in_2d(ctx, ctx->stage_in[0], src.host[b], rows, cols, 4, &pitch)); d_in = ctx->stage_in[0].as<float>(); }
+        const size_t lpitch = round_up(std::max<size_t>(cols, 1), 64);
+        DevBuf &lv = resized ? ctx->stage_out[0] : ctx->levels[b];
+        HIPCHK(ctx, lv.reserve(r1 * lpitch));
         F32Band B;
-        B.ctx = ctx; B.d_in = ctx->stage_in[0].as<float>(); B.rows = rows; B.cols = cols; B.in_pitch = pitch;
+        B.ctx = ctx; B.d_in = d_in; B.rows = rows; B.cols = cols; B.in_pitch = pitch;
         B.strategy = strategy; B.bit_depth = SARPRO_BITDEPTH_U8;
-        B.tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? kTamedCopol : kTamedCrosspol) : 0;
-        B.d_out = ctx->levels[b].p; B.out_pitch = pitch;
+        B.tamed = (!plain && strategy == SARPRO_STRATEGY_TAMED) ? (b == 0 ? kTamedCopol : kTamedCrosspol) : 0;
+        B.d_out = lv.p; B.out_pitch = lpitch;
         B.want_moments = stats_out != nullptr;
         RETCHK(f32_band_run(B));
         if (stats_out) stats_out[b] = B.stats;
         for (int i = 0; i < 256; ++i) combined[i] += B.final_hist[i];
+        if (resized) {
+            HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch));
+            RETCHK(resize_pad_dev(ctx, lv.p, cols, rows, lpitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m));
+        }
+        if (!resized && (out.u8_host[b] || out.u8_dev[b])) {
+            if (out.u8_dev[b]) HIPCHK(ctx, hipMemcpy2DAsync(out.u8_dev[b], out.u8_dev_pitch, lv.p, lpitch, cols, rows, hipMemcpyDeviceToDevice, ctx->stream));
+            else RETCHK(fetch_out_2d(ctx, out.u8_host[b], lv.p, lpitch, cols, rows));
+        }
     }
+    if (meta) *meta = m;
+    if (resized) { // composition on the resized, padded bands (compacted: the flat entry point applies), as the u16 flow does
+        if (!fc || !fr) return SARPRO_HIP_OK;
+        HIPCHK(ctx, ctx->stage_out[1].reserve(fc * fr));
+        HIPCHK(ctx, ctx->stage_out[2].reserve(fc * fr));
+        HIPCHK(ctx, ctx->stage_out[0].reserve(std::max(fc * fr * 3, r1 * round_up(std::max<size_t>(cols, 1), 64))));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[1].p, fc, ctx->resized[0].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[2].p, fc, ctx->resized[1].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
+        RETCHK(sarpro_hip_synrgb_u8_dev(ctx, mode, strategy, ctx->stage_out[1].as<uint8_t>(), ctx->stage_out[2].as<uint8_t>(), fc * fr,
+                                        ctx->stage_out[0].as<uint8_t>()));
+        if (out.rgb_dev) HIPCHK(ctx, hipMemcpyAsync(out.rgb_dev, ctx->stage_out[0].p, fc * fr * 3, hipMemcpyDeviceToDevice, ctx->stream));
+        else HIPCHK(ctx, hipMemcpyAsync(out.rgb_host, ctx->stage_out[0].p, fc * fr * 3, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return SARPRO_HIP_OK;
+    }
+    const size_t lpitch = round_up(std::max<size_t>(cols, 1), 64);
     std::vector<uint8_t> luts(66048), tables(66048);
     int fwc = -1;
     if (strategy == SARPRO_STRATEGY_TAMED || strategy == SARPRO_STRATEGY_CLAHE) { // synthetic_rgb.rs:188-194
@@ -988,19 +1032,61 @@ extern "C" int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *b
     uint8_t *tstage = ctx->h_upload.as<uint8_t>();
     std::memcpy(tstage, tables.data(), 66048);
     HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tstage, 66048, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * pitch * 3));
     ComposeArgs c{};
-    c.b1 = ctx->levels[0].as<uint8_t>(); c.b2 = ctx->levels[1].as<uint8_t>(); c.in_pitch = pitch;
-    c.rgb = ctx->stage_out[0].as<uint8_t>(); c.rgb_pitch_px = pitch; c.rows = (uint32_t)rows; c.cols = (uint32_t)cols;
+    c.b1 = ctx->levels[0].as<uint8_t>(); c.b2 = ctx->levels[1].as<uint8_t>(); c.in_pitch = lpitch;
+    c.rows = (uint32_t)rows; c.cols = (uint32_t)cols;
     c.tables = ctx->tables.as<uint8_t>();
+    if (out.rgb_dev) { c.rgb = out.rgb_dev; c.rgb_pitch_px = out.rgb_dev_pitch_px; }
+    else { HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * lpitch * 3)); c.rgb = ctx->stage_out[0].as<uint8_t>(); c.rgb_pitch_px = lpitch; }
+    const int cvec = (c.rgb_pitch_px % 16 == 0 && (reinterpret_cast<uintptr_t>(c.rgb) & 15) == 0) ? 16 : 1;
     {
         KernelTimer t(ctx, "compose_u8");
-        HIPCHK(ctx, launch_compose_u8(c, 16, ctx->stream));
+        HIPCHK(ctx, launch_compose_u8(c, cvec, ctx->stream));
     }
-    RETCHK(fetch_out_2d(ctx, rgb_out, ctx->stage_out[0].p, pitch * 3, cols * 3, rows));
-    if (u8_band1) RETCHK(fetch_out_2d(ctx, u8_band1, ctx->levels[0].p, pitch, cols, rows));
-    if (u8_band2) RETCHK(fetch_out_2d(ctx, u8_band2, ctx->levels[1].p, pitch, cols, rows));
-    return SARPRO_HIP_OK;
+    if (out.rgb_dev) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return SARPRO_HIP_OK; }
+    return fetch_out_2d(ctx, out.rgb_host, ctx->stage_out[0].p, lpitch * 3, cols * 3, rows);
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_f32(sarpro_hip_ctx *ctx, const float *band1, const float *band2, size_t rows,
+                                             size_t cols, int strategy, int mode, uint8_t *rgb_out, uint8_t *u8_band1,
+                                             uint8_t *u8_band2, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (rows * cols && (!band1 || !band2 || !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    const DualF32Src src{{band1, band2}, {nullptr, nullptr}, 0};
+    const DualF32Out out{rgb_out, nullptr, 0, {u8_band1, u8_band2}, {nullptr, nullptr}, 0};
+    return dualpol_f32_impl(ctx, src, rows, cols, strategy, mode, 0u, false, 0, 0, out, stats_out, nullptr);
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_f32_dev(sarpro_hip_ctx *ctx, const float *d_band1, const float *d_band2, size_t rows, size_t cols,
+                                                 size_t in_pitch, int strategy, int mode, unsigned flags, uint8_t *d_rgb, size_t rgb_pitch_px,
+                                                 uint8_t *d_u8_band1, uint8_t *d_u8_band2, size_t u8_pitch, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (rows * cols && (!d_band1 || !d_band2 || !d_rgb)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (in_pitch < cols || rgb_pitch_px < cols || ((d_u8_band1 || d_u8_band2) && u8_pitch < cols)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    const DualF32Src src{{nullptr, nullptr}, {d_band1, d_band2}, in_pitch};
+    const DualF32Out out{nullptr, d_rgb, rgb_pitch_px, {nullptr, nullptr}, {d_u8_band1, d_u8_band2}, u8_pitch};
+    return dualpol_f32_impl(ctx, src, rows, cols, strategy, mode, flags, false, 0, 0, out, stats_out, nullptr);
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_resized_f32(sarpro_hip_ctx *ctx, const float *band1, const float *band2, size_t rows, size_t cols,
+                                                     int strategy, int mode, unsigned flags, size_t target_size, int pad, uint8_t *rgb_out,
+                                                     sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (rows * cols && (!band1 || !band2 || !rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    const DualF32Src src{{band1, band2}, {nullptr, nullptr}, 0};
+    const DualF32Out out{rgb_out, nullptr, 0, {nullptr, nullptr}, {nullptr, nullptr}, 0};
+    return dualpol_f32_impl(ctx, src, rows, cols, strategy, mode, flags, true, target_size, pad, out, nullptr, meta);
+}
+
+extern "C" int sarpro_hip_dualpol_synrgb_resized_f32_dev(sarpro_hip_ctx *ctx, const float *d_band1, const float *d_band2, size_t rows,
+                                                         size_t cols, size_t in_pitch, int strategy, int mode, unsigned flags,
+                                                         size_t target_size, int pad, uint8_t *d_rgb_out, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (rows * cols && (!d_band1 || !d_band2 || !d_rgb_out)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
+    if (in_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    const DualF32Src src{{nullptr, nullptr}, {d_band1, d_band2}, in_pitch};
+    const DualF32Out out{nullptr, d_rgb_out, 0, {nullptr, nullptr}, {nullptr, nullptr}, 0};
+    return dualpol_f32_impl(ctx, src, rows, cols, strategy, mode, flags, true, target_size, pad, out, nullptr, meta);
 }
 
 // ---------------------------------------------------------------------------------------

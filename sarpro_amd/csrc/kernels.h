@@ -52,6 +52,7 @@ struct ClaheApplyArgs {
                                             // k_level_hist_guard), 2 the bulk form on sampled rows only (see k_chain_predict)
     uint32_t sample_stride, sample_phase;   // hist_mode 2: row r is sampled iff (row_off + r) % sample_stride == sample_phase; stride > 4
     unsigned long long *sample_valid;       // hist_mode 2: [nbands] valid (DN != 0) pixels on the sampled rows, added to
+    const struct ChainSpecState *gate;      // set: the launch is the fused chain's fallback and runs only if gate->verdict != 0
     uint8_t *dump;                          // speculative kernel: kSpecDumpBytes of scratch that edge lanes' full-width stores go to
 };
 
@@ -97,6 +98,25 @@ struct ChainSpecState {
 };
 constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it
 constexpr uint32_t kSpecForceNoSpec = 2u;     // "level 0 or 255 missing": no speculative composition at all
+
+// The fused CLAHE -> RGB pass (kernels.hip 6a): both DN rasters in, interleaved RGB out.
+struct ClaheRgbArgs {
+    const uint16_t *in[kMaxBands];
+    size_t in_pitch;                    // elements, % 8 == 0
+    uint8_t *rgb;
+    size_t rgb_pitch_px;                // % 16 == 0
+    const Rect *rects;                  // interpolation-cell items (512 columns x rows), line-aligned strips
+    int nrects;
+    const double *cdfs[kMaxBands];      // [64][256]
+    const uint8_t *binlut[kMaxBands];   // DN -> CLAHE bin, constant from win_hi on
+    const RowWeight *row_w, *col_w;     // row_w indexed by GLOBAL row
+    int32_t row_off;
+    const struct ChainBandState *dev_state; // win_hi per band
+    struct ChainSpecState *spec;        // spec_ok / floor_pred in, counts and verdict out
+    const uint8_t *tables;              // R2[256] | G2[256] | B2[65536] for the predicted floor
+};
+bool clahe_rgb_fused_supported(const ClaheRgbArgs &a);
+hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid /* persistent workgroups: one per CU */, hipStream_t s);
 
 constexpr size_t kSpecDumpBytes = 256 * 1024;
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);

@@ -576,7 +576,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 
     auto process_row = [&](int r, const U16Vec<VEC> &v, const double dy_v, const bool sampled) { // dy, sampled: wave-uniform
         // (counted first: the row's samples are then dead after the offset lookups, not held across the blend)
-        if (HIST == 2 && count_levels && sampled) { // valid samples of this row: non-zero halfwords, kept ones only
+        if (HIST >= 2 && count_levels && sampled) { // valid samples of this row: non-zero halfwords, kept ones only
             const uint32_t w[4] = {v.v.x, v.v.y, v.v.z, v.v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -666,7 +666,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         }
         pk[0] &= keep[0];
         pk[1] &= keep[1];
-        if (count_levels && (HIST != 2 || sampled)) { // level 0 (incl. masked edge samples) is not counted: bin 0 = pixels - others
+        if (count_levels && (HIST < 2 || sampled)) { // level 0 (incl. masked edge samples) is not counted: bin 0 = pixels - others
             // one predicated ds_add_u32 per pixel, EXEC narrowed to the lanes that count (a shared bin 0 would serialise
             // the no-data wedge); written out because the compiler wraps each predicated atomic in a branch
             const uint32_t one = 1u, two = 2u, zero = 0u, lim = kPartialHistLevels;
@@ -710,6 +710,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 }
             }
         }
+        if (HIST == 3) return; // the sample-only pass writes no levels
         uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out[band]) + (size_t)r * a.out_pitch + col;
         // Every lane issues the 8-byte store, edge lanes into the scratch line: a store inside a divergent branch sits
         // behind an `execz` skip, the waitcnt pass then sees a path through the row without a store and makes the next
@@ -726,7 +727,27 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         }
     };
 
-    if (col < rc.c1 && col + VEC > rc.c0) {
+    if (HIST == 3) { // sample-only pass (the fused CLAHE -> RGB chain's floor prediction): the item's sampled rows, nothing else
+        if (col < rc.c1 && col + VEC > rc.c0) {
+            const int stride = (int)a.sample_stride;
+            const int first = rc.r0 + ((int)a.sample_phase - (a.row_off + rc.r0) % stride + stride) % stride;
+            const int step = kWavesPerBlock * stride;
+            const uint16_t *p = in + col;
+            int r = __builtin_amdgcn_readfirstlane(first + wave_id() * stride);
+            if (r < rc.r1) { // (three rows in flight instead of one measured SLOWER here: 0.069 against 0.057 ms)
+                U16Vec<VEC> cur = SPEC_LOAD(p + (size_t)r * a.in_pitch);
+                double dy = row_w[r].d;
+                for (; r < rc.r1; r += step) {
+                    const int rn = min(r + step, rc.r1 - 1); // (a redundant load at the end, so that the prefetch is unconditional)
+                    const U16Vec<VEC> nxt = SPEC_LOAD(p + (size_t)rn * a.in_pitch);
+                    const double dyn = row_w[rn].d;
+                    process_row(r, cur, dy, true);
+                    cur = nxt;
+                    dy = dyn;
+                }
+            }
+        }
+    } else if (col < rc.c1 && col + VEC > rc.c0) {
         const int step = kWavesPerBlock;
         const uint16_t *p = in + col;
         int r = __builtin_amdgcn_readfirstlane(rc.r0 + wave_id());
@@ -736,24 +757,6 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         // the next row is always loaded (clamped to the item's last row: at worst one redundant load), so the
         // load is unconditional and the compiler can wait with vmcnt(1) -- a conditional prefetch made it wait
         // vmcnt(0) right after issuing it, i.e. no overlap at all inside a wave
-#ifdef SARPRO_PREFETCH2 // experiment: two rows in flight behind the one being processed
-        if (r < rc.r1) {
-            const int lastr = rc.r1 - 1;
-            U16Vec<VEC> cur = SPEC_LOAD(p + (size_t)r * a.in_pitch);
-            double dy = row_w[r].d;
-            int r1n = min(r + step, lastr);
-            U16Vec<VEC> n1 = SPEC_LOAD(p + (size_t)r1n * a.in_pitch);
-            double dy1 = row_w[r1n].d;
-            for (; r < rc.r1; r += step) {
-                const int rn = min(r + 2 * step, lastr);
-                const U16Vec<VEC> n2 = SPEC_LOAD(p + (size_t)rn * a.in_pitch);
-                const double dy2 = row_w[rn].d;
-                process_row(r, cur, dy, smod == phase);
-                cur = n1; dy = dy1; n1 = n2; dy1 = dy2;
-                if (HIST == 2) { smod += step; if (smod >= stride) smod -= stride; }
-            }
-        }
-#else
         if (r < rc.r1) {
             U16Vec<VEC> cur = SPEC_LOAD(p + (size_t)r * a.in_pitch);
             double dy = row_w[r].d; // exact dy of the row, wave-uniform, prefetched like the row itself
@@ -777,11 +780,10 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 if (HIST == 2) { smod += step; if (smod >= stride) smod -= stride; }
             }
         }
-#endif
     }
     if (PARTIAL_HIST && count_levels && lane_high) // lane_high > 0 implies lane_max >= kPartialHistLevels
         atomicAdd(reinterpret_cast<uint32_t *>(lds + SpecLds::hist) + lane_max, lane_high);
-    if (HIST == 2 && count_levels) {
+    if (HIST >= 2 && count_levels) {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) lane_valid += __shfl_xor(lane_valid, m, 64);
         if (lane_id() == 0 && lane_valid) atomicAdd(reinterpret_cast<uint32_t *>(lds + SpecLds::hist) + 320, lane_valid);
@@ -792,6 +794,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 template <int HIST>
 __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
+    if (a.gate && a.gate->verdict == 0) return; // fallback launch of the fused chain: the fused pass's RGB stands
     const Rect rc = a.rects[blockIdx.x];
     const int band = blockIdx.y;
     const double *__restrict__ cdfs = a.cdfs[band];
@@ -837,9 +840,23 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             const int c2 = rc.cstart + i;
             *reinterpret_cast<double *>(lds + SpecLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
         }
-        uint16_t *lut = reinterpret_cast<uint16_t *>(lds + SpecLds::lut);
+        // DN -> offset table: 16 DNs per thread and load (one round trip to L2 instead of one per 256 entries: the per-item staging
+        // of this kernel was ~25 us, visible wherever items are short -- the sample-only pass, small scenes)
         if (lut_lds)
-            for (uint32_t i = b; i <= win_hi; i += kBlock) lut[i] = (uint16_t)(SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u));
+            for (uint32_t g = b; g * 16u <= win_hi; g += kBlock) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(glut + g * 16u);
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                uint32_t e[8];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t dn = g * 16u + k, bin = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    const uint32_t o16 = SpecLds::cdf32 + cdf32_offset(dn ? bin : 256u);
+                    e[k >> 1] = (k & 1) ? (e[k >> 1] | (o16 << 16)) : o16;
+                }
+                uint4 *dst = reinterpret_cast<uint4 *>(lds + SpecLds::lut + g * 32u);
+                dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
+                dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
+            }
     }
     __syncthreads();
     if (lut_lds) clahe_spec_rows<true, HIST>(a, rc, band, lds, win_hi);
@@ -852,14 +869,14 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
         // under-represented (post-stratification by work item; an unweighted sample was off by up to 0.2 % on the headline scene,
         // whose texture classes change every 1250 rows)
         unsigned long long w = 1ull;
-        if (HIST == 2) {
+        if (HIST >= 2) {
             const int stride = (int)a.sample_stride, m = (a.row_off + rc.r0) % stride;
             const int first = rc.r0 + ((int)a.sample_phase - m + stride) % stride;
             const int cnt = first < rc.r1 ? (rc.r1 - 1 - first) / stride + 1 : 0;
             w = cnt ? ((unsigned long long)(rc.r1 - rc.r0) * kSampleWeightOne + (unsigned)cnt / 2) / (unsigned)cnt : 0ull;
         }
         if (n && threadIdx.x) atomicAdd(&ghist[threadIdx.x], (unsigned long long)n * w); // bin 0 restored by the consumer
-        if (HIST == 2 && threadIdx.x == 0) {
+        if (HIST >= 2 && threadIdx.x == 0) {
             const uint32_t nv = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[320];
             if (nv) atomicAdd(&a.sample_valid[band], (unsigned long long)nv * w);
         }
@@ -1102,6 +1119,296 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
                 const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
                 sp->verdict = ok ? 0u : 1u;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 6a. CLAHE blend of BOTH bands + suppressed synRGB composition in ONE sweep (the headline's fused pass): 4 B/px read (two u16
+//     DN rasters) + 3 B/px written (interleaved RGB) = the 7 B/px of algorithmic traffic of save.rs:317-367 at native
+//     resolution; no u8 level raster exists.  What stands between the blend and the composition in the reference -- the u8
+//     rescale of each band (autoscale.rs:348-364) and the floor of the combined level histogram (synthetic_rgb.rs:99-113) -- is
+//     proven / predicted from a sample-only pass over the same blend (kernel 4b, HIST == 3) by k_chain_predict, and the floor is
+//     VERIFIED here exactly (the v_sad_u8 counts of kernel 6's speculative form, over the level bytes of both bands while they
+//     are in registers); refuted, the gated apply -> finish -> compose kernels produce the raster instead.
+//     Round 2's first attempt at this sweep lost to apply + compose; what differs: line-aligned column strips
+//     (the misaligned ones cost the apply pass 10 %), 8 pixels per lane, the exact path inline instead of a queue + fixup pass
+//     (0.18 ms), a sample-only pre-pass over tall items instead of a stratified sample (0.07 + 0.02 ms).
+//     One persistent 1024-thread workgroup per CU; LDS (bytes): compose tables 66,048 | per-wave RGB stage 16 x 1,536 (it also
+//     stages the bin-indexed entries while an item's tables are built) | f64 CDFs of both bands 2 x 257 x 32 (exact path) |
+//     f64 dx of the strip's 512 columns | DN -> bin bytes | the pool of DN-INDEXED 16-byte entries (c00, c10, c01 - c00,
+//     c11 - c10) of both bands: the pixel's gather address is its clamped DN x 16, no offset table in between.  Both windows
+//     must fit the pool (kRgbPoolEntries); otherwise the pass leaves the verdict at "refuted" and the gated kernels run.
+//     Per pixel and band: v_pk_min_u16 (clamp, 2 px) -> SDWA shift -> one 16-B gather -> 4 FMA + add -> 2 v_cvt_pk_u8_f32,
+//     margin test and exact f64 path exactly as in kernel 4b (same bounds: the entry values and operation order are the same).
+// ------------------------------------------------------------------------------------
+constexpr int kRgbBlock = 1024, kRgbWaves = kRgbBlock / kWave;
+constexpr uint32_t kRgbPoolEntries = 3072;
+struct RgbLds {
+    static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[65536]
+    static constexpr uint32_t stage = kComposeTableBytes;                   // [16][1536] RGB of a wave-row | tmp32 [2][257] float4 while staging
+    static constexpr uint32_t cdf64 = stage + kRgbWaves * 1536;             // [2][257][4] double
+    static constexpr uint32_t colw = cdf64 + 2 * 257 * 32;                  // [512] double
+    static constexpr uint32_t binof = colw + 512 * 8;                       // [kRgbPoolEntries] u8: CLAHE bin of the entry's DN
+    static constexpr uint32_t pool = binof + kRgbPoolEntries;               // [kRgbPoolEntries] float4
+    static constexpr uint32_t misc = pool + kRgbPoolEntries * 16;           // scratch words of the epilogue
+    static constexpr uint32_t total = misc + 64;
+};
+static_assert(RgbLds::total <= 160 * 1024, "fused pass: LDS budget");
+static_assert(RgbLds::stage % 16 == 0 && RgbLds::pool % 16 == 0 && RgbLds::cdf64 % 16 == 0, "alignment");
+static_assert(kRgbPoolEntries / 4 + 2 <= kRgbBlock, "one pass of the workgroup expands the whole pool");
+
+__global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    constexpr int VEC = 8;
+    ChainSpecState *sp = a.spec;
+    if (!sp->spec_ok) return;
+    const uint32_t win_hi[2] = {a.dev_state[0].win_hi, a.dev_state[1].win_hi};
+    if ((uint64_t)win_hi[0] + win_hi[1] + 2u > kRgbPoolEntries) return; // windows do not fit: the verdict stays "refuted", the gated kernels run
+    const uint32_t kb[2] = {0u, win_hi[0] + 1u}; // first pool entry of each band
+    const int lane = lane_id(), wave = wave_id();
+    {   // compose tables, once per workgroup
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + RgbLds::tables);
+        for (int i = threadIdx.x; i < kComposeTableBytes / 16; i += kRgbBlock) dst[i] = src[i];
+    }
+    const uint32_t fpred = (uint32_t)sp->floor_pred;
+    const uint32_t t4[3] = {(fpred ? fpred - 1u : 0u) * 0x01010101u, fpred * 0x01010101u, (fpred + 1u) * 0x01010101u};
+    uint32_t sad[3] = {0u, 0u, 0u}, n_all = 0u, n_kept = 0u; // this lane's |x - T| sums, level bytes seen (8 per band-row), kept ones
+    const RowWeight *__restrict__ row_w = a.row_w + a.row_off;
+    const uint32_t stage_w = RgbLds::stage + (uint32_t)wave * 1536u;
+
+    for (int item = blockIdx.x; item < a.nrects; item += gridDim.x) {
+        const Rect rc = a.rects[item];
+        __syncthreads(); // the previous item's rows are done (its tables may go; the compose tables have landed)
+        // ---- this item's tables: bin-indexed (f64 for the exact path, biased f32 for staging), then expanded by DN
+        for (int t = threadIdx.x; t < 2 * 257; t += kRgbBlock) {
+            const int b = t / 257, bin = t - b * 257;
+            double c[4] = {0.0, 0.0, 0.0, 0.0};
+            if (bin < 256) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k] = a.cdfs[b][(size_t)rc.id[k] * 256 + bin];
+            }
+            *reinterpret_cast<double4 *>(lds + RgbLds::cdf64 + (b * 257 + bin) * 32) = make_double4(c[0], c[1], c[2], c[3]);
+            // the f32 entry: as kernel 4b stages it (saturated interior bins -> 1.001, all-zero bins and the invalid entry -> 0.5 / 255)
+            const bool saturated = bin < 256 && c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0 && !(rc.pad[0] & 1);
+            const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
+            const float kz = 0.5f / 255.0f;
+            const float c00 = (float)c[0], c01 = (float)c[1], c10 = (float)c[2], c11 = (float)c[3];
+            const float4 e32 = saturated ? make_float4(1.001f, 1.001f, 0.0f, 0.0f)
+                               : zero    ? make_float4(kz, kz, 0.0f, 0.0f)
+                                         : make_float4(c00, c10, c01 - c00, c11 - c10);
+            *reinterpret_cast<float4 *>(lds + RgbLds::stage + (b * 257 + bin) * 16) = e32;
+        }
+        for (int i = threadIdx.x; i < 512; i += kRgbBlock) {
+            const int c2 = rc.cstart + i;
+            *reinterpret_cast<double *>(lds + RgbLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
+        }
+        // DN -> bin of both windows, FOUR DNs per thread and load: the whole pool in one pass of the workgroup, i.e. one round trip
+        // to L2, issued with the CDF loads above (a byte per thread and pass made three dependent round trips per item)
+        uint32_t q4 = 0u, qdn = 0u;
+        int qb = -1;
+        {
+            const uint32_t n0q = (win_hi[0] >> 2) + 1u, n1q = (win_hi[1] >> 2) + 1u; // n0q + n1q <= kRgbPoolEntries / 4 + 2 <= kRgbBlock
+            if (threadIdx.x < n0q + n1q) {
+                qb = threadIdx.x >= n0q ? 1 : 0;
+                qdn = (threadIdx.x - (qb ? n0q : 0u)) * 4u;
+                q4 = *reinterpret_cast<const uint32_t *>(a.binlut[qb] + qdn);
+            }
+        }
+        __syncthreads();
+        if (qb >= 0) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t dn = qdn + k;
+                if (dn <= win_hi[qb]) {
+                    const uint32_t bin = dn ? (q4 >> (8 * k)) & 0xFFu : 256u;
+                    const uint32_t i = kb[qb] + dn;
+                    *reinterpret_cast<float4 *>(lds + RgbLds::pool + i * 16) = *reinterpret_cast<const float4 *>(lds + RgbLds::stage + (qb * 257 + bin) * 16);
+                    lds[RgbLds::binof + i] = (uint8_t)bin; // (DN = 0 never reaches the exact path: its biased entry is never "near")
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- per-lane geometry of the strip
+        const int col = rc.cstart + lane * VEC;
+        uint32_t keep[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (col + j >= rc.c0 && col + j < rc.c1) keep[j >> 2] |= 0xFFu << (8 * (j & 3));
+        const uint32_t nkeep = (uint32_t)__builtin_popcount(keep[0] & 0x01010101u) + (uint32_t)__builtin_popcount(keep[1] & 0x01010101u);
+        // transposed store: the wave-row's 1536 RGB bytes leave as 96 chunks of 16 B (lanes 0..63, then lanes 0..31).  A chunk is
+        // stored whole only if every pixel it touches belongs to the item; a kept pixel with a byte in a chunk that is not
+        // stored goes out byte by byte from its own lane.  All-full strips (three of five per cell row): every chunk is safe.
+        auto chunk_safe = [&](int k) {
+            const int plo = (16 * k) / 3, phi = (16 * k + 15) / 3;
+            return rc.cstart + plo >= rc.c0 && rc.cstart + phi < rc.c1;
+        };
+        const bool safe1 = chunk_safe(lane), safe2 = lane < 32 && chunk_safe(64 + lane);
+        uint32_t bytewise = 0u;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int pr = lane * VEC + j;
+            const bool kept = col + j >= rc.c0 && col + j < rc.c1;
+            if (kept && !(chunk_safe((3 * pr) / 16) && chunk_safe((3 * pr + 2) / 16))) bytewise |= 1u << j;
+        }
+        float dxf[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dxf[j] = (float)*reinterpret_cast<const double *>(lds + RgbLds::colw + (lane * VEC + j) * 8);
+        const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner;
+        const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
+
+        // the levels of one band's 8 samples, packed as bytes; masked to 0 outside the item
+        auto band_levels = [&](int b, const uint4 &v, const double dy, const double omdy, const float wy1, const float wy2, uint32_t (&pk)[2]) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t hi2 = win_hi[b] | (win_hi[b] << 16);
+            const uint32_t pbase = RgbLds::pool + kb[b] * 16u;
+            uint32_t off[VEC];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+                const v2us c = __builtin_elementwise_min(__builtin_bit_cast(v2us, w[k]), __builtin_bit_cast(v2us, hi2));
+                const uint32_t cw = __builtin_bit_cast(uint32_t, c);
+                uint32_t a0, a1;
+                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(4u), "v"(cw));
+                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(4u), "v"(cw));
+                off[2 * k] = a0; off[2 * k + 1] = a1; // clamped DN x 16
+            }
+            uint32_t pb[2] = {0u, 0u};
+            pk[0] = 0u; pk[1] = 0u;
+#ifndef SARPRO_RGB_AHEAD
+#define SARPRO_RGB_AHEAD 2
+#endif
+            constexpr int kAhead = SARPRO_RGB_AHEAD;
+            v4f cq[VEC];
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) cq[j] = LDS_AT(v4f, pbase + off[j]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (j + kAhead < VEC) cq[j + kAhead] = LDS_AT(v4f, pbase + off[j + kAhead]);
+                const v4f c4 = cq[j];
+                const float top = fmaf(c4.z, dxf[j], c4.x);
+                const float bottom = fmaf(c4.w, dxf[j], c4.y);
+                const float ya = fmaf(bottom, wy2, fmaf(top, wy1, bias));
+                const float yb = ya + two_delta;
+                pk[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(ya, j & 3, pk[j >> 2]);
+                pb[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(yb, j & 3, pb[j >> 2]);
+            }
+            const uint32_t d0 = pk[0] ^ pb[0], d1 = pk[1] ^ pb[1];
+#ifdef SARPRO_ABL_RGB_NOEXACT
+            if (false) {
+#else
+            if (d0 | d1) { // rare: the exact f64 sequence of autoscale.rs:327-329, 602
+#endif
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if (((j < 4 ? d0 : d1) >> (8 * (j & 3))) & 0xFFu) {
+                        const uint32_t bin = lds[RgbLds::binof + kb[b] + (off[j] >> 4)];
+                        const double4 c4 = *reinterpret_cast<const double4 *>(lds + RgbLds::cdf64 + (b * 257 + bin) * 32);
+                        const double dx = *reinterpret_cast<const double *>(lds + RgbLds::colw + (lane * VEC + j) * 8);
+                        const double top = c4.x * (1.0 - dx) + c4.y * dx;
+                        const double bottom = c4.z * (1.0 - dx) + c4.w * dx;
+                        double o = top * omdy + bottom * dy;
+                        o = fmin(fmax(o, 0.0), 1.0);
+                        const uint32_t level = (uint32_t)(o * 255.0);
+                        const uint32_t sh = 8 * (j & 3);
+                        pk[j >> 2] = (pk[j >> 2] & ~(0xFFu << sh)) | (level << sh);
+                    }
+                }
+            }
+            pk[0] &= keep[0];
+            pk[1] &= keep[1];
+        };
+
+        {   // EVERY lane walks the rows, also those whose 8 columns lie outside the item (their levels are masked, nothing of
+            // theirs is stored): the transposed store hands chunk `lane` to lane `lane`, whatever columns that lane computes
+            const int step = kRgbWaves;
+            const int lcol = min(col, (int)a.in_pitch - VEC); // a lane past the row's pitch loads (and ignores) the row's last vector
+            const uint16_t *p0 = a.in[0] + lcol, *p1 = a.in[1] + lcol;
+            int r = __builtin_amdgcn_readfirstlane(rc.r0 + wave);
+            if (r < rc.r1) {
+                uint4 c0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)r * a.in_pitch), c1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)r * a.in_pitch);
+                double dyv = row_w[r].d;
+                for (; r < rc.r1; r += step) {
+                    const int rn = min(r + step, rc.r1 - 1); // the next row of both bands is always in flight
+                    const uint4 n0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)rn * a.in_pitch), n1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)rn * a.in_pitch);
+                    const double dyn = row_w[rn].d;
+                    const double dy = to_sgpr(dyv), omdy = to_sgpr(1.0 - dy);
+                    const float wy1 = to_sgpr((float)omdy * 255.0f), wy2 = to_sgpr((float)dy * 255.0f);
+                    uint32_t l1[2], l2[2];
+                    band_levels(0, c0, dy, omdy, wy1, wy2, l1);
+                    band_levels(1, c1, dy, omdy, wy1, wy2, l2);
+                    // verification counts (kernel 6, SPEC): |x - T| over the 16 level bytes
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        sad[k] = __builtin_amdgcn_sad_u8(l2[1], t4[k], __builtin_amdgcn_sad_u8(l2[0], t4[k], __builtin_amdgcn_sad_u8(l1[1], t4[k], __builtin_amdgcn_sad_u8(l1[0], t4[k], sad[k]))));
+                    n_all += 16u; n_kept += 2u * nkeep;
+                    // composition (synthetic_rgb.rs:158-175 through the folded tables): 8 px -> 24 bytes
+                    uint32_t o[6];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        uint32_t px[4][3];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t v1 = (l1[g] >> (8 * j)) & 0xFFu, v2 = (l2[g] >> (8 * j)) & 0xFFu;
+#ifdef SARPRO_ABL_RGB_NOLOOKUP // timing ablation (garbage raster)
+                            px[j][0] = v1; px[j][1] = v2; px[j][2] = v1 ^ v2;
+#else
+                            px[j][0] = lds[RgbLds::tables + v1]; px[j][1] = lds[RgbLds::tables + 256 + v2]; px[j][2] = lds[RgbLds::tables + 512 + ((v1 << 8) | v2)];
+#endif
+                        }
+                        o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
+                        o[3 * g + 1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
+                        o[3 * g + 2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+                    }
+                    uint8_t *rowp = a.rgb + ((size_t)r * a.rgb_pitch_px + (size_t)rc.cstart) * 3;
+                    // (same wave writes and reads its stage: program order inside a wave, no barrier)
+                    *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24) = make_uint2(o[0], o[1]);
+                    *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24 + 8) = make_uint2(o[2], o[3]);
+                    *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24 + 16) = make_uint2(o[4], o[5]);
+#ifdef SARPRO_ABL_RGB_NOSTORE
+                    if (safe1 && o[0] == 0x12345678u) store_stream16(reinterpret_cast<uint4 *>(rowp) + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + lane * 16));
+#else
+                    if (safe1) store_stream16(reinterpret_cast<uint4 *>(rowp) + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + lane * 16));
+                    if (safe2) store_stream16(reinterpret_cast<uint4 *>(rowp) + 64 + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + 1024 + lane * 16));
+#endif
+                    if (bytewise) {
+                        uint8_t *po = rowp + (size_t)lane * 24;
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j)
+                            if ((bytewise >> j) & 1u) {
+                                const uint32_t b0 = 3 * j;
+                                po[b0] = (uint8_t)(o[b0 >> 2] >> (8 * (b0 & 3)));
+                                po[b0 + 1] = (uint8_t)(o[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3)));
+                                po[b0 + 2] = (uint8_t)(o[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3)));
+                            }
+                    }
+                    c0 = n0; c1 = n1; dyv = dyn;
+                }
+            }
+        }
+    }
+    // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
+    uint32_t ge0 = fpred ? (n_all + sad[0] - sad[1]) >> 1 : n_kept, ge1 = (n_all + sad[1] - sad[2]) >> 1;
+    uint32_t lt0 = n_kept - ge0, lt1 = n_kept - ge1;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { lt0 += __shfl_xor(lt0, m, 64); lt1 += __shfl_xor(lt1, m, 64); }
+    uint32_t *s_lt = reinterpret_cast<uint32_t *>(lds + RgbLds::misc);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_lt[0] = 0u; s_lt[1] = 0u; }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&s_lt[0], lt0); atomicAdd(&s_lt[1], lt1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sp->n_lt[0], (unsigned long long)s_lt[0]);
+        atomicAdd(&sp->n_lt[1], (unsigned long long)s_lt[1]);
+        __threadfence();
+        if (atomicAdd(&sp->done, 1u) == gridDim.x - 1u) {
+            __threadfence();
+            const unsigned long long c0 = atomicAdd(&sp->n_lt[0], 0ull), c1 = atomicAdd(&sp->n_lt[1], 0ull), target = sp->target;
+            const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
+            sp->verdict = ok ? 0u : 1u;
         }
     }
 }
@@ -1378,7 +1685,8 @@ hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, 
 #if SARPRO_LUT_GLOBAL_N > 0
     hipLaunchKernelGGL(k_build_offlut, dim3(512), dim3(256), 0, s, a.binlut[0], a.binlut[nbands > 1 ? 1 : 0]);
 #endif
-    if (a.hist_mode == 2) hipLaunchKernelGGL(k_clahe_apply_u8_spec<2>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+    if (a.hist_mode == 3) hipLaunchKernelGGL(k_clahe_apply_u8_spec<3>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
+    else if (a.hist_mode == 2) hipLaunchKernelGGL(k_clahe_apply_u8_spec<2>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     else if (a.hist_mode == 1) hipLaunchKernelGGL(k_clahe_apply_u8_spec<1>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     else hipLaunchKernelGGL(k_clahe_apply_u8_spec<0>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     return hipGetLastError();
@@ -1428,6 +1736,17 @@ hipError_t opt_in_dynamic_lds(const void *kernel) {
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) done.insert({dev, kernel});
     return e;
+}
+
+bool clahe_rgb_fused_supported(const ClaheRgbArgs &a) {
+    return a.nrects > 0 && a.spec && a.dev_state && a.in_pitch % 8 == 0 && a.rgb_pitch_px % 16 == 0 && (reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.rgb) & 15) == 0;
+}
+hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s) {
+    if (!clahe_rgb_fused_supported(a) || grid <= 0) return hipErrorInvalidValue;
+    if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused))) return e;
+    hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_compose_u8(const ComposeArgs &a, int vec, hipStream_t s) {

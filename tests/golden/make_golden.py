@@ -56,5 +56,40 @@ def main():
     print(path, os.path.getsize(path), "bytes;", out["meta"][0])
 
 
+def api_flow(b1, b2, strategy, target, pad, plain):
+    """api/mod.rs:404-437 (plain) or save.rs:317-351 (Tamed re-autoscale) on f32 bands -> resize -> pad -> synRGB, through the oracle."""
+    us = []
+    for k, x in enumerate((b1, b2)):
+        if not plain and strategy == 5:
+            u = oracle.tamed_synrgb_u8(x, k == 0)
+        else:
+            rc, u = oracle.pipeline(x, 0, strategy)
+            assert rc == 0
+        u, _ = oracle.resize_image_data_with_meta(u, target, pad)
+        us.append(u)
+    return oracle.synrgb(0, strategy, us[0], us[1])
+
+
+def main_f32_flow():
+    """raster_core_v2_f32flow.npz: the reference's DEFAULT flow -- both bands resampled on read (non-integer f32,
+    sentinel1.rs:1074-1108), per-band u8, Lanczos3 resize, pad, synRGB -- for every strategy, with and without the Tamed
+    re-autoscale of save.rs:324-351, at two target sizes."""
+    out = {}
+    b1, b2 = f32data.resampled_scene(ROWS, COLS, 0), f32data.resampled_scene(ROWS, COLS, 1)
+    out["in_f32_band0"], out["in_f32_band1"] = b1, b2
+    for strategy in range(7):
+        for plain in (0, 1):
+            for ti, (target, pad) in enumerate(((40, True), (None, False))):
+                out[f"rgb_s{strategy}_plain{plain}_t{ti}"] = api_flow(b1, b2, strategy, target, pad, bool(plain))
+    out["meta"] = np.array([f"glibc {platform.libc_ver()[1]}; {oracle.lib().sarpro_oracle_version().decode()}"])
+    path = os.path.join(HERE, "raster_core_v2_f32flow.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes;", out["meta"][0])
+
+
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1:] or ["f32flow"]  # v1 is only regenerated on request: `make_golden.py v1`
+    if "v1" in which:
+        main()
+    if "f32flow" in which:
+        main_f32_flow()

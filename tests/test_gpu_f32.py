@@ -5,7 +5,7 @@ import pytest
 
 import f32data
 import oracle
-from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, SarproHipError, synth
+from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, SarproHipError, SyntheticRgbMode as Mode, resize_output_dims, synth
 from sarpro_amd import _lib
 import sarpro_amd as S
 
@@ -132,3 +132,78 @@ def test_clahe_cdfs_on_the_device_equal_the_host_twin(monkeypatch):
         b = c.process_scalar_data_pipeline(x, Bd.U16, St.Clahe)[1]
         assert "chain_cdfs" not in [n for n, _ in c.last_kernel_times()]
     assert np.array_equal(a, ref) and np.array_equal(b, ref)
+
+
+# ---------------------------------------------------------------------------- dual-pol f32 as a first-class path (api/mod.rs:374-449)
+def _api_flow_oracle(b1, b2, strategy, target, pad, mode=0, plain=True):
+    """api/mod.rs:404-437 (plain: both bands through process_scalar_data_pipeline) or save.rs:317-351 (Tamed re-autoscale), then
+    resize -> pad per band and the composition on the final rasters, step by step through the oracle."""
+    us = []
+    for k, b in enumerate((b1, b2)):
+        if not plain and strategy == St.Tamed:
+            u = oracle.tamed_synrgb_u8(b, k == 0)
+        else:
+            rc, u = oracle.pipeline(b, 0, int(strategy))
+            assert rc == 0
+        u, _ = oracle.resize_image_data_with_meta(u, target, pad)
+        us.append(u)
+    return oracle.synrgb(mode, int(strategy), us[0], us[1]), us
+
+
+@pytest.mark.parametrize("strategy", [St.Standard, St.Robust, St.Clahe, St.Tamed, St.Default])
+@pytest.mark.parametrize("target,pad", [(96, True), (150, False), (None, True)])
+@pytest.mark.parametrize("plain", [True, False])
+def test_dualpol_f32_resized_flow_matches_oracle(ctx, strategy, target, pad, plain):
+    """The reference's default flow: bands resampled on read (non-integer f32), per-band u8, resize, pad, synRGB."""
+    from f32data import resampled_scene
+    rows, cols = 200, 264
+    b1, b2 = resampled_scene(rows, cols, 0), resampled_scene(rows, cols, 1)
+    ref, _ = _api_flow_oracle(b1, b2, strategy, target, pad, plain=plain)
+    rgb, m = ctx.dualpol_synrgb_resized_f32(b1, b2, strategy, target, pad, plain_pipeline=plain)
+    assert rgb.shape == ref.shape and np.array_equal(rgb, ref), (strategy, target, pad, plain, int((rgb != ref).sum()))
+
+
+@pytest.mark.parametrize("strategy", [St.Standard, St.Clahe, St.Tamed])
+def test_dualpol_f32_device_resident_entry_points(strategy):
+    import torch
+    from f32data import resampled_scene
+    rows, cols = 264, 392
+    pitch = 448
+    b = [resampled_scene(rows, cols, k) for k in (0, 1)]
+    rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b[0], b[1], int(strategy))
+    assert rc == 0
+    with S.Context(0, timing=True) as c:
+        d = []
+        for x in b:
+            t = torch.zeros((rows, pitch), dtype=torch.float32, device="cuda")
+            t[:, :cols] = torch.from_numpy(x).cuda()
+            d.append(t)
+        rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+        u = [torch.zeros((rows, pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        st = c.dev_dualpol_synrgb_f32(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, Mode.Default, rgb.data_ptr(), pitch,
+                                      u[0].data_ptr(), u[1].data_ptr(), pitch, want_stats=True)
+        assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb)
+        assert np.array_equal(u[0].cpu().numpy()[:, :cols], r1) and np.array_equal(u[1].cpu().numpy()[:, :cols], r2)
+        assert st[0].valid_count == int((b[0] > 1e-5).sum())
+        names = [n for n, _ in c.last_kernel_times()]
+        assert "compose_u8" in names and len(names) > 4  # the composite call reports every kernel of both bands
+        # resized, device in / device out, api/mod.rs flow
+        ref, _ = _api_flow_oracle(b[0], b[1], strategy, 100, True, plain=True)
+        fc, fr = resize_output_dims(cols, rows, 100, True)
+        out = torch.zeros((fr * fc * 3,), dtype=torch.uint8, device="cuda")
+        c.dev_dualpol_synrgb_resized_f32(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, 100, True, out.data_ptr(), plain_pipeline=True)
+        assert np.array_equal(out.cpu().numpy().reshape(fr, fc, 3), ref)
+
+
+def test_batch_driver_with_f32_scenes():
+    from f32data import resampled_scene
+    scenes = [(resampled_scene(120 + 8 * i, 160, 0), resampled_scene(120 + 8 * i, 160, 1)) for i in range(5)]
+    scenes[2] = (scenes[2][0], scenes[2][1][:, :100])  # a band of the wrong shape: null pointer -> this scene fails, the batch goes on
+    outs, rep, st, rc = S.batch_dualpol_synrgb_resized_f32([0, 0], scenes, St.Robust, 64, True, plain_pipeline=True)
+    assert rc == 0 and (rep.processed, rep.errors, rep.skipped) == (4, 1, 0) and st[2] != 0
+    for i, (sc, o) in enumerate(zip(scenes, outs)):
+        if i == 2:
+            assert o is None
+            continue
+        ref, _ = _api_flow_oracle(sc[0], sc[1], St.Robust, 64, True, plain=True)
+        assert np.array_equal(o, ref), i

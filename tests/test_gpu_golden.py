@@ -28,3 +28,18 @@ def test_hip_path_reproduces_golden_vectors(ctx):
         assert np.array_equal(fn(a, b), g[f"polop_{op}"])
     assert np.array_equal(ctx.autoscale_db_image_tamed_synrgb_u8(ins["band0"], True), g["tamed_copol"])
     assert np.array_equal(ctx.autoscale_db_image_tamed_synrgb_u8(ins["band1"], False), g["tamed_crosspol"])
+
+
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster_core_v2_f32flow.npz")
+
+
+def test_hip_path_reproduces_the_f32_flow_golden_vectors(ctx):
+    """The reference's default flow (bands resampled on read -> per-band u8 -> resize -> pad -> synRGB), api/mod.rs:404-437 and
+    save.rs:317-367 variants, every strategy."""
+    g = np.load(GOLD2)
+    b1, b2 = g["in_f32_band0"], g["in_f32_band1"]
+    for s in St:
+        for plain in (0, 1):
+            for ti, (target, pad) in enumerate(((40, True), (None, False))):
+                rgb, _ = ctx.dualpol_synrgb_resized_f32(b1, b2, s, target, pad, plain_pipeline=bool(plain))
+                assert np.array_equal(rgb, g[f"rgb_s{int(s)}_plain{plain}_t{ti}"]), (s, plain, ti)

@@ -24,6 +24,12 @@ def run(c, b1, b2):
     return rgb, u1, u2, names
 
 
+def run_rgb_only(c, b1, b2):
+    """No per-band outputs requested: the chain takes the fused CLAHE -> RGB pass (no level rasters)."""
+    rgb = c.dualpol_synrgb(b1, b2, St.Clahe)
+    return rgb, [n for n, _ in c.last_kernel_times()]
+
+
 def ref(b1, b2):
     rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b1.astype(np.float32), b2.astype(np.float32), int(St.Clahe))
     assert rc == 0
@@ -143,6 +149,112 @@ def test_sampled_route_equals_partial_and_full_histogram_routes(monkeypatch):
             c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
             names = [n for n, _ in c.last_kernel_times()]
             assert ("chain_predict" in names) == (not env or "SARPRO_HIP_SPEC_FORCE" in env), (env, names)
+            for k in env:
+                monkeypatch.delenv(k)
+            out.append(rgb)
+        assert int(out[0].max().item()) > 0
+        for o in out[1:]:
+            assert torch.equal(out[0], o)
+
+
+# ---------------------------------------------------------------------------- the fused CLAHE -> RGB pass (RGB only requested)
+@pytest.mark.parametrize("shape", [(264, 512), (512, 640), (1000, 777), (300, 4100), (2000, 1500), (700, 1100)])
+@pytest.mark.parametrize("seed", [0, 5])
+def test_fused_rgb_pass_matches_oracle(shape, seed, monkeypatch):
+    rows, cols = shape
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
+    b1, b2 = synth.scene_u16(rows, cols, 0, seed=synth.SEED_SCENE_A + seed), synth.scene_u16(rows, cols, 1, seed=synth.SEED_SCENE_A + seed)
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, names = run_rgb_only(c, b1, b2)
+        rep = c.spec_report()
+    assert "clahe_rgb_fused" in names and "clahe_sample" in names
+    assert np.array_equal(rgb, rrgb), (rep, int((rgb != rrgb).sum()))
+    if rep["spec_ok"] and rep["verdict"] == 0:
+        f = rep["floor_pred"]
+        lv = np.concatenate([r1.ravel(), r2.ravel()])
+        assert rep["n_lt"][0] == int((lv < f).sum()) and (f == 37 or rep["n_lt"][1] == int((lv <= f).sum()))
+
+
+@pytest.mark.parametrize("force", ["", "mispredict", "nospec"])
+def test_fused_rgb_pass_fallbacks(force, monkeypatch):
+    """Refuted floor / no identity proof: the gated apply -> finish -> compose kernels produce the raster; accepted: they do nothing.
+    Three scenes in a row on one context: the state of one must not leak into the next."""
+    rows, cols = 900, 1300
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
+    b1, b2 = synth.scene_u16(rows, cols, 0), synth.scene_u16(rows, cols, 1)
+    rrgb, _, _ = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, _ = run_rgb_only(c, b1, b2)
+        assert np.array_equal(rgb, rrgb)
+        if force:
+            monkeypatch.setenv("SARPRO_HIP_SPEC_FORCE", force)
+        rgb, names = run_rgb_only(c, b1, b2)
+        rep = c.spec_report()
+        assert np.array_equal(rgb, rrgb), rep
+        if force:
+            assert rep["verdict"] == 1, rep
+            monkeypatch.delenv("SARPRO_HIP_SPEC_FORCE")
+        rgb, _ = run_rgb_only(c, b1, b2)
+        assert np.array_equal(rgb, rrgb)
+
+
+def test_fused_rgb_pass_steps_aside_for_windows_beyond_its_lds_pool(monkeypatch):
+    """DN windows wider than the pass's pool of DN-indexed LDS entries: the pass returns at once, the gated kernels run."""
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    rng = np.random.default_rng(3)
+    rows, cols = 520, 768
+    b1 = rng.integers(1, 40000, (rows, cols)).astype(np.uint16)  # p99 far beyond 3072 DNs
+    b2 = rng.integers(1, 30000, (rows, cols)).astype(np.uint16)
+    b1[:40] = 0
+    rrgb, _, _ = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, names = run_rgb_only(c, b1, b2)
+        rep = c.spec_report()
+    assert "clahe_rgb_fused" in names and rep["verdict"] == 1
+    assert np.array_equal(rgb, rrgb)
+
+
+@pytest.mark.parametrize("kind", ["two_values", "constant", "all_invalid_band", "edge_heavy"])
+def test_fused_rgb_pass_degenerate_rasters(kind, monkeypatch):
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    rng = np.random.default_rng(11)
+    rows, cols = 264, 520
+    if kind == "two_values":
+        b1 = rng.choice(np.array([120, 2000], np.uint16), size=(rows, cols)); b2 = rng.choice(np.array([300, 900], np.uint16), size=(rows, cols))
+    elif kind == "constant":
+        b1 = np.full((rows, cols), 777, np.uint16); b2 = np.full((rows, cols), 12, np.uint16)
+    elif kind == "all_invalid_band":
+        b1 = np.zeros((rows, cols), np.uint16); b2 = synth.scene_u16(rows, cols, 1)
+    else:  # bright saturated stretches in the extrapolating border cells
+        b1 = synth.scene_u16(rows, cols, 0); b2 = synth.scene_u16(rows, cols, 1)
+        b1[:40, :] = 2500; b2[:, :70] = 900; b1[-30:, -90:] = 2400
+    rrgb, _, _ = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, _ = run_rgb_only(c, b1, b2)
+    assert np.array_equal(rgb, rrgb), kind
+
+
+def test_fused_rgb_route_equals_the_other_routes_at_36mp(monkeypatch):
+    rows, cols = 6000, 6016
+    pitch = cols
+    q = synth.q_tables()
+    with S.Context(0, timing=True) as c:
+        band = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+        for b in range(2):
+            c.dev_synth_scene_u16(synth.SEED_SCENE_A + 9, b, q, rows, cols, 0, rows, band[b].data_ptr(), pitch)
+        out = []
+        for env in ({}, {"SARPRO_HIP_NO_FUSED_RGB": "1"}, {"SARPRO_HIP_NO_SAMPLED_HIST": "1"}, {"SARPRO_HIP_SPEC_FORCE": "mispredict"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+            c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
+            names = [n for n, _ in c.last_kernel_times()]
+            assert ("clahe_rgb_fused" in names) == (not env or "SARPRO_HIP_SPEC_FORCE" in env), (env, names)
+            if not env:
+                assert c.spec_report()["verdict"] == 0  # the product's default at this size: accepted
             for k in env:
                 monkeypatch.delenv(k)
             out.append(rgb)

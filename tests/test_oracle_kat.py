@@ -76,6 +76,20 @@ def test_oracle_matches_committed_golden_vectors():
     assert {1.0, 0.9} <= gammas
 
 
+def test_oracle_reproduces_the_f32_flow_golden_vectors():
+    """tests/golden/raster_core_v2_f32flow.npz: resampled-on-read bands -> per-band u8 -> resize -> pad -> synRGB (api/mod.rs:404-437 and
+    save.rs:317-367 variants); detects libm / compiler drift of the oracle between machines."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    g = np.load(os.path.join(os.path.dirname(GOLD), "raster_core_v2_f32flow.npz"))
+    b1, b2 = g["in_f32_band0"], g["in_f32_band1"]
+    for s in range(7):
+        for plain in (0, 1):
+            for ti, (target, pad) in enumerate(((40, True), (None, False))):
+                assert np.array_equal(make_golden.api_flow(b1, b2, s, target, pad, bool(plain)), g[f"rgb_s{s}_plain{plain}_t{ti}"]), (s, plain, ti)
+
+
 def test_oracle_resize_is_lanczos3_within_fixed_point_error():
     # smooth image (no clipping in the intermediate): the integer pipeline stays within 1 LSB of float Lanczos3
     y, x = np.mgrid[0:240, 0:360]

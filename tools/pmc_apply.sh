@@ -8,11 +8,11 @@ for grp in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_INSTS_VALU 
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/$tag -o pmc --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/profile_one.py 2 4 > $OUT/$tag.log 2>&1
   f=$(find $OUT/$tag -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, os
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        if "clahe_apply" in r["Kernel_Name"]:
+        if os.environ.get("PMC_KERNEL", "clahe_apply") in r["Kernel_Name"]:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 except Exception as e:
     print("ERR", e)
