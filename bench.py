@@ -409,10 +409,13 @@ def pmc_traffic_gb(kernel, local_px):
     names = {"clahe_rgb_fused": "k_clahe_rgb_fused", "clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "clahe_apply_u16": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_pieces",
              "compose_u8": "k_compose_u8", "lut_apply_u16": "k_lut_apply_u16", "lut_compose_u16": "k_lut_compose_u16"}
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
-            t = json.load(f)
-        gb = t[names[kernel]]["total"] * (local_px / 4.0e8)
-        return {"value": round(gb, 3), "unit": "GB", "source": "profiles/r2_traffic.json (rocprofv3 PMC, separate passes)"}
+        for fn in ("r3_traffic.json", "r2_traffic.json"):
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                t = json.load(f)
+            if names[kernel] in t:
+                gb = t[names[kernel]]["total"] * (local_px / 4.0e8)
+                return {"value": round(gb, 3), "unit": "GB", "source": f"profiles/{fn} (rocprofv3 PMC, separate passes, an earlier run of this command's kernels: a committed measurement, not one of this run)"}
+        return None
     except Exception:
         return None
 

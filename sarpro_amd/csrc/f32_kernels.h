@@ -57,6 +57,7 @@ struct F32LevelArgs {
 };
 // out[row * pitch + col] = level for n patches (row, col, level, -)
 hipError_t launch_patch_u16(uint16_t *out, size_t pitch, const uint4 *d_patches, uint32_t n, hipStream_t s);
+hipError_t launch_patch_u8(uint8_t *out, size_t pitch, const uint4 *d_patches, uint32_t n, hipStream_t s);
 
 struct F32TileHistArgs {
     const float *in;
@@ -146,6 +147,11 @@ hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint
                               F32Partial *d_partials, int grid, hipStream_t s, const F32Pol &pol = F32Pol());
 hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
                                const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s, const F32Pol &pol = F32Pol());
+// the 4096 bins without host-built thresholds: min / max from the pre-pass partials (on the device), f64 binning with a margin,
+// samples within 1e-6 of a bin boundary queued as (row, column, bits) for the host (f32_kernels.hip b')
+hipError_t launch_f32_hist4096_direct(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, const F32Partial *d_partials,
+                                      int nparts, unsigned long long *d_hist /* zeroed */, uint32_t *d_uq_count /* zeroed */, uint4 *d_uq_entries,
+                                      uint32_t uq_cap, hipStream_t s, const F32Pol &pol = F32Pol());
 hipError_t launch_f32_level(const F32LevelArgs &a, bool vec, bool out16, hipStream_t s);
 hipError_t launch_f32_tile_hist(const F32TileHistArgs &a, int nrects, bool vec, hipStream_t s);
 hipError_t launch_f32_clahe_apply(const F32ClaheApplyArgs &a, int nrects, bool vec, bool out16, hipStream_t s);

@@ -637,10 +637,10 @@ template <int VEC, bool OUT16>
 __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
     __shared__ float thr[256 + 1];
     __shared__ uint32_t hist[256];
-    if (!OUT16) { thr[threadIdx.x] = threadIdx.x ? a.thr[threadIdx.x] : -INFINITY; hist[threadIdx.x] = 0; }
+    if (!OUT16) { thr[threadIdx.x] = (threadIdx.x && a.thr) ? a.thr[threadIdx.x] : -INFINITY; hist[threadIdx.x] = 0; }
     if (threadIdx.x == 0) thr[256] = INFINITY;
-    __shared__ double logc[256], invc[256]; // table of db_of_f32_fast (u16 levels)
-    if (OUT16) {
+    __shared__ double logc[256], invc[256]; // table of db_of_f32_fast (f64 levels)
+    if (a.f64_levels) {
         const double c = 1.0 + ((double)threadIdx.x + 0.5) / 256.0;
         logc[threadIdx.x] = log2(c);
         invc[threadIdx.x] = 1.0 / c;
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
             const float x = v.get(j);
             uint32_t lv = 0;
             if (col + j < a.cols && x >= a.t_valid) {
-                if (OUT16 && a.f64_levels) {
-                    if (x >= a.t_last) lv = 65535u;
+                if (a.f64_levels) { // (u8 output takes this form on the small-scene direct route: no threshold table at all)
+                    if (x >= a.t_last) lv = (uint32_t)a.max_val;
                     else if (x < a.t_first) lv = 0u;
                     else {
                         const double db = db_of_f32_fast(x, logc, invc); // within ~1e-14 of glibc's value: far inside the 1e-6 margin below
@@ -672,16 +672,18 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
                         if (fabs(y - r) < 1e-6 || !(y == y)) {
                             if (a.f64_levels == 2) {
                                 const uint32_t q = atomicAdd(a.uq_count, 1u);
-                                if (q < a.uq_cap) a.uq_entries[q] = make_uint4(r_row, col + j, __float_as_uint(x), 0u);
-                                lv = (uint32_t)y; // provisional: the host patches it
-                            } else lv = step_search<65535>(a.thr, x);
+                                if (q < a.uq_cap) a.uq_entries[q] = make_uint4(r_row, col + j, __float_as_uint(x), (uint32_t)y); // .w: the provisional level
+                                lv = (uint32_t)y | 0x80000000u; // provisional: the host patches it (and counts it: bit 31 keeps it out of the histogram)
+                            } else lv = OUT16 ? step_search<65535>(a.thr, x) : step_search<255>(thr, x);
                         } else lv = (uint32_t)y;
                     }
                 } else if (a.est.use) lv = OUT16 ? est_search<65535>(a.thr, x, a.est) : est_search<255>(thr, x, a.est);
                 else lv = OUT16 ? step_search<65535>(a.thr, x) : step_search<255>(thr, x);
             }
+            const bool queued_lv = (lv & 0x80000000u) != 0u;
+            lv &= 0x7FFFFFFFu;
             lvs[j] = lv;
-            if (!OUT16 && col + j < a.cols) { if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u); }
+            if (!OUT16 && col + j < a.cols && !queued_lv) { if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u); }
         }
         store_levels<VEC, OUT16>(a.out, (size_t)r * a.out_pitch + col, lvs, (int)min((uint32_t)VEC, a.cols - col), vec_store);
     }
@@ -823,6 +825,19 @@ inline int stream_grid(uint64_t items, int per_cu = 8) {
     return (int)(want < 1 ? 1 : (want < cap ? want : cap));
 }
 
+// Kernels that end by flushing a block-private histogram with global atomics (256 or 4096 hot words shared by every block): on small
+// rasters the flush, not the sweep, is the kernel -- 4096 blocks x 256 adds on 256 addresses took 0.05 ms for a 4 MP band.  At least 32
+// vectors per thread before another block is worth its flush (SARPRO_HIP_HIST_GRID_VPT: tuning switch).
+inline int hist_grid_vectors_per_thread() {
+    if (const char *e = getenv("SARPRO_HIP_HIST_GRID_VPT")) return std::max(1, atoi(e));
+    return 8;
+}
+inline int hist_grid(uint64_t items, int per_cu = 8) {
+    const uint64_t by_work = items / ((uint64_t)kBlock * (uint64_t)hist_grid_vectors_per_thread());
+    const int g = stream_grid(items, per_cu);
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g, std::max<uint64_t>(by_work, 1)));
+}
+
 } // namespace
 
 hipError_t launch_f32_sample_keys(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, uint32_t row_stride,
@@ -908,18 +923,92 @@ hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint
 hipError_t launch_f32_hist4096(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec,
                                const float *d_thr, unsigned long long *d_hist, F32StepEstimate est, hipStream_t s, const F32Pol &pol) {
     const int V = vec ? 4 : 1;
-    dim3 grid(stream_grid((uint64_t)rows * ((cols + V - 1) / V), 4));
+    dim3 grid(hist_grid((uint64_t)rows * ((cols + V - 1) / V), 4));
     if (vec) hipLaunchKernelGGL(k_f32_hist4096<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est, pol);
     else hipLaunchKernelGGL(k_f32_hist4096<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_thr, d_hist, est, pol);
     return hipGetLastError();
 }
 
 namespace {
+__global__ void k_patch_u8(uint8_t *out, size_t pitch, const uint4 *patches, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[(size_t)patches[i].x * pitch + patches[i].y] = (uint8_t)patches[i].z;
+}
+
+// ------------------------------------------------------------------------------------
+// b'. 4096-bin histogram WITHOUT host-built thresholds (small scenes: the 4095 thresholds cost the host 0.35 ms of glibc, the
+//     zone route ~0.1 ms of single-workgroup kernels -- both more than the scene's own passes).  Every block first merges the
+//     pre-pass partials (min / max sample), then bins with the reference's own expression (autoscale.rs:108-117) in f64:
+//     t = clamp((dB - min_dB) * inv_span, 0, 1), idx = min(floor(t * 4096), 4095), with the device's dB (within ~1e-14 of
+//     glibc's: table + series, as the moments use).  The bin is accepted when t * 4096 is farther than 1e-6 from an integer --
+//     the device / glibc difference moves it by ~1e-10 -- and the sample is QUEUED otherwise (a handful per scene) for the host
+//     to bin with glibc.  Samples equal to the minimum / maximum sample are bins 0 / 4095 by construction (t = 0, t = 1).
+// ------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_f32_hist4096_direct(const float *__restrict__ in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid,
+                                                                const F32Partial *__restrict__ partials, int nparts, unsigned long long *__restrict__ g_hist,
+                                                                uint32_t *uq_count, uint4 *uq_entries, uint32_t uq_cap, F32Pol pol) {
+    __shared__ uint32_t hist[4096];
+    __shared__ double logc[256], invc[256];
+    __shared__ float s_mn[kBlock], s_mx[kBlock];
+    for (int i = threadIdx.x; i < 4096; i += kBlock) hist[i] = 0;
+    {
+        const double c = 1.0 + ((double)threadIdx.x + 0.5) / 256.0;
+        logc[threadIdx.x] = log2(c);
+        invc[threadIdx.x] = 1.0 / c;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int i = threadIdx.x; i < nparts; i += kBlock) { mn = fminf(mn, partials[i].minv); mx = fmaxf(mx, partials[i].maxv); }
+        s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+    }
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { s_mn[threadIdx.x] = fminf(s_mn[threadIdx.x], s_mn[threadIdx.x + st]); s_mx[threadIdx.x] = fmaxf(s_mx[threadIdx.x], s_mx[threadIdx.x + st]); }
+        __syncthreads();
+    }
+    const float xmin = s_mn[0], xmax = s_mx[0];
+    if (!(xmax > xmin) || !(xmax < INFINITY)) return; // empty, single-valued or +inf: the host's degenerate arms need no bins
+    const double min_db = db_of_f32_fast(xmin, logc, invc), max_db = db_of_f32_fast(xmax, logc, invc);
+    const double inv_span = 1.0 / (max_db - min_db);
+    StrideWalk<VEC> walk(rows, cols, in, pitch, pol);
+    while (walk.live()) {
+        uint32_t r, col;
+        const F32Vec<VEC> v = walk.next(in, pitch, pol, &r, &col);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float x = v.get(j);
+            if (!(col + j < cols && x >= t_valid)) continue;
+            uint32_t idx;
+            if (x == xmin) idx = 0u;
+            else if (x == xmax) idx = 4095u;
+            else {
+                const double t = fmin(fmax((db_of_f32_fast(x, logc, invc) - min_db) * inv_span, 0.0), 1.0);
+                const double y = t * 4096.0;
+                if (fabs(y - rint(y)) < 1e-6 || !(y == y)) {
+                    const uint32_t q = atomicAdd(uq_count, 1u);
+                    if (q < uq_cap) uq_entries[q] = make_uint4(r, col + j, __float_as_uint(x), 0u);
+                    continue;
+                }
+                idx = min((uint32_t)y, 4095u);
+            }
+            atomicAdd(&hist[idx], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += kBlock)
+        if (hist[i]) atomicAdd(&g_hist[i], (unsigned long long)hist[i]);
+}
+
 __global__ void k_patch_u16(uint16_t *out, size_t pitch, const uint4 *patches, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[(size_t)patches[i].x * pitch + patches[i].y] = (uint16_t)patches[i].z;
 }
 } // namespace
+
+hipError_t launch_patch_u8(uint8_t *out, size_t pitch, const uint4 *d_patches, uint32_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_patch_u8, dim3((n + 255) / 256), dim3(256), 0, s, out, pitch, d_patches, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_patch_u16(uint16_t *out, size_t pitch, const uint4 *d_patches, uint32_t n, hipStream_t s) {
     if (!n) return hipSuccess;
@@ -927,9 +1016,19 @@ hipError_t launch_patch_u16(uint16_t *out, size_t pitch, const uint4 *d_patches,
     return hipGetLastError();
 }
 
+hipError_t launch_f32_hist4096_direct(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, const F32Partial *d_partials,
+                                      int nparts, unsigned long long *d_hist, uint32_t *d_uq_count, uint4 *d_uq_entries, uint32_t uq_cap, hipStream_t s,
+                                      const F32Pol &pol) {
+    const int V = vec ? 4 : 1;
+    dim3 grid(hist_grid((uint64_t)rows * ((cols + V - 1) / V), 4));
+    if (vec) hipLaunchKernelGGL(k_f32_hist4096_direct<4>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials, nparts, d_hist, d_uq_count, d_uq_entries, uq_cap, pol);
+    else hipLaunchKernelGGL(k_f32_hist4096_direct<1>, grid, dim3(kBlock), 0, s, in, pitch, rows, cols, t_valid, d_partials, nparts, d_hist, d_uq_count, d_uq_entries, uq_cap, pol);
+    return hipGetLastError();
+}
+
 hipError_t launch_f32_level(const F32LevelArgs &a, bool vec, bool out16, hipStream_t s) {
     const int V = vec ? 4 : 1;
-    dim3 grid(stream_grid((uint64_t)a.rows * ((a.cols + V - 1) / V)));
+    dim3 grid(out16 ? stream_grid((uint64_t)a.rows * ((a.cols + V - 1) / V)) : hist_grid((uint64_t)a.rows * ((a.cols + V - 1) / V)));
     if (vec) {
         if (out16) hipLaunchKernelGGL((k_f32_level<4, true>), grid, dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_f32_level<4, false>), grid, dim3(kBlock), 0, s, a);

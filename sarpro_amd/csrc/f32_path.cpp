@@ -82,7 +82,22 @@ struct F32Band {
     const uint32_t *zone_kept = nullptr; // per-wave kept counts of the min / max pass
     const char *zone_note = "";
     uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
+    // small-scene direct route (percentile strategies): bins and levels evaluated in f64 on the device with a margin, the few samples
+    // near a boundary settled by the host -- no threshold tables, no zone kernels, two synchronisations per band
+    bool direct = false;
+    uint32_t direct_queued = 0;     // samples the histogram pass queued (entries in ctx->f32zone)
+    uint64_t level_add[256]{};      // u8: levels of the samples the level pass queued (the kernel leaves them out of its histogram)
+    bool level_hist_ready = false;  // direct route, u8: the level histogram came back with the level pass's queue (one synchronisation)
+    uint64_t level_hist_host[256]{};
+    bool idle = false;              // nothing was enqueued since the last synchronisation (the final one can be skipped)
 };
+constexpr uint32_t kQueueHead = 256; // queued samples fetched WITH their count (more than that: a second copy)
+constexpr uint32_t kDirectQueueCap = 65536;
+static uint32_t direct_queue_cap() { // SARPRO_HIP_F32_DIRECT_QCAP: a tiny queue, so that the tests reach the overflow hand-back
+    if (const char *e = getenv("SARPRO_HIP_F32_DIRECT_QCAP")) return (uint32_t)std::min<long>(kDirectQueueCap, std::max<long>(0, atol(e)));
+    return kDirectQueueCap;
+}
+constexpr uint64_t kDirectMaxPx = 16ull << 20; // above this the zone route's fixed ~0.1 ms is small beside its sweeps
 
 // estimate of a step table that is linear in dB: step = (dB(x) - low_db) / range_db * nsteps + bias, dB = 10 log10
 F32StepEstimate step_estimate(double low_db, double range_db, double nsteps, double bias, double gamma = 1.0) {
@@ -117,6 +132,7 @@ int rescale_in_place(F32Band &B, const uint64_t *level_hist) {
         std::memcpy(stage, resc, 256);
         uint8_t *d_map = ctx->f32ws.as<uint8_t>() + kOffMap;
         HIPCHK(ctx, hipMemcpyAsync(d_map, stage, 256, hipMemcpyHostToDevice, ctx->stream));
+        B.idle = false;
         KernelTimer t(ctx, "remap_u8");
         HIPCHK(ctx, launch_remap_u8(reinterpret_cast<uint8_t *>(B.d_out), B.out_pitch, (uint32_t)B.rows, (uint32_t)B.cols, d_map, ctx->stream));
     }
@@ -389,7 +405,8 @@ int f32_phase_a(F32Band &B) {
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     const uint32_t rows = (uint32_t)B.rows, cols = (uint32_t)B.cols;
     B.use_zones = B.have_stats = false;
-    if (B.allow_zones) RETCHK(f32_zone_presample(B));
+    if (B.direct && B.clahe) B.direct = false; // (CLAHE keeps its threshold route: tile histograms and the blend need the bin table)
+    if (B.allow_zones && !B.direct) RETCHK(f32_zone_presample(B));
     if (B.use_zones) return f32_zone_prepass(B);
     const int pgrid = f32_prepass_grid(rows, cols, B.vec);
     F32Partial *d_part = reinterpret_cast<F32Partial *>(ws + kOffPartials);
@@ -400,6 +417,22 @@ int f32_phase_a(F32Band &B) {
     }
     F32Partial *h_part = ctx->h_small.as<F32Partial>();
     HIPCHK(ctx, hipMemcpyAsync(h_part, d_part, sizeof(F32Partial) * (size_t)pgrid, hipMemcpyDeviceToHost, ctx->stream));
+    if (B.direct) { // the 4096 bins in the same stream turn: the kernel merges the partials itself, nothing waits for the host
+        unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws + kOffHist4096);
+        uint32_t *d_qn = reinterpret_cast<uint32_t *>(ws + kOffZoneCounts);
+        HIPCHK(ctx, ctx->f32zone.reserve((size_t)kDirectQueueCap * sizeof(uint4)));
+        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * 4096, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_qn, 0, 4, ctx->stream));
+        {
+            KernelTimer t(ctx, "f32_hist4096_direct");
+            HIPCHK(ctx, launch_f32_hist4096_direct(B.d_in, B.in_pitch, rows, cols, B.t_valid, B.vec, d_part, pgrid, d_hist, d_qn, ctx->f32zone.as<uint4>(),
+                                                   direct_queue_cap(), ctx->stream, B.pol));
+        }
+        uint8_t *h = ctx->h_small.as<uint8_t>() + 64 * 1024; // behind the partials (<= 2048 x 32 B)
+        HIPCHK(ctx, hipMemcpyAsync(h, d_hist, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h + 32768, d_qn, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h + 32768 + 64, ctx->f32zone.p, (size_t)kQueueHead * 16, hipMemcpyDeviceToHost, ctx->stream)); // usually all of them
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < pgrid; ++i) {
         B.local.count += h_part[i].count; B.local.sum_db += h_part[i].sum; B.local.sumsq_db += h_part[i].sumsq;
@@ -490,7 +523,7 @@ int f32_phase_d(F32Band &B) {
         a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
         a.rows = rows; a.cols = cols; a.t_valid = B.t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
         a.pol = B.pol;
-        const bool f64_levels = !u8o && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
+        const bool f64_levels = (!u8o || B.direct) && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
         if (f64_levels) { // 65535 levels: f64 evaluation on the device, the reference's own arithmetic only near a level boundary
             a.low = B.stats.low_clip; a.high = B.stats.high_clip; a.range = std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0);
             a.gamma = B.stats.gamma; a.max_val = (double)nlevels;
@@ -510,34 +543,56 @@ int f32_phase_d(F32Band &B) {
             HIPCHK(ctx, hipMemsetAsync(a.uq_count, 0, 4, ctx->stream));
             {
                 KernelTimer t(ctx, "f32_level");
-                HIPCHK(ctx, launch_f32_level(a, B.vec, true, ctx->stream));
+                HIPCHK(ctx, launch_f32_level(a, B.vec, !u8o, ctx->stream));
             }
+            // count, the first kQueueHead entries and (u8) the level histogram come back together: one synchronisation
             uint32_t *h_n = ctx->h_small.as<uint32_t>();
+            uint32_t *h_e = ctx->h_small.as<uint32_t>() + 4; // 16-byte aligned; reserved in phase a
+            uint64_t *h_lh = reinterpret_cast<uint64_t *>(ctx->h_small.as<uint8_t>() + 16 + (size_t)kUqCap * 16);
             HIPCHK(ctx, hipMemcpyAsync(h_n, a.uq_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_e, a.uq_entries, (size_t)kQueueHead * 16, hipMemcpyDeviceToHost, ctx->stream));
+            if (u8o) HIPCHK(ctx, hipMemcpyAsync(h_lh, d_level_hist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            B.idle = true;
             const uint32_t n = *h_n;
             if (n <= kUqCap) {
+                if (u8o) { std::memcpy(B.level_hist_host, h_lh, sizeof(B.level_hist_host)); B.level_hist_ready = true; }
                 if (n) {
-                    uint32_t *h_e = ctx->h_small.as<uint32_t>() + 4; // 16-byte aligned; reserved in phase a
-                    HIPCHK(ctx, hipMemcpyAsync(h_e, a.uq_entries, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    if (n > kQueueHead) {
+                        HIPCHK(ctx, hipMemcpyAsync(h_e, a.uq_entries, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+                        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    }
+                    uint32_t npatch = 0; // only the samples whose provisional level (entry.w) is not the reference's are rewritten
                     for (uint32_t i = 0; i < n; ++i) {
                         float x;
                         std::memcpy(&x, &h_e[4 * i + 2], 4);
-                        h_e[4 * i + 2] = level_of_db(db_of_f32(x), B.stats.low_clip, B.stats.high_clip, B.stats.gamma, (double)nlevels);
+                        const uint32_t lv = level_of_db(db_of_f32(x), B.stats.low_clip, B.stats.high_clip, B.stats.gamma, (double)nlevels);
+                        if (u8o) B.level_add[lv & 255u] += 1; // the kernel left the queued samples out of its level histogram
+                        if (lv != h_e[4 * i + 3]) {
+                            h_e[4 * npatch + 0] = h_e[4 * i + 0]; h_e[4 * npatch + 1] = h_e[4 * i + 1]; h_e[4 * npatch + 2] = lv;
+                            ++npatch;
+                        }
                     }
-                    HIPCHK(ctx, hipMemcpyAsync(a.uq_entries, h_e, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-                    KernelTimer t(ctx, "f32_level_patch");
-                    HIPCHK(ctx, launch_patch_u16(reinterpret_cast<uint16_t *>(B.d_out), B.out_pitch, a.uq_entries, n, ctx->stream));
+                    if (npatch) {
+                        HIPCHK(ctx, hipMemcpyAsync(a.uq_entries, h_e, (size_t)npatch * 16, hipMemcpyHostToDevice, ctx->stream));
+                        KernelTimer t(ctx, "f32_level_patch");
+                        if (u8o) HIPCHK(ctx, launch_patch_u8(reinterpret_cast<uint8_t *>(B.d_out), B.out_pitch, a.uq_entries, npatch, ctx->stream));
+                        else HIPCHK(ctx, launch_patch_u16(reinterpret_cast<uint16_t *>(B.d_out), B.out_pitch, a.uq_entries, npatch, ctx->stream));
+                        B.idle = false;
+                    }
                 }
                 return SARPRO_HIP_OK;
             }
             queued = false; // overflow: the table route redoes the raster
+            if (u8o) { // (the table route of the u8 form counts every level itself: start from a clean histogram)
+                HIPCHK(ctx, hipMemsetAsync(d_level_hist, 0, sizeof(uint64_t) * 256, ctx->stream));
+                a.f64_levels = 0;
+            }
         }
         build_level_thresholds(B.stats, nlevels, thr);
         thr[nlevels + 1] = INFINITY; // sentinel read by the estimate's verification
         HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * (size_t)(nlevels + 2), hipMemcpyHostToDevice, ctx->stream));
-        if (f64_levels) { a.t_first = thr[1]; a.t_last = thr[nlevels]; a.f64_levels = 1; }
+        if (f64_levels && !u8o) { a.t_first = thr[1]; a.t_last = thr[nlevels]; a.f64_levels = 1; }
         KernelTimer t(ctx, "f32_level");
         HIPCHK(ctx, launch_f32_level(a, B.vec, !u8o, ctx->stream));
         return SARPRO_HIP_OK;
@@ -578,24 +633,77 @@ int f32_phase_e(F32Band &B) {
         return SARPRO_HIP_OK;
     }
     if (B.u8o) {
-        uint64_t *h_lh = ctx->h_small.as<uint64_t>();
-        HIPCHK(ctx, hipMemcpyAsync(h_lh, ctx->f32ws.as<uint8_t>() + kOffLevelHist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         uint64_t lh[256];
-        std::memcpy(lh, h_lh, sizeof(lh));
-        RETCHK(rescale_in_place(B, lh));
+        if (B.level_hist_ready) {
+            std::memcpy(lh, B.level_hist_host, sizeof(lh));
+        } else {
+            uint64_t *h_lh = ctx->h_small.as<uint64_t>();
+            HIPCHK(ctx, hipMemcpyAsync(h_lh, ctx->f32ws.as<uint8_t>() + kOffLevelHist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            std::memcpy(lh, h_lh, sizeof(lh));
+            B.idle = true;
+        }
+        for (int i = 0; i < 256; ++i) lh[i] += B.level_add[i];
+        RETCHK(rescale_in_place(B, lh)); // (enqueues a remap kernel unless the rescale is the identity on the occupied levels: idle = false)
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!B.idle) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SARPRO_HIP_OK;
+}
+
+// Direct route, after phase a: the bins came back with the partials; settle the queued samples with glibc, then the statistics
+// and the window exactly as phase b / c compute them.  A queue that overflowed hands the band back to the threshold route.
+int f32_direct_stats(F32Band &B) {
+    sarpro_hip_ctx *ctx = B.ctx;
+    const sarpro_hip_f32_partial &G = B.global;
+    B.empty = G.count == 0;
+    if (B.empty) return SARPRO_HIP_OK;
+    if (std::isinf(G.max_v)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "non-finite (+inf) sample: the reference's statistics are undefined for it");
+    uint8_t *h = ctx->h_small.as<uint8_t>() + 64 * 1024;
+    uint64_t *h_hist = reinterpret_cast<uint64_t *>(h);
+    uint32_t nq = 0;
+    std::memcpy(&nq, h + 32768, 4);
+    if (nq > direct_queue_cap()) { B.direct = false; return SARPRO_HIP_OK; }
+    B.mean = G.sum_db / (double)G.count;
+    const double var = G.sumsq_db / (double)G.count - B.mean * B.mean;
+    B.std_db = G.count > 1 ? std::sqrt(std::fmax(var, 0.0)) : 0.0;
+    B.min_db = db_of_f32(G.min_v); B.max_db = db_of_f32(G.max_v);
+    if (nq && !(std::fabs(B.max_db - B.min_db) < 2.220446049250313e-16)) {
+        uint32_t *h_e = reinterpret_cast<uint32_t *>(h + 32768 + 64);
+        if (nq > kQueueHead) { // (the first kQueueHead entries came with the count)
+            HIPCHK(ctx, hipMemcpyAsync(h_e, ctx->f32zone.p, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        const double span = B.max_db - B.min_db, inv_span = 1.0 / span; // autoscale.rs:106-117
+        for (uint32_t i = 0; i < nq; ++i) {
+            float x;
+            std::memcpy(&x, &h_e[4 * i + 2], 4);
+            const double t = std::fmin(std::fmax((db_of_f32(x) - B.min_db) * inv_span, 0.0), 1.0);
+            uint64_t idx = (uint64_t)(t * 4096.0);
+            if (idx >= 4096) idx = 4095;
+            h_hist[idx] += 1;
+        }
+    }
+    B.direct_queued = nq;
+    RETCHK(stats_from_bins4096(G.count, B.min_db, B.max_db, B.mean, B.std_db, h_hist, &B.stats));
+    RETCHK(select_window(&B.stats, B.strategy, B.tamed));
+    B.have_stats = true;
+    return SARPRO_HIP_OK;
+}
+
+static bool f32_direct_wanted(const F32Band &B) {
+    if (const char *e = getenv("SARPRO_HIP_F32_DIRECT")) return atoi(e) != 0; // 0: never, 1: at every size (tests)
+    return (uint64_t)B.rows * B.cols <= kDirectMaxPx && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
 }
 
 int f32_band_run(F32Band &B) {
     if (B.ctx->f32_stripe_open) return fail(B.ctx, SARPRO_HIP_ERR_INVALID_ARG, "an f32 row stripe is open on this context: its phases share the context's f32 workspace");
     B.rows_total = B.rows; B.row0 = 0;
     B.allow_zones = true;
+    B.direct = f32_direct_wanted(B);
     RETCHK(f32_phase_a(B));
     if (B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
     B.global = B.local;
+    if (B.direct && !B.use_zones) RETCHK(f32_direct_stats(B)); // (may hand the band back: direct = false, no statistics yet)
     if (B.use_zones) RETCHK(f32_zone_resolve(B));
     if (getenv("SARPRO_HIP_F32_ZONES_DEBUG")) std::fprintf(stderr, "[zones] answered=%d note='%s'\n", (int)B.have_stats, B.zone_note);
     if (B.have_stats) { B.empty = false; }

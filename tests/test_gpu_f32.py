@@ -207,3 +207,45 @@ def test_batch_driver_with_f32_scenes():
             continue
         ref, _ = _api_flow_oracle(sc[0], sc[1], St.Robust, 64, True, plain=True)
         assert np.array_equal(o, ref), i
+
+
+# ---------------------------------------------------------------------------- small-scene direct route vs the threshold / zone routes
+@pytest.mark.parametrize("name,make", CASES)
+@pytest.mark.parametrize("strategy", [s for s in St if s != St.Clahe])
+@pytest.mark.parametrize("bit_depth", list(Bd))
+@pytest.mark.parametrize("route", ["0", "1", "tinyqueue"])
+def test_f32_direct_route_and_its_twins_match_oracle(name, make, strategy, bit_depth, route, monkeypatch):
+    """Scenes up to 16 MP take the direct route (SARPRO_HIP_F32_DIRECT=1 forces it, 0 forbids it): 4096 bins and levels evaluated in f64 on the
+    device, samples within 1e-6 of a boundary queued for the host's glibc -- no threshold tables.  A queue that overflows hands the band
+    back to the threshold route.  Whatever the route: the oracle's raster and statistics."""
+    if route == "tinyqueue":
+        monkeypatch.setenv("SARPRO_HIP_F32_DIRECT", "1")
+        monkeypatch.setenv("SARPRO_HIP_F32_DIRECT_QCAP", "0")
+    else:
+        monkeypatch.setenv("SARPRO_HIP_F32_DIRECT", route)
+    x = make()
+    with S.Context(0, timing=True) as c:
+        u8, u16, st = c.process_scalar_data_pipeline(x, bit_depth, strategy, want_stats=True)
+        names = [n for n, _ in c.last_kernel_times()]
+    rc, ref, so = oracle.pipeline(x, int(bit_depth), int(strategy), want_stats=True)
+    assert rc == 0
+    got = u8 if bit_depth == Bd.U8 else u16
+    assert np.array_equal(got, ref), (name, strategy, bit_depth, route, int((got != ref).sum()))
+    assert ("f32_hist4096_direct" in names) == (route != "0"), names
+    for k in ("valid_count", "min_db", "max_db", "median_db", "p01", "p02", "p05", "p25", "p75", "p95", "p98", "p99", "low_clip", "high_clip", "gamma"):
+        assert getattr(st, k) == getattr(so, k), (k, route)
+
+
+def test_f32_direct_route_with_many_samples_on_bin_boundaries(monkeypatch):
+    """Quantised data: thousands of samples share each value, among them the minimum, the maximum and values that sit on a bin edge."""
+    monkeypatch.setenv("SARPRO_HIP_F32_DIRECT", "1")
+    rng = np.random.default_rng(4)
+    vals = np.float32(10.0) ** (np.arange(0, 4097, 64, dtype=np.float64) / 4096.0 * 3.0).astype(np.float32)  # dB evenly over 30 dB: many land on edges
+    x = rng.choice(vals, size=(300, 520)).astype(np.float32)
+    x[:20] = 0.0
+    with S.Context(0) as c:
+        for s in (St.Standard, St.Robust, St.Adaptive, St.Tamed):
+            for bd in Bd:
+                u8, u16 = c.process_scalar_data_pipeline(x, bd, s)
+                rc, ref = oracle.pipeline(x, int(bd), int(s))
+                assert rc == 0 and np.array_equal(u8 if bd == Bd.U8 else u16, ref), (s, bd)

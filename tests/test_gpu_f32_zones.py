@@ -20,6 +20,12 @@ def names(ctx):
     return [n for n, _ in ctx.last_kernel_times()]
 
 
+@pytest.fixture(autouse=True)
+def _no_direct_route(monkeypatch):
+    """These rasters are small: without this they would take the small-scene direct route, not the zone route under test."""
+    monkeypatch.setenv("SARPRO_HIP_F32_DIRECT", "0")
+
+
 @pytest.mark.parametrize("strategy", ZONE_STRATEGIES)
 @pytest.mark.parametrize("bd", list(Bd))
 @pytest.mark.parametrize("scene", ["ratio", "resampled", "nasty"])

@@ -15,7 +15,7 @@ pitch = (cols + 63) // 64 * 64
 ctx = S.Context(0); q = synth.q_tables()
 band = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
 rgb = [torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
-SWITCHES = ("SARPRO_HIP_NO_CHAIN", "SARPRO_HIP_NO_FUSED", "SARPRO_HIP_NO_LINEAR_HIST", "SARPRO_HIP_FULL_LEVEL_HIST")
+SWITCHES = ("SARPRO_HIP_NO_CHAIN", "SARPRO_HIP_NO_FUSED", "SARPRO_HIP_NO_LINEAR_HIST", "SARPRO_HIP_FULL_LEVEL_HIST", "SARPRO_HIP_NO_FUSED_RGB", "SARPRO_HIP_NO_SAMPLED_HIST")
 bad = 0; t0 = time.time()
 for k in range(n):
     for b in range(2):
