@@ -323,29 +323,35 @@ impl RasterCore {
                 self.chk(unsafe { sys::sarpro_hip_resize_output_dims(cols, rows, ts, pad as c_int, &mut fc, &mut fr) })?;
                 let mut meta = zeroed_meta();
                 let mut rgb = vec![0u8; fc * fr * 3];
-                if target_size.is_none() && !pad {
-                    let (b1, b2) = (processed1.as_standard_layout(), processed2.as_standard_layout());
-                    self.chk(unsafe { sys::sarpro_hip_dualpol_synrgb_f32(self.ctx, b1.as_ptr(), b2.as_ptr(), rows, cols, autoscale as c_int,
-                        syn_mode as c_int, rgb.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut()) })?;
-                    meta.final_cols = cols; meta.final_rows = rows;
-                } else {
-                    // the f32 flavour of the resized flow goes band by band (the fused resized flow is u16-only:
-                    // try_render_multiband_image_u16)
-                    let band = |p: &Array2<f32>, copol: bool| -> Result<(Vec<u8>, f64, f64, usize, usize)> {
-                        let u8s = if autoscale == AutoscaleStrategy::Tamed { self.try_tamed_synrgb_u8(p, copol)? }
-                                  else { self.try_autoscale_band(p, BitDepth::U8, autoscale)?.0 };
-                        let r = self.try_resize_image_data_with_meta(&u8s, None, cols, rows, target_size, BitDepth::U8, pad)?;
-                        Ok((r.2, r.4, r.5, r.6, r.7))
-                    };
-                    let (f1, f2) = (band(processed1, true)?, band(processed2, false)?);
-                    rgb = self.try_create_synthetic_rgb(syn_mode, autoscale, &f1.0, &f2.0)?;
-                    meta.scale_x = f1.1; meta.scale_y = f1.2; meta.pad_left = f1.3; meta.pad_top = f1.4;
-                    meta.final_cols = fc; meta.final_rows = fr;
-                }
+                // one call either way: pipeline x2 (Tamed: band-specific re-autoscale, save.rs:323-327,345-349) -> resize -> pad -> synRGB
+                let (b1, b2) = (processed1.as_standard_layout(), processed2.as_standard_layout());
+                self.chk(unsafe { sys::sarpro_hip_dualpol_synrgb_resized_f32(self.ctx, b1.as_ptr(), b2.as_ptr(), rows, cols, autoscale as c_int,
+                    syn_mode as c_int, 0, ts, pad as c_int, rgb.as_mut_ptr(), &mut meta) })?;
                 Ok(ProcessedImage { width: fc, height: fr, bit_depth: BitDepth::U8, format, gray: None, gray16: None, rgb: Some(rgb),
                     gray_band2: None, gray16_band2: None, resize: meta })
             }
         }
+    }
+
+    /// process_safe_to_buffer_with_mode, multiband JPEG branch (api/mod.rs:404-437): BOTH bands through process_scalar_data_pipeline with
+    /// the caller's strategy (no Tamed re-autoscale), resize, pad, synRGB by mode and strategy -- the reference's default flow, its
+    /// bands resampled on read (non-integer f32).
+    pub fn try_process_multiband_to_rgb(&self, band1: &Array2<f32>, band2: &Array2<f32>, target_size: Option<usize>, pad: bool,
+        autoscale: AutoscaleStrategy, syn_mode: SyntheticRgbMode) -> Result<ProcessedImage> {
+        if band1.dim() != band2.dim() {
+            return Err(HipError { code: sys::SARPRO_HIP_ERR_SHAPE_MISMATCH, message: "band shapes differ".into() });
+        }
+        let (rows, cols) = band1.dim();
+        let (b1, b2) = (band1.as_standard_layout(), band2.as_standard_layout());
+        let (mut fc, mut fr) = (0usize, 0usize);
+        let ts = target_size.unwrap_or(0);
+        self.chk(unsafe { sys::sarpro_hip_resize_output_dims(cols, rows, ts, pad as c_int, &mut fc, &mut fr) })?;
+        let mut rgb = vec![0u8; fc * fr * 3];
+        let mut meta = zeroed_meta();
+        self.chk(unsafe { sys::sarpro_hip_dualpol_synrgb_resized_f32(self.ctx, b1.as_ptr(), b2.as_ptr(), rows, cols, autoscale as c_int,
+            syn_mode as c_int, sys::SARPRO_HIP_DUALPOL_PLAIN_PIPELINE, ts, pad as c_int, rgb.as_mut_ptr(), &mut meta) })?;
+        Ok(ProcessedImage { width: fc, height: fr, bit_depth: BitDepth::U8, format: OutputFormat::JPEG, gray: None, gray16: None,
+            rgb: Some(rgb), gray_band2: None, gray16_band2: None, resize: meta })
     }
 
     /// The JPEG branch of save.rs:317-367 for u16 DN bands in ONE call: autoscale x2 -> resize -> pad -> synRGB on the device,
