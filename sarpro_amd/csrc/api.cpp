@@ -992,7 +992,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
     const uint32_t rows = (uint32_t)J.rows_local, cols = (uint32_t)J.cols;
     RETCHK(ensure_levels(J)); // the fallback's level rasters (allocated once per shape; untouched when the fused RGB stands)
     HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
-    unsigned long long *sample_hist = ctx->level_hist.as<unsigned long long>(), *exact_hist = sample_hist + 256 * kMaxBands;
+    unsigned long long *sample_hist = ctx->level_hist.as<unsigned long long>(), *exact_hist = sample_hist + 256 * kMaxBands * kSampleReplicas;
     ClaheApplyArgs a{};
     for (int b = 0; b < 2; ++b) {
         a.in[b] = J.d_in[b];
@@ -1005,7 +1005,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
     a.row_w = fa.row_w; a.col_w = fa.col_w; a.row_off = fa.row_off;
     a.max_val = 255.0; a.dev_state = d_state; a.lut_cap = ctx->chain_lut_cap;
     a.dump = ctx->spec_dump.as<uint8_t>();
-    a.sample_stride = sample_stride; a.sample_phase = sample_stride / 2; a.sample_valid = d_spec->sample_valid;
+    a.sample_stride = sample_stride; a.sample_phase = sample_stride / 2; a.sample_valid = d_spec->sample_valid_rep;
     {   // the sampled rows of both bands through the blend: level histogram + valid counts, nothing stored
         a.hist_mode = 3u;
         a.rects = J.plan->d_sample_rects.as<Rect>();
@@ -1067,7 +1067,8 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
     HIPCHK(ctx, ctx->tile_bins.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands));
     HIPCHK(ctx, ctx->cdfs.reserve(sizeof(double) * 64 * 256 * kMaxBands));
-    HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands * 2)); // [0, 2): the apply pass's histogram; [2, 4): the gated recount
+    // [kSampleReplicas][2][256]: the apply / sampling pass's histogram (replica 0 alone unless it is sampled); then [2][256]: the gated recount
+    HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands * (kSampleReplicas + 1)));
     HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
     HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
     uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
@@ -1101,7 +1102,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         sa.binlut = ctx->luts.as<uint8_t>();
         sa.binlut_stride = 131072;
         sa.level_hist = ctx->level_hist.as<unsigned long long>(); // cleared here for the apply kernel (one fill kernel less)
-        sa.sample_valid = d_spec ? d_spec->sample_valid : nullptr;
+        sa.sample_valid = d_spec ? d_spec->sample_valid_rep : nullptr;
         KernelTimer t(ctx, "chain_stats");
         RETCHK(chain_stats_scratch(ctx, &sa));
         HIPCHK(ctx, launch_chain_stats(sa, J.nbands, ctx->stream));
@@ -1138,7 +1139,10 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         fa.rects = J.plan->d_rgb_rects.as<Rect>(); fa.nrects = (int)J.plan->rgb_rects.size();
         fa.row_w = J.plan->d_row_w.as<RowWeight>(); fa.col_w = J.plan->d_col_w.as<RowWeight>(); fa.row_off = (int32_t)J.row0;
         fa.dev_state = d_state; fa.spec = d_spec; fa.tables = ctx->tables.as<uint8_t>();
-        if (clahe_rgb_fused_supported(fa)) return job_run_fused_rgb(J, fa, d_rgb, rgb_pitch_px, sample_stride, stats_out);
+        // the sample-only pass costs ~0.025 ms + (apply pass) / stride: 0.056 ms at 17, 0.033 at 33; the wider stride's larger sigma (x 1.4: ~2.4 %
+        // of scenes refuted instead of ~1.7 %, 1 ms each) costs 0.007 ms in expectation
+        const uint32_t fused_stride = getenv("SARPRO_HIP_SAMPLE_STRIDE") ? sample_stride : 33u;
+        if (clahe_rgb_fused_supported(fa)) return job_run_fused_rgb(J, fa, d_rgb, rgb_pitch_px, fused_stride, stats_out);
     }
     // apply: levels into the internal rasters (dual-pol) or straight into the caller's raster (single band)
     const bool direct = !J.synrgb;
@@ -1188,7 +1192,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     if (sampled) {
         a.sample_stride = sample_stride;
         a.sample_phase = sample_stride / 2; // mid-phase: the row weights of the sampled rows average to those of all rows
-        a.sample_valid = d_spec->sample_valid;
+        a.sample_valid = d_spec->sample_valid_rep;
     }
     if (exact_only) {
         KernelTimer t(ctx, "clahe_apply_u16");
@@ -1224,7 +1228,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         if (cvec != 16) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "sampled level histogram without the vector compose pass");
         ChainPredictArgs pa{};
         pa.sample_hist = ctx->level_hist.as<unsigned long long>();
-        pa.exact_hist = final_hist = ctx->level_hist.as<unsigned long long>() + 256 * kMaxBands;
+        pa.exact_hist = final_hist = ctx->level_hist.as<unsigned long long>() + 256 * kMaxBands * kSampleReplicas;
         pa.spec = d_spec;
         pa.state = d_state;
         pa.total_px = (unsigned long long)J.rows_total * J.cols;

@@ -30,7 +30,8 @@ struct ChainStatsArgs {
     int tamed_kind[kMaxBands];       // 0 / 1 copol / 2 crosspol (autoscale.rs:721-727)
     unsigned long long total_px;     // pixels per band (level 0 also counts the invalid ones)
     unsigned long long *level_hist;  // [nbands][256]: cleared by kernel A (levels mode: filled by kernel C; CLAHE: by the apply kernel)
-    unsigned long long *sample_valid;// [nbands] or null: cleared by kernel A (CLAHE chain with a sampled level histogram)
+    unsigned long long *sample_valid;// [kSampleReplicas][kMaxBands] or null: cleared by kernel A together with the histogram's replicas (CLAHE chain with a
+                                     // sampled level histogram: level_hist is then [kSampleReplicas][kMaxBands][256])
     const double *gamma_thr;         // [3][256]: x-thresholds of trunc(pow(x, g) * 255) for g = 0.8, 0.9, 1.1 (host-built)
     ChainStatsPartial *partials;     // scratch [nbands][kChainStatsParts]
     unsigned long long *bins4096;    // scratch [nbands][4096]
@@ -76,7 +77,7 @@ struct LevelRecountArgs {
 };
 // CLAHE chain with a sampled level histogram: identity proof + predicted floor + compose tables (k_chain_predict)
 struct ChainPredictArgs {
-    const unsigned long long *sample_hist; // [2][256] partial level histogram of the sampled rows (bin 0 implied)
+    const unsigned long long *sample_hist; // [kSampleReplicas][2][256] partial level histogram of the sampled rows (bin 0 implied), summed here
     unsigned long long *exact_hist;        // [2][256] cleared here: the gated recount adds into it
     ChainSpecState *spec;
     const ChainBandState *state;           // stats.valid_count per band

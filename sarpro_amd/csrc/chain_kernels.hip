@@ -70,7 +70,11 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_a(ChainStatsArgs a) 
     if (part == 0) { // scratch of the next two kernels
         for (int i = t; i < kStatBins; i += kPartBlock) a.bins4096[(size_t)band * kStatBins + i] = 0ull;
         if (a.level_hist) a.level_hist[(size_t)band * 256 + t] = 0ull; // levels mode: filled by kernel C; CLAHE: by the apply kernel
-        if (t == 0) { a.state[band].win_hi = 65535u; a.state[band].uncertain = 0u; if (a.sample_valid) a.sample_valid[band] = 0ull; }
+        if (a.sample_valid) { // CLAHE chain with a sampled histogram: every replica of the histogram and of the valid counts
+            for (int r = 1; r < kSampleReplicas; ++r) a.level_hist[((size_t)r * kMaxBands + band) * 256 + t] = 0ull;
+            if (t < kSampleReplicas) a.sample_valid[t * kMaxBands + band] = 0ull;
+        }
+        if (t == 0) { a.state[band].win_hi = 65535u; a.state[band].uncertain = 0u; }
     }
     unsigned long long cnt = 0;
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
@@ -580,12 +584,18 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
     const int t = threadIdx.x, wb = t >> 6, ln = t & 63;
     if (wb < 2) {
         const unsigned long long *sh = a.sample_hist + (size_t)wb * 256;
-        unsigned long long v[4], others = 0;
+        unsigned long long v[4], others = 0, sv = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = sh[ln * 4 + k]; if (ln * 4 + k) others += v[k]; }
+        for (int k = 0; k < 4; ++k) {
+            v[k] = 0ull;
+            for (int r = 0; r < kSampleReplicas; ++r) v[k] += sh[(size_t)r * kMaxBands * 256 + ln * 4 + k]; // the sampling pass's replicas (kernels.h)
+            if (ln * 4 + k) others += v[k];
+        }
+        for (int r = 0; r < kSampleReplicas; ++r) sv += a.spec->sample_valid_rep[r * kMaxBands + wb];
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) others += __shfl_xor(others, m, 64);
-        const unsigned long long sv = a.spec->sample_valid[wb], valid = a.state[wb].stats.valid_count;
+        const unsigned long long valid = a.state[wb].stats.valid_count;
+        if (blockIdx.x == 0 && ln == 0) a.spec->sample_valid[wb] = sv;
         const unsigned long long invalid = a.total_px - valid;
         const bool consistent = sv >= others && sv > 0;
         const unsigned long long s0v = consistent ? sv - others : 0ull; // sampled valid pixels at level 0

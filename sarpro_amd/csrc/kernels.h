@@ -51,7 +51,8 @@ struct ClaheApplyArgs {
     uint32_t hist_mode;                     // speculative kernel: 0 full level histogram, 1 levels >= 64 only counted in bulk (see
                                             // k_level_hist_guard), 2 the bulk form on sampled rows only (see k_chain_predict)
     uint32_t sample_stride, sample_phase;   // hist_mode 2: row r is sampled iff (row_off + r) % sample_stride == sample_phase; stride > 4
-    unsigned long long *sample_valid;       // hist_mode 2: [nbands] valid (DN != 0) pixels on the sampled rows, added to
+    unsigned long long *sample_valid;       // hist_mode 2, 3: [kSampleReplicas][nbands] valid (DN != 0) pixels on the sampled rows, added to
+                                            // (hist_mode 2, 3: level_hist[b] is replica 0 of [kSampleReplicas][kMaxBands][256] as well)
     const struct ChainSpecState *gate;      // set: the launch is the fused chain's fallback and runs only if gate->verdict != 0
     uint8_t *dump;                          // speculative kernel: kSpecDumpBytes of scratch that edge lanes' full-width stores go to
 };
@@ -82,7 +83,11 @@ struct ComposeArgs {
 
 // State of the CLAHE chain's speculation on the synRGB floor (device memory, one per context).  k_chain_predict writes it
 // after the apply pass, the speculative compose pass adds its counts and the verdict, the gated exact kernels read it.
-constexpr unsigned long long kSampleWeightOne = 4096; // fixed-point 1.0 of the sampled histogram's per-item weights
+constexpr unsigned long long kSampleWeightOne = 4096;
+// The sampling passes end with every workgroup adding its ~100 occupied bins to the SAME global words: 1760 workgroups on one word
+// serialise for ~25 us (the sample-only pass took 0.035 ms with four rows per item and 0.011 with none).  They add into one of
+// kSampleReplicas copies instead (by workgroup index); k_chain_predict sums the copies.
+constexpr int kSampleReplicas = 16; // fixed-point 1.0 of the sampled histogram's per-item weights
 constexpr int kSpecFloorCap = 37; // synthetic_rgb.rs:110-113: floor + 3 is capped at 40, so every floor >= 37 is the same floor
 struct ChainSpecState {
     uint32_t spec_ok;              // both bands hold level 0 and level 255 (=> the u8 rescale is the identity) and a floor was predicted
@@ -91,7 +96,8 @@ struct ChainSpecState {
     uint32_t done;                 // workgroups of the speculative compose pass that have added their counts
     unsigned long long n_lt[2];    // band-pixels with level < F, < F + 1, counted by the speculative compose pass
     unsigned long long target;     // synthetic_rgb.rs:99-100
-    unsigned long long sample_valid[2]; // valid pixels on the sampled rows, per band, weighted like the histogram (apply pass)
+    unsigned long long sample_valid[2]; // valid pixels on the sampled rows, per band, weighted like the histogram (summed by k_chain_predict)
+    unsigned long long sample_valid_rep[kSampleReplicas * 2]; // [replica][band]: what the workgroups of the sampling pass add to
     double est_lt[2];              // the sample's estimate of n_lt (diagnostics)
     uint32_t force;                // test switches (kSpecForce*)
     uint32_t pad;

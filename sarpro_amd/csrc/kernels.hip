@@ -875,10 +875,11 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
             const int cnt = first < rc.r1 ? (rc.r1 - 1 - first) / stride + 1 : 0;
             w = cnt ? ((unsigned long long)(rc.r1 - rc.r0) * kSampleWeightOne + (unsigned)cnt / 2) / (unsigned)cnt : 0ull;
         }
-        if (n && threadIdx.x) atomicAdd(&ghist[threadIdx.x], (unsigned long long)n * w); // bin 0 restored by the consumer
+        const uint32_t replica = HIST >= 2 ? (blockIdx.x % (uint32_t)kSampleReplicas) : 0u; // (kernels.h: kSampleReplicas)
+        if (n && threadIdx.x) atomicAdd(&ghist[(size_t)replica * 256 * kMaxBands + threadIdx.x], (unsigned long long)n * w); // bin 0 restored by the consumer
         if (HIST >= 2 && threadIdx.x == 0) {
             const uint32_t nv = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[320];
-            if (nv) atomicAdd(&a.sample_valid[band], (unsigned long long)nv * w);
+            if (nv) atomicAdd(&a.sample_valid[replica * kMaxBands + band], (unsigned long long)nv * w);
         }
     }
 }
