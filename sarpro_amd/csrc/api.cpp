@@ -1115,12 +1115,16 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
             ta.out[b] = ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256;
         }
         ta.clear = 1u; // the last reader of the tile histograms
+        if (!J.reduce && !getenv("SARPRO_HIP_SEPARATE_CDFS")) { // one device: the CDFs in the same launch
+            for (int b = 0; b < J.nbands; ++b) ta.cdfs_out[b] = ctx->cdfs.as<double>() + (size_t)b * 64 * 256;
+            ta.rows = (uint32_t)J.rows_total; ta.cols = cols;
+        }
         KernelTimer t(ctx, "tile_bin_hist");
         HIPCHK(ctx, launch_tile_bin_hist(ta, kTiles * kTiles, J.nbands, ctx->stream));
         mark_tile_hist_clean(J);
     }
     RETCHK(chain_reduce(J, ctx->tile_bins.p, 64 * 256 * (size_t)J.nbands, "allreduce_tile_hists"));
-    {
+    if (J.reduce || getenv("SARPRO_HIP_SEPARATE_CDFS")) {
         KernelTimer t(ctx, "chain_cdfs");
         HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
                                       J.nbands, ctx->stream));

@@ -9,6 +9,7 @@
 // tables of the suppressed synRGB LUTs (one per possible floor) and the blue pair tables are
 // constant tables built once on the host with glibc and uploaded at context creation.
 #include "chain_kernels.h"
+#include "device_cdf.h"
 
 #include <cfloat>
 
@@ -164,6 +165,17 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_c(ChainStatsArgs a) 
     const double *__restrict__ db = a.db;
     ChainBandState *out = a.state + band;
     uint8_t *binlut = a.binlut + (size_t)band * a.binlut_stride;
+    // CLAHE: this workgroup's dB values and its share of the 4096 bins are requested before anything depends on them (the kernel is a
+    // chain of dependent round trips to L2: partials -> bins -> dB values; two of the three now overlap the first)
+    constexpr int kPerC = kPartDns / kPartBlock, kOwnC = kStatBins / kPartBlock;
+    double dv_pre[kPerC];
+    unsigned long long own_pre[kOwnC];
+    if (!a.levels_mode) {
+#pragma unroll
+        for (int k = 0; k < kPerC; ++k) dv_pre[k] = db[(uint32_t)part * kPartDns + k * kPartBlock + t];
+    }
+#pragma unroll
+    for (int k = 0; k < kOwnC; ++k) own_pre[k] = a.bins4096[(size_t)band * kStatBins + kOwnC * t + k];
     const BandTotals tot = reduce_partials(a.partials + band * kStatsParts);
     const unsigned long long count = tot.count;
 
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_c(ChainStatsArgs a) 
         constexpr int kOwn = kStatBins / kPartBlock;
         unsigned long long own[kOwn], totb = 0;
 #pragma unroll
-        for (int k = 0; k < kOwn; ++k) { own[k] = a.bins4096[(size_t)band * kStatBins + kOwn * t + k]; totb += own[k]; }
+        for (int k = 0; k < kOwn; ++k) { own[k] = own_pre[k]; totb += own[k]; }
         unsigned long long excl;
         { // block exclusive scan (integers: order-free)
             const int lane = t & 63, wave = t >> 6;
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(kPartBlock) void k_chain_stats_c(ChainStatsArgs a) 
         constexpr int kPer = kPartDns / kPartBlock;
         double dv[kPer];
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) dv[k] = db[dn0 + k * kPartBlock + t];
+        for (int k = 0; k < kPer; ++k) dv[k] = dv_pre[k];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const uint32_t dn = dn0 + k * kPartBlock + t;
@@ -427,37 +439,9 @@ __global__ __launch_bounds__(256) void k_chain_cdfs(const unsigned long long *__
     __shared__ double scr[256];
     __shared__ unsigned long long cum[256];
     const int tile = blockIdx.x, band = blockIdx.y, b = threadIdx.x;
-    const uint32_t tile_h = (rows + kTiles - 1) / kTiles, tile_w = (cols + kTiles - 1) / kTiles;
-    const uint32_t ty = tile / kTiles, tx = tile % kTiles;
-    const uint32_t r0 = min(ty * tile_h, rows), r1 = min((ty + 1) * tile_h, rows);
-    const uint32_t c0 = min(tx * tile_w, cols), c1 = min((tx + 1) * tile_w, cols);
     const size_t base = ((size_t)band * kTiles * kTiles + tile) * 256;
-    unsigned long long hv = tile_bins[base + b];
-
-    const double avg = (double)((unsigned long long)(r1 - r0) * (unsigned long long)(c1 - c0)) / 256.0;
-    const double thr = fmax(kClipLimit * avg, 1.0);
-    double ex = 0.0;
-    if ((double)hv > thr) { ex = (double)hv - thr; hv = (unsigned long long)(uint32_t)thr; } // `as u32` truncates (thr < 2^32 here)
-    scr[b] = ex;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (b < s) scr[b] += scr[b + s]; __syncthreads(); }
-    const double excess = scr[0];
-    __syncthreads();
-    const double add = floor(excess / 256.0);
-    const unsigned long long remainder = (unsigned long long)round(excess - add * 256.0);
-    double hd = (double)hv + add;
-    unsigned long long hn = hd >= 4294967295.0 ? 4294967295ull : (unsigned long long)hd; // `as u32` saturates
-    hn += remainder / 256 + ((unsigned long long)b < remainder % 256 ? 1 : 0);         // round-robin from bin 0
-    cum[b] = hn;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned long long v = b >= off ? cum[b - off] : 0ull;
-        __syncthreads();
-        cum[b] += v;
-        __syncthreads();
-    }
-    const double total = fmax((double)cum[255], 1.0);
-    cdfs[base + b] = clampd((double)cum[b] / total, 0.0, 1.0);
+    const double c = clahe_tile_cdf_entry(tile_bins[base + b], tile, b, true, rows, cols, scr, cum);
+    cdfs[base + b] = c;
 }
 
 // ------------------------------------------------------------------------------------

@@ -140,6 +140,8 @@ struct TileBinHistArgs {
     const uint8_t *binlut[kMaxBands];     // [65536]
     unsigned long long *out[kMaxBands];   // [ntiles][256]
     uint32_t clear;                       // last reader of the tile histograms: zero what was read (the next scene skips its fill)
+    double *cdfs_out[kMaxBands];          // [ntiles][256] or null: also clip / redistribute / CDF of the tile (autoscale.rs:271-302) -- the scene's
+    uint32_t rows, cols;                  // shape, for the tile areas; only where no reduction over ranks sits between bins and CDFs
 };
 hipError_t launch_tile_bin_hist(const TileBinHistArgs &a, int ntiles, int nbands, hipStream_t s);
 hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nbands, bool vec, bool out16,

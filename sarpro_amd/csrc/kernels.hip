@@ -9,6 +9,7 @@
 // f64 multiplies and adds (autoscale.rs:327-329), never as FMAs.
 #include "kernels.h"
 #include "chain_kernels.h"
+#include "device_cdf.h"
 
 #include <algorithm>
 #include <mutex>
@@ -310,6 +311,14 @@ __global__ __launch_bounds__(kTileBinBlock) void k_tile_bin_hist(TileBinHistArgs
     }
     __syncthreads();
     if (threadIdx.x < 256) a.out[band][(size_t)blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
+    if (a.cdfs_out[band]) { // the tile's CDF in the same launch (no reduction over ranks in between: one kernel boundary less on the chain)
+        __shared__ double scr[256];
+        __shared__ unsigned long long cum[256];
+        const bool active = threadIdx.x < 256;
+        const int b = active ? (int)threadIdx.x : 0;
+        const double c = clahe_tile_cdf_entry(active ? h[b] : 0ull, (int)blockIdx.x, b, active, a.rows, a.cols, scr, cum);
+        if (active) a.cdfs_out[band][(size_t)blockIdx.x * 256u + b] = c;
+    }
 }
 
 // ------------------------------------------------------------------------------------
