@@ -33,6 +33,7 @@ struct DevBuf { // grow-only device allocation, freed with its owner
 struct PinnedBuf { // grow-only pinned host allocation, freed with its owner
     void *p = nullptr;
     size_t cap = 0;
+    unsigned flags = hipHostMallocDefault;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
     PinnedBuf &operator=(const PinnedBuf &) = delete;
@@ -40,7 +41,7 @@ struct PinnedBuf { // grow-only pinned host allocation, freed with its owner
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, bytes, flags);
         if (e == hipSuccess) cap = bytes;
         return e;
     }
@@ -117,6 +118,9 @@ struct sarpro_hip_ctx {
     uint32_t chain_lut_cap = 4096;               // LDS capacity (entries) of the apply kernel's offset table
     // pinned host mirrors
     sarpro::PinnedBuf h_ghist, h_small, h_upload;
+    sarpro::PinnedBuf mailbox;   // coherent pinned memory one-workgroup kernels post small results into (f32 flavour: no copy commands, no stream wait)
+    uint32_t mail_seq = 0;       // the sequence word of the last post (word 0 of the mailbox)
+    uint32_t mail_upload_slot = 0;
     // streaming ingest / egress: pinned ring on a side stream
     hipStream_t copy_stream = nullptr;
     hipEvent_t ring_evt[3] = {nullptr, nullptr, nullptr};

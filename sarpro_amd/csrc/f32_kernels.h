@@ -48,6 +48,11 @@ struct F32LevelArgs {
     double low, high, range, gamma, max_val; // range = max(high - low, 1)
     float t_first, t_last;
     int f64_levels;
+    // gamma == 1 (every strategy but the gamma-corrected ones): the whole expression is one line in log2(x),
+    // y = clamp(lin_a * log2(x) + lin_b, 0, lin_ymax), lin_a = 10 log10(2) max_val / range, lin_b = -low max_val / range
+    // (folded into the kernel's log2 table and series coefficients: 7 f64 operations instead of 20)
+    int lin;
+    double lin_a, lin_b, lin_ymax;
     // f64_levels == 2: no 65535-entry table at all -- a sample within 1e-6 of a level boundary is QUEUED (row, column, bits) and
     // the host settles it with the reference's own arithmetic (glibc); thr is then unused.  *uq_count > uq_cap: overflow.
     uint32_t *uq_count;
@@ -137,6 +142,24 @@ hipError_t launch_f32_zone_pick(const F32ZoneSelectArgs &a, hipStream_t s);
 hipError_t launch_f32_sample_sub(const float *d_sample, uint64_t n, float t_valid, const F32ZoneWork *work, uint32_t *d_sub_hist /* zeroed */, hipStream_t s);
 hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s);
 hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int nz_max, int grid, hipStream_t s);
+// Results for the host WITHOUT copy commands: a one-workgroup kernel reduces / copies them into pinned (coherent) host memory and
+// raises a sequence word there; the host spins on that word instead of sleeping in hipStreamSynchronize.  (Four small copies and
+// a stream wait cost a turn 80 us; this costs it ~15.)
+struct F32ZoneMail { // what the host reads after the min / max pass of the zone route
+    unsigned long long count;                  // valid samples
+    float min_v, max_v;                        // +inf / -inf when there are none
+    unsigned long long ge[2 * kMaxZones];      // valid samples >= bounds[k] (even k only: lower bounds)
+    unsigned long long kept;                   // samples in the side buffers
+    uint32_t overflow, pad;                    // a wave's side buffer overflowed
+    F32ZoneWork work;
+};
+hipError_t launch_f32_zone_post(const F32ZoneArgs &a, int grid, F32ZoneMail *mail, uint32_t *flag, uint32_t seq, hipStream_t s);
+struct PostSegs { const void *src[4]; void *dst[4]; uint32_t bytes[4]; int n; }; // bytes: multiples of 4
+hipError_t launch_post(const PostSegs &segs, uint32_t *flag, uint32_t seq, hipStream_t s);
+// host words -> device (the source is pinned coherent memory the device reads directly) and zero fills, one launch: a kernel
+// follows a kernel without the 5-17 us a copy / fill command puts between itself and the next kernel
+struct PrepSegs { const void *src[3]; void *dst[3]; uint32_t bytes[3]; int n; void *zero[4]; uint32_t zbytes[4]; int nz; }; // bytes: multiples of 4
+hipError_t launch_prep(const PrepSegs &segs, hipStream_t s);
 // counts[i] += zone samples x with thr[i] <= x < thr[i + 1], i = 0 .. nthr (thr[0] = -inf implied below thr[1]; thr sorted, nthr <= kZoneMaxThr)
 hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, uint32_t cap, int nregions, const float *d_thr, int nthr,
                                  unsigned long long *d_counts /* [kZoneMaxThr + 1], zeroed */, hipStream_t s);

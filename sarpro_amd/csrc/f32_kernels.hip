@@ -47,20 +47,19 @@ __device__ inline uint32_t est_search(const float *thr, float v, const F32StepEs
 }
 
 // ops.rs:4-44, IEEE f32 (hipcc's default correctly rounded divide); the same function as kernels.hip k_polop_f32
-// num / den for operands that are integers of magnitude < 2^18 (u16 DN, their sums and differences), den != 0: the Newton
-// core of the compiler's IEEE division (LLVM's f32 fdiv expansion) without its v_div_scale / v_div_fmas / v_div_fixup frame.
-// That frame rescales operands whose exponents are extreme and patches inf / nan / zero denominators; for these operands it
-// is the identity, so the quotient is the correctly rounded one, bit for bit -- checked against `/` over ALL 2^32 pairs of
-// u16 values, for the ratio and for the normalised difference (tests/test_gpu_polop_fused.py).
+// num / den for operands that are integers of magnitude < 2^18 (u16 DN, their sums and differences), den != 0: the hardware's
+// reciprocal (1 ulp), the quotient it gives, and ONE correction of that quotient by its exact residual -- 4 instructions
+// against the 10 of the compiler's IEEE division (v_div_scale x2, a refined reciprocal, two corrections, v_div_fmas,
+// v_div_fixup).  The frame rescales extreme exponents and patches inf / nan / zero denominators: the identity for these
+// operands.  The refinement and the second correction matter only when the true quotient lies within ~1e-7 ulp of a rounding
+// boundary, which a ratio of integers this small cannot (its distance from a 25-bit midpoint is at least 2^-25 / den of its
+// own magnitude).  Not taken on trust: checked against `/` over ALL 2^32 pairs of u16 values, for the ratio and for the
+// normalised difference, on the hardware the suite runs on (tests/test_gpu_polop_fused.py; round 2's 8-instruction form and
+// the two forms in between pass the same check).
 __device__ inline float div_small_ints(float num, float den) {
-    float r = __builtin_amdgcn_rcpf(den);
-    const float e0 = __builtin_fmaf(-den, r, 1.0f);
-    r = __builtin_fmaf(e0, r, r);
-    float q = num * r;
-    const float e1 = __builtin_fmaf(-den, q, num);
-    q = __builtin_fmaf(e1, r, q);
-    const float e2 = __builtin_fmaf(-den, q, num);
-    return __builtin_fmaf(e2, r, q);
+    const float r = __builtin_amdgcn_rcpf(den);
+    const float q = num * r;
+    return __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
 }
 
 // ops.rs:10-19 / 22-33 / 35-44: num / den where |den| > 1e-10, else 0
@@ -569,6 +568,88 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     if (threadIdx.x < 2 * kMaxZones) a.ge_counts[(size_t)blockIdx.x * 2 * kMaxZones + threadIdx.x] = gsum[threadIdx.x];
 }
 
+// the min / max pass's per-workgroup results reduced into the host's mailbox (one workgroup of 1024: two turns for the pass's 2048)
+constexpr int kPostBlock = 1024;
+__global__ __launch_bounds__(kPostBlock) void k_f32_zone_post(F32ZoneArgs a, int grid, F32ZoneMail *mail, uint32_t *flag, uint32_t seq) {
+    __shared__ unsigned long long s_sum[2 * kMaxZones + 2];
+    __shared__ float s_mn[kPostBlock / 64], s_mx[kPostBlock / 64];
+    __shared__ uint32_t s_over;
+    if (threadIdx.x < 2 * kMaxZones + 2) s_sum[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_over = 0;
+    __syncthreads();
+    float mn = INFINITY, mx = -INFINITY;
+    unsigned long long cnt = 0, kept = 0, ge[kMaxZones];
+#pragma unroll
+    for (int z = 0; z < kMaxZones; ++z) ge[z] = 0;
+    uint32_t over = 0;
+    const uint32_t wcap = a.cap / kWavesPerBlock;
+    static_assert(kWavesPerBlock == 4 && sizeof(F32Partial) == 32, "vector loads below");
+    for (int i = threadIdx.x; i < grid; i += kPostBlock) { // one workgroup of the pass per thread and turn: all its loads in flight together
+        const F32Partial p = a.partials[i];
+        const uint4 zn = reinterpret_cast<const uint4 *>(a.zone_n)[i];
+        const ulonglong2 *gp = reinterpret_cast<const ulonglong2 *>(a.ge_counts + (size_t)i * 2 * kMaxZones);
+#pragma unroll
+        for (int z = 0; z < kMaxZones; ++z) ge[z] += gp[z].x; // (only the lower bound of a zone is counted)
+        cnt += p.count; mn = fminf(mn, p.minv); mx = fmaxf(mx, p.maxv);
+        kept += (unsigned long long)zn.x + zn.y + zn.z + zn.w;
+        over |= (zn.x > wcap) | (zn.y > wcap) | (zn.z > wcap) | (zn.w > wcap);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, d)); mx = fmaxf(mx, __shfl_xor(mx, d));
+        cnt += __shfl_xor(cnt, d); kept += __shfl_xor(kept, d); over |= __shfl_xor(over, d);
+#pragma unroll
+        for (int z = 0; z < kMaxZones; ++z) ge[z] += __shfl_xor(ge[z], d);
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int z = 0; z < kMaxZones; ++z)
+            if (ge[z]) atomicAdd(&s_sum[2 * z], ge[z]);
+        atomicAdd(&s_sum[2 * kMaxZones], cnt);
+        atomicAdd(&s_sum[2 * kMaxZones + 1], kept);
+        if (over) s_over = 1;
+        s_mn[wave_id()] = mn; s_mx[wave_id()] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kMaxZones) mail->ge[threadIdx.x] = s_sum[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + sizeof(F32ZoneWork) / 4) // (a second wave copies the zone record, word by word)
+        reinterpret_cast<uint32_t *>(&mail->work)[threadIdx.x - 64] = reinterpret_cast<const uint32_t *>(a.work)[threadIdx.x - 64];
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kPostBlock / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+        mail->count = s_sum[2 * kMaxZones]; mail->kept = s_sum[2 * kMaxZones + 1];
+        mail->min_v = mn; mail->max_v = mx;
+        mail->overflow = s_over; mail->pad = 0;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// device words -> the host's mailbox (one workgroup; a few KiB at most)
+__global__ __launch_bounds__(kPostBlock) void k_post(PostSegs g, uint32_t *flag, uint32_t seq) {
+    for (int k = 0; k < g.n; ++k) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(g.src[k]);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(g.dst[k]);
+        for (uint32_t i = threadIdx.x; i < g.bytes[k] / 4; i += kPostBlock) dst[i] = src[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(kBlock) void k_prep(PrepSegs g) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x, nt = gridDim.x * kBlock;
+    for (int k = 0; k < g.n; ++k) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(g.src[k]);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(g.dst[k]);
+        for (uint32_t i = t; i < g.bytes[k] / 4; i += nt) dst[i] = src[i];
+    }
+    for (int k = 0; k < g.nz; ++k) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(g.zero[k]);
+        for (uint32_t i = t; i < g.zbytes[k] / 4; i += nt) dst[i] = 0u;
+    }
+}
+
 // self-test of div_small_ints: every pair (a, b) of u16 values, the ratio a / b (b != 0) and the normalised difference
 // (a - b) / (a + b) (a + b != 0) against the compiler's IEEE division; counts the pairs that differ
 __global__ __launch_bounds__(256) void k_selftest_div_small_ints(unsigned long long *mismatches) {
@@ -633,18 +714,25 @@ __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict
 //    u8: 255 thresholds in LDS + histogram of the levels; u16: 65535 thresholds gathered
 //    from global memory (256 KiB, L2-resident).
 // ------------------------------------------------------------------------------------
-template <int VEC, bool OUT16>
+// MODE 0: threshold table (estimate + verification).  1: the level in f64 with the reference's expression.  2: the same for
+// gamma == 1, folded: y = A log2(x) + B with A log2(c_i) + B in the table and A in the series' coefficients (degree 4: the
+// remainder r^5 / (5 ln 2) < 1e-14 of log2, 2e-9 levels at the narrowest window; the margin below is 1e-6).
+// (A template parameter, not a flag: the f64 forms' registers cost the table form three waves of eight per SIMD.)
+template <int VEC, bool OUT16, int MODE>
 __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
+    constexpr bool F64 = MODE != 0;
     __shared__ float thr[256 + 1];
     __shared__ uint32_t hist[256];
     if (!OUT16) { thr[threadIdx.x] = (threadIdx.x && a.thr) ? a.thr[threadIdx.x] : -INFINITY; hist[threadIdx.x] = 0; }
     if (threadIdx.x == 0) thr[256] = INFINITY;
-    __shared__ double logc[256], invc[256]; // table of db_of_f32_fast (f64 levels)
-    if (a.f64_levels) {
+    __shared__ double logc[F64 ? 256 : 1], invc[F64 ? 256 : 1]; // table of db_of_f32_fast (f64 levels)
+    if (F64) {
         const double c = 1.0 + ((double)threadIdx.x + 0.5) / 256.0;
-        logc[threadIdx.x] = log2(c);
+        logc[threadIdx.x] = MODE == 2 ? fma(a.lin_a, log2(c), a.lin_b) : log2(c);
         invc[threadIdx.x] = 1.0 / c;
     }
+    // log2(1 + r) = r (1 - r / 2 + r^2 / 3 - r^3 / 4) / ln 2, times A
+    const double k1 = a.lin_a * 1.4426950408889634, k2 = k1 * -0.5, k3 = k1 * (1.0 / 3.0), k4 = k1 * -0.25;
     __syncthreads();
     const bool vec_store = a.out_pitch % VEC == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     uint32_t zeros = 0;
@@ -660,14 +748,24 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
             const float x = v.get(j);
             uint32_t lv = 0;
             if (col + j < a.cols && x >= a.t_valid) {
-                if (a.f64_levels) { // (u8 output takes this form on the small-scene direct route: no threshold table at all)
+                if (F64) { // (u8 output takes this form on the small-scene direct route: no threshold table at all)
                     if (x >= a.t_last) lv = (uint32_t)a.max_val;
                     else if (x < a.t_first) lv = 0u;
                     else {
-                        const double db = db_of_f32_fast(x, logc, invc); // within ~1e-14 of glibc's value: far inside the 1e-6 margin below
-                        // a multiplication where the reference divides by `range`: a relative 1e-16, 1e-11 levels, far inside the margin
-                        const double t = (fmin(fmax(db, a.low), a.high) - a.low) * inv_range;
-                        const double y = fmin(fmax((a.gamma == 1.0 ? t : pow(t, a.gamma)) * a.max_val, 0.0), a.max_val);
+                        double y;
+                        if (MODE == 2) {
+                            const uint32_t bits = __float_as_uint(x), mant = bits & 0x7FFFFFu;
+                            const int e = (int)(bits >> 23) - 127;
+                            const double m = __hiloint2double((int)(0x3FF00000u | (mant >> 3)), (int)(mant << 29)); // 1.mant, exactly
+                            const double rr = fma(m, invc[mant >> 15], -1.0);
+                            y = fma(rr, fma(rr, fma(rr, fma(rr, k4, k3), k2), k1), fma(a.lin_a, (double)e, logc[mant >> 15]));
+                            y = fmin(fmax(y, 0.0), a.lin_ymax);
+                        } else {
+                            const double db = db_of_f32_fast(x, logc, invc); // within ~1e-14 of glibc's value: far inside the 1e-6 margin below
+                            // a multiplication where the reference divides by `range`: a relative 1e-16, 1e-11 levels, far inside the margin
+                            const double t = (fmin(fmax(db, a.low), a.high) - a.low) * inv_range;
+                            y = fmin(fmax((a.gamma == 1.0 ? t : pow(t, a.gamma)) * a.max_val, 0.0), a.max_val);
+                        }
                         const double r = rint(y);
                         if (fabs(y - r) < 1e-6 || !(y == y)) {
                             if (a.f64_levels == 2) {
@@ -897,6 +995,23 @@ hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int nz_max, 
     return hipGetLastError();
 }
 
+hipError_t launch_f32_zone_post(const F32ZoneArgs &a, int grid, F32ZoneMail *mail, uint32_t *flag, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_f32_zone_post, dim3(1), dim3(kPostBlock), 0, s, a, grid, mail, flag, seq);
+    return hipGetLastError();
+}
+hipError_t launch_prep(const PrepSegs &segs, hipStream_t s) {
+    uint64_t words = 0;
+    for (int k = 0; k < segs.n; ++k) words += segs.bytes[k] / 4;
+    for (int k = 0; k < segs.nz; ++k) words += segs.zbytes[k] / 4;
+    if (!words) return hipSuccess;
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)std::min<uint64_t>(64, (words + kBlock * 4 - 1) / (kBlock * 4))), dim3(kBlock), 0, s, segs);
+    return hipGetLastError();
+}
+hipError_t launch_post(const PostSegs &segs, uint32_t *flag, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(kPostBlock), 0, s, segs, flag, seq);
+    return hipGetLastError();
+}
+
 hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, uint32_t cap, int nregions, const float *d_thr, int nthr,
                                  unsigned long long *d_counts, hipStream_t s) {
     hipLaunchKernelGGL(k_f32_zone_count, dim3(std::min(nregions, 1024)), dim3(kBlock), 0, s, zone_buf, zone_n, cap, nregions, d_thr, nthr, d_counts);
@@ -1029,13 +1144,21 @@ hipError_t launch_f32_hist4096_direct(const float *in, size_t pitch, uint32_t ro
 hipError_t launch_f32_level(const F32LevelArgs &a, bool vec, bool out16, hipStream_t s) {
     const int V = vec ? 4 : 1;
     dim3 grid(out16 ? stream_grid((uint64_t)a.rows * ((a.cols + V - 1) / V)) : hist_grid((uint64_t)a.rows * ((a.cols + V - 1) / V)));
+    const int mode = a.f64_levels == 0 ? 0 : (a.lin ? 2 : 1);
+#define SARPRO_LEVEL_LAUNCH(V_, O_)                                                                              \
+    do {                                                                                                        \
+        if (mode == 2) hipLaunchKernelGGL((k_f32_level<V_, O_, 2>), grid, dim3(kBlock), 0, s, a);               \
+        else if (mode == 1) hipLaunchKernelGGL((k_f32_level<V_, O_, 1>), grid, dim3(kBlock), 0, s, a);          \
+        else hipLaunchKernelGGL((k_f32_level<V_, O_, 0>), grid, dim3(kBlock), 0, s, a);                         \
+    } while (0)
     if (vec) {
-        if (out16) hipLaunchKernelGGL((k_f32_level<4, true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((k_f32_level<4, false>), grid, dim3(kBlock), 0, s, a);
+        if (out16) SARPRO_LEVEL_LAUNCH(4, true);
+        else SARPRO_LEVEL_LAUNCH(4, false);
     } else {
-        if (out16) hipLaunchKernelGGL((k_f32_level<1, true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((k_f32_level<1, false>), grid, dim3(kBlock), 0, s, a);
+        if (out16) SARPRO_LEVEL_LAUNCH(1, true);
+        else SARPRO_LEVEL_LAUNCH(1, false);
     }
+#undef SARPRO_LEVEL_LAUNCH
     return hipGetLastError();
 }
 

@@ -78,14 +78,15 @@ struct F32Band {
     float zlo[kMaxZones], zhi[kMaxZones];
     uint32_t zcap = 0;
     uint64_t zge[2 * kMaxZones];
-    std::vector<uint32_t> zone_kept_store;
-    const uint32_t *zone_kept = nullptr; // per-wave kept counts of the min / max pass
+    uint64_t zone_kept = 0;       // samples the min / max pass kept in its side buffers
+    bool zone_kept_known = false;
     const char *zone_note = "";
     uint64_t final_hist[256]{}; // histogram of the FINAL u8 raster (u8 output only)
     // small-scene direct route (percentile strategies): bins and levels evaluated in f64 on the device with a margin, the few samples
     // near a boundary settled by the host -- no threshold tables, no zone kernels, two synchronisations per band
     bool direct = false;
     uint32_t direct_queued = 0;     // samples the histogram pass queued (entries in ctx->f32zone)
+    uint8_t *direct_host = nullptr; // host copy of the direct pass's results (mailbox or pinned buffer)
     uint64_t level_add[256]{};      // u8: levels of the samples the level pass queued (the kernel leaves them out of its histogram)
     bool level_hist_ready = false;  // direct route, u8: the level histogram came back with the level pass's queue (one synchronisation)
     uint64_t level_hist_host[256]{};
@@ -93,6 +94,65 @@ struct F32Band {
 };
 constexpr uint32_t kQueueHead = 256; // queued samples fetched WITH their count (more than that: a second copy)
 constexpr uint32_t kDirectQueueCap = 65536;
+// ---- the mailbox: results posted into coherent pinned memory by a one-workgroup kernel, the host spins on a sequence word
+constexpr size_t kMailBytes = 192 * 1024; // word 0: sequence; payload from byte 64 (<= 32 KiB - 64, or everything behind the upload slots)
+static int mail_open(sarpro_hip_ctx *ctx) {
+    if (!ctx->mailbox.p) {
+        ctx->mailbox.flags = hipHostMallocCoherent | hipHostMallocMapped;
+        HIPCHK(ctx, ctx->mailbox.reserve(kMailBytes));
+        std::memset(ctx->mailbox.p, 0, kMailBytes);
+        ctx->mail_seq = 0;
+    }
+    return SARPRO_HIP_OK;
+}
+static uint32_t *mail_flag(sarpro_hip_ctx *ctx) { return ctx->mailbox.as<uint32_t>(); }
+template <typename T> static T *mail_payload(sarpro_hip_ctx *ctx, size_t off = 0) { return reinterpret_cast<T *>(ctx->mailbox.as<uint8_t>() + 64 + off); }
+// waits for the post with this sequence number; a stream that went idle (or failed) without posting ends the wait
+static int mail_wait(sarpro_hip_ctx *ctx, uint32_t seq) {
+    volatile uint32_t *flag = mail_flag(ctx);
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SARPRO_HIP_OK;
+        if ((spins & 0x3FFFu) == 0x3FFFu) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SARPRO_HIP_OK;
+                return fail(ctx, SARPRO_HIP_ERR_HIP, "mailbox: the stream drained without the post");
+            }
+            if (q != hipErrorNotReady) HIPCHK(ctx, q);
+        }
+        __builtin_ia32_pause();
+    }
+}
+// A batch of small host -> device words and zero fills: one kernel with the mailbox on, copy / fill commands without it.
+// Upload sources come from upload_stage(): a slot of the mailbox (two, alternating: the previous upload may still be in flight;
+// the one before it was consumed before the wait that preceded this call) or the pinned upload buffer.
+struct Prep {
+    PrepSegs g{};
+    void upload(const void *h_src, void *d_dst, size_t bytes) { g.src[g.n] = h_src; g.dst[g.n] = d_dst; g.bytes[g.n] = (uint32_t)bytes; ++g.n; }
+    void zero(void *d, size_t bytes) { g.zero[g.nz] = d; g.zbytes[g.nz] = (uint32_t)bytes; ++g.nz; }
+};
+static bool mail_enabled();
+constexpr size_t kUploadSlotBytes = 12 * 1024, kUploadOff = 32 * 1024, kMailBigOff = 64 * 1024; // big payloads: [64 KiB, 192 KiB)
+static void *upload_stage(sarpro_hip_ctx *ctx, size_t bytes) {
+    if (mail_enabled() && bytes <= kUploadSlotBytes && mail_open(ctx) == SARPRO_HIP_OK) {
+        ctx->mail_upload_slot ^= 1u;
+        return ctx->mailbox.as<uint8_t>() + kUploadOff + ctx->mail_upload_slot * kUploadSlotBytes;
+    }
+    return ctx->h_upload.p;
+}
+static int prep_run(sarpro_hip_ctx *ctx, const Prep &p) {
+    bool by_kernel = mail_enabled();
+    for (int k = 0; k < p.g.n; ++k) { // (a source outside the mailbox: the level tables, too large for a slot)
+        const uint8_t *s = static_cast<const uint8_t *>(p.g.src[k]), *m = ctx->mailbox.as<uint8_t>();
+        by_kernel = by_kernel && m && s >= m && s < m + kMailBytes;
+    }
+    if (by_kernel) { HIPCHK(ctx, launch_prep(p.g, ctx->stream)); return SARPRO_HIP_OK; }
+    for (int k = 0; k < p.g.n; ++k) HIPCHK(ctx, hipMemcpyAsync(p.g.dst[k], p.g.src[k], p.g.bytes[k], hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 0; k < p.g.nz; ++k) HIPCHK(ctx, hipMemsetAsync(p.g.zero[k], 0, p.g.zbytes[k], ctx->stream));
+    return SARPRO_HIP_OK;
+}
+static bool mail_enabled() { static const bool on = !getenv("SARPRO_HIP_NO_MAILBOX"); return on; }
+
 static uint32_t direct_queue_cap() { // SARPRO_HIP_F32_DIRECT_QCAP: a tiny queue, so that the tests reach the overflow hand-back
     if (const char *e = getenv("SARPRO_HIP_F32_DIRECT_QCAP")) return (uint32_t)std::min<long>(kDirectQueueCap, std::max<long>(0, atol(e)));
     return kDirectQueueCap;
@@ -201,8 +261,12 @@ int f32_zone_presample(F32Band &B) {
     if (env && !std::strcmp(env, "tiny")) B.zcap = 0; // test switch: no room at all, the first kept sample overflows
     // one buffer: the stored sample now, the kept samples of the min / max pass afterwards
     HIPCHK(ctx, ctx->f32zone.reserve(std::max((size_t)B.zgrid * B.zcap, (size_t)nsrows * spitch) * sizeof(float)));
-    HIPCHK(ctx, hipMemsetAsync(d_keys, 0, sizeof(uint32_t) * kSampleKeys, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_sub, 0, sizeof(uint32_t) * kMaxProbes * kSubKeys, ctx->stream));
+    {
+        Prep pr;
+        pr.zero(d_keys, sizeof(uint32_t) * kSampleKeys);
+        pr.zero(d_sub, sizeof(uint32_t) * kMaxProbes * kSubKeys);
+        RETCHK(prep_run(ctx, pr));
+    }
     F32ZoneSelectArgs sa{};
     sa.work = d_work; sa.key_hist = d_keys; sa.sub_hist = d_sub; sa.npcts = np; sa.t_valid = B.t_valid; sa.max_mass = kZoneMaxMass;
     for (int i = 0; i < np; ++i) sa.pcts[i] = pcts[i];
@@ -240,16 +304,42 @@ int f32_zone_prepass(F32Band &B) {
         KernelTimer t(ctx, "f32_prepass_zones");
         HIPCHK(ctx, launch_f32_prepass_zones(a, B.vec, B.znp, grid, ctx->stream));
     }
-    uint8_t *h = ctx->h_small.as<uint8_t>();
-    F32Partial *h_part = reinterpret_cast<F32Partial *>(h);
-    uint64_t *h_ge = reinterpret_cast<uint64_t *>(h + sizeof(F32Partial) * 2048);
-    uint32_t *h_n = reinterpret_cast<uint32_t *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8);
-    HIPCHK(ctx, hipMemcpyAsync(h_part, a.partials, sizeof(F32Partial) * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h_ge, a.ge_counts, sizeof(uint64_t) * 2 * kMaxZones * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h_n, a.zone_n, sizeof(uint32_t) * 4 * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
-    F32ZoneWork *h_work = reinterpret_cast<F32ZoneWork *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8 + 2048 * 4 * 4);
-    HIPCHK(ctx, hipMemcpyAsync(h_work, a.work, sizeof(F32ZoneWork), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    F32ZoneWork work_copy;
+    const F32ZoneWork *h_work = &work_copy;
+    bool overflow = false;
+    std::memset(B.zge, 0, sizeof(B.zge));
+    if (mail_enabled()) {
+        RETCHK(mail_open(ctx));
+        F32ZoneMail *mail = mail_payload<F32ZoneMail>(ctx);
+        const uint32_t seq = ++ctx->mail_seq;
+        HIPCHK(ctx, launch_f32_zone_post(a, grid, mail, mail_flag(ctx), seq, ctx->stream));
+        RETCHK(mail_wait(ctx, seq));
+        work_copy = mail->work;
+        B.local.count += mail->count;
+        B.local.min_v = std::fmin(B.local.min_v, mail->min_v); B.local.max_v = std::fmax(B.local.max_v, mail->max_v);
+        for (int k = 0; k < 2 * kMaxZones; ++k) B.zge[k] = mail->ge[k];
+        overflow = mail->overflow != 0;
+        B.zone_kept = mail->kept; B.zone_kept_known = true;
+    } else {
+        uint8_t *h = ctx->h_small.as<uint8_t>();
+        F32Partial *h_part = reinterpret_cast<F32Partial *>(h);
+        uint64_t *h_ge = reinterpret_cast<uint64_t *>(h + sizeof(F32Partial) * 2048);
+        uint32_t *h_n = reinterpret_cast<uint32_t *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8);
+        HIPCHK(ctx, hipMemcpyAsync(h_part, a.partials, sizeof(F32Partial) * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_ge, a.ge_counts, sizeof(uint64_t) * 2 * kMaxZones * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_n, a.zone_n, sizeof(uint32_t) * 4 * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+        F32ZoneWork *h_w = reinterpret_cast<F32ZoneWork *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8 + 2048 * 4 * 4);
+        HIPCHK(ctx, hipMemcpyAsync(h_w, a.work, sizeof(F32ZoneWork), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        work_copy = *h_w;
+        B.zone_kept = 0; B.zone_kept_known = true;
+        for (int i = 0; i < grid; ++i) {
+            B.local.count += h_part[i].count;
+            B.local.min_v = std::fmin(B.local.min_v, h_part[i].minv); B.local.max_v = std::fmax(B.local.max_v, h_part[i].maxv);
+            for (int k = 0; k < 2 * kMaxZones; ++k) B.zge[k] += h_ge[(size_t)i * 2 * kMaxZones + k];
+            for (int w = 0; w < 4; ++w) { overflow |= h_n[4 * i + w] > B.zcap / 4; B.zone_kept += h_n[4 * i + w]; }
+        }
+    }
     B.nz = std::min(std::max(h_work->nz, 0), kMaxZones);
     for (int i = 0; i < B.nz; ++i) { B.zlo[i] = h_work->bounds[2 * i]; B.zhi[i] = h_work->bounds[2 * i + 1]; }
     if (B.nz == 0) { B.use_zones = false; B.zone_note = "no zones (sample too small, or zones too heavy)"; }
@@ -260,16 +350,6 @@ int f32_zone_prepass(F32Band &B) {
             std::fprintf(stderr, "[zones]   probe %u: rank %u key %#x base %u\n", i, h_work->probe_rank[i], h_work->probe_key[i], h_work->probe_base[i]);
         for (int i = 0; i < 2 * kMaxZones; i += 2) std::fprintf(stderr, "[zones]   zone %d: [%g, %g)\n", i / 2, (double)h_work->bounds[i], (double)h_work->bounds[i + 1]);
     }
-    std::memset(B.zge, 0, sizeof(B.zge));
-    bool overflow = false;
-    for (int i = 0; i < grid; ++i) {
-        B.local.count += h_part[i].count;
-        B.local.min_v = std::fmin(B.local.min_v, h_part[i].minv); B.local.max_v = std::fmax(B.local.max_v, h_part[i].maxv);
-        for (int k = 0; k < 2 * kMaxZones; ++k) B.zge[k] += h_ge[(size_t)i * 2 * kMaxZones + k];
-        for (int w = 0; w < 4; ++w) overflow |= h_n[4 * i + w] > B.zcap / 4;
-    }
-    B.zone_kept_store.assign(h_n, h_n + 4 * (size_t)grid);
-    B.zone_kept = B.zone_kept_store.data();
     if (overflow) { B.use_zones = false; B.zone_note = "side buffer overflow"; }
     return SARPRO_HIP_OK;
 }
@@ -305,20 +385,34 @@ int f32_zone_resolve(F32Band &B) {
     }
     for (int i = 2; i <= n; ++i)
         if (!(tt[i] >= tt[i - 1])) { B.zone_note = "threshold order"; return SARPRO_HIP_OK; }
-    float *h_thr = ctx->h_upload.as<float>();
+    float *h_thr = static_cast<float *>(upload_stage(ctx, sizeof(float) * (size_t)(n + 1)));
     std::memcpy(h_thr, tt, sizeof(float) * (size_t)(n + 1));
     float *d_thr = reinterpret_cast<float *>(ws + kOffZoneThr);
     unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(ws + kOffZoneCounts);
-    HIPCHK(ctx, hipMemcpyAsync(d_thr, h_thr, sizeof(float) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * (kZoneMaxThr + 1), ctx->stream));
+    {
+        Prep pr;
+        pr.upload(h_thr, d_thr, sizeof(float) * (size_t)(n + 1));
+        pr.zero(d_counts, sizeof(uint64_t) * (kZoneMaxThr + 1));
+        RETCHK(prep_run(ctx, pr));
+    }
     {
         KernelTimer t(ctx, "f32_zone_count");
         HIPCHK(ctx, launch_f32_zone_count(ctx->f32zone.as<float>(), reinterpret_cast<uint32_t *>(ws + kOffZoneN), B.zcap / 4, B.zgrid * 4, d_thr, n, d_counts,
                                           ctx->stream));
     }
     uint64_t *h_counts = ctx->h_small.as<uint64_t>();
-    HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(uint64_t) * (kZoneMaxThr + 1), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (mail_enabled()) {
+        RETCHK(mail_open(ctx));
+        h_counts = mail_payload<uint64_t>(ctx);
+        PostSegs g{};
+        g.n = 1; g.src[0] = d_counts; g.dst[0] = h_counts; g.bytes[0] = (uint32_t)(sizeof(uint64_t) * (size_t)(n + 1));
+        const uint32_t seq = ++ctx->mail_seq;
+        HIPCHK(ctx, launch_post(g, mail_flag(ctx), seq, ctx->stream));
+        RETCHK(mail_wait(ctx, seq));
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(uint64_t) * (kZoneMaxThr + 1), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // cum[i] = valid samples below tt[i], for every i inside a zone
     uint64_t cum[kZoneMaxThr + 2];
     const uint64_t N = G.count;
@@ -330,8 +424,8 @@ int f32_zone_resolve(F32Band &B) {
     { // every kept sample lies in exactly one interval of one zone
         uint64_t kept = 0, counted = 0;
         for (int j = 0; j < B.nz; ++j) counted += cum[zr[j].e] - cum[zr[j].s];
-        for (int i = 0; i < 4 * B.zgrid; ++i) kept += B.zone_kept ? B.zone_kept[i] : 0;
-        if (B.zone_kept && kept != counted) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
+        kept = B.zone_kept;
+        if (B.zone_kept_known && kept != counted) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
     }
     sarpro_hip_stats st{};
     st.valid_count = N; st.min_db = min_db; st.max_db = max_db;
@@ -416,24 +510,51 @@ int f32_phase_a(F32Band &B) {
         HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, B.t_valid, B.vec, moments, d_part, pgrid, ctx->stream, B.pol));
     }
     F32Partial *h_part = ctx->h_small.as<F32Partial>();
-    HIPCHK(ctx, hipMemcpyAsync(h_part, d_part, sizeof(F32Partial) * (size_t)pgrid, hipMemcpyDeviceToHost, ctx->stream));
+    const bool mail = mail_enabled();
+    if (mail) RETCHK(mail_open(ctx));
+    PostSegs pg{};
+    if (mail) { // (big payload area: partials <= 64 KiB | 4096 bins 32 KiB | queue count | queue head 4 KiB)
+        h_part = reinterpret_cast<F32Partial *>(ctx->mailbox.as<uint8_t>() + kMailBigOff);
+        pg.src[0] = d_part; pg.dst[0] = h_part; pg.bytes[0] = (uint32_t)(sizeof(F32Partial) * (size_t)pgrid); pg.n = 1;
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(h_part, d_part, sizeof(F32Partial) * (size_t)pgrid, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    B.direct_host = nullptr;
     if (B.direct) { // the 4096 bins in the same stream turn: the kernel merges the partials itself, nothing waits for the host
         unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws + kOffHist4096);
         uint32_t *d_qn = reinterpret_cast<uint32_t *>(ws + kOffZoneCounts);
         HIPCHK(ctx, ctx->f32zone.reserve((size_t)kDirectQueueCap * sizeof(uint4)));
-        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * 4096, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_qn, 0, 4, ctx->stream));
+        {
+            Prep pr;
+            pr.zero(d_hist, sizeof(uint64_t) * 4096);
+            pr.zero(d_qn, 4);
+            RETCHK(prep_run(ctx, pr));
+        }
         {
             KernelTimer t(ctx, "f32_hist4096_direct");
             HIPCHK(ctx, launch_f32_hist4096_direct(B.d_in, B.in_pitch, rows, cols, B.t_valid, B.vec, d_part, pgrid, d_hist, d_qn, ctx->f32zone.as<uint4>(),
                                                    direct_queue_cap(), ctx->stream, B.pol));
         }
-        uint8_t *h = ctx->h_small.as<uint8_t>() + 64 * 1024; // behind the partials (<= 2048 x 32 B)
-        HIPCHK(ctx, hipMemcpyAsync(h, d_hist, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(h + 32768, d_qn, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(h + 32768 + 64, ctx->f32zone.p, (size_t)kQueueHead * 16, hipMemcpyDeviceToHost, ctx->stream)); // usually all of them
+        uint8_t *h = mail ? ctx->mailbox.as<uint8_t>() + kMailBigOff + 64 * 1024 : ctx->h_small.as<uint8_t>() + 64 * 1024; // behind the partials (<= 2048 x 32 B)
+        B.direct_host = h;
+        if (mail) {
+            pg.src[1] = d_hist; pg.dst[1] = h; pg.bytes[1] = sizeof(uint64_t) * 4096;
+            pg.src[2] = d_qn; pg.dst[2] = h + 32768; pg.bytes[2] = 4;
+            pg.src[3] = ctx->f32zone.p; pg.dst[3] = h + 32768 + 64; pg.bytes[3] = kQueueHead * 16; // usually all of them
+            pg.n = 4;
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(h, d_hist, sizeof(uint64_t) * 4096, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h + 32768, d_qn, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h + 32768 + 64, ctx->f32zone.p, (size_t)kQueueHead * 16, hipMemcpyDeviceToHost, ctx->stream)); // usually all of them
+        }
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (mail) {
+        const uint32_t seq = ++ctx->mail_seq;
+        HIPCHK(ctx, launch_post(pg, mail_flag(ctx), seq, ctx->stream));
+        RETCHK(mail_wait(ctx, seq));
+    } else {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     for (int i = 0; i < pgrid; ++i) {
         B.local.count += h_part[i].count; B.local.sum_db += h_part[i].sum; B.local.sumsq_db += h_part[i].sumsq;
         B.local.min_v = std::fmin(B.local.min_v, h_part[i].minv); B.local.max_v = std::fmax(B.local.max_v, h_part[i].maxv);
@@ -473,8 +594,11 @@ int f32_phase_c(F32Band &B) {
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     unsigned long long *d_tile_bins = reinterpret_cast<unsigned long long *>(ws + kOffTileBins);
     unsigned long long *d_level_hist = reinterpret_cast<unsigned long long *>(ws + kOffLevelHist);
-    if (B.clahe) HIPCHK(ctx, hipMemsetAsync(d_tile_bins, 0, sizeof(uint64_t) * 64 * 256, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_level_hist, 0, sizeof(uint64_t) * 256, ctx->stream));
+    Prep pr;
+    if (B.clahe) pr.zero(d_tile_bins, sizeof(uint64_t) * 64 * 256);
+    pr.zero(d_level_hist, sizeof(uint64_t) * 256);
+    pr.zero(ws + kOffZoneCounts, 4); // the level pass's queue counter (phase d; the zone counts were read before this phase)
+    if (B.empty || !B.have_stats || !B.clahe || B.rows == 0 || B.cols == 0) { RETCHK(prep_run(ctx, pr)); pr = Prep(); }
     if (B.empty) return SARPRO_HIP_OK;
     if (!B.have_stats) {
         uint64_t *h_hist = ctx->h_small.as<uint64_t>();
@@ -486,10 +610,11 @@ int f32_phase_c(F32Band &B) {
     if (!B.clahe || B.rows == 0 || B.cols == 0) return SARPRO_HIP_OK;
     RETCHK(get_plan(ctx, B.rows_total, B.cols, B.row0, B.rows, B.vec ? 4 : 1, &B.plan));
     if (B.stripe_handle && !B.plan_held) { ++B.plan->refs; B.plan_held = true; } // the plan cache never evicts a held plan (dropped in sarpro_hip_stripe_f32_end)
-    float *thr = ctx->h_upload.as<float>();
+    float *thr = static_cast<float *>(upload_stage(ctx, sizeof(float) * 256));
     build_clahe_bin_thresholds(B.stats, thr);
     float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
-    HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
+    pr.upload(thr, d_thr, sizeof(float) * 256); // (with the zero fills above when the statistics were already known: one launch)
+    RETCHK(prep_run(ctx, pr));
     if (B.plan->hist_rects_tiled.empty()) return SARPRO_HIP_OK;
     F32TileHistArgs ta{};
     ta.in = B.d_in; ta.pitch = B.in_pitch; ta.rects = B.plan->d_hist_rects_tiled.as<Rect>();
@@ -527,6 +652,13 @@ int f32_phase_d(F32Band &B) {
         if (f64_levels) { // 65535 levels: f64 evaluation on the device, the reference's own arithmetic only near a level boundary
             a.low = B.stats.low_clip; a.high = B.stats.high_clip; a.range = std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0);
             a.gamma = B.stats.gamma; a.max_val = (double)nlevels;
+            if (a.gamma == 1.0 && !getenv("SARPRO_HIP_F32_LEVEL_GENERAL")) { // (cross-check switch: the general form at gamma == 1)
+                const double inv_range = 1.0 / a.range;
+                a.lin = 1;
+                a.lin_a = 3.0102999566398120 * inv_range * a.max_val; // 10 log10(2)
+                a.lin_b = -a.low * inv_range * a.max_val;
+                a.lin_ymax = (a.high - a.low) * inv_range * a.max_val;
+            }
         }
         // Without the 65535-entry table (1-2 ms of glibc per call): the samples within 1e-6 of a boundary -- a few hundred of
         // 4e8 -- are queued and settled here, with level_of_db.  SARPRO_HIP_F32_LEVEL_TABLE=1 (or a queue that overflows) builds
@@ -540,19 +672,34 @@ int f32_phase_d(F32Band &B) {
             a.uq_cap = kUqCap;
             a.t_first = level_threshold_one(B.stats, nlevels, 1); a.t_last = level_threshold_one(B.stats, nlevels, nlevels);
             a.f64_levels = 2;
-            HIPCHK(ctx, hipMemsetAsync(a.uq_count, 0, 4, ctx->stream));
-            {
+            { // (a.uq_count was zeroed with phase c's fills)
                 KernelTimer t(ctx, "f32_level");
                 HIPCHK(ctx, launch_f32_level(a, B.vec, !u8o, ctx->stream));
             }
-            // count, the first kQueueHead entries and (u8) the level histogram come back together: one synchronisation
+            // count, the first kQueueHead entries and (u8) the level histogram come back together: one turn
             uint32_t *h_n = ctx->h_small.as<uint32_t>();
             uint32_t *h_e = ctx->h_small.as<uint32_t>() + 4; // 16-byte aligned; reserved in phase a
             uint64_t *h_lh = reinterpret_cast<uint64_t *>(ctx->h_small.as<uint8_t>() + 16 + (size_t)kUqCap * 16);
-            HIPCHK(ctx, hipMemcpyAsync(h_n, a.uq_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_e, a.uq_entries, (size_t)kQueueHead * 16, hipMemcpyDeviceToHost, ctx->stream));
-            if (u8o) HIPCHK(ctx, hipMemcpyAsync(h_lh, d_level_hist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (mail_enabled()) { // (the level raster is complete when the post arrives: it follows the level kernel in the stream)
+                RETCHK(mail_open(ctx));
+                uint8_t *m = mail_payload<uint8_t>(ctx);
+                PostSegs g{};
+                g.src[0] = a.uq_count; g.dst[0] = m; g.bytes[0] = 4;
+                g.src[1] = a.uq_entries; g.dst[1] = m + 16; g.bytes[1] = kQueueHead * 16;
+                g.n = 2;
+                if (u8o) { g.src[2] = d_level_hist; g.dst[2] = m + 16 + kQueueHead * 16; g.bytes[2] = sizeof(uint64_t) * 256; g.n = 3; }
+                const uint32_t seq = ++ctx->mail_seq;
+                HIPCHK(ctx, launch_post(g, mail_flag(ctx), seq, ctx->stream));
+                RETCHK(mail_wait(ctx, seq));
+                std::memcpy(h_n, m, 4);
+                std::memcpy(h_e, m + 16, (size_t)kQueueHead * 16);
+                if (u8o) std::memcpy(h_lh, m + 16 + kQueueHead * 16, sizeof(uint64_t) * 256);
+            } else {
+                HIPCHK(ctx, hipMemcpyAsync(h_n, a.uq_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_e, a.uq_entries, (size_t)kQueueHead * 16, hipMemcpyDeviceToHost, ctx->stream));
+                if (u8o) HIPCHK(ctx, hipMemcpyAsync(h_lh, d_level_hist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
             B.idle = true;
             const uint32_t n = *h_n;
             if (n <= kUqCap) {
@@ -638,8 +785,18 @@ int f32_phase_e(F32Band &B) {
             std::memcpy(lh, B.level_hist_host, sizeof(lh));
         } else {
             uint64_t *h_lh = ctx->h_small.as<uint64_t>();
-            HIPCHK(ctx, hipMemcpyAsync(h_lh, ctx->f32ws.as<uint8_t>() + kOffLevelHist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (mail_enabled()) { // (everything before the post in the stream, the level raster included, is complete when it arrives)
+                RETCHK(mail_open(ctx));
+                h_lh = mail_payload<uint64_t>(ctx);
+                PostSegs g{};
+                g.n = 1; g.src[0] = ctx->f32ws.as<uint8_t>() + kOffLevelHist; g.dst[0] = h_lh; g.bytes[0] = sizeof(uint64_t) * 256;
+                const uint32_t seq = ++ctx->mail_seq;
+                HIPCHK(ctx, launch_post(g, mail_flag(ctx), seq, ctx->stream));
+                RETCHK(mail_wait(ctx, seq));
+            } else {
+                HIPCHK(ctx, hipMemcpyAsync(h_lh, ctx->f32ws.as<uint8_t>() + kOffLevelHist, sizeof(uint64_t) * 256, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
             std::memcpy(lh, h_lh, sizeof(lh));
             B.idle = true;
         }
@@ -658,7 +815,7 @@ int f32_direct_stats(F32Band &B) {
     B.empty = G.count == 0;
     if (B.empty) return SARPRO_HIP_OK;
     if (std::isinf(G.max_v)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "non-finite (+inf) sample: the reference's statistics are undefined for it");
-    uint8_t *h = ctx->h_small.as<uint8_t>() + 64 * 1024;
+    uint8_t *h = B.direct_host; // where phase a had the bins, the queue count and the queue's head delivered
     uint64_t *h_hist = reinterpret_cast<uint64_t *>(h);
     uint32_t nq = 0;
     std::memcpy(&nq, h + 32768, 4);
@@ -669,7 +826,8 @@ int f32_direct_stats(F32Band &B) {
     B.min_db = db_of_f32(G.min_v); B.max_db = db_of_f32(G.max_v);
     if (nq && !(std::fabs(B.max_db - B.min_db) < 2.220446049250313e-16)) {
         uint32_t *h_e = reinterpret_cast<uint32_t *>(h + 32768 + 64);
-        if (nq > kQueueHead) { // (the first kQueueHead entries came with the count)
+        if (nq > kQueueHead) { // (the first kQueueHead entries came with the count; all of them: into the pinned buffer, the mailbox has no room)
+            h_e = reinterpret_cast<uint32_t *>(ctx->h_small.as<uint8_t>() + 64 * 1024 + 32768 + 64);
             HIPCHK(ctx, hipMemcpyAsync(h_e, ctx->f32zone.p, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
