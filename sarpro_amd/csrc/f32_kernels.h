@@ -99,6 +99,7 @@ constexpr int kMaxZones = 6;
 constexpr int kMaxProbes = 2 * kMaxZones;
 constexpr int kSampleKeys = 32768; // key = bits >> 16 of a positive f32: 8 exponent + 7 mantissa bits
 constexpr int kSubKeys = 512;
+constexpr int kZoneLutKeys = 8192; // keys the sweep's class table covers (64 octaves from work->kbase; values outside clamp to its ends)
 constexpr int kZoneMaxThr = 1023;  // thresholds (zone bounds included) the count kernel takes: 2^m - 1      // the next 9 mantissa bits: sub-bucket of a probed key
 struct F32ZoneWork { // device memory, written by the zone kernels
     uint32_t ns, kmin, kmax, nprobe;       // sample size, lowest / highest populated key
@@ -107,7 +108,11 @@ struct F32ZoneWork { // device memory, written by the zone kernels
     uint32_t probe_rank[kMaxProbes];
     int32_t nz;                            // zones selected (0: the route steps aside)
     float bounds[2 * kMaxZones];           // lo_0 < hi_0 < lo_1 < hi_1 ...: zone j = [lo_j, hi_j); unused entries +inf
-    float mass_est;                        // estimated share of the valid samples inside the zones
+    float mass_est;                        // estimated share of the valid samples the sweep keeps (whole marked buckets)
+    uint32_t kbase;                        // first key of the class table
+    int32_t zone_run[kMaxZones];           // the run of marked buckets zone j lies in (runs in ascending order; gap g lies below run g)
+    int32_t nrun;                          // runs of kept buckets (0: the sweep keeps nothing)
+    uint32_t run_s[kMaxZones], run_e[kMaxZones]; // first / last key of each run
 };
 struct F32ZoneSelectArgs {
     F32ZoneWork *work;
@@ -118,6 +123,7 @@ struct F32ZoneSelectArgs {
     float t_valid;
     float max_mass;              // zones heavier than this share of the samples: nz = 0
     float sample_fraction;       // sampled rows / rows (1: the "sample" is the scene, the probe ranks are exact)
+    uint8_t *lut;                // [kZoneLutKeys]: the sweep's class table (written after the finalize kernel, from work->run_*)
 };
 struct F32ZoneArgs {
     const float *in;
@@ -126,8 +132,9 @@ struct F32ZoneArgs {
     float t_valid;
     F32Pol pol;
     F32Partial *partials;            // [grid]
-    const F32ZoneWork *work;         // nz, bounds
-    unsigned long long *ge_counts;   // [grid][2 * kMaxZones]: valid samples >= bounds[k], per workgroup
+    const F32ZoneWork *work;         // nz, bounds, kbase
+    const uint32_t *lut;             // [kZoneLutKeys / 4] class bytes, key - kbase: 0x80 | 56 = KEPT (the bucket touches a zone), else 8 x (runs of kept buckets below it)
+    unsigned long long *gap_counts;  // [grid][8]: valid samples in the unkept buckets below run g (g = 0 .. 6; entry 7 unused), per workgroup
     float *zone_buf;                 // wave v of workgroup w appends to [w * cap + v * cap / 4, + cap / 4): cap % 4 == 0
     uint32_t cap;
     uint32_t *zone_n;                // [grid * 4]: samples each wave found inside zones (> cap / 4: overflow, the route is abandoned)
@@ -141,14 +148,13 @@ hipError_t launch_selftest_div_small_ints(unsigned long long *d_mismatches /* ze
 hipError_t launch_f32_zone_pick(const F32ZoneSelectArgs &a, hipStream_t s);
 hipError_t launch_f32_sample_sub(const float *d_sample, uint64_t n, float t_valid, const F32ZoneWork *work, uint32_t *d_sub_hist /* zeroed */, hipStream_t s);
 hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s);
-hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int nz_max, int grid, hipStream_t s);
+hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int grid, hipStream_t s);
 // Results for the host WITHOUT copy commands: a one-workgroup kernel reduces / copies them into pinned (coherent) host memory and
 // raises a sequence word there; the host spins on that word instead of sleeping in hipStreamSynchronize.  (Four small copies and
 // a stream wait cost a turn 80 us; this costs it ~15.)
 struct F32ZoneMail { // what the host reads after the min / max pass of the zone route
-    unsigned long long count;                  // valid samples
-    float min_v, max_v;                        // +inf / -inf when there are none
-    unsigned long long ge[2 * kMaxZones];      // valid samples >= bounds[k] (even k only: lower bounds)
+    float min_v, max_v;                        // +inf / -inf when there are no valid samples
+    unsigned long long gap[8];                 // valid samples in the unkept buckets below run g
     unsigned long long kept;                   // samples in the side buffers
     uint32_t overflow, pad;                    // a wave's side buffer overflowed
     F32ZoneWork work;

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void k_f32_zone_finalize(F32ZoneSelectArgs a) {
     const int t = threadIdx.x;
     const int np = (int)w->nprobe;
     if (w->ns < 20000u || w->kmax >= 0x7F80u) {
-        if (t == 0) w->nz = 0;
+        if (t == 0) { w->nz = 0; w->kbase = 0; w->nrun = 0; } // one gap, nothing kept: the sweep still counts
         if (t < 2 * kMaxZones) w->bounds[t] = INFINITY;
         return;
     }
@@ -458,52 +458,92 @@ __global__ __launch_bounds__(64) void k_f32_zone_finalize(F32ZoneSelectArgs a) {
     }
     __syncthreads();
     const int m = s_m;
-    // share of the sample inside the zones, edge buckets weighted by their overlap (the wave's lanes take buckets in turn)
-    double mass = 0.0;
-    for (int j = 0; j < m; ++j) {
-        const uint32_t b0 = __float_as_uint(zl[j]), b1 = isinf(zh[j]) ? 0x7F800000u : __float_as_uint(zh[j]);
-        for (uint32_t k = (b0 >> 16) + t; k <= min(b1 >> 16, (uint32_t)kSampleKeys - 1); k += 64) {
-            const double s0 = fmax((double)b0, (double)(k << 16)), s1 = fmin((double)b1, (double)((k + 1) << 16));
-            if (s1 > s0) mass += (double)a.key_hist[k] * (s1 - s0) / 65536.0;
+    // The sweep classifies by the float's leading 16 bits: a bucket that touches a zone is KEPT whole (its samples go to the side
+    // buffer, the count kernel sorts them against the exact thresholds), the buckets between two runs of kept buckets form a gap
+    // whose samples are only counted.  Runs in ascending order; zones whose buckets touch share a run.
+    __shared__ uint32_t run_s[kMaxZones], run_e[kMaxZones];
+    __shared__ int s_nrun;
+    if (t == 0) {
+        const uint32_t kmid = (w->kmin + w->kmax) / 2;
+        const uint32_t kbase = kmid > (uint32_t)kZoneLutKeys / 2 ? kmid - (uint32_t)kZoneLutKeys / 2 : 0u;
+        const uint32_t klast = kbase + (uint32_t)kZoneLutKeys - 1;
+        int nr = 0;
+        for (int j = 0; j < m; ++j) {
+            const uint32_t b0 = __float_as_uint(zl[j]), b1 = isinf(zh[j]) ? 0x7F800000u : __float_as_uint(zh[j]);
+            const uint32_t ks = min(max(b0 >> 16, kbase), klast), ke = min(max((b1 - 1u) >> 16, kbase), klast);
+            if (nr && ks <= run_e[nr - 1] + 1u) run_e[nr - 1] = max(run_e[nr - 1], ke);
+            else { run_s[nr] = ks; run_e[nr] = ke; ++nr; }
+            w->zone_run[j] = nr - 1;
         }
+        for (int j = m; j < kMaxZones; ++j) w->zone_run[j] = -1;
+        s_nrun = nr;
+        w->kbase = kbase;
     }
+    __syncthreads();
+    const int nr = s_nrun;
+    double mass = 0.0; // share of the sample in kept buckets
+    for (int r = 0; r < nr; ++r)
+        for (uint32_t k = run_s[r] + t; k <= run_e[r]; k += 64) mass += (double)a.key_hist[k];
     for (int d = 32; d > 0; d >>= 1) mass += __shfl_down(mass, d);
     if (t != 0) return;
     mass /= (double)w->ns;
     w->mass_est = (float)mass;
     for (int k = 0; k < 2 * kMaxZones; ++k) w->bounds[k] = INFINITY;
-    w->nz = (float)(1.3 * mass + 0.004) <= a.max_mass ? m : 0;
+    // (a sample whose populated keys span more than the table: nothing sensible to select)
+    w->nz = ((float)(1.3 * mass + 0.004) <= a.max_mass && w->kmax - w->kmin + 2u < (uint32_t)kZoneLutKeys) ? m : 0;
+    w->nrun = w->nz > 0 ? nr : 0; // (0: the min / max pass keeps nothing)
+    for (int r = 0; r < nr; ++r) { w->run_s[r] = run_s[r]; w->run_e[r] = run_e[r]; }
     if (w->nz > 0)
-        for (int j = 0; j < m; ++j) { w->bounds[2 * j] = zl[j]; w->bounds[2 * j + 1] = zh[j]; } // else the min / max pass keeps nothing
+        for (int j = 0; j < m; ++j) { w->bounds[2 * j] = zl[j]; w->bounds[2 * j + 1] = zh[j]; }
 }
 
-// NZ = number of zones (template: only the live bounds are compared).  Counts are kept per wave in scalar registers
-// (v_cmp -> s_bcnt1): one VALU instruction per bound and sample.
-template <int VEC, int NZ>
+// the sweep's class table from the runs: four keys per thread
+__global__ __launch_bounds__(kBlock) void k_f32_zone_lut(const F32ZoneWork *__restrict__ w, uint32_t *__restrict__ lut) {
+    const uint32_t i4 = blockIdx.x * kBlock + threadIdx.x;
+    if (i4 >= (uint32_t)kZoneLutKeys / 4) return;
+    const int nr = w->nrun;
+    uint32_t word = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t k = w->kbase + 4 * i4 + b;
+        uint32_t cls = 0;
+        for (int r = 0; r < nr; ++r) {
+            if (k > w->run_e[r]) cls += 8u;
+            else if (k >= w->run_s[r]) { cls = 0x80u | 56u; break; }
+        }
+        word |= cls << (8 * b);
+    }
+    lut[i4] = word;
+}
+
+// The min / max pass of the zone route.  Per sample: the class byte of its leading 16 bits (LDS table), one 64-bit add into
+// eight packed 8-bit counters (one per gap; unpacked every 63 turns), and -- for a kept bucket -- the append to the wave's side
+// buffer.  The cost does not depend on the number of zones (round 2 compared every sample with every bound: 0.53 / 0.71 / 0.79 ms
+// for 2 / 4 / 5 zones).
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     // Valid samples are positive floats: they order like their bit patterns read as signed integers, an invalid one is replaced
-    // by -1.0f (a negative integer, below every bound).  Integer compares have no NaN twin, min / max are VOP2.
-    int bd[2 * NZ];
-#pragma unroll
-    for (int k = 0; k < 2 * NZ; ++k) bd[k] = __float_as_int(a.work->bounds[k]);
-    // wave-uniform counters (a wave sees < 2^32 samples: total / waves of the grid)
-    // (only the LOWER bound of a zone is counted: the zone's own population comes out of the count kernel)
-    uint32_t cnt = 0, ge[NZ];
-#pragma unroll
-    for (int k = 0; k < NZ; ++k) ge[k] = 0;
-    int mn = 0x7F800000, mx = (int)0x80000000;
-    __shared__ unsigned long long gsum[2 * kMaxZones + 1];
+    // by -1.0f (a negative integer).  Integer compares have no NaN twin, min / max are VOP2.
+    __shared__ uint32_t lut[kZoneLutKeys / 4];
     __shared__ float ring[kWavesPerBlock][128]; // kept samples on their way out: flushed 64 at a time, one coalesced store
-    if (threadIdx.x <= 2 * kMaxZones) gsum[threadIdx.x] = 0;
+    __shared__ unsigned long long gsum[8];
+    for (int i = threadIdx.x; i < kZoneLutKeys / 4; i += kBlock) lut[i] = a.lut[i];
+    if (threadIdx.x < 8) gsum[threadIdx.x] = 0;
+    const int kbase = (int)a.work->kbase;
     __syncthreads();
+    const uint8_t *lutb = reinterpret_cast<const uint8_t *>(lut);
+    int mn = 0x7F800000, mx = (int)0x80000000;
+    unsigned long long acc = 0;
+    uint32_t gap[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) gap[k] = 0;
     // every WAVE appends to its own quarter of the workgroup's region: the cursor is a scalar, no atomics
     const uint32_t wcap = a.cap / kWavesPerBlock;
     float *mine = a.zone_buf + (size_t)blockIdx.x * a.cap + (size_t)wave_id() * wcap;
     float *myring = ring[wave_id()];
     uint32_t cursor = 0, flushed = 0;
     StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.pitch, a.pol);
-    // A wave-uniform trip count (lane 0 holds the wave's smallest item index, so it runs longest): with a divergent loop exit
-    // the compiler keeps the wave-level counters in vector registers and pays vector adds for them.
+    // A wave-uniform trip count (lane 0 holds the wave's smallest item index, so it runs longest): the cursor stays scalar
     const uint64_t first = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u);
     const uint32_t nit = __builtin_amdgcn_readfirstlane(first < walk.total ? (uint32_t)((walk.total - first + walk.step - 1) / walk.step) : 0u);
     for (uint32_t it = 0; it < nit; ++it) {
@@ -513,22 +553,17 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float x = v.get(j);
-            if (!(col + j < a.cols && x >= a.t_valid)) x = -1.0f; // NaN included
-            const int xi = __float_as_int(x);
-            cnt += (uint32_t)__popcll(__ballot(xi >= 0));
-            mn = min(mn, xi >= 0 ? xi : 0x7F800000);
+            const bool ok = col + j < a.cols && x >= a.t_valid; // NaN fails
+            const int xi = ok ? __float_as_int(x) : (int)0xBF800000;
+            mn = min(mn, ok ? xi : 0x7F800000);
             mx = max(mx, xi);
-            bool inz = false;
-#pragma unroll
-            for (int z = 0; z < NZ; ++z) {
-                const bool g0 = xi >= bd[2 * z], g1 = xi >= bd[2 * z + 1];
-                ge[z] += (uint32_t)__popcll(__ballot(g0));
-                inz |= g0 != g1; // g1 implies g0
-            }
-            const unsigned long long zm = __ballot(inz);
+            const int idx = min(max((xi >> 16) - kbase, 0), kZoneLutKeys - 1);
+            const uint32_t cls = ok ? (uint32_t)lutb[idx] : 56u; // an invalid sample: counter 7, which nobody reads
+            acc += 1ull << (cls & 63u);
+            const unsigned long long zm = __ballot(cls > 0x7Fu);
             if (zm) {
                 const uint32_t pos = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(zm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zm, 0u));
-                if (inz) myring[pos & 127u] = x;
+                if (cls > 0x7Fu) myring[pos & 127u] = x;
                 cursor += (uint32_t)__popcll(zm);
                 if (cursor - flushed >= 64u) { // the wave's own LDS writes are visible to it in program order
                     const uint32_t p = flushed + (uint32_t)lane_id();
@@ -537,35 +572,35 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
                 }
             }
         }
+        if (it % 63u == 62u || it + 1 == nit) { // 63 turns x 4 samples < 256: no counter has overflowed
+#pragma unroll
+            for (int k = 0; k < 7; ++k) gap[k] += (uint32_t)(acc >> (8 * k)) & 0xFFu;
+            acc = 0;
+        }
     }
     {
         const uint32_t p = flushed + (uint32_t)lane_id();
         if (p < cursor && p < wcap) mine[p] = myring[p & 127u];
     }
-    // the lane with the smallest item index stays in the loop longest: lane 0 of every wave holds the wave's totals
-    __shared__ F32Partial part[kBlock];
-    part[threadIdx.x] = F32Partial{0, 0.0, 0.0, mn == 0x7F800000 ? INFINITY : __int_as_float(mn), mx < 0 ? -INFINITY : __int_as_float(mx)};
-    if (lane_id() == 0) {
-        atomicAdd(&gsum[2 * kMaxZones], (unsigned long long)cnt);
 #pragma unroll
-        for (int k = 0; k < NZ; ++k) atomicAdd(&gsum[2 * k], (unsigned long long)ge[k]);
+    for (int d = 32; d > 0; d >>= 1) {
+        mn = min(mn, __shfl_xor(mn, d)); mx = max(mx, __shfl_xor(mx, d));
+#pragma unroll
+        for (int k = 0; k < 7; ++k) gap[k] += __shfl_xor(gap[k], d);
+    }
+    __shared__ int s_mn[kWavesPerBlock], s_mx[kWavesPerBlock];
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&gsum[k], (unsigned long long)gap[k]);
+        s_mn[wave_id()] = mn; s_mx[wave_id()] = mx;
         a.zone_n[blockIdx.x * kWavesPerBlock + wave_id()] = cursor;
     }
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            F32Partial x = part[threadIdx.x], y = part[threadIdx.x + s];
-            x.minv = fminf(x.minv, y.minv); x.maxv = fmaxf(x.maxv, y.maxv);
-            part[threadIdx.x] = x;
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        F32Partial p = part[0];
-        p.count = gsum[2 * kMaxZones];
-        a.partials[blockIdx.x] = p;
+        for (int w = 1; w < kWavesPerBlock; ++w) { mn = min(mn, s_mn[w]); mx = max(mx, s_mx[w]); }
+        a.partials[blockIdx.x] = F32Partial{0, 0.0, 0.0, mn == 0x7F800000 ? INFINITY : __int_as_float(mn), mx < 0 ? -INFINITY : __int_as_float(mx)};
     }
-    if (threadIdx.x < 2 * kMaxZones) a.ge_counts[(size_t)blockIdx.x * 2 * kMaxZones + threadIdx.x] = gsum[threadIdx.x];
+    if (threadIdx.x < 8) a.gap_counts[(size_t)blockIdx.x * 8 + threadIdx.x] = gsum[threadIdx.x];
 }
 
 // the min / max pass's per-workgroup results reduced into the host's mailbox (one workgroup of 1024: two turns for the pass's 2048)
@@ -578,45 +613,44 @@ __global__ __launch_bounds__(kPostBlock) void k_f32_zone_post(F32ZoneArgs a, int
     if (threadIdx.x == 0) s_over = 0;
     __syncthreads();
     float mn = INFINITY, mx = -INFINITY;
-    unsigned long long cnt = 0, kept = 0, ge[kMaxZones];
+    unsigned long long kept = 0, ge[8];
 #pragma unroll
-    for (int z = 0; z < kMaxZones; ++z) ge[z] = 0;
+    for (int z = 0; z < 8; ++z) ge[z] = 0;
     uint32_t over = 0;
     const uint32_t wcap = a.cap / kWavesPerBlock;
     static_assert(kWavesPerBlock == 4 && sizeof(F32Partial) == 32, "vector loads below");
     for (int i = threadIdx.x; i < grid; i += kPostBlock) { // one workgroup of the pass per thread and turn: all its loads in flight together
         const F32Partial p = a.partials[i];
         const uint4 zn = reinterpret_cast<const uint4 *>(a.zone_n)[i];
-        const ulonglong2 *gp = reinterpret_cast<const ulonglong2 *>(a.ge_counts + (size_t)i * 2 * kMaxZones);
+        const ulonglong2 *gp = reinterpret_cast<const ulonglong2 *>(a.gap_counts + (size_t)i * 8);
 #pragma unroll
-        for (int z = 0; z < kMaxZones; ++z) ge[z] += gp[z].x; // (only the lower bound of a zone is counted)
-        cnt += p.count; mn = fminf(mn, p.minv); mx = fmaxf(mx, p.maxv);
+        for (int z = 0; z < 4; ++z) { const ulonglong2 g2 = gp[z]; ge[2 * z] += g2.x; ge[2 * z + 1] += g2.y; }
+        mn = fminf(mn, p.minv); mx = fmaxf(mx, p.maxv);
         kept += (unsigned long long)zn.x + zn.y + zn.z + zn.w;
         over |= (zn.x > wcap) | (zn.y > wcap) | (zn.z > wcap) | (zn.w > wcap);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, d)); mx = fmaxf(mx, __shfl_xor(mx, d));
-        cnt += __shfl_xor(cnt, d); kept += __shfl_xor(kept, d); over |= __shfl_xor(over, d);
+        kept += __shfl_xor(kept, d); over |= __shfl_xor(over, d);
 #pragma unroll
-        for (int z = 0; z < kMaxZones; ++z) ge[z] += __shfl_xor(ge[z], d);
+        for (int z = 0; z < 8; ++z) ge[z] += __shfl_xor(ge[z], d);
     }
     if (lane_id() == 0) {
 #pragma unroll
-        for (int z = 0; z < kMaxZones; ++z)
-            if (ge[z]) atomicAdd(&s_sum[2 * z], ge[z]);
-        atomicAdd(&s_sum[2 * kMaxZones], cnt);
+        for (int z = 0; z < 8; ++z)
+            if (ge[z]) atomicAdd(&s_sum[z], ge[z]);
         atomicAdd(&s_sum[2 * kMaxZones + 1], kept);
         if (over) s_over = 1;
         s_mn[wave_id()] = mn; s_mx[wave_id()] = mx;
     }
     __syncthreads();
-    if (threadIdx.x < 2 * kMaxZones) mail->ge[threadIdx.x] = s_sum[threadIdx.x];
+    if (threadIdx.x < 8) mail->gap[threadIdx.x] = s_sum[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + sizeof(F32ZoneWork) / 4) // (a second wave copies the zone record, word by word)
         reinterpret_cast<uint32_t *>(&mail->work)[threadIdx.x - 64] = reinterpret_cast<const uint32_t *>(a.work)[threadIdx.x - 64];
     if (threadIdx.x == 0) {
         for (int w = 1; w < kPostBlock / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
-        mail->count = s_sum[2 * kMaxZones]; mail->kept = s_sum[2 * kMaxZones + 1];
+        mail->kept = s_sum[2 * kMaxZones + 1];
         mail->min_v = mn; mail->max_v = mx;
         mail->overflow = s_over; mail->pad = 0;
     }
@@ -973,25 +1007,13 @@ hipError_t launch_f32_sample_sub(const float *d_sample, uint64_t n, float t_vali
 
 hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_f32_zone_finalize, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_f32_zone_lut, dim3(kZoneLutKeys / 4 / kBlock), dim3(kBlock), 0, s, a.work, reinterpret_cast<uint32_t *>(a.lut));
     return hipGetLastError();
 }
 
-template <int VEC>
-static void launch_prepass_zones_nz(const F32ZoneArgs &a, int nz, int grid, hipStream_t s) {
-    switch (nz) {
-    case 1: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 1>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 2>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 3>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 4>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    case 5: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, 5>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_f32_prepass_zones<VEC, kMaxZones>), dim3(grid), dim3(kBlock), 0, s, a); break;
-    }
-}
-
-// nz_max: an upper bound of the number of zones the selection can produce (the number of percentiles): unused bounds are +inf
-hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int nz_max, int grid, hipStream_t s) {
-    if (vec) launch_prepass_zones_nz<4>(a, nz_max, grid, s);
-    else launch_prepass_zones_nz<1>(a, nz_max, grid, s);
+hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int grid, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((k_f32_prepass_zones<4>), dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_f32_prepass_zones<1>), dim3(grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

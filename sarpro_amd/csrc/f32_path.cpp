@@ -53,7 +53,8 @@ constexpr size_t kOffZoneThr = kOffZoneN + 2048 * 4 * 4;             // (kZoneMa
 constexpr size_t kOffZoneCounts = kOffZoneThr + 8192;                // (kZoneMaxThr + 1) x 8 B
 constexpr size_t kOffSubHist = kOffZoneCounts + 16384;               // kMaxProbes x kSubKeys x 4 B
 constexpr size_t kOffZoneWork = kOffSubHist + kMaxProbes * kSubKeys * 4;
-constexpr size_t kWsBytes = kOffZoneWork + 4096;
+constexpr size_t kOffZoneLut = kOffZoneWork + 4096;                  // kZoneLutKeys class bytes
+constexpr size_t kWsBytes = kOffZoneLut + kZoneLutKeys;
 
 struct F32Band {
     sarpro_hip_ctx *ctx = nullptr;
@@ -77,7 +78,8 @@ struct F32Band {
     int nz = 0, znp = 0, zgrid = 0;
     float zlo[kMaxZones], zhi[kMaxZones];
     uint32_t zcap = 0;
-    uint64_t zge[2 * kMaxZones];
+    uint64_t zgap[8];             // valid samples in the unkept buckets below run g of kept buckets
+    int zrun[kMaxZones];          // the run zone j lies in
     uint64_t zone_kept = 0;       // samples the min / max pass kept in its side buffers
     bool zone_kept_known = false;
     const char *zone_note = "";
@@ -271,6 +273,7 @@ int f32_zone_presample(F32Band &B) {
     sa.work = d_work; sa.key_hist = d_keys; sa.sub_hist = d_sub; sa.npcts = np; sa.t_valid = B.t_valid; sa.max_mass = kZoneMaxMass;
     for (int i = 0; i < np; ++i) sa.pcts[i] = pcts[i];
     sa.sample_fraction = stride == 1 ? 1.0f : (float)nsrows / (float)B.rows;
+    sa.lut = ws + kOffZoneLut;
     {
         KernelTimer t(ctx, "f32_sample_keys");
         HIPCHK(ctx, launch_f32_sample_keys(B.d_in, B.in_pitch, (uint32_t)B.rows, (uint32_t)B.cols, B.t_valid, B.vec, stride, ctx->f32zone.as<float>(),
@@ -287,7 +290,7 @@ int f32_zone_presample(F32Band &B) {
     return SARPRO_HIP_OK;
 }
 
-// the min / max pass of the zone route: B.local, B.zge, overflow check
+// the min / max pass of the zone route: B.local, B.zgap, B.zone_kept, overflow check
 int f32_zone_prepass(F32Band &B) {
     sarpro_hip_ctx *ctx = B.ctx;
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
@@ -296,18 +299,19 @@ int f32_zone_prepass(F32Band &B) {
     a.in = B.d_in; a.pitch = B.in_pitch; a.rows = (uint32_t)B.rows; a.cols = (uint32_t)B.cols; a.t_valid = B.t_valid; a.pol = B.pol;
     a.partials = reinterpret_cast<F32Partial *>(ws + kOffPartials);
     a.work = reinterpret_cast<const F32ZoneWork *>(ws + kOffZoneWork);
-    a.ge_counts = reinterpret_cast<unsigned long long *>(ws + kOffZoneGe);
+    a.gap_counts = reinterpret_cast<unsigned long long *>(ws + kOffZoneGe);
+    a.lut = reinterpret_cast<const uint32_t *>(ws + kOffZoneLut);
     a.zone_buf = ctx->f32zone.as<float>();
     a.cap = B.zcap;
     a.zone_n = reinterpret_cast<uint32_t *>(ws + kOffZoneN);
     {
         KernelTimer t(ctx, "f32_prepass_zones");
-        HIPCHK(ctx, launch_f32_prepass_zones(a, B.vec, B.znp, grid, ctx->stream));
+        HIPCHK(ctx, launch_f32_prepass_zones(a, B.vec, grid, ctx->stream));
     }
     F32ZoneWork work_copy;
     const F32ZoneWork *h_work = &work_copy;
     bool overflow = false;
-    std::memset(B.zge, 0, sizeof(B.zge));
+    std::memset(B.zgap, 0, sizeof(B.zgap));
     if (mail_enabled()) {
         RETCHK(mail_open(ctx));
         F32ZoneMail *mail = mail_payload<F32ZoneMail>(ctx);
@@ -315,9 +319,8 @@ int f32_zone_prepass(F32Band &B) {
         HIPCHK(ctx, launch_f32_zone_post(a, grid, mail, mail_flag(ctx), seq, ctx->stream));
         RETCHK(mail_wait(ctx, seq));
         work_copy = mail->work;
-        B.local.count += mail->count;
         B.local.min_v = std::fmin(B.local.min_v, mail->min_v); B.local.max_v = std::fmax(B.local.max_v, mail->max_v);
-        for (int k = 0; k < 2 * kMaxZones; ++k) B.zge[k] = mail->ge[k];
+        for (int k = 0; k < 7; ++k) B.zgap[k] = mail->gap[k];
         overflow = mail->overflow != 0;
         B.zone_kept = mail->kept; B.zone_kept_known = true;
     } else {
@@ -326,7 +329,7 @@ int f32_zone_prepass(F32Band &B) {
         uint64_t *h_ge = reinterpret_cast<uint64_t *>(h + sizeof(F32Partial) * 2048);
         uint32_t *h_n = reinterpret_cast<uint32_t *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8);
         HIPCHK(ctx, hipMemcpyAsync(h_part, a.partials, sizeof(F32Partial) * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(h_ge, a.ge_counts, sizeof(uint64_t) * 2 * kMaxZones * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_ge, a.gap_counts, sizeof(uint64_t) * 8 * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(h_n, a.zone_n, sizeof(uint32_t) * 4 * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
         F32ZoneWork *h_w = reinterpret_cast<F32ZoneWork *>(h + sizeof(F32Partial) * 2048 + 2048 * 2 * kMaxZones * 8 + 2048 * 4 * 4);
         HIPCHK(ctx, hipMemcpyAsync(h_w, a.work, sizeof(F32ZoneWork), hipMemcpyDeviceToHost, ctx->stream));
@@ -334,14 +337,16 @@ int f32_zone_prepass(F32Band &B) {
         work_copy = *h_w;
         B.zone_kept = 0; B.zone_kept_known = true;
         for (int i = 0; i < grid; ++i) {
-            B.local.count += h_part[i].count;
             B.local.min_v = std::fmin(B.local.min_v, h_part[i].minv); B.local.max_v = std::fmax(B.local.max_v, h_part[i].maxv);
-            for (int k = 0; k < 2 * kMaxZones; ++k) B.zge[k] += h_ge[(size_t)i * 2 * kMaxZones + k];
+            for (int k = 0; k < 7; ++k) B.zgap[k] += h_ge[(size_t)i * 8 + k];
             for (int w = 0; w < 4; ++w) { overflow |= h_n[4 * i + w] > B.zcap / 4; B.zone_kept += h_n[4 * i + w]; }
         }
     }
+    // every valid sample was either counted in a gap or kept
+    for (int k = 0; k < 7; ++k) B.local.count += B.zgap[k];
+    B.local.count += B.zone_kept;
     B.nz = std::min(std::max(h_work->nz, 0), kMaxZones);
-    for (int i = 0; i < B.nz; ++i) { B.zlo[i] = h_work->bounds[2 * i]; B.zhi[i] = h_work->bounds[2 * i + 1]; }
+    for (int i = 0; i < B.nz; ++i) { B.zlo[i] = h_work->bounds[2 * i]; B.zhi[i] = h_work->bounds[2 * i + 1]; B.zrun[i] = std::min(std::max(h_work->zone_run[i], 0), 6); }
     if (B.nz == 0) { B.use_zones = false; B.zone_note = "no zones (sample too small, or zones too heavy)"; }
     if (getenv("SARPRO_HIP_F32_ZONES_DEBUG")) {
         std::fprintf(stderr, "[zones] ns=%u kmin=%#x kmax=%#x nprobe=%u nz=%d mass_est=%.4f cap=%u grid=%d\n", h_work->ns, h_work->kmin, h_work->kmax,
@@ -416,14 +421,19 @@ int f32_zone_resolve(F32Band &B) {
     // cum[i] = valid samples below tt[i], for every i inside a zone
     uint64_t cum[kZoneMaxThr + 2];
     const uint64_t N = G.count;
+    // below a threshold inside run r: the gaps 0 .. r and the kept samples the count kernel found below it (kept samples between
+    // the zones proper -- the rest of their buckets -- fall into the intervals between zone bounds and count here)
+    uint64_t kept_below[kZoneMaxThr + 2];
+    kept_below[0] = 0;
+    for (int i = 0; i <= n; ++i) kept_below[i + 1] = kept_below[i] + h_counts[i]; // kept_below[i] = kept samples below tt[i], i >= 1
     for (int j = 0; j < B.nz; ++j) {
-        uint64_t c = N - B.zge[2 * j];
+        uint64_t c = kept_below[zr[j].s];
+        for (int g = 0; g <= B.zrun[j]; ++g) c += B.zgap[g];
         for (int i = zr[j].s; i <= zr[j].e; ++i) { cum[i] = c; c += h_counts[i]; }
         if (cum[zr[j].e] > N) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
     }
     { // every kept sample lies in exactly one interval of one zone
-        uint64_t kept = 0, counted = 0;
-        for (int j = 0; j < B.nz; ++j) counted += cum[zr[j].e] - cum[zr[j].s];
+        uint64_t kept = 0, counted = kept_below[n + 1];
         kept = B.zone_kept;
         if (B.zone_kept_known && kept != counted) { B.zone_note = "count mismatch"; return SARPRO_HIP_OK; }
     }
