@@ -331,22 +331,35 @@ __global__ __launch_bounds__(1024) void k_f32_zone_pick(F32ZoneSelectArgs a) {
     __shared__ uint32_t s_kmin, s_kmax, s_rank[kMaxProbes];
     const int t = threadIdx.x;
     constexpr int per = kSampleKeys / 1024;
+    static_assert(per == 32, "eight 16-byte loads per thread");
     uint32_t sum = 0, lo = 0xFFFFFFFFu, hi = 0;
+    uint32_t hk[per];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.key_hist + t * per);
+#pragma unroll
+        for (int q = 0; q < per / 4; ++q) { const uint4 v = src[q]; hk[4 * q] = v.x; hk[4 * q + 1] = v.y; hk[4 * q + 2] = v.z; hk[4 * q + 3] = v.w; }
+    }
+#pragma unroll
     for (int k = 0; k < per; ++k) {
-        const uint32_t h = a.key_hist[t * per + k];
-        sum += h;
-        if (h) { lo = min(lo, (uint32_t)(t * per + k)); hi = max(hi, (uint32_t)(t * per + k)); }
+        sum += hk[k];
+        if (hk[k]) { lo = min(lo, (uint32_t)(t * per + k)); hi = max(hi, (uint32_t)(t * per + k)); }
     }
     if (t == 0) { s_kmin = 0xFFFFFFFFu; s_kmax = 0; }
-    incl[t] = sum;
+    // inclusive prefix over the 1024 threads: inside the wave by shuffles, across the 16 waves through LDS
+    __shared__ uint32_t wave_tot[16];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d); if ((t & 63) >= d) inc += v; }
+    if ((t & 63) == 63) wave_tot[t >> 6] = inc;
     __syncthreads();
     if (lo != 0xFFFFFFFFu) { atomicMin(&s_kmin, lo); atomicMax(&s_kmax, hi); }
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = t >= d ? incl[t - d] : 0;
-        __syncthreads();
-        incl[t] += v;
-        __syncthreads();
+    {
+        uint32_t before = 0;
+        for (int w = 0; w < (t >> 6); ++w) before += wave_tot[w];
+        inc += before;
     }
+    incl[t] = inc;
+    __syncthreads();
     const uint32_t ns = incl[1023];
     if (t == 0) {
         // rank error of a row sample: 6 sigma of a simple random sample of that size (finite-population corrected), never
@@ -367,12 +380,14 @@ __global__ __launch_bounds__(1024) void k_f32_zone_pick(F32ZoneSelectArgs a) {
     for (int i = 0; i < 2 * a.npcts; ++i) {
         const uint32_t r = s_rank[i];
         if (excl <= r && r < incl[t]) {
-            uint32_t c = excl;
-            for (int k = 0; k < per; ++k) {
-                const uint32_t h = a.key_hist[t * per + k];
-                if (r < c + h) { a.work->probe_key[i] = t * per + k; a.work->probe_base[i] = c; a.work->probe_rank[i] = r; break; }
-                c += h;
+            uint32_t c = excl, cbase = 0;
+            int found = -1;
+#pragma unroll
+            for (int k = 0; k < per; ++k) { // (registers, static indices: no dependent loads, no early exit)
+                if (found < 0 && r < c + hk[k]) { found = k; cbase = c; }
+                c += hk[k];
             }
+            if (found >= 0) { a.work->probe_key[i] = t * per + found; a.work->probe_base[i] = cbase; a.work->probe_rank[i] = r; }
         }
     }
 }
@@ -390,15 +405,21 @@ __global__ __launch_bounds__(kBlock) void k_f32_sample_sub(const float *__restri
     __syncthreads();
     if ((int)threadIdx.x < np) atomicOr(&probed[(pk[threadIdx.x] & (kSampleKeys - 1)) >> 5], 1u << (pk[threadIdx.x] & 31u));
     __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-        const float x = sample[i];
-        if (!(x >= t_valid)) continue;
+    auto one = [&](float x) {
+        if (!(x >= t_valid)) return;
         const uint32_t bits = __float_as_uint(x), key = bits >> 16;
-        if (key >= (uint32_t)kSampleKeys || !((probed[key >> 5] >> (key & 31u)) & 1u)) continue;
+        if (key >= (uint32_t)kSampleKeys || !((probed[key >> 5] >> (key & 31u)) & 1u)) return;
 #pragma unroll
         for (int p = 0; p < kMaxProbes; ++p)
             if (key == pk[p]) atomicAdd(&sub[p * kSubKeys + ((bits >> 7) & (kSubKeys - 1))], 1u); // equal probe keys: each keeps its own copy
+    };
+    // (the stored sample's pitch is a multiple of 4 and its base an allocation: whole vectors)
+    const uint64_t n4 = n / 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * kBlock) {
+        const float4 v = reinterpret_cast<const float4 *>(sample)[i];
+        one(v.x); one(v.y); one(v.z); one(v.w);
     }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) one(sample[i]);
     __syncthreads();
     for (int i = threadIdx.x; i < kMaxProbes * kSubKeys; i += kBlock)
         if (sub[i]) atomicAdd(&g_sub[i], sub[i]);
@@ -418,16 +439,32 @@ __global__ __launch_bounds__(64) void k_f32_zone_finalize(F32ZoneSelectArgs a) {
     __shared__ uint32_t subl[kMaxProbes * kSubKeys];
     for (int i = t; i < np * kSubKeys; i += 64) subl[i] = a.sub_hist[i];
     __syncthreads();
-    if (t < np) {
-        uint32_t c = w->probe_base[t], sb = kSubKeys - 1;
-        const uint32_t r = w->probe_rank[t];
-        for (int k = 0; k < kSubKeys; ++k) {
-            const uint32_t h = subl[t * kSubKeys + k];
-            if (r < c + h) { sb = k; break; }
-            c += h;
+    // the sub-bucket holding each probe rank: the wave scans a probe's 512 counts together, eight per lane
+    static_assert(kSubKeys == 512, "eight sub-buckets per lane");
+    for (int p = 0; p < np; ++p) {
+        uint32_t h8[8], mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { h8[k] = subl[p * kSubKeys + t * 8 + k]; mine += h8[k]; }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d); if (t >= d) inc += v; }
+        const uint32_t r = w->probe_rank[p];
+        uint32_t c = w->probe_base[p] + inc - mine; // counts below this lane's first sub-bucket
+        // the FIRST sub-bucket k with r < c_k + h_k (ranks beyond the last one: the last sub-bucket)
+        const bool here = r < c + mine; // (cumulative ends do not decrease: the lanes that say yes form a suffix)
+        const unsigned long long who = __ballot(here);
+        if (who ? (t == (int)__builtin_ctzll(who)) : (t == 63)) {
+            uint32_t sb = who ? 0u : (uint32_t)kSubKeys - 1u;
+            if (who) {
+                sb = t * 8 + 7;
+                for (int k = 0; k < 8; ++k) {
+                    if (r < c + h8[k]) { sb = t * 8 + k; break; }
+                    c += h8[k];
+                }
+            }
+            const uint32_t base = (w->probe_key[p] << 16) | (sb << 7);
+            edge[p] = (p & 1) ? base + (1u << 7) : base;
         }
-        const uint32_t base = (w->probe_key[t] << 16) | (sb << 7);
-        edge[t] = (t & 1) ? base + (1u << 7) : base;
     }
     __syncthreads();
     __shared__ float zl[kMaxZones], zh[kMaxZones];
