@@ -171,6 +171,7 @@ hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, 
                                  unsigned long long *d_counts /* [kZoneMaxThr + 1], zeroed */, hipStream_t s);
 
 int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec);
+int f32_zone_grid(uint32_t rows, uint32_t cols, bool vec); // grid of launch_f32_prepass_zones (<= 2048)
 // moments = false: count / min / max only (no per-sample f64 log10: the pass is then memory-bound)
 hipError_t launch_f32_prepass(const float *in, size_t pitch, uint32_t rows, uint32_t cols, float t_valid, bool vec, bool moments,
                               F32Partial *d_partials, int grid, hipStream_t s, const F32Pol &pol = F32Pol());

@@ -183,12 +183,15 @@ struct StrideWalk {
     uint64_t idx, total, step;
     uint32_t r, vc, vpr, step_r, step_c;
     typename F32Vec<VEC>::Raw cur;
-    __device__ StrideWalk(uint32_t rows, uint32_t cols, const float *in, size_t pitch, const F32Pol &pol) {
+    // (phase, nphase): this walk takes every nphase-th item of the lane's sequence, starting with the phase-th -- a kernel that
+    // runs nphase walks side by side has nphase loads in flight per lane
+    __device__ StrideWalk(uint32_t rows, uint32_t cols, const float *in, size_t pitch, const F32Pol &pol, uint32_t phase = 0, uint32_t nphase = 1) {
         vpr = (cols + VEC - 1) / VEC;
         total = (uint64_t)rows * vpr;
-        step = (uint64_t)gridDim.x * blockDim.x;
+        const uint64_t step0 = (uint64_t)gridDim.x * blockDim.x;
+        step = step0 * nphase;
         step_r = (uint32_t)(step / vpr); step_c = (uint32_t)(step % vpr);
-        idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + step0 * phase;
         r = (uint32_t)(idx / vpr); vc = (uint32_t)(idx % vpr);
         if (idx < total) cur = F32Vec<VEC>::load_raw(in, pitch, pol, r, (size_t)vc * VEC);
     }
@@ -553,6 +556,13 @@ __global__ __launch_bounds__(kBlock) void k_f32_zone_lut(const F32ZoneWork *__re
     lut[i4] = word;
 }
 
+// 1 << (s mod 64): the hardware shift reads six bits of the amount, the language wants them masked first
+__device__ inline unsigned long long shl64_one(uint32_t s) {
+    unsigned long long r;
+    asm("v_lshlrev_b64 %0, %1, %2" : "=v"(r) : "v"(s), "v"(1ull));
+    return r;
+}
+
 // The min / max pass of the zone route.  Per sample: the class byte of its leading 16 bits (LDS table), one 64-bit add into
 // eight packed 8-bit counters (one per gap; unpacked every 63 turns), and -- for a kept bucket -- the append to the wave's side
 // buffer.  The cost does not depend on the number of zones (round 2 compared every sample with every bound: 0.53 / 0.71 / 0.79 ms
@@ -562,7 +572,8 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     // Valid samples are positive floats: they order like their bit patterns read as signed integers, an invalid one is replaced
     // by -1.0f (a negative integer).  Integer compares have no NaN twin, min / max are VOP2.
     __shared__ uint32_t lut[kZoneLutKeys / 4];
-    __shared__ float ring[kWavesPerBlock][128]; // kept samples on their way out: flushed 64 at a time, one coalesced store
+    constexpr uint32_t kRing = 512; // kept samples on their way out: flushed 64 at a time, one coalesced store (a turn adds up to 64 x VEC)
+    __shared__ float ring[kWavesPerBlock][kRing];
     __shared__ unsigned long long gsum[8];
     for (int i = threadIdx.x; i < kZoneLutKeys / 4; i += kBlock) lut[i] = a.lut[i];
     if (threadIdx.x < 8) gsum[threadIdx.x] = 0;
@@ -579,34 +590,51 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     float *mine = a.zone_buf + (size_t)blockIdx.x * a.cap + (size_t)wave_id() * wcap;
     float *myring = ring[wave_id()];
     uint32_t cursor = 0, flushed = 0;
-    StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.pitch, a.pol);
+    StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.pitch, a.pol, 0, 2), walk_b(a.rows, a.cols, a.in, a.pitch, a.pol, 1, 2);
+    const bool whole_rows = a.cols % VEC == 0 && a.t_valid > 0.0f;
     // A wave-uniform trip count (lane 0 holds the wave's smallest item index, so it runs longest): the cursor stays scalar
     const uint64_t first = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u);
-    const uint32_t nit = __builtin_amdgcn_readfirstlane(first < walk.total ? (uint32_t)((walk.total - first + walk.step - 1) / walk.step) : 0u);
+    // (two walks side by side: turn `it` takes the first walk's item when it is even, the second's when it is odd)
+    const uint64_t step0 = walk.step / 2;
+    const uint32_t nit = __builtin_amdgcn_readfirstlane(first < walk.total ? (uint32_t)((walk.total - first + step0 - 1) / step0) : 0u);
     for (uint32_t it = 0; it < nit; ++it) {
         uint32_t r = 0, col = 0xFFFFFFF0u; // a lane past its last item: every sample fails the column test
         F32Vec<VEC> v{};
-        if (walk.live()) v = walk.next(a.in, a.pitch, a.pol, &r, &col);
+        if (it & 1u) { if (walk_b.live()) v = walk_b.next(a.in, a.pitch, a.pol, &r, &col); }
+        else if (walk.live()) v = walk.next(a.in, a.pitch, a.pol, &r, &col);
+        // the VEC samples side by side (no branch between them: their table reads and counter updates interleave), then ONE
+        // append for all the kept ones
+        float xs[VEC];
+        bool keep[VEC];
+        unsigned long long zm[VEC], any = 0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            float x = v.get(j);
-            const bool ok = col + j < a.cols && x >= a.t_valid; // NaN fails
-            const int xi = ok ? __float_as_int(x) : (int)0xBF800000;
-            mn = min(mn, ok ? xi : 0x7F800000);
+            xs[j] = v.get(j);
+            // (whole vectors only -- cols % VEC == 0 -- need no column test: a lane past its last item holds zeros, which are invalid)
+            const bool ok = (whole_rows || col + j < a.cols) && xs[j] >= a.t_valid; // NaN fails
+            const int xi = ok ? __float_as_int(xs[j]) : (int)0xBF800000;
+            mn = (int)min((uint32_t)mn, (uint32_t)xi); // valid samples are non-negative integers, the invalid one is a huge unsigned
             mx = max(mx, xi);
             const int idx = min(max((xi >> 16) - kbase, 0), kZoneLutKeys - 1);
             const uint32_t cls = ok ? (uint32_t)lutb[idx] : 56u; // an invalid sample: counter 7, which nobody reads
-            acc += 1ull << (cls & 63u);
-            const unsigned long long zm = __ballot(cls > 0x7Fu);
-            if (zm) {
-                const uint32_t pos = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(zm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zm, 0u));
-                if (cls > 0x7Fu) myring[pos & 127u] = x;
-                cursor += (uint32_t)__popcll(zm);
-                if (cursor - flushed >= 64u) { // the wave's own LDS writes are visible to it in program order
-                    const uint32_t p = flushed + (uint32_t)lane_id();
-                    if (p < wcap) mine[p] = myring[p & 127u];
-                    flushed += 64u;
-                }
+            acc += shl64_one(cls);
+            keep[j] = cls > 0x7Fu;
+            zm[j] = __ballot(keep[j]);
+            any |= zm[j];
+        }
+        if (any) {
+            uint32_t base = cursor;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(zm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zm[j], 0u));
+                if (keep[j]) myring[pos & (kRing - 1u)] = xs[j];
+                base += (uint32_t)__popcll(zm[j]);
+            }
+            cursor = base;
+            while (cursor - flushed >= 64u) { // the wave's own LDS writes are visible to it in program order
+                const uint32_t p = flushed + (uint32_t)lane_id();
+                if (p < wcap) mine[p] = myring[p & (kRing - 1u)];
+                flushed += 64u;
             }
         }
         if (it % 63u == 62u || it + 1 == nit) { // 63 turns x 4 samples < 256: no counter has overflowed
@@ -617,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     }
     {
         const uint32_t p = flushed + (uint32_t)lane_id();
-        if (p < cursor && p < wcap) mine[p] = myring[p & 127u];
+        if (p < cursor && p < wcap) mine[p] = myring[p & (kRing - 1u)];
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -1075,6 +1103,14 @@ hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, 
                                  unsigned long long *d_counts, hipStream_t s) {
     hipLaunchKernelGGL(k_f32_zone_count, dim3(std::min(nregions, 1024)), dim3(kBlock), 0, s, zone_buf, zone_n, cap, nregions, d_thr, nthr, d_counts);
     return hipGetLastError();
+}
+
+// The zone sweep's turn is one long dependent chain (divide, table read, packed-counter add): it needs more waves per SIMD than
+// the plain min / max pass to hide it -- 400 MP, log-ratio of u16 bands: 0.81 / 0.50 / 0.44 / 0.46 ms with 2 / 4 / 6 / 8 workgroups per CU
+int f32_zone_grid(uint32_t rows, uint32_t cols, bool vec) {
+    static const int per_cu = getenv("SARPRO_HIP_ZONE_PER_CU") ? std::max(1, std::min(8, atoi(getenv("SARPRO_HIP_ZONE_PER_CU")))) : 6; // (<= 8: 2048 partials)
+    const int V = vec ? 4 : 1;
+    return stream_grid((uint64_t)rows * ((cols + V - 1) / V), per_cu);
 }
 
 int f32_prepass_grid(uint32_t rows, uint32_t cols, bool vec) {

@@ -257,7 +257,7 @@ int f32_zone_presample(F32Band &B) {
     const uint32_t stride = (uint32_t)std::max<uint64_t>(1, B.rows / 640);
     const uint32_t nsrows = ((uint32_t)B.rows + stride - 1) / stride;
     const uint32_t spitch = ((uint32_t)B.cols + 3) / 4 * 4;
-    B.zgrid = f32_prepass_grid((uint32_t)B.rows, (uint32_t)B.cols, B.vec);
+    B.zgrid = f32_zone_grid((uint32_t)B.rows, (uint32_t)B.cols, B.vec);
     const double share = (double)px / (double)B.zgrid;
     B.zcap = (uint32_t)std::max(1024.0, share * (double)kZoneMaxMass) / 4 * 4; // a quarter per wave
     if (env && !std::strcmp(env, "tiny")) B.zcap = 0; // test switch: no room at all, the first kept sample overflows
