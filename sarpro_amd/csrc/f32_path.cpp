@@ -153,7 +153,7 @@ static int prep_run(sarpro_hip_ctx *ctx, const Prep &p) {
     for (int k = 0; k < p.g.nz; ++k) HIPCHK(ctx, hipMemsetAsync(p.g.zero[k], 0, p.g.zbytes[k], ctx->stream));
     return SARPRO_HIP_OK;
 }
-static bool mail_enabled() { static const bool on = !getenv("SARPRO_HIP_NO_MAILBOX"); return on; }
+static bool mail_enabled() { return !getenv("SARPRO_HIP_NO_MAILBOX"); } // (cross-check switch: copy / fill commands and stream waits, as round 2)
 
 static uint32_t direct_queue_cap() { // SARPRO_HIP_F32_DIRECT_QCAP: a tiny queue, so that the tests reach the overflow hand-back
     if (const char *e = getenv("SARPRO_HIP_F32_DIRECT_QCAP")) return (uint32_t)std::min<long>(kDirectQueueCap, std::max<long>(0, atol(e)));

@@ -137,3 +137,43 @@ def test_zone_route_inside_the_dual_pol_f32_product(strategy, monkeypatch):
         rgb = c.dualpol_synrgb(b[0], b[1], strategy)
         assert np.array_equal(rgb, ref)
         assert "f32_prepass_zones" in names(c)
+
+
+@pytest.mark.parametrize("strategy,bd", [(St.Clahe, Bd.U16), (St.Robust, Bd.U16), (St.Standard, Bd.U8), (St.Tamed, Bd.U8)])
+@pytest.mark.parametrize("switch", ["SARPRO_HIP_NO_MAILBOX", "SARPRO_HIP_F32_LEVEL_GENERAL"])
+def test_round3_cross_check_switches(strategy, bd, switch, monkeypatch):
+    """The host turns through the pinned mailbox (post / prep kernels) against copy and fill commands with stream waits, and
+    the folded gamma = 1 level line against the reference's expression term by term: same raster, same statistics, and the
+    oracle's raster.  1500 x 1700: the zone sweep runs more than 63 turns per lane (its packed counters are unpacked in between)."""
+    x = f32data.ratio_scene(1500, 1700)
+    rc, ref = oracle.pipeline(x, int(bd), int(strategy))
+    assert rc == 0
+    outs = []
+    with S.Context(0, timing=True) as c:
+        for on in (False, True):
+            if on:
+                monkeypatch.setenv(switch, "1")
+            else:
+                monkeypatch.delenv(switch, raising=False)
+            got = c.process_scalar_data_pipeline(x, bd, strategy)
+            outs.append(got[0] if bd == Bd.U8 else got[1])
+    assert np.array_equal(outs[0], outs[1]), (strategy, bd, switch)
+    assert np.array_equal(outs[0], ref), (strategy, bd, switch)
+
+
+def test_zone_sweep_counts_every_valid_sample_whatever_the_table_says(monkeypatch):
+    """The sweep's class table decides only WHERE a sample is counted (a gap's counter or the side buffer): the valid count
+    it reports must be the scene's, also when the selection stepped aside (table of one gap) and for values far outside the
+    table's 64 octaves (clamped to its ends)."""
+    rng = np.random.default_rng(5)
+    x = np.exp(rng.normal(0.0, 1.0, (900, 1100))).astype(np.float32)
+    x[::7, ::5] = 0.0           # invalid
+    x[3, 3] = 1e-30             # far below the table
+    x[5, 8] = 1e30              # far above it
+    for strategy in (St.Robust, St.Clahe):
+        rc, ref = oracle.pipeline(x, int(Bd.U8), int(strategy))
+        assert rc == 0
+        with S.Context(0, timing=True) as c:
+            got = c.process_scalar_data_pipeline(x, Bd.U8, strategy)
+            assert np.array_equal(got[0], ref), strategy
+            assert "f32_prepass_zones" in names(c)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-pixel cost of the headline chain's three sweeps at several scene sizes, scaled to 400 MP: scenes whose level rasters
+"""Per-pixel cost of the headline chain's sweeps (histograms, sample pass, fused CLAHE -> RGB pass; or apply + compose) at several scene sizes, scaled to 400 MP: scenes whose level rasters
 fit the 256-MiB Infinity Cache show what the compose pass would cost if its inputs did not come from HBM."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,5 +23,5 @@ for side in [int(x) for x in (sys.argv[1:] or ["20000", "10000", "7000", "5000",
                     acc.setdefault(n, []).append(ms)
         med = {n: sorted(v)[len(v) // 2] for n, v in acc.items()}
         sc = 4e8 / (rows * cols)
-        print(side, {k: round(med[k] * sc, 4) for k in ("dn_hist_u16", "clahe_apply_u8_spec", "compose_u8") if k in med}, "ms scaled to 400 MP; raw total", round(sum(v for k, v in med.items() if not k.startswith("host")), 4), flush=True)
+        print(side, {k: round(med[k] * sc, 4) for k in ("dn_hist_u16", "clahe_sample", "clahe_rgb_fused", "clahe_apply_u8_spec", "compose_u8") if k in med}, "ms scaled to 400 MP; raw total", round(sum(v for k, v in med.items() if not k.startswith("host")), 4), flush=True)
     del d, rgb
