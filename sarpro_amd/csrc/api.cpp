@@ -129,6 +129,8 @@ extern "C" void sarpro_hip_comm_destroy(sarpro_hip_ctx *ctx);
 
 extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->band_worker) { ctx->band_worker->stop(); delete ctx->band_worker; ctx->band_worker = nullptr; }
+    if (ctx->twin) { sarpro_hip_ctx_destroy(ctx->twin); ctx->twin = nullptr; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     sarpro_hip_comm_destroy(ctx);

@@ -2,8 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -82,6 +87,69 @@ struct KernelTime { const char *name; hipEvent_t start, stop; };
 
 } // namespace sarpro
 
+namespace sarpro {
+// One persistent helper thread of a context: runs one job at a time (the OTHER band of a dual-pol f32 product, on the context's
+// twin -- its own stream and workspaces -- while the caller's thread runs the first band).
+struct BandWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    std::atomic<bool> pending{false}, finished{false};
+    bool quit = false;
+    int rc = 0;
+    void start() { th = std::thread([this] { run(); }); }
+    // Calls come back to back when scenes stream: both sides spin for a short while before they sleep on the condition variable
+    // (a futex wake-up costs the second band 20-60 us of a 230-us call).
+    static bool spin_until(const std::atomic<bool> &flag, int spins) {
+        for (int i = 0; i < spins; ++i) {
+            if (flag.load(std::memory_order_acquire)) return true;
+            __builtin_ia32_pause();
+        }
+        return flag.load(std::memory_order_acquire);
+    }
+    void run() {
+        for (;;) {
+            if (!spin_until(pending, 20000)) {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return pending.load(std::memory_order_acquire) || quit; });
+                if (quit) return;
+            }
+            const int r = job();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                rc = r;
+                pending.store(false, std::memory_order_release);
+                finished.store(true, std::memory_order_release);
+            }
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            finished.store(false, std::memory_order_release);
+            pending.store(true, std::memory_order_release);
+        }
+        cv.notify_all();
+    }
+    int wait() {
+        if (!spin_until(finished, 20000)) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return finished.load(std::memory_order_acquire); });
+        }
+        std::lock_guard<std::mutex> lk(m); // (the worker publishes rc under the lock)
+        return rc;
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+} // namespace sarpro
+
 struct sarpro_hip_ctx {
     int device = 0;
     unsigned flags = 0;
@@ -131,6 +199,8 @@ struct sarpro_hip_ctx {
     // per-kernel timing of the last call
     bool timing = false;
     bool async_dev = false;                      // SARPRO_HIP_CTX_ASYNC_DEV
+    sarpro_hip_ctx *twin = nullptr;              // a second context on the same device (own stream, own workspaces): the other band of a dual-pol f32 product
+    sarpro::BandWorker *band_worker = nullptr;   // ... and the thread that drives it
     bool f32_stripe_open = false;                // an open sarpro_hip_stripe_f32 owns the f32 workspace until its _end
     int timing_hold = 0;                         // > 0: timing_reset is a no-op (a composite call holds its steps' event pairs)
     bool async_pending = false;                  // event pairs of enqueued-but-unread calls are kept until read

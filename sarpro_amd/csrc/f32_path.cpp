@@ -1251,32 +1251,75 @@ static int dualpol_f32_impl(sarpro_hip_ctx *ctx, const DualF32Src &src, size_t r
     const size_t opitch = round_up(std::max<size_t>(fc, 1), 64);
     uint64_t combined[256];
     std::memset(combined, 0, sizeof(combined));
-    size_t pitch = 0;
-    for (int b = 0; b < 2; ++b) {
-        const float *d_in = nullptr;
-        if (src.dev[b]) { d_in = src.dev[b]; pitch = src.dev_pitch; }
-        else { RETCHK(stage_in_2d(ctx, ctx->stage_in[0], src.host[b], rows, cols, 4, &pitch)); d_in = ctx->stage_in[0].as<float>(); }
-        const size_t lpitch = round_up(std::max<size_t>(cols, 1), 64);
-        DevBuf &lv = resized ? ctx->stage_out[0] : ctx->levels[b];
-        HIPCHK(ctx, lv.reserve(r1 * lpitch));
+    const size_t lpitch_b = round_up(std::max<size_t>(cols, 1), 64);
+    // One band: autoscale to u8 levels (levels[b], or a scratch raster of the WORKING context when a resize follows), the
+    // resize + pad into resized[b], the optional copy of the levels.  `w` is the context whose stream and f32 workspaces do the
+    // work: the caller's, or its twin for the second band (buffers named through `ctx` were reserved by the caller beforehand).
+    struct BandResult { uint64_t hist[256]; sarpro_hip_stats stats; sarpro_hip_resize_meta m; };
+    BandResult res[2];
+    for (int b = 0; b < 2; ++b) { std::memset(&res[b], 0, sizeof(res[b])); res[b].m = m; }
+    auto one_band = [&](sarpro_hip_ctx *w, int b, const float *d_in, size_t pitch) -> int {
+        uint8_t *lv = resized ? w->stage_out[0].as<uint8_t>() : ctx->levels[b].as<uint8_t>();
         F32Band B;
-        B.ctx = ctx; B.d_in = d_in; B.rows = rows; B.cols = cols; B.in_pitch = pitch;
+        B.ctx = w; B.d_in = d_in; B.rows = rows; B.cols = cols; B.in_pitch = pitch;
         B.strategy = strategy; B.bit_depth = SARPRO_BITDEPTH_U8;
         B.tamed = (!plain && strategy == SARPRO_STRATEGY_TAMED) ? (b == 0 ? kTamedCopol : kTamedCrosspol) : 0;
-        B.d_out = lv.p; B.out_pitch = lpitch;
+        B.d_out = lv; B.out_pitch = lpitch_b;
         B.want_moments = stats_out != nullptr;
         RETCHK(f32_band_run(B));
-        if (stats_out) stats_out[b] = B.stats;
-        for (int i = 0; i < 256; ++i) combined[i] += B.final_hist[i];
-        if (resized) {
-            HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch));
-            RETCHK(resize_pad_dev(ctx, lv.p, cols, rows, lpitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m));
+        res[b].stats = B.stats;
+        std::memcpy(res[b].hist, B.final_hist, sizeof(res[b].hist));
+        if (resized) RETCHK(resize_pad_dev(w, lv, cols, rows, lpitch_b, target_size, 1, pad, ctx->resized[b].p, opitch, &res[b].m));
+        if (!resized && out.u8_dev[b])
+            HIPCHK(w, hipMemcpy2DAsync(out.u8_dev[b], out.u8_dev_pitch, lv, lpitch_b, cols, rows, hipMemcpyDeviceToDevice, w->stream));
+        return SARPRO_HIP_OK;
+    };
+    // Device-resident bands: the second band runs on the context's twin (own stream, workspaces and mailbox) from a helper thread
+    // while this thread runs the first -- at the reference's usual 2048^2 a band is a chain of short kernels and two host turns,
+    // and two of them side by side take little longer than one.  (A timing context keeps one stream: its kernel table is per
+    // context.  SARPRO_HIP_NO_BAND_TWIN=1: one band after the other, as host-resident bands go.)
+    const bool twin = src.dev[0] && src.dev[1] && !ctx->timing && !ctx->f32_stripe_open && !getenv("SARPRO_HIP_NO_BAND_TWIN");
+    if (twin) {
+        if (!ctx->twin) {
+            if (sarpro_hip_ctx_create(ctx->device, ctx->flags & ~(unsigned)SARPRO_HIP_CTX_TIMING, &ctx->twin) != SARPRO_HIP_OK)
+                return fail(ctx, SARPRO_HIP_ERR_HIP, "dual-pol f32: the second band's context could not be created");
+            ctx->band_worker = new BandWorker();
+            ctx->band_worker->start();
         }
-        if (!resized && (out.u8_host[b] || out.u8_dev[b])) {
-            if (out.u8_dev[b]) HIPCHK(ctx, hipMemcpy2DAsync(out.u8_dev[b], out.u8_dev_pitch, lv.p, lpitch, cols, rows, hipMemcpyDeviceToDevice, ctx->stream));
-            else RETCHK(fetch_out_2d(ctx, out.u8_host[b], lv.p, lpitch, cols, rows));
+        sarpro_hip_ctx *t = ctx->twin;
+        for (int b = 0; b < 2; ++b) {
+            if (!resized) HIPCHK(ctx, ctx->levels[b].reserve(r1 * lpitch_b));
+            else HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch));
+        }
+        if (resized) { HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * lpitch_b)); HIPCHK(ctx, t->stage_out[0].reserve(r1 * lpitch_b)); }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (the bands may come from work still queued on this context's stream)
+        ctx->band_worker->submit([&, t]() -> int {
+            if (hipSetDevice(t->device) != hipSuccess) return SARPRO_HIP_ERR_HIP;
+            int rc = one_band(t, 1, src.dev[1], src.dev_pitch);
+            if (rc == SARPRO_HIP_OK && hipStreamSynchronize(t->stream) != hipSuccess) rc = SARPRO_HIP_ERR_HIP;
+            return rc;
+        });
+        const int rc0 = one_band(ctx, 0, src.dev[0], src.dev_pitch);
+        const int rc1 = ctx->band_worker->wait(); // (always: the job holds references to this frame)
+        if (rc0 != SARPRO_HIP_OK) return rc0;
+        if (rc1 != SARPRO_HIP_OK) return fail(ctx, rc1, t->err.empty() ? "dual-pol f32: the second band failed" : t->err.c_str());
+    } else {
+        for (int b = 0; b < 2; ++b) {
+            const float *d_in = nullptr;
+            size_t pitch = 0;
+            if (src.dev[b]) { d_in = src.dev[b]; pitch = src.dev_pitch; }
+            else { RETCHK(stage_in_2d(ctx, ctx->stage_in[0], src.host[b], rows, cols, 4, &pitch)); d_in = ctx->stage_in[0].as<float>(); }
+            if (!resized) HIPCHK(ctx, ctx->levels[b].reserve(r1 * lpitch_b));
+            else { HIPCHK(ctx, ctx->stage_out[0].reserve(r1 * lpitch_b)); HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch)); }
+            RETCHK(one_band(ctx, b, d_in, pitch));
+            if (!resized && out.u8_host[b]) RETCHK(fetch_out_2d(ctx, out.u8_host[b], ctx->levels[b].p, lpitch_b, cols, rows));
         }
     }
+    for (int b = 0; b < 2; ++b) {
+        if (stats_out) stats_out[b] = res[b].stats;
+        for (int i = 0; i < 256; ++i) combined[i] += res[b].hist[i];
+    }
+    if (resized) m = res[0].m;
     if (meta) *meta = m;
     if (resized) { // composition on the resized, padded bands (compacted: the flat entry point applies), as the u16 flow does
         if (!fc || !fr) return SARPRO_HIP_OK;
@@ -1305,9 +1348,17 @@ static int dualpol_f32_impl(sarpro_hip_ctx *ctx, const DualF32Src &src, size_t r
     for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
     fold_compose_tables(luts.data(), fwc, ident, ident, tables.data());
     HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
-    uint8_t *tstage = ctx->h_upload.as<uint8_t>();
-    std::memcpy(tstage, tables.data(), 66048);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tstage, 66048, hipMemcpyHostToDevice, ctx->stream));
+    if (mail_enabled() && mail_open(ctx) == SARPRO_HIP_OK) { // the tables through the mailbox's big-payload area (both bands' turns are over): a kernel, not a copy command
+        uint8_t *tstage = ctx->mailbox.as<uint8_t>() + kMailBigOff;
+        std::memcpy(tstage, tables.data(), 66048);
+        Prep pr;
+        pr.upload(tstage, ctx->tables.p, 66048);
+        RETCHK(prep_run(ctx, pr));
+    } else {
+        uint8_t *tstage = ctx->h_upload.as<uint8_t>();
+        std::memcpy(tstage, tables.data(), 66048);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tstage, 66048, hipMemcpyHostToDevice, ctx->stream));
+    }
     ComposeArgs c{};
     c.b1 = ctx->levels[0].as<uint8_t>(); c.b2 = ctx->levels[1].as<uint8_t>(); c.in_pitch = lpitch;
     c.rows = (uint32_t)rows; c.cols = (uint32_t)cols;

@@ -195,6 +195,44 @@ def test_dualpol_f32_device_resident_entry_points(strategy):
         assert np.array_equal(out.cpu().numpy().reshape(fr, fc, 3), ref)
 
 
+@pytest.mark.parametrize("strategy", [St.Default, St.Clahe, St.Tamed, St.Robust])
+@pytest.mark.parametrize("twin", [True, False])
+def test_dualpol_f32_second_band_on_the_twin_context(strategy, twin, monkeypatch):
+    """Device-resident bands on a context WITHOUT the timing table: the second band runs on the context's twin (own stream and
+    workspaces) from a helper thread while the caller's thread runs the first; SARPRO_HIP_NO_BAND_TWIN=1: one after the other.
+    Native and resized flows, repeated calls on one context (the twin and its thread persist), the oracle's rasters."""
+    import torch
+    from f32data import resampled_scene
+    if not twin:
+        monkeypatch.setenv("SARPRO_HIP_NO_BAND_TWIN", "1")
+    with S.Context(0) as c:
+        for rows, cols, pitch in ((264, 392, 448), (300, 200, 256)):
+            b = [resampled_scene(rows, cols, k) for k in (0, 1)]
+            rc, rrgb, r1, r2 = oracle.dualpol_synrgb(b[0], b[1], int(strategy))
+            assert rc == 0
+            d = []
+            for x in b:
+                t = torch.zeros((rows, pitch), dtype=torch.float32, device="cuda")
+                t[:, :cols] = torch.from_numpy(x).cuda()
+                d.append(t)
+            rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+            u = [torch.zeros((rows, pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            torch.cuda.synchronize()
+            for _ in range(3):
+                st = c.dev_dualpol_synrgb_f32(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, Mode.Default, rgb.data_ptr(), pitch,
+                                              u[0].data_ptr(), u[1].data_ptr(), pitch, want_stats=True)
+                assert np.array_equal(rgb.cpu().numpy().reshape(rows, pitch, 3)[:, :cols], rrgb)
+                assert np.array_equal(u[0].cpu().numpy()[:, :cols], r1) and np.array_equal(u[1].cpu().numpy()[:, :cols], r2)
+                assert st[0].valid_count == int((b[0] > 1e-5).sum()) and st[1].valid_count == int((b[1] > 1e-5).sum())
+            for plain in (True, False):
+                ref, _ = _api_flow_oracle(b[0], b[1], strategy, 100, True, plain=plain)
+                fc, fr = resize_output_dims(cols, rows, 100, True)
+                out = torch.zeros((fr * fc * 3,), dtype=torch.uint8, device="cuda")
+                c.dev_dualpol_synrgb_resized_f32(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, 100, True, out.data_ptr(),
+                                                 plain_pipeline=plain)
+                assert np.array_equal(out.cpu().numpy().reshape(fr, fc, 3), ref), (strategy, plain)
+
+
 def test_batch_driver_with_f32_scenes():
     from f32data import resampled_scene
     scenes = [(resampled_scene(120 + 8 * i, 160, 0), resampled_scene(120 + 8 * i, 160, 1)) for i in range(5)]
