@@ -1004,6 +1004,105 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
     }
 }
 
+// e'. The same for u8 output, speculative: the blend in f32 from a 16-byte entry (c00, c10, c01 - c00, c11 - c10) per bin decides
+//     the level unless o * 255 lies within the margin of an integer; those samples take the reference's f64 sequence.  The
+//     construction, its error bound and the margins are those of the u16 flavour's kernel (kernels.hip 4b: 2^-12 in interior
+//     cells, 2^-10 where the cell extrapolates; all-zero and, in interior cells, all-one bins get biased entries that never come
+//     near an integer; an invalid sample reads entry 256 = "all zero").  What it saves here: 32 bytes of f64 CDFs per sample from
+//     LDS (half of it bank conflicts) and ten f64 operations.  SARPRO_HIP_NO_SPEC=1: the f64 kernel above.
+constexpr float kF32SpecDeltaEdge = 1.0f / 1024.0f, kF32SpecDeltaInner = 1.0f / 4096.0f;
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyArgs a) {
+    __shared__ __align__(16) double cdf4[256 * 4];
+    __shared__ __align__(16) float4 e32[256 + 1];
+    __shared__ float thr[256 + 1];
+    __shared__ uint32_t hist[256];
+    const Rect rc = a.rects[blockIdx.x];
+    const bool edge = (rc.pad[0] & 1) != 0;
+    {
+        const int b = threadIdx.x;
+        double c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = a.cdfs[(size_t)rc.id[k] * 256 + b]; cdf4[b * 4 + k] = c[k]; }
+        const bool saturated = c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0 && !edge;
+        const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
+        const float kz = 0.5f / 255.0f;
+        const float c00 = (float)c[0], c01 = (float)c[1], c10 = (float)c[2], c11 = (float)c[3];
+        e32[b] = saturated ? make_float4(1.001f, 1.001f, 0.0f, 0.0f) : zero ? make_float4(kz, kz, 0.0f, 0.0f) : make_float4(c00, c10, c01 - c00, c11 - c10);
+        if (b == 0) e32[256] = make_float4(kz, kz, 0.0f, 0.0f);
+        thr[b] = b ? a.thr[b] : -INFINITY;
+        if (b == 0) thr[256] = INFINITY;
+        hist[b] = 0;
+    }
+    __syncthreads();
+    const int col = rc.cstart + lane_id() * VEC;
+    const bool lane_on = col < rc.c1 && col + VEC > rc.c0;
+    const bool vec_store = a.out_pitch % VEC == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+    const float near_delta = edge ? kF32SpecDeltaEdge : kF32SpecDeltaInner;
+    const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
+    uint32_t zeros = 0;
+    double dx[VEC], omdx[VEC];
+    float dxf[VEC];
+    bool own[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = col + j;
+        own[j] = c >= rc.c0 && c < rc.c1;
+        const RowWeight w = a.col_w[own[j] ? c : rc.c0];
+        dx[j] = w.d; omdx[j] = w.omd; dxf[j] = (float)w.d;
+    }
+    if (lane_on) {
+        int r = rc.r0 + wave_id();
+        typename F32Vec<VEC>::Raw cur{};
+        if (r < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r, col);
+        for (; r < rc.r1; r += kWavesPerBlock) {
+            const typename F32Vec<VEC>::Raw mine = cur;
+            if (r + kWavesPerBlock < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r + kWavesPerBlock, col); // next row in flight
+            const F32Vec<VEC> v = F32Vec<VEC>::make(mine, a.pol);
+            const RowWeight rw = a.row_w[r];
+            const float wy1 = (float)rw.omd * 255.0f, wy2 = (float)rw.d * 255.0f;
+            uint32_t lvs[VEC], bins[VEC], flagged = 0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { // the four samples side by side: bins, entries, f32 blends
+                const float x = v.get(j);
+                const bool valid = own[j] && x >= a.t_valid;
+                bins[j] = valid ? (a.est.use ? est_search<255>(thr, x, a.est) : step_search<255>(thr, x)) : 256u;
+                const float4 e = e32[bins[j]];
+                const float top = fmaf(e.z, dxf[j], e.x), bottom = fmaf(e.w, dxf[j], e.y);
+                const float ya = fmaf(bottom, wy2, fmaf(top, wy1, bias));
+                const uint32_t la = __builtin_amdgcn_cvt_pk_u8_f32(ya, 0, 0u), lb = __builtin_amdgcn_cvt_pk_u8_f32(ya + two_delta, 0, 0u);
+                lvs[j] = la;
+                flagged |= (la != lb ? 1u : 0u) << j;
+            }
+            if (flagged) { // within the margin of an integer: the reference's own sequence decides
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if (!((flagged >> j) & 1u)) continue;
+                    const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bins[j] * 4]); // (a flagged sample is valid: entry 256 is never near)
+                    const double top = c4.x * omdx[j] + c4.y * dx[j];
+                    const double bottom = c4.z * omdx[j] + c4.w * dx[j];
+                    double o = top * rw.omd + bottom * rw.d;
+                    o = fmin(fmax(o, 0.0), 1.0);
+                    lvs[j] = (uint32_t)(o * 255.0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (own[j]) { if (lvs[j] == 0) ++zeros; else atomicAdd(&hist[lvs[j]], 1u); }
+            if (col >= rc.c0 && col + VEC <= rc.c1) {
+                store_levels<VEC, false>(a.out, (size_t)r * a.out_pitch + col, lvs, VEC, vec_store);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (own[j]) reinterpret_cast<uint8_t *>(a.out)[(size_t)r * a.out_pitch + col + j] = (uint8_t)lvs[j];
+            }
+        }
+    }
+    if (zeros) atomicAdd(&hist[0], zeros);
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&a.level_hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------
 // f. process_scalar_data_inplace (pipeline.rs:8-40): the dB buffer and the validity mask.
 //    mask is exact (threshold compare); db is the device's f64 log10 (<= 1 ulp from glibc's).
@@ -1266,6 +1365,11 @@ hipError_t launch_f32_tile_hist(const F32TileHistArgs &a, int nrects, bool vec, 
 
 hipError_t launch_f32_clahe_apply(const F32ClaheApplyArgs &a, int nrects, bool vec, bool out16, hipStream_t s) {
     if (nrects <= 0) return hipSuccess;
+    if (!out16 && a.max_val == 255.0 && !getenv("SARPRO_HIP_NO_SPEC")) {
+        if (vec) hipLaunchKernelGGL((k_f32_clahe_apply_spec<4>), dim3(nrects), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_f32_clahe_apply_spec<1>), dim3(nrects), dim3(kBlock), 0, s, a);
+        return hipGetLastError();
+    }
     if (vec) {
         if (out16) hipLaunchKernelGGL((k_f32_clahe_apply<4, true>), dim3(nrects), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_f32_clahe_apply<4, false>), dim3(nrects), dim3(kBlock), 0, s, a);

@@ -177,3 +177,33 @@ def test_zone_sweep_counts_every_valid_sample_whatever_the_table_says(monkeypatc
             got = c.process_scalar_data_pipeline(x, Bd.U8, strategy)
             assert np.array_equal(got[0], ref), strategy
             assert "f32_prepass_zones" in names(c)
+
+
+def test_f32_clahe_u8_speculative_blend_equals_the_f64_blend_and_the_oracle(monkeypatch):
+    """u8 CLAHE of f32 samples: the f32 blend with a margin (f32_kernels.hip e') against the reference's f64 sequence for every
+    sample (SARPRO_HIP_NO_SPEC=1) on a 5000 x 4000 pol-op raster, and against the oracle on a 1500 x 1700 one."""
+    x = f32data.ratio_scene(1500, 1700)
+    rc, ref = oracle.pipeline(x, int(Bd.U8), int(St.Clahe))
+    assert rc == 0
+    with S.Context(0, timing=True) as c:
+        got = c.process_scalar_data_pipeline(x, Bd.U8, St.Clahe)
+        assert np.array_equal(got[0], ref)
+        assert "f32_clahe_apply" in names(c)
+    rows, cols, pitch = 5000, 4000, 4032
+    q = synth.q_tables()
+    with S.Context(0) as c:
+        d = [torch.zeros((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+        for k in range(2):
+            c.dev_synth_scene_u16(synth.SEED_SCENE_A + 5, k, q, rows, cols, 0, rows, d[k].data_ptr(), pitch)
+        outs = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("SARPRO_HIP_NO_SPEC", env)
+            else:
+                monkeypatch.delenv("SARPRO_HIP_NO_SPEC", raising=False)
+            o = torch.zeros((rows, pitch), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            c.dev_polop_autoscale_band(Op.LogRatio, d[0].data_ptr(), d[1].data_ptr(), True, rows, cols, pitch, St.Clahe, Bd.U8, o.data_ptr(), pitch,
+                                       want_stats=False)
+            outs.append(o[:, :cols].clone())
+        assert torch.equal(outs[0], outs[1])
