@@ -46,6 +46,30 @@ __device__ inline uint32_t est_search(const float *thr, float v, const F32StepEs
     return step_search<N>(thr, v);
 }
 
+// est_search for M samples at once: all estimates, then all table reads, then all verifications -- no branch between the samples,
+// so their chains (v_log_f32, two dependent LDS reads) overlap; ONE branch for the samples whose estimate failed.
+template <int N, int M>
+__device__ inline void est_search_m(const float *thr, const float (&v)[M], const F32StepEstimate &e, uint32_t (&k)[M]) {
+    if (e.gamma == 1.0f) {
+        float t0[M], t1[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) k[j] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_logf(v[j]), e.a_mul, e.b_add), 0.0f, (float)N);
+#pragma unroll
+        for (int j = 0; j < M; ++j) { t0[j] = thr[k[j]]; t1[j] = thr[k[j] + 1]; }
+        uint32_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) bad |= (t0[j] <= v[j] && v[j] < t1[j]) ? 0u : (1u << j);
+        if (bad) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if ((bad >> j) & 1u) k[j] = step_search<N>(thr, v[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j) k[j] = est_search<N>(thr, v[j], e);
+    }
+}
+
 // ops.rs:4-44, IEEE f32 (hipcc's default correctly rounded divide); the same function as kernels.hip k_polop_f32
 // num / den for operands that are integers of magnitude < 2^18 (u16 DN, their sums and differences), den != 0: the hardware's
 // reciprocal (1 ulp), the quotient it gives, and ONE correction of that quotient by its exact residual -- 4 instructions
@@ -572,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     // Valid samples are positive floats: they order like their bit patterns read as signed integers, an invalid one is replaced
     // by -1.0f (a negative integer).  Integer compares have no NaN twin, min / max are VOP2.
     __shared__ uint32_t lut[kZoneLutKeys / 4];
-    constexpr uint32_t kRing = 512; // kept samples on their way out: flushed 64 at a time, one coalesced store (a turn adds up to 64 x VEC)
+    constexpr uint32_t kRing = 1024; // kept samples on their way out: flushed 64 at a time, one coalesced store (a turn adds up to 64 x 2 VEC)
     __shared__ float ring[kWavesPerBlock][kRing];
     __shared__ unsigned long long gsum[8];
     for (int i = threadIdx.x; i < kZoneLutKeys / 4; i += kBlock) lut[i] = a.lut[i];
@@ -594,24 +618,23 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     const bool whole_rows = a.cols % VEC == 0 && a.t_valid > 0.0f;
     // A wave-uniform trip count (lane 0 holds the wave's smallest item index, so it runs longest): the cursor stays scalar
     const uint64_t first = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u);
-    // (two walks side by side: turn `it` takes the first walk's item when it is even, the second's when it is odd)
-    const uint64_t step0 = walk.step / 2;
-    const uint32_t nit = __builtin_amdgcn_readfirstlane(first < walk.total ? (uint32_t)((walk.total - first + step0 - 1) / step0) : 0u);
+    // (two walks side by side, both items in every turn: 2 x VEC independent chains of divide -> table read -> counter add)
+    constexpr int M = 2 * VEC;
+    const uint32_t nit = __builtin_amdgcn_readfirstlane(first < walk.total ? (uint32_t)((walk.total - first + walk.step - 1) / walk.step) : 0u);
     for (uint32_t it = 0; it < nit; ++it) {
-        uint32_t r = 0, col = 0xFFFFFFF0u; // a lane past its last item: every sample fails the column test
-        F32Vec<VEC> v{};
-        if (it & 1u) { if (walk_b.live()) v = walk_b.next(a.in, a.pitch, a.pol, &r, &col); }
-        else if (walk.live()) v = walk.next(a.in, a.pitch, a.pol, &r, &col);
-        // the VEC samples side by side (no branch between them: their table reads and counter updates interleave), then ONE
-        // append for all the kept ones
-        float xs[VEC];
-        bool keep[VEC];
-        unsigned long long zm[VEC], any = 0;
+        uint32_t r0 = 0, col0 = 0xFFFFFFF0u, r1 = 0, col1 = 0xFFFFFFF0u; // a lane past its last item: every sample fails the column test
+        F32Vec<VEC> v0{}, v1{};
+        if (walk.live()) v0 = walk.next(a.in, a.pitch, a.pol, &r0, &col0);
+        if (walk_b.live()) v1 = walk_b.next(a.in, a.pitch, a.pol, &r1, &col1);
+        float xs[M];
+        bool keep[M];
+        unsigned long long zm[M], any = 0;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            xs[j] = v.get(j);
+        for (int j = 0; j < M; ++j) {
+            xs[j] = j < VEC ? v0.get(j % VEC) : v1.get(j % VEC);
+            const uint32_t colj = (j < VEC ? col0 : col1) + (uint32_t)(j % VEC);
             // (whole vectors only -- cols % VEC == 0 -- need no column test: a lane past its last item holds zeros, which are invalid)
-            const bool ok = (whole_rows || col + j < a.cols) && xs[j] >= a.t_valid; // NaN fails
+            const bool ok = (whole_rows || colj < a.cols) && xs[j] >= a.t_valid; // NaN fails
             const int xi = ok ? __float_as_int(xs[j]) : (int)0xBF800000;
             mn = (int)min((uint32_t)mn, (uint32_t)xi); // valid samples are non-negative integers, the invalid one is a huge unsigned
             mx = max(mx, xi);
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
         if (any) {
             uint32_t base = cursor;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
+            for (int j = 0; j < M; ++j) {
                 const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(zm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zm[j], 0u));
                 if (keep[j]) myring[pos & (kRing - 1u)] = xs[j];
                 base += (uint32_t)__popcll(zm[j]);
@@ -637,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
                 flushed += 64u;
             }
         }
-        if (it % 63u == 62u || it + 1 == nit) { // 63 turns x 4 samples < 256: no counter has overflowed
+        if (it % 31u == 30u || it + 1 == nit) { // 31 turns x 2 VEC samples < 256: no counter has overflowed
 #pragma unroll
             for (int k = 0; k < 7; ++k) gap[k] += (uint32_t)(acc >> (8 * k)) & 0xFFu;
             acc = 0;
@@ -905,19 +928,39 @@ __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
     const Rect rc = a.rects[blockIdx.x];
     const int col = rc.cstart + lane_id() * VEC;
     if (col < rc.c1 && col + VEC > rc.c0) {
-        int r = rc.r0 + wave_id();
-        typename F32Vec<VEC>::Raw cur{};
-        if (r < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r, col);
-        for (; r < rc.r1; r += kWavesPerBlock) {
-            const typename F32Vec<VEC>::Raw mine = cur;
-            if (r + kWavesPerBlock < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r + kWavesPerBlock, col); // next row in flight
-            const F32Vec<VEC> v = F32Vec<VEC>::make(mine, a.pol);
+        // TWO rows per turn (rows r and r + 4 of the wave's sequence), their 2 x VEC chains of divide -> log -> table reads -> LDS add
+        // side by side: the pass is bound by the latency of one such chain, not by instruction count or HBM
+        constexpr int S = kWavesPerBlock;
+        bool own[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const int c = col + j;
-                const float x = v.get(j);
-                if (c >= rc.c0 && c < rc.c1 && x >= a.t_valid) atomicAdd(&hist[a.est.use ? est_search<255>(thr, x, a.est) : step_search<255>(thr, x)], 1u);
+        for (int j = 0; j < VEC; ++j) own[j] = col + j >= rc.c0 && col + j < rc.c1;
+        int r = rc.r0 + wave_id();
+        typename F32Vec<VEC>::Raw cur0{}, cur1{};
+        if (r < rc.r1) cur0 = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r, col);
+        if (r + S < rc.r1) cur1 = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r + S, col);
+        for (; r < rc.r1; r += 2 * S) {
+            const typename F32Vec<VEC>::Raw m0 = cur0, m1 = cur1;
+            const bool second = r + S < rc.r1;
+            if (r + 2 * S < rc.r1) cur0 = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r + 2 * S, col); // the next turn's rows in flight
+            if (r + 3 * S < rc.r1) cur1 = F32Vec<VEC>::load_raw(a.in, a.pitch, a.pol, r + 3 * S, col);
+            const F32Vec<VEC> v0 = F32Vec<VEC>::make(m0, a.pol), v1 = F32Vec<VEC>::make(m1, a.pol);
+            uint32_t bin[2 * VEC];
+            bool ok[2 * VEC];
+            float xs[2 * VEC];
+#pragma unroll
+            for (int j = 0; j < 2 * VEC; ++j) {
+                const float x = j < VEC ? v0.get(j % VEC) : v1.get(j % VEC);
+                ok[j] = own[j % VEC] && x >= a.t_valid && (j < VEC || second);
+                xs[j] = ok[j] ? x : 1.0f; // (a sample that does not count still gets a bin: any finite value will do)
             }
+            if (a.est.use) est_search_m<255, 2 * VEC>(thr, xs, a.est, bin);
+            else {
+#pragma unroll
+                for (int j = 0; j < 2 * VEC; ++j) bin[j] = step_search<255>(thr, xs[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * VEC; ++j)
+                if (ok[j]) atomicAdd(&hist[bin[j]], 1u);
         }
     }
     __syncthreads();
