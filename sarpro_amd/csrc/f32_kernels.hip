@@ -1000,42 +1000,72 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
         omdx[j] = w.omd;
     }
     if (lane_on) {
-        int r = rc.r0 + wave_id();
-        typename F32Vec<VEC>::Raw cur{};
-        if (r < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r, col);
-        for (; r < rc.r1; r += kWavesPerBlock) {
-            const typename F32Vec<VEC>::Raw mine = cur;
-            if (r + kWavesPerBlock < rc.r1) cur = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r + kWavesPerBlock, col); // next row in flight
-            const F32Vec<VEC> v = F32Vec<VEC>::make(mine, a.pol);
-            const RowWeight rw = a.row_w[r];
-            uint32_t lvs[VEC];
+        // The VEC samples of a row side by side with no branch between them -- bins (estimates verified together), then the f64
+        // blends: the pass is bound by the latency of one sample's chain (divide, log, two table reads, 32 bytes of CDF from LDS, ten
+        // dependent f64 operations), not by instruction count: 0.64 -> 0.53 ms at 400 MP.  (R rows per turn: R = 2 needs the
+        // registers of eight f64 chains and runs at 0.73.)
+        constexpr int R = 1, S = kWavesPerBlock, M = R * VEC;
+        bool own[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const int c = col + j;
-                const bool own = c >= rc.c0 && c < rc.c1;
-                const float x = v.get(j);
-                uint32_t lv = 0;
-                if (own && x >= a.t_valid) {
-                    const uint32_t bin = a.est.use ? est_search<255>(thr, x, a.est) : step_search<255>(thr, x);
-                    const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
-                    const double top = c4.x * omdx[j] + c4.y * dx[j];
-                    const double bottom = c4.z * omdx[j] + c4.w * dx[j];
-                    double o = top * rw.omd + bottom * rw.d;
-                    o = fmin(fmax(o, 0.0), 1.0);
-                    lv = (uint32_t)(o * a.max_val);
-                }
-                lvs[j] = lv;
-                if (!OUT16 && own) { if (lv == 0) ++zeros; else atomicAdd(&hist[lv], 1u); }
+        for (int j = 0; j < VEC; ++j) own[j] = col + j >= rc.c0 && col + j < rc.c1;
+        const bool whole = col >= rc.c0 && col + VEC <= rc.c1;
+        int r = rc.r0 + wave_id();
+        typename F32Vec<VEC>::Raw cur[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) { cur[k] = typename F32Vec<VEC>::Raw{}; if (r + k * S < rc.r1) cur[k] = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r + k * S, col); }
+        for (; r < rc.r1; r += R * S) {
+            typename F32Vec<VEC>::Raw mine[R];
+            RowWeight rw[R];
+            bool rowok[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                mine[k] = cur[k];
+                rowok[k] = r + k * S < rc.r1;
+                if (r + (R + k) * S < rc.r1) cur[k] = F32Vec<VEC>::load_raw(a.in, a.in_pitch, a.pol, r + (R + k) * S, col); // the next turn's rows in flight
+                rw[k] = a.row_w[min(r + k * S, (int)rc.r1 - 1)];
             }
-            if (col >= rc.c0 && col + VEC <= rc.c1) {
-                store_levels<VEC, OUT16>(a.out, (size_t)r * a.out_pitch + col, lvs, VEC, vec_store);
-            } else {
+            uint32_t lvs[M], bins[M];
+            float xs[M];
+            bool ok[M];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const F32Vec<VEC> v = F32Vec<VEC>::make(mine[k], a.pol);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const int c = col + j;
-                    if (c < rc.c0 || c >= rc.c1) continue;
-                    if (OUT16) reinterpret_cast<uint16_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint16_t)lvs[j];
-                    else reinterpret_cast<uint8_t *>(a.out)[(size_t)r * a.out_pitch + c] = (uint8_t)lvs[j];
+                    const float x = v.get(j);
+                    ok[k * VEC + j] = rowok[k] && own[j] && x >= a.t_valid;
+                    xs[k * VEC + j] = ok[k * VEC + j] ? x : 1.0f; // (a sample that does not count still gets a bin: any finite value will do)
+                }
+            }
+            if (a.est.use) est_search_m<255, M>(thr, xs, a.est, bins);
+            else {
+#pragma unroll
+                for (int j = 0; j < M; ++j) bins[j] = step_search<255>(thr, xs[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const int k = i / VEC, j = i % VEC;
+                const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bins[i] * 4]);
+                const double top = c4.x * omdx[j] + c4.y * dx[j];
+                const double bottom = c4.z * omdx[j] + c4.w * dx[j];
+                double o = top * rw[k].omd + bottom * rw[k].d;
+                o = fmin(fmax(o, 0.0), 1.0);
+                lvs[i] = ok[i] ? (uint32_t)(o * a.max_val) : 0u;
+                if (!OUT16 && rowok[k] && own[j]) { if (lvs[i] == 0) ++zeros; else atomicAdd(&hist[lvs[i]], 1u); }
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (!rowok[k]) continue;
+                const size_t row = (size_t)(r + k * S);
+                if (whole) {
+                    store_levels<VEC, OUT16>(a.out, row * a.out_pitch + col, &lvs[k * VEC], VEC, vec_store);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        if (!own[j]) continue;
+                        if (OUT16) reinterpret_cast<uint16_t *>(a.out)[row * a.out_pitch + col + j] = (uint16_t)lvs[k * VEC + j];
+                        else reinterpret_cast<uint8_t *>(a.out)[row * a.out_pitch + col + j] = (uint8_t)lvs[k * VEC + j];
+                    }
                 }
             }
         }
@@ -1105,11 +1135,22 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyAr
             const RowWeight rw = a.row_w[r];
             const float wy1 = (float)rw.omd * 255.0f, wy2 = (float)rw.d * 255.0f;
             uint32_t lvs[VEC], bins[VEC], flagged = 0;
+            float xs[VEC];
+            bool valid[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { // the four samples side by side: bins, entries, f32 blends
+            for (int j = 0; j < VEC; ++j) {
                 const float x = v.get(j);
-                const bool valid = own[j] && x >= a.t_valid;
-                bins[j] = valid ? (a.est.use ? est_search<255>(thr, x, a.est) : step_search<255>(thr, x)) : 256u;
+                valid[j] = own[j] && x >= a.t_valid;
+                xs[j] = valid[j] ? x : 1.0f;
+            }
+            if (a.est.use) est_search_m<255, VEC>(thr, xs, a.est, bins); // estimates of all four verified together
+            else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) bins[j] = step_search<255>(thr, xs[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { // the four samples side by side: entries, f32 blends
+                bins[j] = valid[j] ? bins[j] : 256u;
                 const float4 e = e32[bins[j]];
                 const float top = fmaf(e.z, dxf[j], e.x), bottom = fmaf(e.w, dxf[j], e.y);
                 const float ya = fmaf(bottom, wy2, fmaf(top, wy1, bias));
