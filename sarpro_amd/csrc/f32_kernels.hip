@@ -172,6 +172,60 @@ template <> struct F32Vec<4> {
         return o;
     }
 };
+// Eight samples per lane: one 16-byte load per band of u16 operands (the four-sample form reads 8 bytes per lane and band).
+template <> struct F32Vec<8> {
+    float v[8];
+    __device__ float get(int j) const { return v[j]; }
+    struct Raw { uint4 a, b, c, d; }; // raster: a, b | f32 operands: a, b = first, c, d = second | u16 operands: a = first, c = second
+    __device__ static Raw load_raw(const float *in, size_t pitch, const F32Pol &p, size_t r, size_t col) {
+        Raw w;
+        w.a = w.b = w.c = w.d = make_uint4(0, 0, 0, 0);
+        if (p.op < 0) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(in + r * pitch + col);
+            w.a = q[0]; w.b = q[1];
+        } else if (p.u16) {
+            w.a = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(p.a) + r * p.pitch + col);
+            w.c = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(p.b) + r * p.pitch + col);
+        } else {
+            const uint4 *qa = reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p.a) + r * p.pitch + col);
+            const uint4 *qb = reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p.b) + r * p.pitch + col);
+            w.a = qa[0]; w.b = qa[1]; w.c = qb[0]; w.d = qb[1];
+        }
+        return w;
+    }
+    __device__ static F32Vec make(const Raw &w, const F32Pol &p) {
+        F32Vec o;
+        const uint32_t wa[8] = {w.a.x, w.a.y, w.a.z, w.a.w, w.b.x, w.b.y, w.b.z, w.b.w};
+        const uint32_t wc[8] = {w.c.x, w.c.y, w.c.z, w.c.w, w.d.x, w.d.y, w.d.z, w.d.w};
+        if (p.op < 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = __uint_as_float(wa[j]);
+            return o;
+        }
+        float x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (p.u16) {
+                x[j] = (float)((j & 1) ? (wa[j >> 1] >> 16) : (wa[j >> 1] & 0xFFFFu));
+                y[j] = (float)((j & 1) ? (wc[j >> 1] >> 16) : (wc[j >> 1] & 0xFFFFu));
+            } else { x[j] = __uint_as_float(wa[j]); y[j] = __uint_as_float(wc[j]); }
+        }
+        if (p.op == SARPRO_OP_RATIO || p.op == SARPRO_OP_LOGRATIO) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = p.u16 ? ratio_one<true>(x[j], y[j]) : ratio_one<false>(x[j], y[j]);
+        } else if (p.op == SARPRO_OP_NDIFF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = p.u16 ? ratio_one<true>(x[j] - y[j], x[j] + y[j]) : ratio_one<false>(x[j] - y[j], x[j] + y[j]);
+        } else if (p.op == SARPRO_OP_SUM) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = x[j] + y[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = x[j] - y[j];
+        }
+        return o;
+    }
+};
 template <> struct F32Vec<1> {
     float v;
     __device__ static F32Vec load(const float *p) { F32Vec r; r.v = *p; return r; }
@@ -591,7 +645,8 @@ __device__ inline unsigned long long shl64_one(uint32_t s) {
 // eight packed 8-bit counters (one per gap; unpacked every 63 turns), and -- for a kept bucket -- the append to the wave's side
 // buffer.  The cost does not depend on the number of zones (round 2 compared every sample with every bound: 0.53 / 0.71 / 0.79 ms
 // for 2 / 4 / 5 zones).
-template <int VEC>
+// NW walks of VEC samples side by side per turn: <4, 2> for f32 rasters, <8, 1> for u16 operands (one 16-byte load per band and lane)
+template <int VEC, int NW>
 __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     // Valid samples are positive floats: they order like their bit patterns read as signed integers, an invalid one is replaced
     // by -1.0f (a negative integer).  Integer compares have no NaN twin, min / max are VOP2.
@@ -614,18 +669,19 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass_zones(F32ZoneArgs a) {
     float *mine = a.zone_buf + (size_t)blockIdx.x * a.cap + (size_t)wave_id() * wcap;
     float *myring = ring[wave_id()];
     uint32_t cursor = 0, flushed = 0;
-    StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.pitch, a.pol, 0, 2), walk_b(a.rows, a.cols, a.in, a.pitch, a.pol, 1, 2);
+    StrideWalk<VEC> walk(a.rows, a.cols, a.in, a.pitch, a.pol, 0, NW), walk_b(a.rows, a.cols, a.in, a.pitch, a.pol, NW - 1, NW);
     const bool whole_rows = a.cols % VEC == 0 && a.t_valid > 0.0f;
     // A wave-uniform trip count (lane 0 holds the wave's smallest item index, so it runs longest): the cursor stays scalar
     const uint64_t first = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u);
     // (two walks side by side, both items in every turn: 2 x VEC independent chains of divide -> table read -> counter add)
-    constexpr int M = 2 * VEC;
+    constexpr int M = NW * VEC;
+    static_assert(M <= 8 && NW <= 2, "31 turns of M samples must fit an 8-bit counter; the ring takes 64 x M per turn");
     const uint32_t nit = __builtin_amdgcn_readfirstlane(first < walk.total ? (uint32_t)((walk.total - first + walk.step - 1) / walk.step) : 0u);
     for (uint32_t it = 0; it < nit; ++it) {
         uint32_t r0 = 0, col0 = 0xFFFFFFF0u, r1 = 0, col1 = 0xFFFFFFF0u; // a lane past its last item: every sample fails the column test
         F32Vec<VEC> v0{}, v1{};
         if (walk.live()) v0 = walk.next(a.in, a.pitch, a.pol, &r0, &col0);
-        if (walk_b.live()) v1 = walk_b.next(a.in, a.pitch, a.pol, &r1, &col1);
+        if (NW == 2 && walk_b.live()) v1 = walk_b.next(a.in, a.pitch, a.pol, &r1, &col1);
         float xs[M];
         bool keep[M];
         unsigned long long zm[M], any = 0;
@@ -1260,8 +1316,10 @@ hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int grid, hipStream_t s) {
-    if (vec) hipLaunchKernelGGL((k_f32_prepass_zones<4>), dim3(grid), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((k_f32_prepass_zones<1>), dim3(grid), dim3(kBlock), 0, s, a);
+    const bool v8 = vec && a.pol.op >= 0 && a.pol.u16 && a.pol.pitch % 8 == 0 && !getenv("SARPRO_HIP_F32_NO_VEC8");
+    if (v8) hipLaunchKernelGGL((k_f32_prepass_zones<8, 1>), dim3(grid), dim3(kBlock), 0, s, a);
+    else if (vec) hipLaunchKernelGGL((k_f32_prepass_zones<4, 2>), dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_f32_prepass_zones<1, 2>), dim3(grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
