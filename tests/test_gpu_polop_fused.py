@@ -75,3 +75,30 @@ def test_fast_division_of_the_u16_kernels_is_the_ieee_division_for_every_pair(ct
     """ops.rs:10-33 on u16 DN: the kernels divide with the Newton core of the IEEE division (no rescaling frame).  All 2^32 pairs,
     a / b and (a - b) / (a + b), against the compiler's correctly rounded division: no pair may differ."""
     assert ctx.selftest_polop_division() == 0
+
+
+@pytest.mark.parametrize("op", [Op.LogRatio, Op.NDiff, Op.Diff])
+@pytest.mark.parametrize("cols,pitch", [(1000, 1024), (1003, 1008), (1003, 1004)])
+def test_zone_sweep_with_eight_or_four_samples_per_lane(op, cols, pitch, monkeypatch):
+    """u16 operands, device-resident: the zone sweep reads eight samples per lane when the pitch allows (pitch % 8 == 0), four
+    otherwise or with SARPRO_HIP_F32_NO_VEC8=1; ragged rows (cols % 8 != 0); every form gives the oracle's raster."""
+    rows = 700
+    a, b = synth.scene_u16(rows, cols, 0), synth.scene_u16(rows, cols, 1)
+    want = ref(op, a, b, Bd.U16, St.Robust)
+    monkeypatch.setenv("SARPRO_HIP_F32_DIRECT", "0")  # (small raster: keep it on the zone route)
+    monkeypatch.setenv("SARPRO_HIP_F32_ZONES", "force")
+    with S.Context(0, timing=True) as c:
+        d = []
+        for x in (a, b):
+            t = torch.zeros((rows, pitch), dtype=torch.int16, device="cuda")
+            t[:, :cols] = torch.from_numpy(x.view(np.int16)).cuda()
+            d.append(t)
+        for no8 in (False, True):
+            if no8:
+                monkeypatch.setenv("SARPRO_HIP_F32_NO_VEC8", "1")
+            else:
+                monkeypatch.delenv("SARPRO_HIP_F32_NO_VEC8", raising=False)
+            o = torch.zeros((rows, pitch), dtype=torch.int16, device="cuda")
+            c.dev_polop_autoscale_band(op, d[0].data_ptr(), d[1].data_ptr(), True, rows, cols, pitch, St.Robust, Bd.U16, o.data_ptr(), pitch, want_stats=False)
+            assert "f32_prepass_zones" in [n for n, _ in c.last_kernel_times()]
+            assert np.array_equal(o[:, :cols].cpu().numpy().view(np.uint16), want), (op, cols, pitch, no8)
