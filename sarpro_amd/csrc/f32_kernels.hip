@@ -850,10 +850,22 @@ __global__ __launch_bounds__(kBlock) void k_f32_zone_count(const float *__restri
     for (int i = threadIdx.x; i <= kZoneMaxThr + 1; i += kBlock) thr[i] = (i >= 1 && i <= nthr) ? g_thr[i] : (i ? INFINITY : -INFINITY);
     for (int i = threadIdx.x; i <= kZoneMaxThr; i += kBlock) hist[i] = 0;
     __syncthreads();
-    for (int w = blockIdx.x; w < nregions; w += gridDim.x) {
+    // a region (one wave's side buffer of the sweep) per WAVE and turn, four loads in flight per lane: the regions are short
+    // (a few thousand samples) and a workgroup looping over one of them waited on every load
+    auto count_one = [&](float v) {
+        // (a handful of zones holds some tens of thresholds, not 1023: as many search steps as their number needs)
+        const uint32_t k = nthr <= 63 ? step_search<63>(thr, v) : (nthr <= 255 ? step_search<255>(thr, v) : step_search<kZoneMaxThr>(thr, v));
+        atomicAdd(&hist[k], 1u);
+    };
+    for (int w = blockIdx.x * kWavesPerBlock + wave_id(); w < nregions; w += gridDim.x * kWavesPerBlock) {
         const uint32_t n = min(zone_n[w], cap);
         const float *src = zone_buf + (size_t)w * cap;
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hist[step_search<kZoneMaxThr>(thr, src[i])], 1u);
+        uint32_t i = lane_id();
+        for (; i + 192 < n; i += 256) {
+            const float v0 = src[i], v1 = src[i + 64], v2 = src[i + 128], v3 = src[i + 192];
+            count_one(v0); count_one(v1); count_one(v2); count_one(v3);
+        }
+        for (; i < n; i += 64) count_one(src[i]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= kZoneMaxThr; i += kBlock)
