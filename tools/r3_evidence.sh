@@ -24,6 +24,7 @@ python3 tools/spec_accuracy.py 4 > $O/spec_accuracy.txt 2>&1
 python3 tools/size_sweep.py > $O/size_sweep.txt 2>&1
 python3 tools/time_configs.py > $O/time_configs.json 2>&1
 python3 tools/time_f32_routes.py > $O/time_f32_routes.txt 2>&1
+python3 tools/time_dualpol_f32.py 1024 2048 4096 > $O/time_dualpol_f32.txt 2>&1
 python3 tools/time_strategies.py > $O/time_strategies.txt 2>&1
 python3 tools/resident_batch_rate.py > $O/resident_batch_rate.txt 2>&1
 timeout 600 python3 tools/soak_spec_vs_exact.py 6 > $O/soak_spec_vs_exact.txt 2>&1
