@@ -30,6 +30,7 @@ python3 tools/resident_batch_rate.py > $O/resident_batch_rate.txt 2>&1
 timeout 600 python3 tools/soak_spec_vs_exact.py 6 > $O/soak_spec_vs_exact.txt 2>&1
 timeout 600 python3 tools/soak_routes.py 2 > $O/soak_routes.txt 2>&1
 timeout 600 python3 tools/soak_zones.py 300 > $O/soak_zones.txt 2>&1
+timeout 600 python3 tools/soak_f32_switches.py 2000 > $O/soak_f32_switches.txt 2>&1
 # 5. f32 flavour (config 3(ii)): SQ counters, and the kernel timeline of one call with its gaps
 bash tools/pmc_f32.sh $O/pmc_f32 > $O/pmc_f32.txt 2>&1; rm -rf $O/pmc_f32
 (cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace -d $O/trace_f32 -- python3 $R/tools/trace_f32.py > $O/trace_f32.log 2>&1)
