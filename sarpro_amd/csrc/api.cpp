@@ -13,6 +13,7 @@
 #include "chain_kernels.h"
 #include "context.h"
 #include "internal.h"
+#include "resize_kernels.h"
 
 using namespace sarpro;
 
@@ -473,6 +474,7 @@ struct U16Job {
     bool clear_after_sum = false; // untiled chain: k_sum_tile_hists is the last reader of the tile histogram and zeroes it
     size_t tile_hist_bytes = 0;   // footprint of this job's histogram pass in ctx->tile_hist[0]
     bool allow_async = false; // the entry point may return once the device chain is enqueued (SARPRO_HIP_CTX_ASYNC_DEV)
+    bool tables_only = false; // percentile chain: stop at the DN -> final u8 tables (band_u8_table_dev)
     StripePlan *plan = nullptr;
     // host-side state between phases
     sarpro_hip_stats stats[kMaxBands];
@@ -1310,7 +1312,7 @@ static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands],
     bool any_out = false;
     for (int b = 0; b < J.nbands; ++b)
         if (d_out[b]) { any_out = true; if (out_pitch % 8 != 0 || !ptr_aligned16(d_out[b])) return false; }
-    return J.synrgb || any_out;
+    return J.synrgb || any_out || J.tables_only;
 }
 
 constexpr int kRerunOnHostRoute = 1; // u16 levels with gamma != 1 that the device could not certify (see k_chain_stats_c)
@@ -1464,6 +1466,27 @@ extern "C" int sarpro_hip_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, const uint
 }
 
 namespace sarpro {
+int band_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed, ResizeLutSrc *out) {
+    out->lut = nullptr; out->dev_state = nullptr; out->band = 0; out->lut_cap = 0;
+    U16Job J;
+    J.ctx = ctx; J.nbands = 1; J.d_in[0] = d_in;
+    J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = in_pitch;
+    J.strategy = tamed ? SARPRO_STRATEGY_TAMED : strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.tamed_force = tamed;
+    J.tables_only = true;
+    timing_reset(ctx);
+    RETCHK(job_init(J));
+    void *outs[kMaxBands] = {nullptr, nullptr};
+    if (!rows || !cols || !chain_levels_eligible(J, outs, 0, nullptr, 0)) return SARPRO_HIP_OK;
+    HostTimer t(ctx, "host:chain(enqueue+final sync)");
+    const int rc = job_run_chain_levels(J, outs, 0, nullptr, 0, nullptr);
+    if (rc == kRerunOnHostRoute) return SARPRO_HIP_OK;
+    RETCHK(rc);
+    out->lut = ctx->luts.as<uint8_t>();
+    out->dev_state = reinterpret_cast<const ChainBandState *>(ctx->chain_state.as<uint8_t>());
+    out->lut_cap = (ctx->chain_levels_cap + 15u) & ~15u;
+    return SARPRO_HIP_OK;
+}
+
 int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
                 uint8_t *d_out, size_t out_pitch) {
     U16Job J;

@@ -41,8 +41,16 @@ int stream_upload_band(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *
                        uint16_t *d_dst, size_t pitch, size_t chunk_rows);
 int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
                 uint8_t *d_out, size_t out_pitch);
+// the same band up to its DN -> final u8 TABLE (percentile strategies on the device chain: the table is the whole autoscale), for
+// a consumer that applies it itself (the horizontal resize pass).  out->lut == nullptr: this band / strategy has no such table
+// (CLAHE, host route): take band_u8_dev.  The table and the state it points to live in the context until its next chain.
+struct ResizeLutSrc;
+int band_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed, ResizeLutSrc *out);
 int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);
+// lut_src != nullptr: d_in is the u16 DN raster (in_pitch in u16 elements, elem_size 1 = the output's) and the horizontal pass reads
+// it through the table; returns kResizeLutUnsupported (nothing enqueued) when that form does not apply to this shape
+constexpr int kResizeLutUnsupported = 0x5251;
 int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t rows, size_t in_pitch, size_t target_size,
-                   int elem_size, int pad, void *d_out, size_t out_pitch, sarpro_hip_resize_meta *meta);
+                   int elem_size, int pad, void *d_out, size_t out_pitch, sarpro_hip_resize_meta *meta, const ResizeLutSrc *lut_src = nullptr);
 
 } // namespace sarpro

@@ -20,6 +20,17 @@ struct ResizePassArgs {
 constexpr uint32_t kResizeHBlock = 256;
 
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s);
+// The horizontal u8 pass reading u16 DN through the band's DN -> u8 table (the percentile strategies' whole autoscale is that table,
+// kernels.hip 5): level = DN ? table[min(DN, win_hi)] : 0 while the row windows are staged, so the u8 level raster is neither
+// written nor read.  a.src = the DN raster, a.src_pitch in u16 elements.  Returns hipErrorNotSupported when the register-resident
+// form does not apply (window too wide, unaligned raster): the caller materialises the level raster and takes launch_resize_h.
+struct ResizeLutSrc {
+    const uint8_t *lut;                     // 65536 final u8 values
+    const struct ChainBandState *dev_state; // [band].win_hi: the table is constant from there on
+    int band;
+    uint32_t lut_cap;                       // the window is staged in LDS when win_hi < lut_cap (bytes of LDS reserved for it)
+};
+hipError_t launch_resize_h_lut(const ResizePassArgs &a, const ResizeLutSrc &l, uint32_t rows, hipStream_t s);
 hipError_t launch_resize_v(const ResizePassArgs &a, int elem_size, hipStream_t s);
 constexpr size_t kResizeRowLdsMax = 160 * 1024; // a source row up to this size is staged in LDS; longer rows read their taps from memory
 

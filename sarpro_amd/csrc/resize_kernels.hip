@@ -4,6 +4,7 @@
 // intermediate, then vertical pass.  Both passes are bound by reading their input once from HBM.
 #include "resize_kernels.h"
 #include "kernels.h"
+#include "chain_kernels.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -56,9 +57,18 @@ __global__ __launch_bounds__(kBlock) void k_resize_h(ResizePassArgs a) {
 // multiply-adds, and every term is an exact integer well inside i32 (|sum px k| < 2^31 is the crate's own guarantee), so the
 // result equals the tap-by-tap i32 sum of the generic kernel bit for bit.  Algorithmic traffic: the band once (1 B/px) in,
 // out_size / in_size of it out.
-template <int NCHUNK>
-__global__ __launch_bounds__(kResizeHBlock) void k_resize_h_u8_dot(ResizePassArgs a, uint32_t rows, uint32_t span_bytes /* LDS bytes per staged row */) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
+// SRC16: the rows are u16 DN and become u8 levels through the band's table while they are staged (ResizeLutSrc); the table's window
+// sits in LDS ahead of the row buffers.
+template <int NCHUNK, bool SRC16>
+__global__ __launch_bounds__(kResizeHBlock) void k_resize_h_u8_dot(ResizePassArgs a, uint32_t rows, uint32_t span_bytes /* LDS bytes per staged row */, ResizeLutSrc lsrc) {
+    extern __shared__ __align__(16) unsigned char lds_all[];
+    const uint32_t win_hi = SRC16 ? lsrc.dev_state[lsrc.band].win_hi : 0u;
+    const bool lut_lds = SRC16 && win_hi < lsrc.lut_cap;
+    unsigned char *lds_raw = lds_all + (SRC16 ? lsrc.lut_cap : 0u); // (lut_cap is a multiple of 16)
+    if (lut_lds) {
+        for (uint32_t i = threadIdx.x; i <= win_hi; i += kResizeHBlock) lds_all[i] = i ? lsrc.lut[i] : (uint8_t)0; // (DN = 0 is invalid: level 0 whatever the table says)
+        __syncthreads();
+    }
     constexpr int R = kResizeHRows; // rows per step: one barrier per R rows, R independent sums per thread
     const uint32_t first = blockIdx.x * kResizeHBlock;
     const uint32_t ox = first + threadIdx.x;
@@ -89,25 +99,48 @@ __global__ __launch_bounds__(kResizeHBlock) void k_resize_h_u8_dot(ResizePassArg
     // staging: the step's R row windows are nvec 16-byte vectors each; thread t carries vectors t, t + 256, ... (kResizeHVecs at most)
     const uint32_t nvec = span_bytes / 16, ntot = nvec * R;
     const size_t row_bytes = a.src_pitch; // the window may reach past the row's pitch at the right edge (zero coefficients there): clamped
-    auto fetch = [&](uint32_t r0, uint4 (&q)[kResizeHVecs]) {
+    constexpr int QW = SRC16 ? 2 : 1; // 16 staged pixels are 16 bytes of levels or 32 bytes of DN
+    auto fetch = [&](uint32_t r0, uint4 (&q)[kResizeHVecs * QW]) {
 #pragma unroll
         for (int i = 0; i < kResizeHVecs; ++i) {
             const uint32_t v = threadIdx.x + (uint32_t)i * kResizeHBlock;
-            q[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < QW; ++w) q[i * QW + w] = make_uint4(0, 0, 0, 0);
             if (v < ntot) {
                 const uint32_t rr = v / nvec, vv = v - rr * nvec;
                 const uint32_t r = min(r0 + rr, rows - 1);
-                const size_t off = (size_t)bx0 + (size_t)vv * 16;
-                const uint8_t *row = src + (size_t)r * row_bytes;
-                if (off < row_bytes) q[i] = *reinterpret_cast<const uint4 *>(row + off); // off and the pitch are multiples of 16: never partial
+                const size_t off = (size_t)bx0 + (size_t)vv * 16; // in pixels
+                if (off < row_bytes) { // off and the pitch are multiples of 16 pixels: never partial
+                    if (SRC16) {
+                        const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.src) + (size_t)r * row_bytes + off);
+                        q[i * QW] = p[0]; q[i * QW + QW - 1] = p[1];
+                    } else q[i * QW] = *reinterpret_cast<const uint4 *>(src + (size_t)r * row_bytes + off);
+                }
             }
         }
     };
-    auto put = [&](const uint4 (&q)[kResizeHVecs], unsigned char *buf) {
+    // DN pair -> two level bytes (kernels.hip 5: DN ? table[min(DN, win_hi)] : 0)
+    const uint32_t hi2 = win_hi | (win_hi << 16);
+    auto levels2 = [&](uint32_t w) -> uint32_t {
+        typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+        const uint32_t c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2us, w), __builtin_bit_cast(v2us, hi2))); // both DNs clamped at once
+        const uint32_t c0 = c & 0xFFFFu, c1 = c >> 16;
+        if (lut_lds) return (uint32_t)lds_all[c0] | ((uint32_t)lds_all[c1] << 8); // (entry 0 of the staged copy is 0)
+        return (c0 ? (uint32_t)lsrc.lut[c0] : 0u) | ((c1 ? (uint32_t)lsrc.lut[c1] : 0u) << 8);
+    };
+    auto put = [&](const uint4 (&q)[kResizeHVecs * QW], unsigned char *buf) {
 #pragma unroll
         for (int i = 0; i < kResizeHVecs; ++i) {
             const uint32_t v = threadIdx.x + (uint32_t)i * kResizeHBlock;
-            if (v < ntot) *reinterpret_cast<uint4 *>(buf + (size_t)v * 16) = q[i];
+            if (v < ntot) {
+                uint4 o = q[i * QW];
+                if (SRC16) {
+                    const uint4 lo4 = q[i * QW], hi4 = q[i * QW + QW - 1];
+                    o.x = levels2(lo4.x) | (levels2(lo4.y) << 16); o.y = levels2(lo4.z) | (levels2(lo4.w) << 16);
+                    o.z = levels2(hi4.x) | (levels2(hi4.y) << 16); o.w = levels2(hi4.z) | (levels2(hi4.w) << 16);
+                }
+                *reinterpret_cast<uint4 *>(buf + (size_t)v * 16) = o;
+            }
         }
     };
     const uint32_t step = gridDim.y * R;
@@ -115,7 +148,7 @@ __global__ __launch_bounds__(kResizeHBlock) void k_resize_h_u8_dot(ResizePassArg
     if (r >= rows) return;
     const size_t buf_bytes = (size_t)span_bytes * R;
     int cur = 0;
-    uint4 q[kResizeHVecs];
+    uint4 q[kResizeHVecs * QW];
     fetch(r, q);
     put(q, lds_raw);
     __syncthreads();
@@ -210,32 +243,47 @@ __global__ __launch_bounds__(kBlock) void k_resize_v(ResizePassArgs a) {
 
 } // namespace
 
+// the register-resident form: SRC16 = false reads u8 levels, true reads u16 DN through a table (lut_cap bytes of LDS ahead of the rows)
+template <bool SRC16>
+static hipError_t launch_resize_h_dot(const ResizePassArgs &a, const ResizeLutSrc &l, uint32_t rows, hipStream_t s) {
+    if (!a.window) return hipErrorNotSupported;
+    const uint32_t nchunk = (15 + a.window + 15) / 16;
+    const uint32_t span = (a.block_span + 15 + nchunk * 16 + 15) / 16 * 16; // bytes of a row that one block's 256 outputs read
+    if (!(nchunk <= 8 && (size_t)span * kResizeHRows <= (size_t)kResizeHVecs * kResizeHBlock * 16 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 &&
+          a.src_pitch % 16 == 0))
+        return hipErrorNotSupported;
+    const uint32_t gx = (a.out_size + kResizeHBlock - 1) / kResizeHBlock;
+    const uint32_t steps = (rows + kResizeHRows - 1) / kResizeHRows;
+    uint32_t blocks = 2048; // ~2048 blocks, each walks its share of the rows
+    if (const char *e = getenv("SARPRO_HIP_RESIZE_BLOCKS")) blocks = (uint32_t)std::max(1, atoi(e));
+    const uint32_t gy = std::min<uint32_t>(steps, std::max<uint32_t>(1, blocks / gx));
+    const dim3 grid(gx, gy), block(kResizeHBlock);
+    const size_t lds = (size_t)span * kResizeHRows * 2 + (SRC16 ? l.lut_cap : 0u);
+    if (lds > 64 * 1024) return hipErrorNotSupported;
+    switch (nchunk) {
+    case 1: hipLaunchKernelGGL((k_resize_h_u8_dot<1, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    case 2: hipLaunchKernelGGL((k_resize_h_u8_dot<2, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    case 3: hipLaunchKernelGGL((k_resize_h_u8_dot<3, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    case 4: hipLaunchKernelGGL((k_resize_h_u8_dot<4, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    case 5: hipLaunchKernelGGL((k_resize_h_u8_dot<5, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    case 6: hipLaunchKernelGGL((k_resize_h_u8_dot<6, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    case 7: hipLaunchKernelGGL((k_resize_h_u8_dot<7, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    default: hipLaunchKernelGGL((k_resize_h_u8_dot<8, SRC16>), grid, block, lds, s, a, rows, span, l); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_h_lut(const ResizePassArgs &a, const ResizeLutSrc &l, uint32_t rows, hipStream_t s) {
+    if (!rows || !a.out_size) return hipSuccess;
+    if (!l.lut || !l.dev_state || l.lut_cap % 16 != 0 || getenv("SARPRO_HIP_RESIZE_GENERIC")) return hipErrorNotSupported;
+    return launch_resize_h_dot<true>(a, l, rows, s);
+}
+
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s) {
     if (!rows || !a.out_size) return hipSuccess;
     if (elem_size == 1 && a.window && !getenv("SARPRO_HIP_RESIZE_GENERIC")) { // the register-resident form where its window fits
-        const uint32_t nchunk = (15 + a.window + 15) / 16;
-        const uint32_t span = (a.block_span + 15 + nchunk * 16 + 15) / 16 * 16; // bytes of a row that one block's 256 outputs read
-        if (nchunk <= 8 && (size_t)span * kResizeHRows <= (size_t)kResizeHVecs * kResizeHBlock * 16 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 &&
-            a.src_pitch % 16 == 0) {
-            const uint32_t gx = (a.out_size + kResizeHBlock - 1) / kResizeHBlock;
-            const uint32_t steps = (rows + kResizeHRows - 1) / kResizeHRows;
-            uint32_t blocks = 2048; // ~2048 blocks, each walks its share of the rows
-            if (const char *e = getenv("SARPRO_HIP_RESIZE_BLOCKS")) blocks = (uint32_t)std::max(1, atoi(e));
-            const uint32_t gy = std::min<uint32_t>(steps, std::max<uint32_t>(1, blocks / gx));
-            const dim3 grid(gx, gy), block(kResizeHBlock);
-            const size_t lds = (size_t)span * kResizeHRows * 2;
-            switch (nchunk) {
-            case 1: hipLaunchKernelGGL(k_resize_h_u8_dot<1>, grid, block, lds, s, a, rows, span); break;
-            case 2: hipLaunchKernelGGL(k_resize_h_u8_dot<2>, grid, block, lds, s, a, rows, span); break;
-            case 3: hipLaunchKernelGGL(k_resize_h_u8_dot<3>, grid, block, lds, s, a, rows, span); break;
-            case 4: hipLaunchKernelGGL(k_resize_h_u8_dot<4>, grid, block, lds, s, a, rows, span); break;
-            case 5: hipLaunchKernelGGL(k_resize_h_u8_dot<5>, grid, block, lds, s, a, rows, span); break;
-            case 6: hipLaunchKernelGGL(k_resize_h_u8_dot<6>, grid, block, lds, s, a, rows, span); break;
-            case 7: hipLaunchKernelGGL(k_resize_h_u8_dot<7>, grid, block, lds, s, a, rows, span); break;
-            default: hipLaunchKernelGGL(k_resize_h_u8_dot<8>, grid, block, lds, s, a, rows, span); break;
-            }
-            return hipGetLastError();
-        }
+        const hipError_t e = launch_resize_h_dot<false>(a, ResizeLutSrc{}, rows, s);
+        if (e != hipErrorNotSupported) return e;
     }
     const size_t lds = ((size_t)a.in_size * elem_size + 15) & ~(size_t)15;
     if (lds > kResizeRowLdsMax) {

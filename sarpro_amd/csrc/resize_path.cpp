@@ -85,8 +85,9 @@ namespace sarpro {
 
 // d_out must hold final_rows x out_pitch elements (see sarpro_hip_resize_output_dims)
 int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t rows, size_t in_pitch, size_t target_size,
-                   int elem_size, int pad, void *d_out, size_t out_pitch, sarpro_hip_resize_meta *meta) {
+                   int elem_size, int pad, void *d_out, size_t out_pitch, sarpro_hip_resize_meta *meta, const ResizeLutSrc *lut_src) {
     if (elem_size != 1 && elem_size != 2) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad element size");
+    if (lut_src && elem_size != 1) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "a DN table gives u8 levels");
     if (in_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     size_t nc = cols, nr = rows;
@@ -98,6 +99,17 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     if (out_pitch < fc) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "out_pitch < final columns");
     if (meta) { meta->final_cols = fc; meta->final_rows = fr; meta->scale_x = sx; meta->scale_y = sy; meta->pad_left = pad_left; meta->pad_top = pad_top; }
     if (!fc || !fr) return SARPRO_HIP_OK;
+    if (lut_src && !do_resize) return kResizeLutUnsupported; // (a copy, not a pass: the caller materialises the levels)
+    if (lut_src && (!nc || !nr)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "target size collapses a dimension to zero");
+    ResizePassArgs ah{}, av{};
+    if (lut_src) { // probe BEFORE anything is enqueued: the register-resident horizontal pass must take this shape
+        RETCHK(get_coeffs(ctx, 0, (uint32_t)cols, (uint32_t)nc, elem_size, &ah));
+        const uint32_t nchunk = (15 + ah.window + 15) / 16;
+        const size_t span = ((size_t)ah.block_span + 15 + nchunk * 16 + 15) / 16 * 16;
+        if (!ah.window || nchunk > 8 || span * 2 > 2 * (size_t)kResizeHBlock * 16 || (reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || in_pitch % 16 != 0 ||
+            span * 4 + lut_src->lut_cap > 64 * 1024 || getenv("SARPRO_HIP_RESIZE_GENERIC"))
+            return kResizeLutUnsupported;
+    }
     uint8_t *out = reinterpret_cast<uint8_t *>(d_out);
     if (pad) HIPCHK(ctx, hipMemset2DAsync(out, out_pitch * elem_size, 0, fc * elem_size, fr, ctx->stream));
     uint8_t *dst = out + (pad_top * out_pitch + pad_left) * elem_size;
@@ -112,7 +124,6 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     // horizontal pass -> intermediate (rows x nc), vertical pass -> destination window
     const size_t tmp_pitch = round_up(nc, 64);
     HIPCHK(ctx, ctx->resize_tmp.reserve(rows * tmp_pitch * elem_size));
-    ResizePassArgs ah{}, av{};
     RETCHK(get_coeffs(ctx, 0, (uint32_t)cols, (uint32_t)nc, elem_size, &ah));
     RETCHK(get_coeffs(ctx, 1, (uint32_t)rows, (uint32_t)nr, elem_size, &av));
     ah.src = d_in; ah.src_pitch = in_pitch; ah.dst = ctx->resize_tmp.p; ah.dst_pitch = tmp_pitch;
@@ -121,7 +132,11 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     av.width = (uint32_t)nc; av.max_val = ah.max_val;
     {
         KernelTimer t(ctx, "resize_h");
-        HIPCHK(ctx, launch_resize_h(ah, (uint32_t)rows, elem_size, ctx->stream));
+        if (lut_src) {
+            const hipError_t e = launch_resize_h_lut(ah, *lut_src, (uint32_t)rows, ctx->stream);
+            if (e == hipErrorNotSupported) return fail(ctx, SARPRO_HIP_ERR_HIP, "resize: the table form was probed and then refused"); // (the probe above mirrors the launcher)
+            HIPCHK(ctx, e);
+        } else HIPCHK(ctx, launch_resize_h(ah, (uint32_t)rows, elem_size, ctx->stream));
     }
     {
         KernelTimer t(ctx, "resize_v");
@@ -232,9 +247,23 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
         // per-band u8 at native resolution (pipeline.rs:42; Tamed: autoscale.rs:710 with the band's polarisation)
         const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0;
         if (!d_in) d_in = ctx->stage_in[0].as<uint16_t>();
-        RETCHK(band_u8_dev(ctx, d_in, rows, cols, pitch, strategy, tamed, ctx->stage_out[0].as<uint8_t>(), pitch));
         HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch));
-        RETCHK(resize_pad_dev(ctx, ctx->stage_out[0].p, cols, rows, pitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m));
+        // The percentile strategies' autoscale is a DN -> u8 table: the horizontal resize pass reads the DN raster through it and the
+        // native-resolution level raster (1 B/px written, 1 B/px read again) never exists.  CLAHE, shapes the register-resident pass
+        // does not take, SARPRO_HIP_NO_RESIZE_LUT=1: the level raster, then the u8 passes.
+        bool done = false;
+        if (!getenv("SARPRO_HIP_NO_RESIZE_LUT")) {
+            ResizeLutSrc ls{};
+            RETCHK(band_u8_table_dev(ctx, d_in, rows, cols, pitch, strategy, tamed, &ls));
+            if (ls.lut) {
+                const int rc = resize_pad_dev(ctx, d_in, cols, rows, pitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m, &ls);
+                if (rc != kResizeLutUnsupported) { RETCHK(rc); done = true; }
+            }
+        }
+        if (!done) {
+            RETCHK(band_u8_dev(ctx, d_in, rows, cols, pitch, strategy, tamed, ctx->stage_out[0].as<uint8_t>(), pitch));
+            RETCHK(resize_pad_dev(ctx, ctx->stage_out[0].p, cols, rows, pitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m));
+        }
     }
     if (meta) *meta = m;
     if (!fc || !fr) return SARPRO_HIP_OK;

@@ -133,3 +133,42 @@ def test_400mp_to_2048_resize_is_float_lanczos3_within_one_lsb():
     err = (out.to(torch.float64) - ref).abs().max().item()
     assert err <= 1.0, err
     assert int(out.max().item()) > 200 and int(out.min().item()) < 60
+
+
+@pytest.mark.parametrize("strategy", [St.Standard, St.Robust, St.Tamed, St.Default, St.Clahe])
+@pytest.mark.parametrize("shape,target", [((300, 4200), 410), ((700, 2000), 256), ((513, 1030), 77), ((200, 700), 699), ((90, 9000), 200)])
+def test_horizontal_pass_through_the_autoscale_table_equals_the_level_raster_route_and_the_oracle(strategy, shape, target, monkeypatch):
+    """Percentile strategies: the horizontal resize pass reads the u16 DN raster through the band's DN -> u8 table, the native-
+    resolution level raster never exists (no lut_apply_u16 kernel); SARPRO_HIP_NO_RESIZE_LUT=1 materialises it first.  Both give
+    the oracle's RGB; CLAHE (no such table) and shapes the register-resident pass does not take go the level-raster way by
+    themselves."""
+    import sarpro_amd as S
+    rows, cols = shape
+    b1, b2 = synth.scene_u16(rows, cols, 0), synth.scene_u16(rows, cols, 1)
+    us = []
+    for k, b in enumerate((b1, b2)):
+        x = b.astype(np.float32)
+        u = oracle.tamed_synrgb_u8(x, k == 0) if strategy == St.Tamed else oracle.pipeline(x, 0, int(strategy))[1]
+        us.append(oracle.resize_image_data_with_meta(u, target, True)[0])
+    ref = oracle.synrgb(0, int(strategy), us[0], us[1])
+    outs = []
+    with S.Context(0, timing=True) as c:
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SARPRO_HIP_NO_RESIZE_LUT", "1")
+            else:
+                monkeypatch.delenv("SARPRO_HIP_NO_RESIZE_LUT", raising=False)
+            rgb, m = c.dualpol_synrgb_resized(b1, b2, strategy, target, True)
+            names = [n for n, _ in c.last_kernel_times()]
+            # the register-resident pass takes windows of up to 8 x 16 bytes (window = 2 ceil(3 scale) + 1 taps)
+            import math
+            nc, _ = resize_output_dims(cols, rows, target, False)
+            window = 2 * math.ceil(3.0 * max(cols / nc, 1.0)) + 1
+            through_table = (15 + window + 15) // 16 <= 8
+            if not off and strategy != St.Clahe:
+                assert ("lut_apply_u16" not in names) == through_table, (names, window)
+            if strategy == St.Clahe:
+                assert "clahe_apply_u8_spec" in names or "clahe_apply_u16" in names or any(n.startswith("clahe") for n in names)
+            outs.append(rgb)
+    assert np.array_equal(outs[0], outs[1]), (strategy, shape, target)
+    assert outs[0].shape == ref.shape and np.array_equal(outs[0], ref), (strategy, shape, target)

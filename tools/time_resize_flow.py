@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 2 as a device-resident flow (400 MP dual-pol -> Robust u8 x2 -> Lanczos3 to 2048^2 -> pad -> synRGB): wall
-time per scene and every kernel of the composite call, with the register-resident resize kernels and with the generic ones
-(SARPRO_HIP_RESIZE_GENERIC=1)."""
+time per scene and every kernel of the composite call, with the horizontal pass reading the DN raster through the autoscale table (default), with the u8 level raster and the
+register-resident resize kernels (SARPRO_HIP_NO_RESIZE_LUT=1), and with the generic kernels (SARPRO_HIP_RESIZE_GENERIC=1)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,8 +11,10 @@ rows = cols = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 target = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 pitch = (cols + 63) // 64 * 64
 q = synth.q_tables()
-for env in ("", "1"):
-    if env:
+for env in ("", "nolut", "1"):
+    if env == "nolut":
+        os.environ["SARPRO_HIP_NO_RESIZE_LUT"] = "1"
+    if env == "1":
         os.environ["SARPRO_HIP_RESIZE_GENERIC"] = "1"
     with S.Context(0, timing=True) as c:
         band = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
@@ -28,4 +30,4 @@ for env in ("", "1"):
         kt = {}
         for k, v in c.last_kernel_times():
             kt[k] = round(kt.get(k, 0) + v, 4)
-        print("generic" if env else "register-resident", "ms/scene", round(sorted(dts)[2], 3), kt, flush=True)
+        print({"": "DN through the table in the horizontal pass", "nolut": "level raster, register-resident passes", "1": "level raster, generic passes"}[env], "ms/scene", round(sorted(dts)[2], 3), kt, flush=True)
