@@ -490,7 +490,7 @@ struct U16Job {
     bool clahe() const { return strategy == SARPRO_STRATEGY_CLAHE; }
     int tamed_kind(int band) const {
         if (tamed_force) return tamed_force;
-        if (synrgb && strategy == SARPRO_STRATEGY_TAMED) return band == 0 ? kTamedCopol : kTamedCrosspol;
+        if ((synrgb || (tables_only && nbands == 2)) && strategy == SARPRO_STRATEGY_TAMED) return band == 0 ? kTamedCopol : kTamedCrosspol;
         return kNotTamedSynrgb;
     }
     bool u8_out() const { return synrgb || tamed_force || bit_depth == SARPRO_BITDEPTH_U8; }
@@ -1466,12 +1466,16 @@ extern "C" int sarpro_hip_autoscale_band_u16_dev(sarpro_hip_ctx *ctx, const uint
 }
 
 namespace sarpro {
-int band_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed, ResizeLutSrc *out) {
-    out->lut = nullptr; out->dev_state = nullptr; out->band = 0; out->lut_cap = 0;
+// nb = 1: one band (tamed: 0 / 1 copol / 2 crosspol, as band_u8_dev).  nb = 2: the two bands of a dual-pol product in ONE chain
+// (one histogram pass, one statistics chain, one synchronisation; strategy Tamed: band 0 copol, band 1 crosspol; `tamed` unused).
+int bands_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *const d_in[], int nb, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
+                       ResizeLutSrc *out) {
+    for (int b = 0; b < nb; ++b) { out[b].lut = nullptr; out[b].dev_state = nullptr; out[b].band = b; out[b].lut_cap = 0; }
     U16Job J;
-    J.ctx = ctx; J.nbands = 1; J.d_in[0] = d_in;
+    J.ctx = ctx; J.nbands = nb;
+    for (int b = 0; b < nb; ++b) J.d_in[b] = d_in[b];
     J.rows_total = J.rows_local = rows; J.cols = cols; J.in_pitch = in_pitch;
-    J.strategy = tamed ? SARPRO_STRATEGY_TAMED : strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.tamed_force = tamed;
+    J.strategy = (nb == 1 && tamed) ? SARPRO_STRATEGY_TAMED : strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.tamed_force = nb == 1 ? tamed : 0;
     J.tables_only = true;
     timing_reset(ctx);
     RETCHK(job_init(J));
@@ -1481,10 +1485,16 @@ int band_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, si
     const int rc = job_run_chain_levels(J, outs, 0, nullptr, 0, nullptr);
     if (rc == kRerunOnHostRoute) return SARPRO_HIP_OK;
     RETCHK(rc);
-    out->lut = ctx->luts.as<uint8_t>();
-    out->dev_state = reinterpret_cast<const ChainBandState *>(ctx->chain_state.as<uint8_t>());
-    out->lut_cap = (ctx->chain_levels_cap + 15u) & ~15u;
+    for (int b = 0; b < nb; ++b) {
+        out[b].lut = ctx->luts.as<uint8_t>() + (size_t)b * 131072;
+        out[b].dev_state = reinterpret_cast<const ChainBandState *>(ctx->chain_state.as<uint8_t>());
+        out[b].lut_cap = (ctx->chain_levels_cap + 15u) & ~15u;
+    }
     return SARPRO_HIP_OK;
+}
+int band_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed, ResizeLutSrc *out) {
+    const uint16_t *const in[1] = {d_in};
+    return bands_u8_table_dev(ctx, in, 1, rows, cols, in_pitch, strategy, tamed, out);
 }
 
 int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,

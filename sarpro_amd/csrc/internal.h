@@ -46,6 +46,9 @@ int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t c
 // (CLAHE, host route): take band_u8_dev.  The table and the state it points to live in the context until its next chain.
 struct ResizeLutSrc;
 int band_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed, ResizeLutSrc *out);
+// both bands of a dual-pol product in one chain (nb = 2; Tamed: band 0 copol, band 1 crosspol) or one band (nb = 1, as above); out[nb]
+int bands_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *const d_in[], int nb, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
+                       ResizeLutSrc *out);
 int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);
 // lut_src != nullptr: d_in is the u16 DN raster (in_pitch in u16 elements, elem_size 1 = the output's) and the horizontal pass reads
 // it through the table; returns kResizeLutUnsupported (nothing enqueued) when that form does not apply to this shape

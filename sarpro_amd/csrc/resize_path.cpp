@@ -227,7 +227,25 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
     const size_t opitch = round_up(std::max<size_t>(fc, 1), 64);
     sarpro_hip_resize_meta m{};
     TimingHold hold(ctx); // last_kernel_times: every kernel of both bands, the resize passes and the composition
+    // Device-resident bands, percentile strategy: BOTH bands' tables from one chain (one histogram launch, one statistics chain, one
+    // synchronisation instead of two of each), then the two horizontal passes through them
+    ResizeLutSrc both[2]{};
+    bool both_done[2] = {false, false};
+    if (dev_bands && !getenv("SARPRO_HIP_NO_RESIZE_LUT") && rows && cols) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        RETCHK(bands_u8_table_dev(ctx, dev_bands, 2, rows, cols, dev_pitch, strategy, 0, both));
+        if (both[0].lut && both[1].lut) {
+            for (int b = 0; b < 2; ++b) {
+                HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(fr, 1) * opitch));
+                const int rc = resize_pad_dev(ctx, dev_bands[b], cols, rows, dev_pitch, target_size, 1, pad, ctx->resized[b].p, opitch, &m, &both[b]);
+                if (rc == kResizeLutUnsupported) break; // (the same answer for both bands: same shape)
+                RETCHK(rc);
+                both_done[b] = true;
+            }
+        }
+    }
     for (int b = 0; b < 2; ++b) {
+        if (both_done[b]) continue;
         size_t pitch = 0;
         const uint16_t *d_in = nullptr;
         if (dev_bands) {

@@ -172,3 +172,21 @@ def test_horizontal_pass_through_the_autoscale_table_equals_the_level_raster_rou
             outs.append(rgb)
     assert np.array_equal(outs[0], outs[1]), (strategy, shape, target)
     assert outs[0].shape == ref.shape and np.array_equal(outs[0], ref), (strategy, shape, target)
+    # device-resident bands: both bands' tables come from ONE chain (Tamed: band 0 copol, band 1 crosspol)
+    import torch
+    pitch = (cols + 63) // 64 * 64
+    fc, fr = resize_output_dims(cols, rows, target, True)
+    with S.Context(0, timing=True) as c:
+        d = []
+        for b in (b1, b2):
+            t = torch.zeros((rows, pitch), dtype=torch.int16, device="cuda")
+            t[:, :cols] = torch.from_numpy(b.view(np.int16)).cuda()
+            d.append(t)
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SARPRO_HIP_NO_RESIZE_LUT", "1")
+            else:
+                monkeypatch.delenv("SARPRO_HIP_NO_RESIZE_LUT", raising=False)
+            o = torch.zeros((fr * fc * 3,), dtype=torch.uint8, device="cuda")
+            c.dev_dualpol_synrgb_resized(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, strategy, target, True, o.data_ptr())
+            assert np.array_equal(o.cpu().numpy().reshape(fr, fc, 3), ref), (strategy, shape, target, off)
