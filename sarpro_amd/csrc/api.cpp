@@ -1577,8 +1577,9 @@ extern "C" int sarpro_hip_synrgb_u8_dev(sarpro_hip_ctx *ctx, int mode, int strat
     for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
     fold_compose_tables(luts.data(), fwc, ident, ident, tables.data());
     HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, tables.data(), 66048, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, ctx->h_upload.reserve(2 * 131072 + 2 * 64 * 256 * 8 + 66048 + 1024));
+    std::memcpy(ctx->h_upload.p, tables.data(), 66048); // pinned and the context's own: the copy needs no wait of its own
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p, ctx->h_upload.p, 66048, hipMemcpyHostToDevice, ctx->stream));
     const bool al = ptr_aligned16(d_b1) && ptr_aligned16(d_b2) && ptr_aligned16(d_rgb);
     ComposeArgs c{};
     c.tables = ctx->tables.as<uint8_t>();

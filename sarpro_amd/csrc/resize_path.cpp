@@ -285,15 +285,23 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
     }
     if (meta) *meta = m;
     if (!fc || !fr) return SARPRO_HIP_OK;
-    // composition on the resized, padded bands: compact them (pitch == cols) so the flat entry point applies
-    HIPCHK(ctx, ctx->stage_out[1].reserve(fc * fr));
-    HIPCHK(ctx, ctx->stage_out[2].reserve(fc * fr));
-    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max(fc * fr * 3, r1 * round_up(std::max<size_t>(cols, 1), 64))));
-    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[1].p, fc, ctx->resized[0].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[2].p, fc, ctx->resized[1].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
-    RETCHK(sarpro_hip_synrgb_u8_dev(ctx, mode, strategy, ctx->stage_out[1].as<uint8_t>(), ctx->stage_out[2].as<uint8_t>(), fc * fr,
-                                    ctx->stage_out[0].as<uint8_t>()));
-    HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->stage_out[0].p, fc * fr * 3, dev_bands ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    // composition on the resized, padded bands through the flat entry point: compacted first when their pitch is not their width
+    // (2048 columns: it is), straight into the caller's raster when that lives on the device
+    const uint8_t *cb[2] = {ctx->resized[0].as<uint8_t>(), ctx->resized[1].as<uint8_t>()};
+    if (opitch != fc) {
+        HIPCHK(ctx, ctx->stage_out[1].reserve(fc * fr));
+        HIPCHK(ctx, ctx->stage_out[2].reserve(fc * fr));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[1].p, fc, ctx->resized[0].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[2].p, fc, ctx->resized[1].p, opitch, fc, fr, hipMemcpyDeviceToDevice, ctx->stream));
+        cb[0] = ctx->stage_out[1].as<uint8_t>(); cb[1] = ctx->stage_out[2].as<uint8_t>();
+    }
+    if (dev_bands && (reinterpret_cast<uintptr_t>(rgb_out) & 15) == 0) {
+        RETCHK(sarpro_hip_synrgb_u8_dev(ctx, mode, strategy, cb[0], cb[1], fc * fr, rgb_out));
+    } else {
+        HIPCHK(ctx, ctx->stage_out[0].reserve(std::max(fc * fr * 3, r1 * round_up(std::max<size_t>(cols, 1), 64))));
+        RETCHK(sarpro_hip_synrgb_u8_dev(ctx, mode, strategy, cb[0], cb[1], fc * fr, ctx->stage_out[0].as<uint8_t>()));
+        HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->stage_out[0].p, fc * fr * 3, dev_bands ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SARPRO_HIP_OK;
 }
