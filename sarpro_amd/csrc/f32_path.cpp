@@ -509,7 +509,7 @@ int f32_phase_a(F32Band &B) {
     uint8_t *ws = ctx->f32ws.as<uint8_t>();
     const uint32_t rows = (uint32_t)B.rows, cols = (uint32_t)B.cols;
     B.use_zones = B.have_stats = false;
-    if (B.direct && B.clahe) B.direct = false; // (CLAHE keeps its threshold route: tile histograms and the blend need the bin table)
+    // (CLAHE takes the direct route for its statistics only: tile histograms and the blend keep the host-built bin table)
     if (B.allow_zones && !B.direct) RETCHK(f32_zone_presample(B));
     if (B.use_zones) return f32_zone_prepass(B);
     const int pgrid = f32_prepass_grid(rows, cols, B.vec);
