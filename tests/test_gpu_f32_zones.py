@@ -179,9 +179,11 @@ def test_zone_sweep_counts_every_valid_sample_whatever_the_table_says(monkeypatc
             assert "f32_prepass_zones" in names(c)
 
 
-def test_f32_clahe_u8_speculative_blend_equals_the_f64_blend_and_the_oracle(monkeypatch):
+@pytest.mark.parametrize("big", [(5000, 4000, 4032), (20000, 20000, 20032)])
+def test_f32_clahe_u8_speculative_blend_equals_the_f64_blend_and_the_oracle(big, monkeypatch):
     """u8 CLAHE of f32 samples: the f32 blend with a margin (f32_kernels.hip e') against the reference's f64 sequence for every
-    sample (SARPRO_HIP_NO_SPEC=1) on a 5000 x 4000 pol-op raster, and against the oracle on a 1500 x 1700 one."""
+    sample (SARPRO_HIP_NO_SPEC=1) on a 5000 x 4000 pol-op raster and on BASELINE.json's 20000 x 20000, and against the oracle on a
+    1500 x 1700 one."""
     x = f32data.ratio_scene(1500, 1700)
     rc, ref = oracle.pipeline(x, int(Bd.U8), int(St.Clahe))
     assert rc == 0
@@ -189,7 +191,7 @@ def test_f32_clahe_u8_speculative_blend_equals_the_f64_blend_and_the_oracle(monk
         got = c.process_scalar_data_pipeline(x, Bd.U8, St.Clahe)
         assert np.array_equal(got[0], ref)
         assert "f32_clahe_apply" in names(c)
-    rows, cols, pitch = 5000, 4000, 4032
+    rows, cols, pitch = big
     q = synth.q_tables()
     with S.Context(0) as c:
         d = [torch.zeros((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
