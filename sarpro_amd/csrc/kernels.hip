@@ -1152,8 +1152,12 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
 //     Per pixel and band: v_pk_min_u16 (clamp, 2 px) -> SDWA shift -> one 16-B gather -> 4 FMA + add -> 2 v_cvt_pk_u8_f32,
 //     margin test and exact f64 path exactly as in kernel 4b (same bounds: the entry values and operation order are the same).
 // ------------------------------------------------------------------------------------
-constexpr int kRgbBlock = 1024, kRgbWaves = kRgbBlock / kWave;
-constexpr uint32_t kRgbPoolEntries = 3072;
+#ifndef SARPRO_RGB_BLOCK // (occupancy experiment: -DSARPRO_RGB_BLOCK=512 -DSARPRO_RGB_POOL=2040)
+#define SARPRO_RGB_BLOCK 1024
+#define SARPRO_RGB_POOL 3072
+#endif
+constexpr int kRgbBlock = SARPRO_RGB_BLOCK, kRgbWaves = kRgbBlock / kWave;
+constexpr uint32_t kRgbPoolEntries = SARPRO_RGB_POOL;
 struct RgbLds {
     static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[65536]
     static constexpr uint32_t stage = kComposeTableBytes;                   // [16][1536] RGB of a wave-row | tmp32 [2][257] float4 while staging
