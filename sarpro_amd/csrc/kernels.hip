@@ -478,6 +478,9 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     serialise the no-data wedge (measured: +7 % on the whole kernel).
 // ------------------------------------------------------------------------------------
 constexpr float kSpecDeltaEdge = 1.0f / 1024.0f, kSpecDeltaInner = 1.0f / 4096.0f;
+#ifdef SARPRO_SPEC_MEASURE // instrumented build (tools/spec_margin.py): the largest |y32 - y| the speculative blend produced, per margin class
+__device__ uint32_t g_spec_max_err[2]; // float bits; [0] interior cells, [1] extrapolating cells
+#endif
 constexpr uint32_t kPartialHistLevels = 64; // partial level histogram: levels below this are counted one by one
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -582,6 +585,9 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
     constexpr bool PARTIAL_HIST = HIST != 0;
     uint32_t lane_max = 0u, lane_high = 0u; // PARTIAL_HIST: this lane's highest level and its count of levels >= kPartialHistLevels
     uint32_t lane_valid = 0u;               // HIST == 2: this lane's kept samples with DN != 0 on the sampled rows
+#ifdef SARPRO_SPEC_MEASURE
+    float spec_err = 0.0f;
+#endif
 
     auto process_row = [&](int r, const U16Vec<VEC> &v, const double dy_v, const bool sampled) { // dy, sampled: wave-uniform
         // (counted first: the row's samples are then dead after the offset lookups, not held across the blend)
@@ -651,6 +657,18 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
             const float yb = ya + two_delta;
             pk[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(ya, j & 3, pk[j >> 2]);
             pb[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(yb, j & 3, pb[j >> 2]);
+#ifdef SARPRO_SPEC_MEASURE
+            {   // the reference's y for EVERY sample (unclamped), against the f32 value; biased entries (all-zero / all-one bins) excluded
+                const double4 e4 = *reinterpret_cast<const double4 *>(lds + SpecLds::cdf64 + cdf32_entry(off[j] - SpecLds::cdf32) * 32u);
+                const bool biased = (e4.x == 0.0 && e4.y == 0.0 && e4.z == 0.0 && e4.w == 0.0) ||
+                                    (e4.x == 1.0 && e4.y == 1.0 && e4.z == 1.0 && e4.w == 1.0 && !(rc.pad[0] & 1));
+                const double dxe = *reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
+                const double te = e4.x * (1.0 - dxe) + e4.y * dxe, be = e4.z * (1.0 - dxe) + e4.w * dxe;
+                const double ye = (te * omdy + be * dy) * 255.0;
+                const float err = (float)fabs(((double)ya - (double)bias) - ye);
+                if (!biased && ((keep[j >> 2] >> (8 * (j & 3))) & 0xFFu)) spec_err = fmaxf(spec_err, err);
+            }
+#endif
         }
         const uint32_t d0 = pk[0] ^ pb[0], d1 = pk[1] ^ pb[1];
 #ifdef SARPRO_ABL_NOEXACT // timing ablation (garbage raster): no exact path
@@ -797,6 +815,11 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         for (int m = 32; m > 0; m >>= 1) lane_valid += __shfl_xor(lane_valid, m, 64);
         if (lane_id() == 0 && lane_valid) atomicAdd(reinterpret_cast<uint32_t *>(lds + SpecLds::hist) + 320, lane_valid);
     }
+#ifdef SARPRO_SPEC_MEASURE
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) spec_err = fmaxf(spec_err, __shfl_xor(spec_err, m, 64));
+    if (lane_id() == 0 && spec_err > 0.0f) atomicMax(&g_spec_max_err[(rc.pad[0] & 1) ? 1 : 0], __float_as_uint(spec_err));
+#endif
 }
 
 // one kernel per histogram mode (known on the host): each gets the registers ITS row loop needs, not the maximum of all three
@@ -1832,3 +1855,15 @@ hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q, 
 }
 
 } // namespace sarpro
+
+#ifdef SARPRO_SPEC_MEASURE
+// instrumented build only: reads and clears the largest speculation errors seen so far (interior cells, extrapolating cells)
+extern "C" int sarpro_hip_debug_spec_max_err(float out[2]) {
+    uint32_t h[2] = {0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(sarpro::g_spec_max_err), sizeof(h)) != hipSuccess) return -1;
+    const uint32_t z[2] = {0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sarpro::g_spec_max_err), z, sizeof(z)) != hipSuccess) return -1;
+    for (int i = 0; i < 2; ++i) { float f; __builtin_memcpy(&f, &h[i], 4); out[i] = f; }
+    return 0;
+}
+#endif
