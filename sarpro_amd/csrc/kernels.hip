@@ -472,6 +472,10 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     extrapolates (first half tile row / column), kSpecDeltaInner = 1/4096 = 2.4e-4 elsewhere --
 //     2x the respective worst case (round 1 ran with 4x: twice as many pixels on the exact path).  Outside the margin floor(y32) = floor(y), inside it the exact
 //     path decides.  The reference's own f64 rounding (1e-13) is far below it.
+//     (The test compares the bytes of ya = y32 - 0.5 - delta and yb = fl(ya + 2 delta): yb's own rounding, <= u |yb| = 1.5e-5
+//     (3.6e-5 where the cell extrapolates), eats into the upper side, so what must hold is delta > err + u |yb|: 1.37e-4 /
+//     5.3e-4 -- the margins are 1.8x that.  Measured over 3.2e9 samples (tools/spec_margin.py, an instrumented build that
+//     evaluates the reference's y for every sample): |y32 - y| <= 4.4e-5 interior, 7.8e-5 extrapolating.)
 //     All-zero and all-one CDF entries, whose exact results are known, get biased f32 entries that land
 //     mid-interval (see the staging code), so they never reach the exact path.
 //     Level 0 goes to a per-lane dummy histogram word (bin 0 = pixels - other bins): a shared word would
