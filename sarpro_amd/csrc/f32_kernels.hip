@@ -888,11 +888,24 @@ __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict
     while (walk.live()) {
         uint32_t r, col;
         const F32Vec<VEC> v = walk.next(in, pitch, pol, &r, &col);
+        // the VEC samples side by side: estimates, table reads and verifications of all of them together (est_search_m)
+        float xs[VEC];
+        bool ok[VEC];
+        uint32_t bin[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float x = v.get(j);
-            if (col + j < cols && x >= t_valid) atomicAdd(&hist[est.use ? est_search<4095>(thr, x, est) : step_search<4095>(thr, x)], 1u);
+            ok[j] = col + j < cols && x >= t_valid;
+            xs[j] = ok[j] ? x : 1.0f; // (a sample that does not count still gets a bin: any finite value will do)
         }
+        if (est.use) est_search_m<4095, VEC>(thr, xs, est, bin);
+        else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) bin[j] = step_search<4095>(thr, xs[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (ok[j]) atomicAdd(&hist[bin[j]], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += kBlock)
