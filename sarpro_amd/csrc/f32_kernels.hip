@@ -339,18 +339,19 @@ __global__ __launch_bounds__(kBlock) void k_f32_prepass(const float *__restrict_
     while (walk.live()) {
         uint32_t r, col;
         const F32Vec<VEC> v = walk.next(in, pitch, pol, &r, &col);
+        // no branch between the samples of a vector (their logarithms overlap); a sample that does not count adds exact zeros, in
+        // the same order as before: the partial sums keep their bits
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float x = v.get(j);
-            if (col + j < cols && x >= t_valid) {
-                ++cnt;
-                mn = fminf(mn, x);
-                mx = fmaxf(mx, x);
-                if (MOMENTS) {
-                    const double db = db_of_f32_fast(x, logc, invc);
-                    sum += db;
-                    sumsq += db * db;
-                }
+            const bool ok = col + j < cols && x >= t_valid;
+            cnt += ok ? 1u : 0u;
+            mn = fminf(mn, ok ? x : INFINITY);
+            mx = fmaxf(mx, ok ? x : -INFINITY);
+            if (MOMENTS) {
+                const double db = db_of_f32_fast(ok ? x : 1.0f, logc, invc);
+                sum += ok ? db : 0.0;
+                sumsq += ok ? db * db : 0.0;
             }
         }
     }
