@@ -1,0 +1,140 @@
+"""EVERY pixel of every full-size BASELINE.json configuration against the ORACLE ITSELF (oracle/sarpro_oracle.c, one thread --
+the reference's behaviour).  Nothing of the product stands on the expected side here: the oracle gets the scene's samples as the
+`Array2<f32>` the reference's readers hand over, runs the reference's per-pixel loops (pipeline.rs:42-67, autoscale.rs:452-659,
+synthetic_rgb.rs:88-178, ops.rs:35-44) and its raster is compared with the GPU's with `==` over all 4 * 10^8 pixels.
+
+The single-thread oracle needs 7-15 s per 400 MP band (bench.py times the whole headline at ~28 s), so the module costs about
+two minutes of host time; the decomposition tests of test_gpu_dev.py / test_gpu_baseline_configs.py stay as diagnostics (they say
+WHICH stage differs when one of these fails)."""
+import numpy as np
+import pytest
+
+import oracle
+import sarpro_amd as S
+from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, PolarizationOperation as Op, SyntheticRgbMode as Mode, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROWS = COLS = 20000
+PITCH = 20032
+
+
+@pytest.fixture(scope="module")
+def scene():
+    """The bench generator's scene A at the metric's size: device-resident u16 bands + the same samples as host f32 arrays
+    (what the oracle is fed).  The device generator is checked against the numpy one in test_gpu_u16.py."""
+    q = synth.q_tables()
+    c = S.Context(0, timing=True)
+    band = [torch.empty((ROWS, PITCH), dtype=torch.int16, device="cuda") for _ in range(2)]
+    host = []
+    for k in (0, 1):
+        c.dev_synth_scene_u16(synth.SEED_SCENE_A, k, q, ROWS, COLS, 0, ROWS, band[k].data_ptr(), PITCH)
+        host.append(band[k][:, :COLS].contiguous().cpu().numpy().view(np.uint16).astype(np.float32))
+    yield c, band, host
+    c.close()
+
+
+def _same(dev_t, ref: np.ndarray, what: str):
+    """dev_t: device tensor view [rows, cols(, 3)] ; ref: the oracle's raster.  Compared on the device, slab by slab."""
+    step = 2500
+    bad = 0
+    for r0 in range(0, ref.shape[0], step):
+        want = torch.from_numpy(ref[r0:r0 + step]).cuda()
+        got = dev_t[r0:r0 + step]
+        if want.dtype == torch.uint16:
+            want = want.view(torch.int16)
+        bad += int((got != want).sum().item())
+    assert bad == 0, f"{what}: {bad} of {ref.size} raster entries differ from the oracle"
+
+
+def test_headline_400mp_clahe_synrgb_equals_oracle_every_pixel(scene):
+    """The metric's workload: calibrate + CLAHE u8 x 2 + suppressed synRGB (save.rs:317-367) at 20000 x 20000, both GPU routes
+    (the fused CLAHE -> RGB pass that bench.py times, and the apply + compose route with its per-band u8 rasters) == oracle."""
+    c, band, host = scene
+    rc, ref, r1, r2 = oracle.dualpol_synrgb(host[0], host[1], int(St.Clahe))
+    assert rc == 0
+    rgb = torch.zeros((ROWS, PITCH * 3), dtype=torch.uint8, device="cuda")
+    c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Mode.Default, rgb.data_ptr(), PITCH,
+                             want_stats=False)
+    names = [n for n, _ in c.last_kernel_times()]
+    assert "clahe_rgb_fused" in names, names  # the route of the bench line
+    rep = c.spec_report()
+    assert rep["spec_ok"] == 1 and rep["verdict"] == 0, rep  # the prediction stood: the raster below is the fused pass's own
+    _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, "fused route RGB")
+    rgb.zero_()
+    u8 = [torch.zeros((ROWS, PITCH), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Mode.Default, rgb.data_ptr(), PITCH,
+                             u8[0].data_ptr(), u8[1].data_ptr(), PITCH)
+    names = [n for n, _ in c.last_kernel_times()]
+    assert "clahe_rgb_fused" not in names and "clahe_apply_u8_spec" in names, names
+    _same(u8[0][:, :COLS], r1, "CLAHE u8 band 1")
+    _same(u8[1][:, :COLS], r2, "CLAHE u8 band 2")
+    _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, "apply + compose route RGB")
+
+
+def test_config1_400mp_robust_u8_and_resized_synrgb_equal_oracle_every_pixel(scene):
+    """configs[1]: Robust autoscale of both 400 MP bands -> u8 (every pixel == oracle.pipeline), the native-resolution default
+    synRGB of those rasters (every pixel), and the config's flow -- Lanczos3 to 2048^2 + pad + synRGB -- from the ORACLE's rasters."""
+    c, band, host = scene
+    ref8 = []
+    for k in (0, 1):
+        rc, r = oracle.pipeline(host[k], 0, int(St.Robust))
+        assert rc == 0
+        ref8.append(r)
+    rgb = torch.zeros((ROWS, PITCH * 3), dtype=torch.uint8, device="cuda")
+    u8 = [torch.zeros((ROWS, PITCH), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Robust, Mode.Default, rgb.data_ptr(), PITCH,
+                             u8[0].data_ptr(), u8[1].data_ptr(), PITCH)
+    for k in (0, 1):
+        _same(u8[k][:, :COLS], ref8[k], f"Robust u8 band {k + 1}")
+    del u8
+    ref_rgb = oracle.synrgb(0, int(St.Robust), ref8[0], ref8[1])
+    _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref_rgb, "Robust native-resolution synRGB")
+    # the fused calibrate -> stretch -> compose pass (no per-band rasters requested) gives the same RGB
+    rgb.zero_()
+    c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Robust, Mode.Default, rgb.data_ptr(), PITCH,
+                             want_stats=False)
+    assert "lut_compose_u16" in [n for n, _ in c.last_kernel_times()]
+    _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref_rgb, "fused percentile pass RGB")
+    del rgb, ref_rgb
+    small = [oracle.resize_image_data_with_meta(x, 2048, True)[0] for x in ref8]
+    want = oracle.synrgb(0, int(St.Robust), small[0], small[1])
+    fc, fr = S.resize_output_dims(COLS, ROWS, 2048, True)
+    out = torch.zeros((fr * fc * 3,), dtype=torch.uint8, device="cuda")
+    c.dev_dualpol_synrgb_resized(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Robust, 2048, True, out.data_ptr())
+    assert (fr, fc) == (2048, 2048) and np.array_equal(out.cpu().numpy().reshape(fr, fc, 3), want)
+
+
+def test_config2_400mp_clahe_u16_bands_and_log_ratio_band_equal_oracle_every_pixel(scene):
+    """configs[2]: CLAHE with u16 output of VV, of VH and of the log-ratio pol-op band (ops.rs:35-44 -> pipeline.rs:42-67),
+    every pixel == oracle.  The pol-op band runs both ways: computed inside the f32 flavour's passes from the u16 DN
+    (sarpro_hip_polop_autoscale_band_u16_dev) and as a materialised f32 raster (polop_f32_dev -> autoscale_band_f32_dev)."""
+    c, band, host = scene
+    out16 = torch.zeros((ROWS, PITCH), dtype=torch.int16, device="cuda")
+    for k in (0, 1):
+        rc, ref = oracle.pipeline(host[k], 1, int(St.Clahe))
+        assert rc == 0
+        out16.zero_()
+        c.dev_autoscale_band_u16(band[k].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Bd.U16, out16.data_ptr(), PITCH)
+        _same(out16[:, :COLS], ref, f"CLAHE u16 band {k + 1}")
+        del ref
+    ref_ratio = oracle.polop(int(Op.LogRatio), host[0], host[1])
+    rc, ref = oracle.pipeline(ref_ratio, 1, int(St.Clahe))
+    assert rc == 0
+    out16.zero_()
+    c.dev_polop_autoscale_band(Op.LogRatio, band[0].data_ptr(), band[1].data_ptr(), True, ROWS, COLS, PITCH, St.Clahe, Bd.U16,
+                               out16.data_ptr(), PITCH, want_stats=False)
+    _same(out16[:, :COLS], ref, "CLAHE u16 of the log-ratio band (pol-op inside the passes)")
+    f = []
+    for k in (0, 1):
+        x = band[k][:, :COLS].to(torch.float32).contiguous()
+        x[x < 0] += 65536.0  # the u16 bit pattern was held as int16
+        f.append(x)
+    ratio = torch.empty((ROWS, COLS), dtype=torch.float32, device="cuda")
+    c.dev_polop_f32(Op.LogRatio, f[0].data_ptr(), f[1].data_ptr(), ROWS * COLS, ratio.data_ptr())
+    del f
+    _same(ratio.view(torch.int32), ref_ratio.view(np.int32), "log-ratio band (f32 bit patterns)")
+    out16.zero_()
+    c.dev_autoscale_band_f32(ratio.data_ptr(), ROWS, COLS, COLS, St.Clahe, Bd.U16, out16.data_ptr(), PITCH)
+    _same(out16[:, :COLS], ref, "CLAHE u16 of the materialised log-ratio raster")
