@@ -287,3 +287,41 @@ def test_f32_direct_route_with_many_samples_on_bin_boundaries(monkeypatch):
                 u8, u16 = c.process_scalar_data_pipeline(x, bd, s)
                 rc, ref = oracle.pipeline(x, int(bd), int(s))
                 assert rc == 0 and np.array_equal(u8 if bd == Bd.U8 else u16, ref), (s, bd)
+
+
+@pytest.mark.parametrize("bit_depth", list(Bd))
+def test_f32_level_queue_overflow_takes_the_table_route_and_still_returns_complete(bit_depth, monkeypatch):
+    """The f64 level kernel queues the samples within 1e-6 of a level boundary for the host's glibc; a queue that overflows sends
+    the band to the threshold-table route, which enqueues a copy and a second level kernel -- and the call must not return before
+    those are done (`idle` stayed set and the u16 form skipped its only synchronisation).  Samples that sit exactly
+    on level thresholds + a zero-capacity queue (SARPRO_HIP_F32_LEVEL_QCAP=0) force the route; the raster is read back on torch's
+    stream right after the call, without any other synchronisation."""
+    torch = pytest.importorskip("torch")
+    rows, cols = 700, 1040
+    x = f32data.resampled_scene(rows, cols).copy()
+    with S.Context(0) as c:
+        _, _, st = c.process_scalar_data_pipeline(x, bit_depth, St.Robust, want_stats=True)
+    thr = S.host_f32_level_thresholds(st, bit_depth)
+    inner = thr[np.isfinite(thr) & (thr > 0)][5:-5]
+    picks = inner[:: max(1, len(inner) // 40)]
+    flat = x.ravel()
+    order = np.argsort(flat)
+    for t in picks:  # each threshold value replaces the sample closest to it: the distribution (and with it the window) stays put
+        i = order[min(np.searchsorted(flat[order], t), flat.size - 1)]
+        flat[i] = t
+    rc, ref, so = oracle.pipeline(x, int(bit_depth), int(St.Robust), want_stats=True)
+    assert rc == 0 and so.low_clip == st.low_clip and so.high_clip == st.high_clip  # the inserted samples ARE thresholds of this raster
+    monkeypatch.setenv("SARPRO_HIP_F32_DIRECT", "1" if bit_depth == Bd.U8 else "0")  # (u8 takes the f64 level kernel on the direct route only)
+    monkeypatch.setenv("SARPRO_HIP_F32_LEVEL_QCAP", "0")
+    d_in = torch.from_numpy(x).cuda()
+    dt = torch.uint8 if bit_depth == Bd.U8 else torch.int16
+    with S.Context(0, timing=True) as c:
+        for _ in range(3):
+            d_out = torch.zeros((rows, cols), dtype=dt, device="cuda")
+            torch.cuda.synchronize()
+            c.dev_autoscale_band_f32(d_in.data_ptr(), rows, cols, cols, St.Robust, bit_depth, d_out.data_ptr(), cols, want_stats=False)
+            got = d_out.cpu().numpy()  # torch's stream: nothing orders it behind the library's but the call having returned complete
+            names = [n for n, _ in c.last_kernel_times()]
+            assert names.count("f32_level") == 2, names  # queue overflow -> table route
+            got = got.view(np.uint16) if bit_depth == Bd.U16 else got
+            assert np.array_equal(got, ref), int((got != ref).sum())
