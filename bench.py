@@ -54,6 +54,8 @@ def main():
                                                                "N > 1: row-stripe mode over RCCL and the PCIe-inclusive leg on all ranks)")
     ap.add_argument("--secondary-only", action="store_true", help=argparse.SUPPRESS)  # the child process that measures the N = 1 secondary records
     ap.add_argument("--pitch-align", type=int, default=64, help="row pitch of the resident rasters, rounded up to this many elements")
+    ap.add_argument("--scenes", type=int, default=0, help="how many of sarpro_amd.synth.BENCH_SCENES the timed steps cycle over (0 = all of them; 1 = scene A only, "
+                                                          "the workload of rounds 1-3)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -96,12 +98,23 @@ def main():
         seed = synth.SEED_SCENE_A
     else:
         row0, rows_local = 0, rows
-        seed = synth.SEED_SCENE_A + rank  # batch: one scene per rank
+        seed = synth.SEED_SCENE_A + 16 * rank  # batch: every rank its own scenes
 
-    band = [torch.empty((max(rows_local, 1), pitch), dtype=torch.int16, device=dev) for _ in range(2)]
+    # The timed steps cycle over K resident scenes that differ in DISTRIBUTION (class maps, sigma sets, with and without invalid
+    # pixels, amplitude windows beyond the fused pass's LDS pool, a constant band): the speculative route of the CLAHE chain can
+    # miss on them, and a miss costs what it costs inside `value`.  Scene A (rounds 1-3) is step 0.  A row stripe is one scene.
+    striped = args.mode == "stripe" and world > 1
+    scene_defs = synth.BENCH_SCENES[:1] if striped else synth.BENCH_SCENES[:(args.scenes or len(synth.BENCH_SCENES))]
+    scenes = []
+    for name, off, flags, qkw, what in scene_defs:
+        qs = synth.q_tables(**qkw) if qkw else q
+        bands = [torch.empty((max(rows_local, 1), pitch), dtype=torch.int16, device=dev) for _ in range(2)]
+        for b in range(2):
+            ctx.dev_synth_scene_u16(seed + off, b, qs, rows, cols, row0, rows_local, bands[b].data_ptr(), pitch, flags)
+        scenes.append(bands)
+    K = len(scenes)
+    band = scenes[0]
     rgb = torch.empty((max(rows_local, 1), pitch * 3), dtype=torch.uint8, device=dev)
-    for b in range(2):
-        ctx.dev_synth_scene_u16(seed, b, q, rows, cols, row0, rows_local, band[b].data_ptr(), pitch)
 
     if args.mode == "stripe" and world > 1:
         # library-owned RCCL communicator (xGMI): rank 0 makes the id, everyone joins
@@ -109,13 +122,14 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
 
-    def step():
-        if args.mode == "stripe" and world > 1:
+    def step(i=0):
+        b = scenes[i % K]
+        if striped:
             # one call: device-resident chain with its RCCL all-reduces enqueued on the library's stream
-            ctx.stripe_run_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, row0, rows_local, pitch, strategy,
+            ctx.stripe_run_u16(b[0].data_ptr(), b[1].data_ptr(), rows, cols, row0, rows_local, pitch, strategy,
                                SyntheticRgbMode.Default, rgb.data_ptr(), pitch)
         else:
-            ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, strategy,
+            ctx.dev_dualpol_synrgb_u16(b[0].data_ptr(), b[1].data_ptr(), rows, cols, pitch, strategy,
                                        SyntheticRgbMode.Default, rgb.data_ptr(), pitch, want_stats=False)
 
     def barrier():
@@ -129,9 +143,25 @@ def main():
     # dozen of them per step would be measurement overhead inside `value`.  The per-kernel breakdown comes from
     # EXTRA_STEPS fully instrumented steps AFTER the timed region.
     EXTRA_STEPS = 3
+    # Before anything is timed every scene runs once, synchronously: which route it takes (sarpro_hip_ctx_spec_report: accepted /
+    # refuted / unproven / pool_overflow -- a property of the scene, the chain is deterministic) and what one synchronous call costs.
+    # Rank 0 keeps scene A's RGB raster on the host: the CPU baseline below compares it with the oracle's, pixel by pixel.
+    outcomes, scene_sync_ms, rgb_a_host = [], [], None
+    for i in range(K):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(i)
+        ctx.synchronize()
+        scene_sync_ms.append((time.perf_counter() - t0) * 1e3)
+        try:
+            outcomes.append(ctx.spec_report()["outcome"] if (strategy == AutoscaleStrategy.Clahe and not striped) else "n/a")
+        except Exception:
+            outcomes.append("n/a")  # (no speculative chain ran: a scene below the route's size threshold)
+        if i == 0 and rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_full and not striped:
+            rgb_a_host = rgb.view(max(rows_local, 1), pitch, 3)[:, :cols].cpu().numpy()
     wtimes: dict[str, float] = {}
-    for _ in range(args.warmup):
-        step()
+    for w in range(args.warmup):
+        step(w)
         ctx.synchronize()
         for name, ms in ctx.last_kernel_times():
             if not name.startswith("host:"):
@@ -144,18 +174,33 @@ def main():
     dtimes: list[float] = []  # the dominant kernel's launches inside the timed region
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
         if not use_async:
             dtimes += [ms for name, ms in ctx.last_kernel_times() if name == dom_warm]  # HIP events on the library's stream
     barrier()
     elapsed = time.perf_counter() - t0
-    if use_async:  # the event pairs of all K enqueued scenes, read after the timed region
+    if use_async:  # the event pairs of all the enqueued scenes, read after the timed region
         dtimes += [ms for name, ms in ctx.last_kernel_times() if name == dom_warm]
+    # the fused pass returns at once on a scene whose speculation never started (unproven) or whose windows exceed its pool:
+    # such launches moved no bytes and are left out of the roofline average (one launch of the dominant kernel per step)
+    if K > 1 and len(dtimes) == args.steps and dom_warm == "clahe_rgb_fused":
+        dtimes = [ms for i, ms in enumerate(dtimes) if outcomes[i % K] in ("accepted", "refuted")]
+
+    def timed_subset(idx):  # the same enqueue pattern over a subset of the scenes (beside `value`, after the timed region)
+        idx = idx or [0]  # (every rank takes part in the barriers, whatever its scenes did)
+        barrier()
+        t = time.perf_counter()
+        for i in range(args.steps):
+            step(idx[i % len(idx)])
+        barrier()
+        return (time.perf_counter() - t) / args.steps * 1e3
+    ms_accepted = timed_subset([i for i in range(K) if outcomes[i] in ("accepted", "n/a")]) if K > 1 else None
+    ms_scene_a = timed_subset([0]) if K > 1 else None
     ctx.time_only(None)
     ktimes: dict[str, list[float]] = {}
-    for _ in range(EXTRA_STEPS):
-        step()
+    for _ in range(EXTRA_STEPS):  # (scene A: the per-kernel breakdown of the route that is taken when the speculation holds)
+        step(0)
         ctx.synchronize()
         for name, ms in ctx.last_kernel_times():
             ktimes.setdefault(name, []).append(ms)
@@ -201,18 +246,34 @@ def main():
             "scaling": "strong" if (args.mode == "stripe" and world > 1) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"dual-pol u16 {rows}x{cols} scene resident in HBM -> dB + {strategy.name} autoscale u8 x2 "
-                                   f"-> synRGB ({'suppressed' if strategy.name in ('Clahe', 'Tamed') else 'default'} variant) interleaved u8, native resolution (save.rs:317-367)",
+                                   f"-> synRGB ({'suppressed' if strategy.name in ('Clahe', 'Tamed') else 'default'} variant) interleaved u8, native resolution (save.rs:317-367); "
+                                   + (f"the steps cycle over {K} resident scenes that differ in distribution ({', '.join(d[0] for d in scene_defs)}), scene A = the scene of rounds 1-3 first"
+                                      if K > 1 else "one scene (A) in every step"),
                        "mode": args.mode if world > 1 else "single", "rows": rows, "cols": cols,
                        "scenes_per_step": scenes_per_step,
+                       "scenes": [{"name": d[0], "what": d[4], "route": outcomes[i], "ms_one_synchronous_call": round(scene_sync_ms[i], 3)} for i, d in enumerate(scene_defs)],
                        "enqueue": "stream-ordered, one synchronisation after the K steps" if use_async else "one host round trip per step"},
             "roofline": roofline,
         }
+        if strategy == AutoscaleStrategy.Clahe and not striped:
+            # what the speculative route (sampled level histogram -> proven identity + predicted floor -> fused CLAHE -> RGB pass
+            # that verifies the floor) did over the TIMED steps: accepted = its RGB stood; refuted = the floor was mispredicted,
+            # unproven = level 0 or 255 not proven in both bands, pool_overflow = DN windows beyond the pass's LDS pool: in those
+            # three the exact apply -> finish -> compose kernels produced the raster (inside `value`)
+            per_step = [outcomes[i % K] for i in range(args.steps)]
+            out["spec"] = {k: per_step.count(k) for k in ("accepted", "refuted", "unproven", "pool_overflow")}
+            out["ms_per_step_accepted_scenes"] = round(ms_accepted, 3) if ms_accepted is not None else out["ms_per_step"]
+            out["ms_per_step_scene_a"] = round(ms_scene_a, 3) if ms_scene_a is not None else out["ms_per_step"]
     else:
         out = None
     # ---- everything below is beside the headline: it runs after the timed region, with the headline's rasters freed, and a
     # failure in it costs its own record, never the line
-    single_ms = elapsed / args.steps * 1e3  # one rank, one whole scene (batch mode): the N = 1 reference of the stripe leg
-    del band, rgb
+    # one rank, one whole scene A (batch mode): the N = 1 reference of the stripe leg, which runs scene A
+    single_ms = ms_scene_a if ms_scene_a is not None else elapsed / args.steps * 1e3
+    if rank == 0:  # the measured headline, on stderr, BEFORE anything beside it runs: a hang or a kill further down still leaves it in the log
+        print("bench.py headline (the full record follows on stdout): " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}),
+              file=sys.stderr, flush=True)
+    del band, rgb, scenes
     torch.cuda.empty_cache()
     if world > 1 and not args.no_secondary:
         sec = {}
@@ -225,17 +286,21 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(ctx, q, args.cpu_sample, int(strategy), torch, dev, rows if not args.no_cpu_full else 0, cols)
+                out["cpu_baseline"] = cpu_baseline(ctx, q, args.cpu_sample, int(strategy), torch, dev, rows if not args.no_cpu_full else 0, cols, rgb_a_host)
             except Exception as e:
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     ctx.close()
+    parity_failed = False
     if rank == 0:
         if sec_child is not None:
             out["secondary"] = secondary_collect(sec_child)
         print(json.dumps(out), flush=True)
+        parity_failed = isinstance(out.get("cpu_baseline"), dict) and out["cpu_baseline"].get("gpu_equals_oracle_full_size") is False
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:  # the line is out (a reader sees the flag); the exit code says the same
+        sys.exit("bench.py: the GPU's RGB raster of scene A differs from the CPU oracle's at full size")
 
 
 def self_launch(args):
@@ -329,18 +394,32 @@ def multi_rank_records(torch, dist, dev, rank, world, rows, cols, strategy, sing
     def barrier():
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
 
+    def all_ranks_ok(ok):
+        """A rank that failed its own set-up (context, allocations) must not leave its peers inside a collective: every rank
+        learns here whether ALL of them are ready, and the leg is skipped by all of them together otherwise."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     # (i) row stripes of one scene
-    try:
+    ctx = band = rgb = None
+    err = None
+    try:  # the fallible per-rank set-up, no collective in it
         ctx = sarpro_amd.Context(dev.index, timing=True)
-        uid = [sarpro_amd.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
         r0s, nrs = sarpro_amd.host_stripe_plan(rows, world)
         row0, rl = r0s[rank], nrs[rank]
         band = [torch.empty((max(rl, 1), pitch), dtype=torch.int16, device=dev) for _ in range(2)]
         rgb = torch.empty((max(rl, 1), pitch * 3), dtype=torch.uint8, device=dev)
         for b in range(2):
             ctx.dev_synth_scene_u16(synth.SEED_SCENE_A, b, q, rows, cols, row0, rl, band[b].data_ptr(), pitch)
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    try:
+        if not all_ranks_ok(err is None):
+            raise RuntimeError(err or "another rank failed its set-up: the leg is skipped on every rank")
+        uid = [sarpro_amd.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
 
         def stripe():
             ctx.stripe_run_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, row0, rl, pitch, strategy, SyntheticRgbMode.Default, rgb.data_ptr(), pitch)
@@ -359,13 +438,16 @@ def multi_rank_records(torch, dist, dev, rank, world, rows, cols, strategy, sing
                          "ms_per_scene": round(ms, 3), "value": round(rows * cols / ms / 1e3, 1), "unit": "Mpix/s", "scaling": "strong",
                          "speedup_vs_n1": round(single_ms / ms, 2) if single_ms else None, "n1_ms_per_scene": round(single_ms, 3) if single_ms else None,
                          "allreduce_us_max_over_ranks": ar, "kernels_ms_rank0": {k: round(v, 4) for k, v in kt.items() if not k.startswith("host:")}}
-        del band, rgb
-        ctx.close()
     except Exception as e:
         out["stripe"] = {"error": f"{type(e).__name__}: {e}"}
+    del band, rgb
+    if ctx is not None:
+        ctx.close()
     torch.cuda.empty_cache()
     # (ii) PCIe-inclusive leg, all ranks at once
-    try:
+    ctx = None
+    err = None
+    try:  # set-up without collectives, then one agreement
         ctx = sarpro_amd.Context(dev.index)
         dband = torch.empty((rows, pitch), dtype=torch.int16, device=dev)
         host = []
@@ -378,6 +460,11 @@ def multi_rank_records(torch, dist, dev, rank, world, rows, cols, strategy, sing
         rgb_h = torch.empty((rows, cols, 3), dtype=torch.uint8, pin_memory=True)
         b1, b2 = (h.numpy().view(np.uint16) for h in host)
         o = rgb_h.numpy()
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    try:
+        if not all_ranks_ok(err is None):
+            raise RuntimeError(err or "another rank failed its set-up: the leg is skipped on every rank")
 
         def e2e():
             rc = lib.sarpro_hip_dualpol_synrgb_u16(ctx._h, b1.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p), rows, cols, int(strategy), 0,
@@ -396,9 +483,10 @@ def multi_rank_records(torch, dist, dev, rank, world, rows, cols, strategy, sing
                                 "ms_per_scene_max_over_ranks": round(ms, 2), "value": round(world * px / ms / 1e3, 1), "unit": "Mpix/s aggregate",
                                 "pcie_gb_s_aggregate": round(world * (2 * px * 2 + px * 3) / ms / 1e6, 1), "pcie_gb_s_per_rank": round((2 * px * 2 + px * 3) / ms / 1e6, 1)}
         del host, rgb_h
-        ctx.close()
     except Exception as e:
         out["e2e_all_ranks"] = {"error": f"{type(e).__name__}: {e}"}
+    if ctx is not None:
+        ctx.close()
     return out
 
 
@@ -420,7 +508,7 @@ def pmc_traffic_gb(kernel, local_px):
         return None
 
 
-def cpu_baseline(ctx, q, side, strategy, torch, dev, full_rows=0, full_cols=0):
+def cpu_baseline(ctx, q, side, strategy, torch, dev, full_rows=0, full_cols=0, gpu_rgb=None):
     """Time the CPU oracle on the same synthetic workload: (i) ONE thread -- the reference's behaviour, its hot path has no
     threads -- median of 3 runs on a side x side sample, and ONE run on the metric's own configuration
     (full_rows x full_cols, ~30 s) beside it, so that "the per-pixel cost does not depend on the scene size" is shown, not
@@ -483,6 +571,10 @@ def cpu_baseline(ctx, q, side, strategy, torch, dev, full_rows=0, full_cols=0):
             out["full_size"] = {"value": out["value"], "unit": "Mpix/s", "cores": 1, "seconds": round(t1, 1),
                                 "what": f"{full_rows}x{full_cols} dual-pol scene (the metric's configuration), whole path, one run on 1 host thread"}
             out["sample"] = f"value: one {full_rows}x{full_cols} run ({t1:.1f} s); sample_value: " + out["sample"]
+            if gpu_rgb is not None:  # the oracle as the checker: EVERY pixel of the GPU's raster of the same scene (scene A, fused route)
+                out["gpu_equals_oracle_full_size"] = bool(gpu_rgb.shape == rgbf.shape and np.array_equal(gpu_rgb, rgbf))
+                if not out["gpu_equals_oracle_full_size"]:
+                    out["gpu_vs_oracle_differing_bytes"] = int((gpu_rgb != rgbf).sum()) if gpu_rgb.shape == rgbf.shape else -1
             if mt is not None:
                 (t2,), (rc2, rgb2) = timed(lambda: oracle.dualpol_clahe_synrgb_mt(fb[0], fb[1]), 1)
                 out["row_parallel"]["full_size"] = {"value": round(px / t2 / 1e6, 1), "unit": "Mpix/s", "seconds": round(t2, 2),

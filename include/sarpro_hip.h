@@ -303,6 +303,19 @@ int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **names_out, fl
  * dozen kernels timed one by one runs ~6 % slower than untimed, timed on its dominant kernel only ~0.5 %. */
 int sarpro_hip_ctx_time_only(sarpro_hip_ctx *ctx, const char *kernel_name);
 
+/* ---- context attributes: the route switches.  Every fast route of the library has a slower twin that must give the same raster
+ * ("Cross-check switches"), plus a few test hooks and planner tuning values.  They live on the CONTEXT: each
+ * attribute NAME (e.g. "NO_SPEC", "SAMPLE_STRIDE"; an optional "SARPRO_HIP_" prefix is accepted) is either unset (the default
+ * behaviour) or set to an integer; a switch is on when set and non-zero.  The environment variable SARPRO_HIP_<NAME> is read ONCE,
+ * when the context is created, as the attribute's initial value (a non-numeric word counts as 1; SPEC_FORCE takes
+ * "mispredict" = 1 and / or "nospec" = 2, F32_ZONES takes "tiny" = 2); no call path reads the environment afterwards.  A context's
+ * twin (the second band of a dual-pol f32 product) follows its parent.  Planner attributes (STRIP_ALIGN, CHUNK_ROWS, ...) act when a
+ * shape's plan is first built.  sarpro_hip_attr_name(i) enumerates the names (NULL past the last). */
+int sarpro_hip_ctx_set_attr(sarpro_hip_ctx *ctx, const char *name, int64_t value);
+int sarpro_hip_ctx_reset_attr(sarpro_hip_ctx *ctx, const char *name); /* back to "unset" */
+int sarpro_hip_ctx_get_attr(const sarpro_hip_ctx *ctx, const char *name, int64_t *value, int *is_set);
+const char *sarpro_hip_attr_name(int index);
+
 /* Diagnostics of the last speculative CLAHE chain of this context.  A whole dual-pol u8 scene (>= 32 MP) counts its level
  * histogram on sampled rows only; from the sample the chain PROVES that the u8 rescale of autoscale.rs:348-364 is the
  * identity (levels 0 and 255 occur) and PREDICTS the suppressed-synRGB floor (synthetic_rgb.rs:99-113), composes with the
@@ -312,7 +325,7 @@ int sarpro_hip_ctx_time_only(sarpro_hip_ctx *ctx, const char *kernel_name);
 typedef struct {
     uint32_t spec_ok, verdict;
     int32_t floor_pred;       /* predicted floor before the +3 cushion; 37 stands for "37 or more" (the cushion caps at 40) */
-    uint32_t pad;
+    uint32_t pool_overflow;   /* 1: spec_ok, but the fused CLAHE -> RGB pass stepped aside (the bands' DN windows exceed its LDS pool): verdict 1 */
     uint64_t n_lt[2];         /* band-pixels with level < floor_pred, < floor_pred + 1 (exact, counted by the compose pass) */
     uint64_t target;          /* synthetic_rgb.rs:99-100 */
     double est_lt[2];         /* the sample's estimate of n_lt */
@@ -478,6 +491,11 @@ int sarpro_hip_host_synrgb_luts(int strategy, const uint64_t combined_hist[256],
                                 uint8_t *luts_out, int *floor_out);
 /* CLAHE shape check: 0 when the reference's tile arithmetic underflows (autoscale.rs:250,254). */
 int sarpro_hip_host_clahe_shape_ok(size_t rows, size_t cols);
+/* autoscale.rs:327-329 for a bin whose four tile CDFs are all 1.0 (every sample from p99 up): level 255 or -- in the first half tile
+ * row / column, where a blend weight is negative and (1 - d) + d can round below 1.0 -- 254, by the pixel's row and column alone.
+ * col_class[cols] in {0, 1, 2}; bit k of row_bits[rows]: a saturated pixel of that row in a column of class k gets 255 (else 254).
+ * What the fused CLAHE -> RGB pass uses instead of the f64 blend for such samples.  SARPRO_HIP_ERR_UNSUPPORTED_SHAPE: no table. */
+int sarpro_hip_host_clahe_saturated_levels(size_t rows, size_t cols, uint8_t *col_class, uint8_t *row_bits);
 /* Row-stripe plan: stripes aligned to CLAHE tile rows (tile_h = ceil(rows/8)).
  * row0_out / nrows_out hold nranks entries. */
 int sarpro_hip_host_stripe_plan(size_t rows, int nranks, size_t *row0_out, size_t *nrows_out);
@@ -501,6 +519,17 @@ int sarpro_hip_host_f32_clahe_bin_thresholds(const sarpro_hip_stats *stats, floa
 int sarpro_hip_synth_scene_u16_dev(sarpro_hip_ctx *ctx, uint64_t seed, int band,
                                    const uint16_t *q_tables_host, size_t rows_total, size_t cols,
                                    size_t row0, size_t rows_local, uint16_t *d_out, size_t pitch);
+/* The same generator with the scene's structure selectable (bench.py cycles its timed steps over scenes that differ in
+ * distribution, not only in seed).  flags: bit 0 no no-data wedges (no invalid pixel anywhere), bit 1 no bright targets,
+ * bits 4-7 class map (0: (r/b + 3 c/b) mod 4, the generator above; 1: (r/b xor c/b) mod 4; 2: diagonal bands ((r + c) / b) mod 4;
+ * 3: one class -- table 1 -- everywhere), bits 8-15 class blocks per side (0 = 16: b = ceil(rows / 16)). */
+#define SARPRO_HIP_SYNTH_NO_WEDGE 1u
+#define SARPRO_HIP_SYNTH_NO_BRIGHT 2u
+#define SARPRO_HIP_SYNTH_MAP(m) (((unsigned)(m) & 15u) << 4)
+#define SARPRO_HIP_SYNTH_BLOCKS(n) (((unsigned)(n) & 255u) << 8)
+int sarpro_hip_synth_scene_u16_dev_ex(sarpro_hip_ctx *ctx, uint64_t seed, int band,
+                                      const uint16_t *q_tables_host, size_t rows_total, size_t cols,
+                                      size_t row0, size_t rows_local, uint16_t *d_out, size_t pitch, uint32_t flags);
 
 #ifdef __cplusplus
 }

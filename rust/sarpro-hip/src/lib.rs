@@ -143,6 +143,31 @@ impl RasterCore {
     pub fn stream(&self) -> *mut c_void { unsafe { sys::sarpro_hip_ctx_stream(self.ctx) } }
     pub fn synchronize(&self) -> Result<()> { self.chk(unsafe { sys::sarpro_hip_ctx_synchronize(self.ctx) }) }
 
+    // ------------------------------------------------------------------ context attributes (route switches)
+    /// A route switch of this context ("NO_SPEC", "SAMPLE_STRIDE", ...: include/sarpro_hip.h, "context attributes").  The environment
+    /// variable `SARPRO_HIP_<NAME>` only supplies the attribute's initial value when the context is created; nothing reads it later.
+    pub fn set_attr(&self, name: &str, value: i64) -> Result<()> {
+        let n = std::ffi::CString::new(name).map_err(|_| HipError { code: sys::SARPRO_HIP_ERR_INVALID_ARG, message: "attribute name holds a NUL".into() })?;
+        self.chk(unsafe { sys::sarpro_hip_ctx_set_attr(self.ctx, n.as_ptr(), value) })
+    }
+    /// back to "unset" (the default route)
+    pub fn reset_attr(&self, name: &str) -> Result<()> {
+        let n = std::ffi::CString::new(name).map_err(|_| HipError { code: sys::SARPRO_HIP_ERR_INVALID_ARG, message: "attribute name holds a NUL".into() })?;
+        self.chk(unsafe { sys::sarpro_hip_ctx_reset_attr(self.ctx, n.as_ptr()) })
+    }
+    /// `Some(value)` when the attribute is set
+    pub fn attr(&self, name: &str) -> Result<Option<i64>> {
+        let n = std::ffi::CString::new(name).map_err(|_| HipError { code: sys::SARPRO_HIP_ERR_INVALID_ARG, message: "attribute name holds a NUL".into() })?;
+        let (mut v, mut set) = (0i64, 0 as c_int);
+        self.chk(unsafe { sys::sarpro_hip_ctx_get_attr(self.ctx, n.as_ptr(), &mut v, &mut set) })?;
+        Ok(if set != 0 { Some(v) } else { None })
+    }
+    /// the names `set_attr` accepts
+    pub fn attr_names() -> Vec<String> {
+        (0..).map(|i| unsafe { sys::sarpro_hip_attr_name(i) }).take_while(|p| !p.is_null())
+            .map(|p| unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned()).collect()
+    }
+
     // ------------------------------------------------------------------ pipeline.rs
     /// pipeline.rs:8 -- `(db, valid_mask)`
     pub fn try_process_scalar_data_inplace(&self, processed: &Array2<f32>) -> Result<(Array2<f64>, Vec<bool>)> {

@@ -96,7 +96,8 @@ SYMBOLS = [
     "sarpro_hip_dualpol_synrgb_resized_u16", "sarpro_hip_dualpol_synrgb_resized_u16_dev", "sarpro_hip_dualpol_synrgb_f32_dev",
     "sarpro_hip_dualpol_synrgb_resized_f32", "sarpro_hip_dualpol_synrgb_resized_f32_dev", "sarpro_hip_batch_dualpol_synrgb_resized_f32", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
     "sarpro_hip_batch_dualpol_synrgb_resized_u16",
-    "sarpro_hip_synth_scene_u16_dev",
+    "sarpro_hip_synth_scene_u16_dev", "sarpro_hip_synth_scene_u16_dev_ex",
+    "sarpro_hip_host_clahe_saturated_levels", "sarpro_hip_ctx_set_attr", "sarpro_hip_ctx_reset_attr", "sarpro_hip_ctx_get_attr", "sarpro_hip_attr_name",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -168,11 +169,15 @@ _proto("sarpro_hip_ctx_time_only", _i, _vp, C.c_char_p)
 
 
 class SpecReport(C.Structure):
-    _fields_ = [("spec_ok", C.c_uint32), ("verdict", C.c_uint32), ("floor_pred", C.c_int32), ("pad", C.c_uint32),
+    _fields_ = [("spec_ok", C.c_uint32), ("verdict", C.c_uint32), ("floor_pred", C.c_int32), ("pool_overflow", C.c_uint32),
                 ("n_lt", C.c_uint64 * 2), ("target", C.c_uint64), ("est_lt", C.c_double * 2), ("sample_valid", C.c_uint64 * 2)]
 
 
 _proto("sarpro_hip_ctx_spec_report", _i, _vp, C.POINTER(SpecReport))
+_proto("sarpro_hip_ctx_set_attr", _i, _vp, C.c_char_p, C.c_int64)
+_proto("sarpro_hip_ctx_reset_attr", _i, _vp, C.c_char_p)
+_proto("sarpro_hip_ctx_get_attr", _i, _vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int))
+_proto("sarpro_hip_attr_name", C.c_char_p, _i)
 _proto("sarpro_hip_stripe_begin_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, C.POINTER(_vp))
 _proto("sarpro_hip_stripe_phase1", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
 _proto("sarpro_hip_stripe_phase2", _i, _vp, C.POINTER(_vp), C.POINTER(_sz))
@@ -203,8 +208,10 @@ _proto("sarpro_hip_host_clahe_cdfs", _i, _vp, _sz, _sz, _vp)
 _proto("sarpro_hip_host_u8_rescale_lut", _i, C.c_uint, C.c_uint, _vp)
 _proto("sarpro_hip_host_synrgb_luts", _i, _i, _vp, _u64, _vp, C.POINTER(_i))
 _proto("sarpro_hip_host_clahe_shape_ok", _i, _sz, _sz)
+_proto("sarpro_hip_host_clahe_saturated_levels", _i, _sz, _sz, _vp, _vp)
 _proto("sarpro_hip_host_stripe_plan", _i, _sz, _i, _vp, _vp)
 _proto("sarpro_hip_synth_scene_u16_dev", _i, _vp, _u64, _i, _vp, _sz, _sz, _sz, _sz, _vp, _sz)
+_proto("sarpro_hip_synth_scene_u16_dev_ex", _i, _vp, _u64, _i, _vp, _sz, _sz, _sz, _sz, _vp, _sz, C.c_uint32)
 _proto("sarpro_hip_host_f32_valid_threshold", C.c_float)
 _proto("sarpro_hip_host_f32_bin4096_thresholds", _i, C.c_double, C.c_double, _vp)
 _proto("sarpro_hip_host_f32_level_thresholds", _i, _S, _i, _vp)

@@ -45,6 +45,8 @@ def _vp(a):
 class Context:
     """One sarpro_hip_ctx: a device, a stream, a grow-only workspace.  One per host thread."""
 
+    _live = None  # weakref.WeakSet of the open contexts (the test suite mirrors route-switch changes onto them: tests/conftest.py)
+
     def __init__(self, device: int = 0, timing: bool = False, async_dev: bool = False):
         h = C.c_void_p()
         # async_dev: SARPRO_HIP_CTX_ASYNC_DEV -- dev_dualpol_synrgb_u16 returns once enqueued; call synchronize()
@@ -53,6 +55,10 @@ class Context:
             raise SarproHipError(rc, (lib.sarpro_hip_last_error(None) or b"").decode())
         self._h = h
         self.device = device
+        if Context._live is None:
+            import weakref
+            Context._live = weakref.WeakSet()
+        Context._live.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -94,7 +100,42 @@ class Context:
         r = SpecReport()
         self._chk(lib.sarpro_hip_ctx_spec_report(self._h, C.byref(r)))
         return {"spec_ok": int(r.spec_ok), "verdict": int(r.verdict), "floor_pred": int(r.floor_pred), "n_lt": [int(x) for x in r.n_lt],
-                "target": int(r.target), "est_lt": [float(x) for x in r.est_lt], "sample_valid": [int(x) for x in r.sample_valid]}
+                "target": int(r.target), "est_lt": [float(x) for x in r.est_lt], "sample_valid": [int(x) for x in r.sample_valid], "pool_overflow": int(r.pool_overflow),
+                "outcome": ("unproven" if not r.spec_ok else "pool_overflow" if r.pool_overflow else "refuted" if r.verdict else "accepted")}
+
+    # ------------------------------------------------------------------ context attributes (route switches)
+    def set_attr(self, name: str, value=1):
+        """sarpro_hip_ctx_set_attr: `name` as in DESIGN.md's list of cross-check switches ("NO_SPEC", "SAMPLE_STRIDE", ...; the
+        SARPRO_HIP_ prefix is optional).  value None resets the attribute to "unset"; the two word-valued attributes also take their
+        words (SPEC_FORCE: "mispredict", "nospec", "mispredict,nospec"; F32_ZONES: "tiny")."""
+        if value is None:
+            return self.reset_attr(name)
+        if isinstance(value, str):
+            words = {"mispredict": 1, "nospec": 2, "mispredict,nospec": 3, "nospec,mispredict": 3, "tiny": 2}
+            try:
+                value = words[value] if value in words else int(value)
+            except ValueError:
+                value = 1  # any other word switches the attribute on, as a bare environment variable does at creation
+        self._chk(lib.sarpro_hip_ctx_set_attr(self._h, name.encode(), int(value)))
+
+    def reset_attr(self, name: str):
+        self._chk(lib.sarpro_hip_ctx_reset_attr(self._h, name.encode()))
+
+    def get_attr(self, name: str):
+        """-> the attribute's value, or None when it is unset"""
+        v, st = C.c_int64(0), C.c_int(0)
+        self._chk(lib.sarpro_hip_ctx_get_attr(self._h, name.encode(), C.byref(v), C.byref(st)))
+        return int(v.value) if st.value else None
+
+    @staticmethod
+    def attr_names():
+        out, i = [], 0
+        while True:
+            n = lib.sarpro_hip_attr_name(i)
+            if not n:
+                return out
+            out.append(n.decode())
+            i += 1
 
     def time_only(self, kernel_name=None):
         """Bracket only this kernel with events (None: every kernel); see sarpro_hip_ctx_time_only."""
@@ -359,11 +400,12 @@ class Context:
         self._chk(lib.sarpro_hip_synrgb_u8_dev(self._h, int(mode), int(strategy), _vp(d_b1), _vp(d_b2), n, _vp(d_rgb)))
 
     def dev_synth_scene_u16(self, seed: int, band: int, q_tables: np.ndarray, rows_total: int, cols: int,
-                            row0: int, rows_local: int, d_out: int, pitch: int):
+                            row0: int, rows_local: int, d_out: int, pitch: int, flags: int = 0):
+        """flags: synth.NO_WEDGE | synth.NO_BRIGHT | synth.class_map(m) | synth.blocks(n) (sarpro_hip_synth_scene_u16_dev_ex)"""
         q = np.ascontiguousarray(q_tables, np.uint16)
         assert q.shape == (2, 4, 65536)
-        self._chk(lib.sarpro_hip_synth_scene_u16_dev(self._h, seed, band, _vp(q), rows_total, cols, row0, rows_local,
-                                                     _vp(d_out), pitch))
+        self._chk(lib.sarpro_hip_synth_scene_u16_dev_ex(self._h, seed, band, _vp(q), rows_total, cols, row0, rows_local,
+                                                        _vp(d_out), pitch, flags))
 
     # ------------------------------------------------------------------ row-stripe protocol
     def stripe_begin_u16(self, d_b1: int, d_b2: int, rows_total: int, cols: int, row0: int, rows_local: int,
@@ -620,6 +662,16 @@ def host_synrgb_luts(strategy, combined_hist: np.ndarray | None = None, n_per_ba
     if rc:
         raise SarproHipError(rc, "host_synrgb_luts")
     return luts[:256].copy(), luts[256:512].copy(), luts[512:].reshape(256, 256).copy(), fl.value
+
+
+def host_clahe_saturated_levels(rows: int, cols: int):
+    """(col_class[cols], row_bits[rows]) of sarpro_hip_host_clahe_saturated_levels; the level of a saturated pixel (r, c) is
+    255 if (row_bits[r] >> col_class[c]) & 1 else 254."""
+    cc, rb = np.zeros(cols, np.uint8), np.zeros(rows, np.uint8)
+    rc = lib.sarpro_hip_host_clahe_saturated_levels(rows, cols, _vp(cc), _vp(rb))
+    if rc != _lib.OK:
+        raise SarproHipError(rc, "no saturation table for this shape")
+    return cc, rb
 
 
 def host_clahe_shape_ok(rows: int, cols: int) -> bool:

@@ -95,6 +95,67 @@ HostTimer::~HostTimer() {
 } // namespace sarpro
 
 // ---------------------------------------------------------------------------------------
+// context attributes
+// ---------------------------------------------------------------------------------------
+namespace sarpro {
+static const char *const kAttrNames[A_COUNT] = {
+#define X(n) #n,
+    SARPRO_ATTR_LIST(X)
+#undef X
+};
+const char *attr_name(int a) { return a >= 0 && a < A_COUNT ? kAttrNames[a] : nullptr; }
+int attr_index(const char *name) {
+    if (!name) return -1;
+    if (!strncmp(name, "SARPRO_HIP_", 11)) name += 11;
+    for (int a = 0; a < A_COUNT; ++a)
+        if (!strcmp(name, kAttrNames[a])) return a;
+    return -1;
+}
+// The value of a switch as the environment (or a caller) spells it: a number; "" or any other word = 1 (the variable's presence
+// used to be the switch); the two word-valued ones: SPEC_FORCE = "mispredict" (1) and / or "nospec" (2), F32_ZONES = "tiny" (2).
+static long long attr_parse(int a, const char *e) {
+    if (a == A_SPEC_FORCE && !(e[0] >= '0' && e[0] <= '9'))
+        return (strstr(e, "mispredict") ? (long long)kSpecForceMispredict : 0) | (strstr(e, "nospec") ? (long long)kSpecForceNoSpec : 0);
+    if (a == A_F32_ZONES && !strcmp(e, "tiny")) return 2;
+    char *end = nullptr;
+    const long long v = strtoll(e, &end, 10);
+    return (end && end != e && *end == 0) ? v : 1;
+}
+void attrs_from_environment(AttrSet *out) {
+    for (int a = 0; a < A_COUNT; ++a) {
+        const std::string var = std::string("SARPRO_HIP_") + kAttrNames[a];
+        if (const char *e = getenv(var.c_str())) { out->set[a] = true; out->v[a] = attr_parse(a, e); }
+    }
+}
+} // namespace sarpro
+
+extern "C" int sarpro_hip_ctx_set_attr(sarpro_hip_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const int a = sarpro::attr_index(name);
+    if (a < 0) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "unknown context attribute");
+    ctx->attrs.set[a] = true; ctx->attrs.v[a] = value;
+    if (ctx->twin) { ctx->twin->attrs.set[a] = true; ctx->twin->attrs.v[a] = value; }
+    return SARPRO_HIP_OK;
+}
+extern "C" int sarpro_hip_ctx_reset_attr(sarpro_hip_ctx *ctx, const char *name) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const int a = sarpro::attr_index(name);
+    if (a < 0) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "unknown context attribute");
+    ctx->attrs.set[a] = false; ctx->attrs.v[a] = 0;
+    if (ctx->twin) { ctx->twin->attrs.set[a] = false; ctx->twin->attrs.v[a] = 0; }
+    return SARPRO_HIP_OK;
+}
+extern "C" int sarpro_hip_ctx_get_attr(const sarpro_hip_ctx *ctx, const char *name, int64_t *value, int *is_set) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const int a = sarpro::attr_index(name);
+    if (a < 0) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (value) *value = ctx->attrs.v[a];
+    if (is_set) *is_set = ctx->attrs.set[a] ? 1 : 0;
+    return SARPRO_HIP_OK;
+}
+extern "C" const char *sarpro_hip_attr_name(int index) { return sarpro::attr_name(index); }
+
+// ---------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------
 extern "C" const char *sarpro_hip_version(void) { return "sarpro-hip 0.1 (gfx950)"; }
@@ -115,6 +176,7 @@ extern "C" int sarpro_hip_ctx_create(int device, unsigned flags, sarpro_hip_ctx 
     ctx->flags = flags;
     ctx->timing = (flags & SARPRO_HIP_CTX_TIMING) != 0;
     ctx->async_dev = (flags & SARPRO_HIP_CTX_ASYNC_DEV) != 0;
+    sarpro::attrs_from_environment(&ctx->attrs); // the route switches' defaults: read here, never again
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_err = hipGetErrorString(e);
         delete ctx;
@@ -175,6 +237,7 @@ extern "C" int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_r
     out->n_lt[0] = st.n_lt[0]; out->n_lt[1] = st.n_lt[1]; out->target = st.target;
     out->est_lt[0] = st.est_lt[0]; out->est_lt[1] = st.est_lt[1];
     out->sample_valid[0] = st.sample_valid[0]; out->sample_valid[1] = st.sample_valid[1];
+    out->pool_overflow = st.pool_overflow;
     return SARPRO_HIP_OK;
 }
 
@@ -210,17 +273,15 @@ namespace sarpro {
 // so with the vector width alone (8) nearly every segment straddled a line at both ends: +13 % of HBM traffic on the apply
 // pass by the PMC counters (profiles/r2_traffic.json).  The leading lanes of a cell's first strip are masked instead.
 constexpr size_t kRgbItemRows = 256, kSampleItemRows = 1024;
-static size_t strip_align(int vecw) {
+static size_t strip_align(const StripePlan &P, int vecw) { // (STRIP_ALIGN: planner tuning, read when the plan is built)
     if (vecw != 8 && vecw != 4) return (size_t)vecw;
-    size_t a = 64;
-    if (const char *e = getenv("SARPRO_HIP_STRIP_ALIGN")) a = (size_t)std::max(1, atoi(e));
-    return std::max<size_t>(vecw, a / vecw * vecw);
+    return std::max<size_t>(vecw, P.strip_align_px / vecw * vecw);
 }
 
 static void push_strips(std::vector<Rect> &out, const StripePlan &P, size_t lo, size_t hi, size_t c0, size_t c1,
                         const int ids[4], size_t chunk_rows, int vecw, int flags = 0) {
     if (lo >= hi || c0 >= c1) return;
-    const size_t strip = 64 * (size_t)vecw, align = strip_align(vecw);
+    const size_t strip = 64 * (size_t)vecw, align = strip_align(P, vecw);
     for (size_t cs = c0 / align * align; cs < c1; cs += strip) {
         Rect r{};
         r.c0 = (int32_t)std::max(c0, cs);
@@ -292,8 +353,7 @@ static void build_pieces(StripePlan *P, int grid) {
             if (c0 >= c1) continue;
             const RowWeight &cw = g.col_w[c0];
             const bool neg = rw.d < 0.0 || cw.d < 0.0; // constant sign inside the cut cell
-            size_t palign = 4; // (pieces: 64-px alignment measured 5 % SLOWER on the histogram pass, unlike the strips of the apply pass)
-            if (const char *e = getenv("SARPRO_HIP_PIECE_ALIGN")) palign = (size_t)std::max(4, atoi(e) / 4 * 4);
+            const size_t palign = P->piece_align; // (pieces: 64-px alignment measured 5 % SLOWER on the histogram pass, unlike the strips of the apply pass)
             const size_t cstart = c0 / palign * palign;
             size_t nch = (c1 - cstart + 255) / 256, off = 0;
             while (nch > 0) {
@@ -361,11 +421,14 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     }
     StripePlan *P = new StripePlan();
     P->rows_total = rows_total; P->cols = cols; P->row0 = row0; P->rows_local = rows_local; P->vecw = vecw;
+    if (ctx->attrs.is_set(A_STRIP_ALIGN)) P->strip_align_px = (size_t)std::max<long long>(1, ctx->attrs.val(A_STRIP_ALIGN, 64));
+    if (ctx->attrs.is_set(A_PIECE_ALIGN)) P->piece_align = (size_t)std::max<long long>(4, ctx->attrs.val(A_PIECE_ALIGN, 4) / 4 * 4);
     build_clahe_geometry(rows_total, cols, &P->geom);
     const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
     const size_t target_items = 4096;
     size_t chunk_rows = std::min<size_t>(128, std::max<size_t>(16, (rows_local * strips_across + target_items - 1) / target_items)); // <= 128 rows: with line-aligned strips 112..160 rows measured 3-4 % faster than 234 and than 96, 64 rows 12 % slower (per-item table staging), 512 rows 10 % slower (the resident workgroups drift apart and lose the sweep's DRAM locality)
-    if (const char *e = getenv("SARPRO_HIP_CHUNK_ROWS")) chunk_rows = (size_t)std::max(8, atoi(e)); // experiments
+    const AttrSet &at = ctx->attrs; // planner tuning (experiments): read when a plan is built, the plan is cached per shape
+    if (at.is_set(A_CHUNK_ROWS)) chunk_rows = (size_t)std::max<long long>(8, at.val(A_CHUNK_ROWS, 0));
     const ClaheGeometry &g = P->geom;
     const bool split = false; // edge lanes are masked inside the vector kernels; no separate sliver items
     for (size_t ty = 0; ty < (size_t)kTiles; ++ty) {
@@ -407,14 +470,15 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
             // bit 0: the cell holds negative blend weights (dy < 0 or dx < 0) -- the speculative apply kernel widens its f32
             // error margin there
             const bool neg = rw.d < 0.0 || cw.d < 0.0;
-            add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw, neg ? 1 : 0);
+            const int cell_flags = (neg ? 1 : 0) | (rw.d < 0.0 ? 2 : 0) | (cw.d < 0.0 ? 4 : 0); // bit 1 / 2: which weight is negative (the margin depends on it)
+            add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw, cell_flags);
             if (vecw == 8 && row0 == 0 && rows_local == rows_total) { // the fused CLAHE -> RGB pass: 16 waves walk an item, so items are taller
                 size_t frows = kRgbItemRows;
-                if (const char *e = getenv("SARPRO_HIP_RGB_ITEM_ROWS")) frows = (size_t)std::max(16, atoi(e)); // experiments
-                add_rects(P->rgb_rects, nullptr, *P, r0, r1, c0, c1, ids, frows, vecw, neg ? 1 : 0);
+                if (at.is_set(A_RGB_ITEM_ROWS)) frows = (size_t)std::max<long long>(16, at.val(A_RGB_ITEM_ROWS, 0));
+                add_rects(P->rgb_rects, nullptr, *P, r0, r1, c0, c1, ids, frows, vecw, cell_flags);
                 size_t srows = kSampleItemRows;
-                if (const char *e = getenv("SARPRO_HIP_SAMPLE_ITEM_ROWS")) srows = (size_t)std::max(16, atoi(e)); // experiments
-                add_rects(P->sample_rects, nullptr, *P, r0, r1, c0, c1, ids, srows, vecw, neg ? 1 : 0);
+                if (at.is_set(A_SAMPLE_ITEM_ROWS)) srows = (size_t)std::max<long long>(16, at.val(A_SAMPLE_ITEM_ROWS, 0));
+                add_rects(P->sample_rects, nullptr, *P, r0, r1, c0, c1, ids, srows, vecw, cell_flags);
             }
         }
     }
@@ -426,7 +490,7 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
             return x.r0 != y.r0 ? x.r0 < y.r0 : x.cstart < y.cstart;
         });
     };
-    if (!getenv("SARPRO_HIP_NO_SWEEP_ORDER")) {
+    if (!at.on(A_NO_SWEEP_ORDER)) {
         sweep_order(P->hist_rects_tiled);
         sweep_order(P->hist_rects_flat);
         sweep_order(P->apply_rects);
@@ -440,6 +504,15 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_rgb_rects, P->rgb_rects.data(), P->rgb_rects.size() * sizeof(Rect));
+    if (!rc && !P->rgb_rects.empty()) { // the fused pass's saturation tables (host_logic.h); the column table padded so that every lane's 8-byte load is in range
+        std::vector<uint8_t> cc, rb;
+        P->sat_ok = clahe_saturated_levels(g, &cc, &rb);
+        if (P->sat_ok) {
+            cc.resize(round_up(cols, 64) + 64, 0);
+            rc = upload_vec(ctx, P->d_sat_col, cc.data(), cc.size());
+            if (!rc) rc = upload_vec(ctx, P->d_sat_row, rb.data(), rb.size());
+        }
+    }
     if (!rc) rc = upload_vec(ctx, P->d_sample_rects, P->sample_rects.data(), P->sample_rects.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_tiled, P->hist_sliver_tiled.data(), P->hist_sliver_tiled.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_flat, P->hist_sliver_flat.data(), P->hist_sliver_flat.size() * sizeof(Rect));
@@ -558,7 +631,7 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     a.rects = (tiled ? J.plan->d_hist_rects_tiled : J.plan->d_hist_rects_flat).as<Rect>() + first;
     a.lds_bins = 8192;
     const int nrects = last - first;
-    if (J.vec && tiled && J.nbands == 2 && J.plan->piece_grid > 0 && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_PIECE_HIST")) {
+    if (J.vec && tiled && J.nbands == 2 && J.plan->piece_grid > 0 && first == 0 && last == nall && nall > 0 && !ctx->attrs.on(A_NO_PIECE_HIST)) {
         // whole tiled pass, both bands: persistent workgroups on balanced pieces (piece_kernels.hip k_dn_hist_pieces)
         DnHistPiecesArgs pa{};
         for (int b = 0; b < 2; ++b) { pa.in[b] = a.in[b]; pa.tile_hist[b] = a.tile_hist[b]; }
@@ -566,7 +639,7 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
         pa.lds_bins = a.lds_bins;
         KernelTimer t(ctx, "dn_hist_u16");
         HIPCHK(ctx, launch_dn_hist_pieces(pa, J.plan->piece_grid, ctx->stream));
-    } else if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !getenv("SARPRO_HIP_NO_LINEAR_HIST")) {
+    } else if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !ctx->attrs.on(A_NO_LINEAR_HIST)) {
         KernelTimer t(ctx, "dn_hist_u16"); // whole untiled pass in one go: the in-order sweep
         HIPCHK(ctx, launch_dn_hist_u16_linear(a, (uint32_t)J.rows_local, (uint32_t)J.cols, J.nbands, ctx->stream));
     } else if (nrects > 0) {
@@ -726,7 +799,7 @@ static int job_phase3(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch)
         if (u8o) HIPCHK(ctx, hipMemsetAsync(ctx->level_hist.p, 0, sizeof(uint64_t) * 256 * kMaxBands, ctx->stream));
         const bool vec = J.vec && a.out_pitch % 8 == 0 && ptr_aligned16(a.out[0]) && (J.nbands < 2 || ptr_aligned16(a.out[1]));
         if (vec != J.vec) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "output raster must be 16-byte aligned with pitch % 8 == 0 when the input is");
-        if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands) && !getenv("SARPRO_HIP_NO_SPEC")) {
+        if (J.vec && u8o && clahe_apply_spec_ok(a, J.nbands) && !ctx->attrs.on(A_NO_SPEC)) {
             HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
             a.dump = ctx->spec_dump.as<uint8_t>();
             KernelTimer t(ctx, "clahe_apply_u8_spec");
@@ -781,7 +854,7 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
     // intermediate u8 rasters
     bool fused = false;
     if (!J.clahe() && J.synrgb && !d_out[0] && !d_out[1] && J.vec && J.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 &&
-        ptr_aligned16(d_rgb) && !getenv("SARPRO_HIP_NO_FUSED")) {
+        ptr_aligned16(d_rgb) && !ctx->attrs.on(A_NO_FUSED)) {
         LutComposeArgs probe{};
         probe.win_hi[0] = J.lut[0].win_hi; probe.win_hi[1] = J.lut[1].win_hi;
         fused = lut_compose_fits(probe);
@@ -930,7 +1003,7 @@ static int chain_prepare(sarpro_hip_ctx *ctx) {
 }
 
 static bool chain_eligible(const U16Job &J) {
-    if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
+    if (J.ctx->attrs.on(A_NO_CHAIN)) return false;
     // u16 output (no rescale, no composition) takes the same chain up to the blend, with the exact f64 kernel
     return J.clahe() && (J.u8_out() || !J.synrgb) && J.vec && !J.tamed_force && (J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total));
 }
@@ -975,13 +1048,8 @@ static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_
 // Scenes below this size keep the exact partial histogram: their chain is launch-bound, the gated kernels would cost more than
 // the sampled histogram saves.  SARPRO_HIP_SAMPLED_HIST_MIN_PX overrides (the tests run the speculative chain on small rasters).
 constexpr size_t kSampledHistMinPx = 32u << 20;
-static uint32_t spec_force_flags() { // SARPRO_HIP_SPEC_FORCE=mispredict,nospec: every rare branch of the speculative chain is testable
-    const char *e = getenv("SARPRO_HIP_SPEC_FORCE");
-    uint32_t f = 0;
-    if (!e) return f;
-    if (strstr(e, "mispredict")) f |= kSpecForceMispredict;
-    if (strstr(e, "nospec")) f |= kSpecForceNoSpec;
-    return f;
+static uint32_t spec_force_flags(const sarpro_hip_ctx *ctx) { // SPEC_FORCE = mispredict (1) | nospec (2): every rare branch of the speculative chain is testable
+    return (uint32_t)ctx->attrs.val(A_SPEC_FORCE, 0) & (kSpecForceMispredict | kSpecForceNoSpec);
 }
 
 static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_state);
@@ -1024,7 +1092,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         pa.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
         pa.tables = ctx->tables.as<uint8_t>();
         pa.supp_rg = consts + kChainOffSupp; pa.blue_pair_supp = consts + kChainOffBlue;
-        pa.force = spec_force_flags();
+        pa.force = spec_force_flags(ctx);
         KernelTimer t(ctx, "chain_predict");
         HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
     }
@@ -1079,15 +1147,15 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
     // Dual-pol u8 scene on one device: the level histogram is counted on sampled rows only and the composition is speculative
     // (k_chain_predict); SARPRO_HIP_NO_SAMPLED_HIST=1 keeps the partial histogram of every row and the unconditional tail.
-    const bool exact_only = getenv("SARPRO_HIP_NO_SPEC") != nullptr; // cross-check: every pixel through the exact f64 blend
+    const bool exact_only = ctx->attrs.on(A_NO_SPEC); // cross-check: every pixel through the exact f64 blend
     const size_t rgb_pitch_ok = rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb);
-    bool sampled = J.synrgb && J.nbands == 2 && J.u8_out() && !J.reduce && !exact_only && !getenv("SARPRO_HIP_FULL_LEVEL_HIST") &&
-                   !getenv("SARPRO_HIP_NO_SAMPLED_HIST") && d_rgb && rgb_pitch_ok && J.row0 == 0 && J.rows_local == J.rows_total;
+    bool sampled = J.synrgb && J.nbands == 2 && J.u8_out() && !J.reduce && !exact_only && !ctx->attrs.on(A_FULL_LEVEL_HIST) &&
+                   !ctx->attrs.on(A_NO_SAMPLED_HIST) && d_rgb && rgb_pitch_ok && J.row0 == 0 && J.rows_local == J.rows_total;
     uint32_t sample_stride = 17; // sampled rows cost the apply pass ~0.4 % each ninth: 9 -> 17 -> 33 measured 0.540 / 0.535 / 0.529 ms; the estimate's sigma grows with sqrt(stride)
     if (sampled) {
         size_t min_px = kSampledHistMinPx;
-        if (const char *e = getenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX")) min_px = (size_t)strtoull(e, nullptr, 10);
-        if (const char *e = getenv("SARPRO_HIP_SAMPLE_STRIDE")) sample_stride = (uint32_t)std::max(5, atoi(e));
+        if (ctx->attrs.is_set(A_SAMPLED_HIST_MIN_PX)) min_px = (size_t)std::max<long long>(0, ctx->attrs.val(A_SAMPLED_HIST_MIN_PX, 0));
+        if (ctx->attrs.is_set(A_SAMPLE_STRIDE)) sample_stride = (uint32_t)std::max<long long>(5, ctx->attrs.val(A_SAMPLE_STRIDE, 0));
         if ((size_t)J.rows_total * J.cols < min_px) sampled = false;
     }
     ChainSpecState *d_spec = nullptr;
@@ -1119,7 +1187,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
             ta.out[b] = ctx->tile_bins.as<unsigned long long>() + (size_t)b * 64 * 256;
         }
         ta.clear = 1u; // the last reader of the tile histograms
-        if (!J.reduce && !getenv("SARPRO_HIP_SEPARATE_CDFS")) { // one device: the CDFs in the same launch
+        if (!J.reduce && !ctx->attrs.on(A_SEPARATE_CDFS)) { // one device: the CDFs in the same launch
             for (int b = 0; b < J.nbands; ++b) ta.cdfs_out[b] = ctx->cdfs.as<double>() + (size_t)b * 64 * 256;
             ta.rows = (uint32_t)J.rows_total; ta.cols = cols;
         }
@@ -1128,7 +1196,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         mark_tile_hist_clean(J);
     }
     RETCHK(chain_reduce(J, ctx->tile_bins.p, 64 * 256 * (size_t)J.nbands, "allreduce_tile_hists"));
-    if (J.reduce || getenv("SARPRO_HIP_SEPARATE_CDFS")) {
+    if (J.reduce || ctx->attrs.on(A_SEPARATE_CDFS)) {
         KernelTimer t(ctx, "chain_cdfs");
         HIPCHK(ctx, launch_chain_cdfs(ctx->tile_bins.as<unsigned long long>(), ctx->cdfs.as<double>(), (uint32_t)J.rows_total, cols,
                                       J.nbands, ctx->stream));
@@ -1136,7 +1204,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     // Whole dual-pol u8 scene, RGB only: the fused pass (kernels.hip 6a) -- sample-only pass -> identity proof + predicted floor +
     // tables -> ONE sweep DN, DN -> RGB that verifies the floor; refuted (or unproven, or windows beyond the pass's LDS pool), the
     // gated apply -> finish -> compose kernels below produce the raster.  SARPRO_HIP_NO_FUSED_RGB=1: the apply + compose route.
-    if (sampled && !d_out[0] && !d_out[1] && !J.plan->rgb_rects.empty() && !getenv("SARPRO_HIP_NO_FUSED_RGB")) {
+    if (sampled && !d_out[0] && !d_out[1] && !J.plan->rgb_rects.empty() && !ctx->attrs.on(A_NO_FUSED_RGB)) {
         ClaheRgbArgs fa{};
         for (int b = 0; b < 2; ++b) {
             fa.in[b] = J.d_in[b];
@@ -1147,9 +1215,11 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         fa.rects = J.plan->d_rgb_rects.as<Rect>(); fa.nrects = (int)J.plan->rgb_rects.size();
         fa.row_w = J.plan->d_row_w.as<RowWeight>(); fa.col_w = J.plan->d_col_w.as<RowWeight>(); fa.row_off = (int32_t)J.row0;
         fa.dev_state = d_state; fa.spec = d_spec; fa.tables = ctx->tables.as<uint8_t>();
+        fa.sat_ok = J.plan->sat_ok ? 1u : 0u; fa.sat_col = J.plan->d_sat_col.as<uint8_t>(); fa.sat_row = J.plan->d_sat_row.as<uint8_t>();
+        fa.sat_cols = (uint32_t)(round_up(J.cols, 64) + 64);
         // the sample-only pass costs ~0.025 ms + (apply pass) / stride: 0.056 ms at 17, 0.033 at 33; the wider stride's larger sigma (x 1.4: ~2.4 %
         // of scenes refuted instead of ~1.7 %, 1 ms each) costs 0.007 ms in expectation
-        const uint32_t fused_stride = getenv("SARPRO_HIP_SAMPLE_STRIDE") ? sample_stride : 33u;
+        const uint32_t fused_stride = ctx->attrs.is_set(A_SAMPLE_STRIDE) ? sample_stride : 33u;
         if (clahe_rgb_fused_supported(fa)) return job_run_fused_rgb(J, fa, d_rgb, rgb_pitch_px, fused_stride, stats_out);
     }
     // apply: levels into the internal rasters (dual-pol) or straight into the caller's raster (single band)
@@ -1196,7 +1266,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     // (the level histogram was cleared by the statistics kernels)
     // whole scene on this device: levels >= 64 are only counted in bulk (chain_kernels.hip k_level_hist_guard); a row
     // stripe keeps the full histogram, which is what the ranks sum
-    a.hist_mode = sampled ? 2u : (!J.reduce && !exact_only && !getenv("SARPRO_HIP_FULL_LEVEL_HIST")) ? 1u : 0u;
+    a.hist_mode = sampled ? 2u : (!J.reduce && !exact_only && !ctx->attrs.on(A_FULL_LEVEL_HIST)) ? 1u : 0u;
     if (sampled) {
         a.sample_stride = sample_stride;
         a.sample_phase = sample_stride / 2; // mid-phase: the row weights of the sampled rows average to those of all rows
@@ -1246,7 +1316,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         pa.tables = ctx->tables.as<uint8_t>();
         pa.supp_rg = consts + kChainOffSupp;
         pa.blue_pair_supp = consts + kChainOffBlue;
-        pa.force = spec_force_flags();
+        pa.force = spec_force_flags(ctx);
         {
             KernelTimer t(ctx, "chain_predict");
             HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
@@ -1305,7 +1375,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
 // dual-pol -> RGB (fused pass) and / or per-band u8 rasters (table pass), all with device-built tables
 static bool chain_levels_eligible(const U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, const uint8_t *d_rgb,
                                   size_t rgb_pitch_px) {
-    if (const char *e = getenv("SARPRO_HIP_NO_CHAIN")) if (atoi(e)) return false;
+    if (J.ctx->attrs.on(A_NO_CHAIN)) return false;
     if (J.clahe() || !J.vec || !(J.reduce || (J.row0 == 0 && J.rows_local == J.rows_total))) return false;
     if (!J.u8_out() && J.synrgb) return false; // u16 levels: per-band rasters only
     if (J.synrgb && !(J.nbands == 2 && J.in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb))) return false;
@@ -1409,7 +1479,7 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
         hi = std::max(hi, h_state[b].win_hi);
         uncertain = uncertain || (u16o && h_state[b].uncertain);
     }
-    if (u16o && getenv("SARPRO_HIP_FORCE_UNCERTAIN")) uncertain = true; // test hook: exercise the rerun
+    if (u16o && ctx->attrs.on(A_FORCE_UNCERTAIN)) uncertain = true; // test hook: exercise the rerun
     if (uncertain) return kRerunOnHostRoute;
     // LDS capacity (bytes per band) of the NEXT scene's DN tables (speed only)
     ctx->chain_levels_cap = std::min<uint32_t>(16384, std::max<uint32_t>(2048, (hi + 1 + 1023) / 1024 * 1024));
@@ -1868,9 +1938,9 @@ extern "C" int sarpro_hip_synrgb_u8(sarpro_hip_ctx *ctx, int mode, int strategy,
 // ---------------------------------------------------------------------------------------
 // synthetic scene
 // ---------------------------------------------------------------------------------------
-extern "C" int sarpro_hip_synth_scene_u16_dev(sarpro_hip_ctx *ctx, uint64_t seed, int band, const uint16_t *q_tables_host,
-                                              size_t rows_total, size_t cols, size_t row0, size_t rows_local,
-                                              uint16_t *d_out, size_t pitch) {
+extern "C" int sarpro_hip_synth_scene_u16_dev_ex(sarpro_hip_ctx *ctx, uint64_t seed, int band, const uint16_t *q_tables_host,
+                                                 size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                                                 uint16_t *d_out, size_t pitch, uint32_t flags) {
     if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
     if (band < 0 || band > 1 || !q_tables_host || (!d_out && rows_local * cols) || pitch < cols)
         return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synthetic scene arguments");
@@ -1878,9 +1948,14 @@ extern "C" int sarpro_hip_synth_scene_u16_dev(sarpro_hip_ctx *ctx, uint64_t seed
     const size_t qbytes = sizeof(uint16_t) * 4 * 65536;
     HIPCHK(ctx, ctx->qtab.reserve(qbytes));
     HIPCHK(ctx, hipMemcpyAsync(ctx->qtab.p, q_tables_host + (size_t)band * 4 * 65536, qbytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, launch_synth_scene_u16(seed, band, ctx->qtab.as<uint16_t>(), rows_total, cols, row0, rows_local, d_out, pitch, ctx->stream));
+    HIPCHK(ctx, launch_synth_scene_u16(seed, band, ctx->qtab.as<uint16_t>(), rows_total, cols, row0, rows_local, d_out, pitch, flags, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SARPRO_HIP_OK;
+}
+extern "C" int sarpro_hip_synth_scene_u16_dev(sarpro_hip_ctx *ctx, uint64_t seed, int band, const uint16_t *q_tables_host,
+                                              size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                                              uint16_t *d_out, size_t pitch) {
+    return sarpro_hip_synth_scene_u16_dev_ex(ctx, seed, band, q_tables_host, rows_total, cols, row0, rows_local, d_out, pitch, 0u);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -67,9 +67,15 @@ static int bind_thread_to_device_numa(int dev) {
     std::vector<int> cpus(4096);
     const int n = sarpro_hip_host_parse_cpulist(list, cpus.data(), (int)cpus.size());
     if (n <= 0) return -1;
-    cpu_set_t set;
+    // only CPUs the thread may already run on: a mask set by taskset / numactl / a job scheduler is narrowed, never widened
+    cpu_set_t allowed, set;
+    CPU_ZERO(&allowed);
+    if (pthread_getaffinity_np(pthread_self(), sizeof(allowed), &allowed) != 0) return -1;
     CPU_ZERO(&set);
-    for (int i = 0; i < n; ++i) if (cpus[i] >= 0 && cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &set);
+    int kept = 0;
+    for (int i = 0; i < n; ++i)
+        if (cpus[i] >= 0 && cpus[i] < CPU_SETSIZE && CPU_ISSET(cpus[i], &allowed)) { CPU_SET(cpus[i], &set); ++kept; }
+    if (kept == 0) return -1; // the node's CPUs are all outside the inherited mask: stay where the caller put us
     if (pthread_setaffinity_np(pthread_self(), sizeof(set), &set) != 0) return -1;
     return node;
 }

@@ -65,8 +65,11 @@ struct StripePlan {
     std::vector<Rect> hist_rects_tiled, hist_sliver_tiled; // per-tile DN histogram items
     std::vector<Rect> hist_rects_flat, hist_sliver_flat;   // single-histogram items (non-CLAHE)
     std::vector<Rect> apply_rects, apply_sliver;           // interpolation-cell items
+    size_t strip_align_px = 64, piece_align = 4;           // planner tuning (attributes STRIP_ALIGN, PIECE_ALIGN), fixed when the plan is built
     std::vector<Rect> rgb_rects, sample_rects;             // whole scene, vecw == 8: taller cell items of the fused CLAHE -> RGB pass (256 rows) and of its sample-only pre-pass (1024 rows)
     DevBuf d_rgb_rects, d_sample_rects;
+    DevBuf d_sat_col, d_sat_row;                           // fused pass: saturation classes of the columns / level bits of the rows (ClaheRgbArgs)
+    bool sat_ok = false;
     DevBuf d_hist_rects_tiled, d_hist_rects_flat, d_apply_rects, d_row_w, d_col_w;
     DevBuf d_hist_sliver_tiled, d_hist_sliver_flat, d_apply_sliver;
     // whole scene, vecw == 8: every persistent workgroup's pieces, balanced by cost (piece_kernels.hip)
@@ -76,7 +79,7 @@ struct StripePlan {
     DevBuf d_piece_items, d_piece_first;
     int refs = 0; // open stripe handles that hold this plan (the cache never evicts those)
     void release_all() {
-        d_piece_items.release(); d_piece_first.release(); d_rgb_rects.release(); d_sample_rects.release();
+        d_piece_items.release(); d_piece_first.release(); d_rgb_rects.release(); d_sample_rects.release(); d_sat_col.release(); d_sat_row.release();
         d_hist_rects_tiled.release(); d_hist_rects_flat.release(); d_apply_rects.release();
         d_hist_sliver_tiled.release(); d_hist_sliver_flat.release(); d_apply_sliver.release();
         d_row_w.release(); d_col_w.release();
@@ -104,13 +107,17 @@ struct BandWorker {
     static bool spin_until(const std::atomic<bool> &flag, int spins) {
         for (int i = 0; i < spins; ++i) {
             if (flag.load(std::memory_order_acquire)) return true;
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
         }
         return flag.load(std::memory_order_acquire);
     }
     void run() {
         for (;;) {
-            if (!spin_until(pending, 20000)) {
+            if (!spin_until(pending, 4000)) { // (~0.1 ms: scenes that stream arrive within it; an idle helper then sleeps on the condition variable)
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return pending.load(std::memory_order_acquire) || quit; });
                 if (quit) return;
@@ -150,9 +157,39 @@ struct BandWorker {
 };
 } // namespace sarpro
 
+// ---- context attributes: the route switches (cross-check twins of every fast route, test hooks, planner tuning).  A switch is
+// a (set, value) pair on the CONTEXT: read from the environment (SARPRO_HIP_<NAME>) once, when the context is created, and from then
+// on only through sarpro_hip_ctx_set_attr / _reset_attr -- no getenv on any call path (a library that re-reads the process
+// environment per call races with setenv in other threads and cannot be driven from the Rust surface).
+#define SARPRO_ATTR_LIST(X) \
+    X(NO_CHAIN) X(NO_FUSED) X(NO_SPEC) X(NO_PIECE_HIST) X(NO_LINEAR_HIST) X(NO_SWEEP_ORDER) X(FULL_LEVEL_HIST) X(NO_SAMPLED_HIST) \
+    X(SAMPLED_HIST_MIN_PX) X(SAMPLE_STRIDE) X(SEPARATE_CDFS) X(NO_FUSED_RGB) X(SPEC_FORCE) X(FORCE_UNCERTAIN) \
+    X(STRIP_ALIGN) X(PIECE_ALIGN) X(CHUNK_ROWS) X(RGB_ITEM_ROWS) X(SAMPLE_ITEM_ROWS) \
+    X(NO_MAILBOX) X(NO_STEP_ESTIMATE) X(F32_ZONES) X(F32_ZONES_DEBUG) X(F32_DIRECT) X(F32_DIRECT_QCAP) X(F32_LEVEL_GENERAL) \
+    X(F32_LEVEL_TABLE) X(F32_LEVEL_QCAP) X(F32_HOST_CDFS) X(F32_NO_VEC8) X(NO_BAND_TWIN) X(RESIZE_GENERIC) X(NO_RESIZE_LUT)
+namespace sarpro {
+enum Attr : int {
+#define X(n) A_##n,
+    SARPRO_ATTR_LIST(X)
+#undef X
+    A_COUNT
+};
+struct AttrSet {
+    long long v[A_COUNT] = {};
+    bool set[A_COUNT] = {};
+    bool on(Attr a) const { return set[a] && v[a] != 0; }                     // a switch: set and non-zero
+    long long val(Attr a, long long dflt) const { return set[a] ? v[a] : dflt; } // a value: the default when unset
+    bool is_set(Attr a) const { return set[a]; }
+};
+const char *attr_name(int a);                         // "NO_CHAIN", ... (without the SARPRO_HIP_ prefix); nullptr past the end
+int attr_index(const char *name);                     // with or without the prefix; -1: unknown
+void attrs_from_environment(AttrSet *out);            // once per context, at creation
+} // namespace sarpro
+
 struct sarpro_hip_ctx {
     int device = 0;
     unsigned flags = 0;
+    sarpro::AttrSet attrs;
     hipStream_t stream = nullptr;
     std::string err;
 

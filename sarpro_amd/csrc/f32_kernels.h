@@ -88,6 +88,7 @@ struct F32ClaheApplyArgs {
     double max_val;
     F32StepEstimate est;
     F32Pol pol;
+    uint32_t no_spec;                // context attribute NO_SPEC: the f64 blend for every sample also at u8 output (cross-check)
 };
 
 // ---- percentiles without the 4096-bin sweep (f32_path.cpp: zone route) ----
@@ -138,6 +139,7 @@ struct F32ZoneArgs {
     float *zone_buf;                 // wave v of workgroup w appends to [w * cap + v * cap / 4, + cap / 4): cap % 4 == 0
     uint32_t cap;
     uint32_t *zone_n;                // [grid * 4]: samples each wave found inside zones (> cap / 4: overflow, the route is abandoned)
+    uint32_t no_vec8;                // context attribute F32_NO_VEC8: four samples per lane also for u16 operands (cross-check)
 };
 // rows r = stride/2, stride/2 + stride, ...: the samples (pol-op applied) stored row by row in `sample` (nsrows x sample_pitch) and
 // the histogram of their leading bits

@@ -1165,7 +1165,12 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
 //     cells, 2^-10 where the cell extrapolates; all-zero and, in interior cells, all-one bins get biased entries that never come
 //     near an integer; an invalid sample reads entry 256 = "all zero").  What it saves here: 32 bytes of f64 CDFs per sample from
 //     LDS (half of it bank conflicts) and ten f64 operations.  SARPRO_HIP_NO_SPEC=1: the f64 kernel above.
+#ifdef SARPRO_SPEC_DELTA_R3
 constexpr float kF32SpecDeltaEdge = 1.0f / 1024.0f, kF32SpecDeltaInner = 1.0f / 4096.0f;
+#else
+constexpr float kF32SpecDeltaEdge = 6.2e-4f, kF32SpecDeltaInner = 1.6e-4f; // (kernels.hip 4b: 1.17x what the error bound requires)
+#endif
+constexpr float kF32SpecDeltaEdgeY = 3.0e-4f, kF32SpecDeltaEdgeX = 2.6e-4f; // cells that extrapolate along one axis only (kernels.hip 4b)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyArgs a) {
     __shared__ __align__(16) double cdf4[256 * 4];
@@ -1193,7 +1198,11 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyAr
     const int col = rc.cstart + lane_id() * VEC;
     const bool lane_on = col < rc.c1 && col + VEC > rc.c0;
     const bool vec_store = a.out_pitch % VEC == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+#ifdef SARPRO_SPEC_DELTA_R3
     const float near_delta = edge ? kF32SpecDeltaEdge : kF32SpecDeltaInner;
+#else
+    const float near_delta = !edge ? kF32SpecDeltaInner : (rc.pad[0] & 6) == 2 ? kF32SpecDeltaEdgeY : (rc.pad[0] & 6) == 4 ? kF32SpecDeltaEdgeX : kF32SpecDeltaEdge;
+#endif
     const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
     uint32_t zeros = 0;
     double dx[VEC], omdx[VEC];
@@ -1290,10 +1299,7 @@ inline int stream_grid(uint64_t items, int per_cu = 8) {
 // Kernels that end by flushing a block-private histogram with global atomics (256 or 4096 hot words shared by every block): on small
 // rasters the flush, not the sweep, is the kernel -- 4096 blocks x 256 adds on 256 addresses took 0.05 ms for a 4 MP band.  At least 32
 // vectors per thread before another block is worth its flush (SARPRO_HIP_HIST_GRID_VPT: tuning switch).
-inline int hist_grid_vectors_per_thread() {
-    if (const char *e = getenv("SARPRO_HIP_HIST_GRID_VPT")) return std::max(1, atoi(e));
-    return 8;
-}
+inline int hist_grid_vectors_per_thread() { return 8; }
 inline int hist_grid(uint64_t items, int per_cu = 8) {
     const uint64_t by_work = items / ((uint64_t)kBlock * (uint64_t)hist_grid_vectors_per_thread());
     const int g = stream_grid(items, per_cu);
@@ -1342,7 +1348,7 @@ hipError_t launch_f32_zone_finalize(const F32ZoneSelectArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_f32_prepass_zones(const F32ZoneArgs &a, bool vec, int grid, hipStream_t s) {
-    const bool v8 = vec && a.pol.op >= 0 && a.pol.u16 && a.pol.pitch % 8 == 0 && !getenv("SARPRO_HIP_F32_NO_VEC8");
+    const bool v8 = vec && a.pol.op >= 0 && a.pol.u16 && a.pol.pitch % 8 == 0 && !a.no_vec8;
     if (v8) hipLaunchKernelGGL((k_f32_prepass_zones<8, 1>), dim3(grid), dim3(kBlock), 0, s, a);
     else if (vec) hipLaunchKernelGGL((k_f32_prepass_zones<4, 2>), dim3(grid), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((k_f32_prepass_zones<1, 2>), dim3(grid), dim3(kBlock), 0, s, a);
@@ -1375,7 +1381,7 @@ hipError_t launch_f32_zone_count(const float *zone_buf, const uint32_t *zone_n, 
 // The zone sweep's turn is one long dependent chain (divide, table read, packed-counter add): it needs more waves per SIMD than
 // the plain min / max pass to hide it -- 400 MP, log-ratio of u16 bands: 0.81 / 0.50 / 0.44 / 0.46 ms with 2 / 4 / 6 / 8 workgroups per CU
 int f32_zone_grid(uint32_t rows, uint32_t cols, bool vec) {
-    static const int per_cu = getenv("SARPRO_HIP_ZONE_PER_CU") ? std::max(1, std::min(8, atoi(getenv("SARPRO_HIP_ZONE_PER_CU")))) : 6; // (<= 8: 2048 partials)
+    const int per_cu = 6; // (<= 8: 2048 partials)
     const int V = vec ? 4 : 1;
     return stream_grid((uint64_t)rows * ((cols + V - 1) / V), per_cu);
 }
@@ -1533,7 +1539,7 @@ hipError_t launch_f32_tile_hist(const F32TileHistArgs &a, int nrects, bool vec, 
 
 hipError_t launch_f32_clahe_apply(const F32ClaheApplyArgs &a, int nrects, bool vec, bool out16, hipStream_t s) {
     if (nrects <= 0) return hipSuccess;
-    if (!out16 && a.max_val == 255.0 && !getenv("SARPRO_HIP_NO_SPEC")) {
+    if (!out16 && a.max_val == 255.0 && !a.no_spec) {
         if (vec) hipLaunchKernelGGL((k_f32_clahe_apply_spec<4>), dim3(nrects), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_f32_clahe_apply_spec<1>), dim3(nrects), dim3(kBlock), 0, s, a);
         return hipGetLastError();

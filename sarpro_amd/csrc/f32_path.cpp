@@ -110,6 +110,13 @@ static int mail_open(sarpro_hip_ctx *ctx) {
 static uint32_t *mail_flag(sarpro_hip_ctx *ctx) { return ctx->mailbox.as<uint32_t>(); }
 template <typename T> static T *mail_payload(sarpro_hip_ctx *ctx, size_t off = 0) { return reinterpret_cast<T *>(ctx->mailbox.as<uint8_t>() + 64 + off); }
 // waits for the post with this sequence number; a stream that went idle (or failed) without posting ends the wait
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
 static int mail_wait(sarpro_hip_ctx *ctx, uint32_t seq) {
     volatile uint32_t *flag = mail_flag(ctx);
     for (uint32_t spins = 0;; ++spins) {
@@ -122,7 +129,9 @@ static int mail_wait(sarpro_hip_ctx *ctx, uint32_t seq) {
             }
             if (q != hipErrorNotReady) HIPCHK(ctx, q);
         }
-        __builtin_ia32_pause();
+        cpu_relax();
+        // a post that does not come within ~2 ms (a stalled device, a debugger, an oversubscribed host): stop burning the core
+        if (spins > (1u << 18)) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
 // A batch of small host -> device words and zero fills: one kernel with the mailbox on, copy / fill commands without it.
@@ -133,17 +142,17 @@ struct Prep {
     void upload(const void *h_src, void *d_dst, size_t bytes) { g.src[g.n] = h_src; g.dst[g.n] = d_dst; g.bytes[g.n] = (uint32_t)bytes; ++g.n; }
     void zero(void *d, size_t bytes) { g.zero[g.nz] = d; g.zbytes[g.nz] = (uint32_t)bytes; ++g.nz; }
 };
-static bool mail_enabled();
+static bool mail_enabled(const sarpro_hip_ctx *ctx);
 constexpr size_t kUploadSlotBytes = 12 * 1024, kUploadOff = 32 * 1024, kMailBigOff = 64 * 1024; // big payloads: [64 KiB, 192 KiB)
 static void *upload_stage(sarpro_hip_ctx *ctx, size_t bytes) {
-    if (mail_enabled() && bytes <= kUploadSlotBytes && mail_open(ctx) == SARPRO_HIP_OK) {
+    if (mail_enabled(ctx) && bytes <= kUploadSlotBytes && mail_open(ctx) == SARPRO_HIP_OK) {
         ctx->mail_upload_slot ^= 1u;
         return ctx->mailbox.as<uint8_t>() + kUploadOff + ctx->mail_upload_slot * kUploadSlotBytes;
     }
     return ctx->h_upload.p;
 }
 static int prep_run(sarpro_hip_ctx *ctx, const Prep &p) {
-    bool by_kernel = mail_enabled();
+    bool by_kernel = mail_enabled(ctx);
     for (int k = 0; k < p.g.n; ++k) { // (a source outside the mailbox: the level tables, too large for a slot)
         const uint8_t *s = static_cast<const uint8_t *>(p.g.src[k]), *m = ctx->mailbox.as<uint8_t>();
         by_kernel = by_kernel && m && s >= m && s < m + kMailBytes;
@@ -153,22 +162,21 @@ static int prep_run(sarpro_hip_ctx *ctx, const Prep &p) {
     for (int k = 0; k < p.g.nz; ++k) HIPCHK(ctx, hipMemsetAsync(p.g.zero[k], 0, p.g.zbytes[k], ctx->stream));
     return SARPRO_HIP_OK;
 }
-static bool mail_enabled() { return !getenv("SARPRO_HIP_NO_MAILBOX"); } // (cross-check switch: copy / fill commands and stream waits, as round 2)
+static bool mail_enabled(const sarpro_hip_ctx *ctx) { return !ctx->attrs.on(A_NO_MAILBOX); } // (cross-check switch: copy / fill commands and stream waits, as round 2)
 
-static uint32_t direct_queue_cap() { // SARPRO_HIP_F32_DIRECT_QCAP: a tiny queue, so that the tests reach the overflow hand-back
-    if (const char *e = getenv("SARPRO_HIP_F32_DIRECT_QCAP")) return (uint32_t)std::min<long>(kDirectQueueCap, std::max<long>(0, atol(e)));
-    return kDirectQueueCap;
+static uint32_t direct_queue_cap(const sarpro_hip_ctx *ctx) { // F32_DIRECT_QCAP: a tiny queue, so that the tests reach the overflow hand-back
+    return (uint32_t)std::min<long long>(kDirectQueueCap, std::max<long long>(0, ctx->attrs.val(A_F32_DIRECT_QCAP, kDirectQueueCap)));
 }
 constexpr uint64_t kDirectMaxPx = 16ull << 20; // above this the zone route's fixed ~0.1 ms is small beside its sweeps
 
 // estimate of a step table that is linear in dB: step = (dB(x) - low_db) / range_db * nsteps + bias, dB = 10 log10
-F32StepEstimate step_estimate(double low_db, double range_db, double nsteps, double bias, double gamma = 1.0) {
+F32StepEstimate step_estimate(const sarpro_hip_ctx *ctx, double low_db, double range_db, double nsteps, double bias, double gamma = 1.0) {
     F32StepEstimate e{};
     const double inv_x0 = std::pow(10.0, -low_db / 10.0), scale = 3.010299956639812 / range_db; // 10 log10(2)
     e.inv_x0 = (float)inv_x0; e.scale = (float)scale; e.bias = (float)bias; e.gamma = (float)gamma; e.nsteps = (float)nsteps;
     e.a_mul = (float)(scale * nsteps); e.b_add = (float)(std::log2(inv_x0) * scale * nsteps + bias);
     e.use = std::isfinite(e.inv_x0) && e.inv_x0 > 1e-30f && std::isfinite(e.scale) && e.scale * e.nsteps < 3.0e6f && std::isfinite(e.b_add) &&
-            !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
+            !ctx->attrs.on(A_NO_STEP_ESTIMATE);
     return e;
 }
 
@@ -243,8 +251,8 @@ constexpr float kZoneMaxMass = 0.10f;
 int f32_zone_presample(F32Band &B) {
     sarpro_hip_ctx *ctx = B.ctx;
     B.use_zones = false;
-    const char *env = getenv("SARPRO_HIP_F32_ZONES");
-    if (env && !std::strcmp(env, "0")) return SARPRO_HIP_OK;
+    const long long zones_attr = ctx->attrs.val(A_F32_ZONES, 1); // 0: never (the 4096-bin sweep), 2 ("tiny"): no room in the side buffers
+    if (zones_attr == 0) return SARPRO_HIP_OK;
     double pcts[8];
     const int np = needed_percentiles(B.strategy, B.tamed, pcts);
     const uint64_t px = (uint64_t)B.rows * B.cols;
@@ -260,7 +268,7 @@ int f32_zone_presample(F32Band &B) {
     B.zgrid = f32_zone_grid((uint32_t)B.rows, (uint32_t)B.cols, B.vec);
     const double share = (double)px / (double)B.zgrid;
     B.zcap = (uint32_t)std::max(1024.0, share * (double)kZoneMaxMass) / 4 * 4; // a quarter per wave
-    if (env && !std::strcmp(env, "tiny")) B.zcap = 0; // test switch: no room at all, the first kept sample overflows
+    if (zones_attr == 2) B.zcap = 0; // test switch: no room at all, the first kept sample overflows
     // one buffer: the stored sample now, the kept samples of the min / max pass afterwards
     HIPCHK(ctx, ctx->f32zone.reserve(std::max((size_t)B.zgrid * B.zcap, (size_t)nsrows * spitch) * sizeof(float)));
     {
@@ -306,13 +314,14 @@ int f32_zone_prepass(F32Band &B) {
     a.zone_n = reinterpret_cast<uint32_t *>(ws + kOffZoneN);
     {
         KernelTimer t(ctx, "f32_prepass_zones");
+        a.no_vec8 = ctx->attrs.on(A_F32_NO_VEC8) ? 1u : 0u;
         HIPCHK(ctx, launch_f32_prepass_zones(a, B.vec, grid, ctx->stream));
     }
     F32ZoneWork work_copy;
     const F32ZoneWork *h_work = &work_copy;
     bool overflow = false;
     std::memset(B.zgap, 0, sizeof(B.zgap));
-    if (mail_enabled()) {
+    if (mail_enabled(ctx)) {
         RETCHK(mail_open(ctx));
         F32ZoneMail *mail = mail_payload<F32ZoneMail>(ctx);
         const uint32_t seq = ++ctx->mail_seq;
@@ -348,7 +357,7 @@ int f32_zone_prepass(F32Band &B) {
     B.nz = std::min(std::max(h_work->nz, 0), kMaxZones);
     for (int i = 0; i < B.nz; ++i) { B.zlo[i] = h_work->bounds[2 * i]; B.zhi[i] = h_work->bounds[2 * i + 1]; B.zrun[i] = std::min(std::max(h_work->zone_run[i], 0), 6); }
     if (B.nz == 0) { B.use_zones = false; B.zone_note = "no zones (sample too small, or zones too heavy)"; }
-    if (getenv("SARPRO_HIP_F32_ZONES_DEBUG")) {
+    if (ctx->attrs.on(A_F32_ZONES_DEBUG)) {
         std::fprintf(stderr, "[zones] ns=%u kmin=%#x kmax=%#x nprobe=%u nz=%d mass_est=%.4f cap=%u grid=%d\n", h_work->ns, h_work->kmin, h_work->kmax,
                      h_work->nprobe, h_work->nz, (double)h_work->mass_est, B.zcap, B.zgrid);
         for (unsigned i = 0; i < h_work->nprobe && i < (unsigned)kMaxProbes; ++i)
@@ -406,7 +415,7 @@ int f32_zone_resolve(F32Band &B) {
                                           ctx->stream));
     }
     uint64_t *h_counts = ctx->h_small.as<uint64_t>();
-    if (mail_enabled()) {
+    if (mail_enabled(ctx)) {
         RETCHK(mail_open(ctx));
         h_counts = mail_payload<uint64_t>(ctx);
         PostSegs g{};
@@ -520,7 +529,7 @@ int f32_phase_a(F32Band &B) {
         HIPCHK(ctx, launch_f32_prepass(B.d_in, B.in_pitch, rows, cols, B.t_valid, B.vec, moments, d_part, pgrid, ctx->stream, B.pol));
     }
     F32Partial *h_part = ctx->h_small.as<F32Partial>();
-    const bool mail = mail_enabled();
+    const bool mail = mail_enabled(ctx);
     if (mail) RETCHK(mail_open(ctx));
     PostSegs pg{};
     if (mail) { // (big payload area: partials <= 64 KiB | 4096 bins 32 KiB | queue count | queue head 4 KiB)
@@ -543,7 +552,7 @@ int f32_phase_a(F32Band &B) {
         {
             KernelTimer t(ctx, "f32_hist4096_direct");
             HIPCHK(ctx, launch_f32_hist4096_direct(B.d_in, B.in_pitch, rows, cols, B.t_valid, B.vec, d_part, pgrid, d_hist, d_qn, ctx->f32zone.as<uint4>(),
-                                                   direct_queue_cap(), ctx->stream, B.pol));
+                                                   direct_queue_cap(ctx), ctx->stream, B.pol));
         }
         uint8_t *h = mail ? ctx->mailbox.as<uint8_t>() + kMailBigOff + 64 * 1024 : ctx->h_small.as<uint8_t>() + 64 * 1024; // behind the partials (<= 2048 x 32 B)
         B.direct_host = h;
@@ -593,7 +602,7 @@ int f32_phase_b(F32Band &B) {
         HIPCHK(ctx, hipMemcpyAsync(d_thr, thr, sizeof(float) * 4096, hipMemcpyHostToDevice, ctx->stream));
         KernelTimer t(ctx, "f32_hist4096");
         HIPCHK(ctx, launch_f32_hist4096(B.d_in, B.in_pitch, (uint32_t)B.rows, (uint32_t)B.cols, B.t_valid, B.vec, d_thr, d_hist,
-                                        step_estimate(B.min_db, B.max_db - B.min_db, 4096.0, 0.0), ctx->stream, B.pol));
+                                        step_estimate(ctx, B.min_db, B.max_db - B.min_db, 4096.0, 0.0), ctx->stream, B.pol));
     }
     return SARPRO_HIP_OK;
 }
@@ -630,7 +639,7 @@ int f32_phase_c(F32Band &B) {
     ta.in = B.d_in; ta.pitch = B.in_pitch; ta.rects = B.plan->d_hist_rects_tiled.as<Rect>();
     ta.t_valid = B.t_valid; ta.thr = d_thr; ta.tile_bins = d_tile_bins;
     ta.pol = B.pol;
-    ta.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
+    ta.est = step_estimate(ctx, B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
     KernelTimer t(ctx, "f32_tile_hist");
     HIPCHK(ctx, launch_f32_tile_hist(ta, (int)B.plan->hist_rects_tiled.size(), B.vec, ctx->stream));
     return SARPRO_HIP_OK;
@@ -654,15 +663,15 @@ int f32_phase_d(F32Band &B) {
         float *thr = ctx->h_upload.as<float>();
         float *d_thr = reinterpret_cast<float *>(ws + kOffThrLevel);
         F32LevelArgs a{};
-        a.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), (double)nlevels, 0.0, B.stats.gamma);
+        a.est = step_estimate(ctx, B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), (double)nlevels, 0.0, B.stats.gamma);
         a.in = B.d_in; a.out = B.d_out; a.in_pitch = B.in_pitch; a.out_pitch = B.out_pitch;
         a.rows = rows; a.cols = cols; a.t_valid = B.t_valid; a.thr = d_thr; a.level_hist = d_level_hist;
         a.pol = B.pol;
-        const bool f64_levels = (!u8o || B.direct) && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
+        const bool f64_levels = (!u8o || B.direct) && !ctx->attrs.on(A_NO_STEP_ESTIMATE);
         if (f64_levels) { // 65535 levels: f64 evaluation on the device, the reference's own arithmetic only near a level boundary
             a.low = B.stats.low_clip; a.high = B.stats.high_clip; a.range = std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0);
             a.gamma = B.stats.gamma; a.max_val = (double)nlevels;
-            if (a.gamma == 1.0 && !getenv("SARPRO_HIP_F32_LEVEL_GENERAL")) { // (cross-check switch: the general form at gamma == 1)
+            if (a.gamma == 1.0 && !ctx->attrs.on(A_F32_LEVEL_GENERAL)) { // (cross-check switch: the general form at gamma == 1)
                 const double inv_range = 1.0 / a.range;
                 a.lin = 1;
                 a.lin_a = 3.0102999566398120 * inv_range * a.max_val; // 10 log10(2)
@@ -673,10 +682,12 @@ int f32_phase_d(F32Band &B) {
         // Without the 65535-entry table (1-2 ms of glibc per call): the samples within 1e-6 of a boundary -- a few hundred of
         // 4e8 -- are queued and settled here, with level_of_db.  SARPRO_HIP_F32_LEVEL_TABLE=1 (or a queue that overflows) builds
         // the table and lets the kernel search it instead.
-        constexpr uint32_t kUqCap = 65536;
-        bool queued = f64_levels && !getenv("SARPRO_HIP_F32_LEVEL_TABLE");
+        constexpr uint32_t kUqCapMax = 65536;
+        // F32_LEVEL_QCAP: a tiny queue, so that the tests reach the overflow route below
+        const uint32_t kUqCap = (uint32_t)std::min<long long>(kUqCapMax, std::max<long long>(0, ctx->attrs.val(A_F32_LEVEL_QCAP, kUqCapMax)));
+        bool queued = f64_levels && !ctx->attrs.on(A_F32_LEVEL_TABLE);
         if (queued) {
-            HIPCHK(ctx, ctx->f32zone.reserve((size_t)kUqCap * sizeof(uint4)));
+            HIPCHK(ctx, ctx->f32zone.reserve((size_t)kUqCapMax * sizeof(uint4)));
             a.uq_count = reinterpret_cast<uint32_t *>(ws + kOffZoneCounts);
             a.uq_entries = ctx->f32zone.as<uint4>();
             a.uq_cap = kUqCap;
@@ -689,8 +700,8 @@ int f32_phase_d(F32Band &B) {
             // count, the first kQueueHead entries and (u8) the level histogram come back together: one turn
             uint32_t *h_n = ctx->h_small.as<uint32_t>();
             uint32_t *h_e = ctx->h_small.as<uint32_t>() + 4; // 16-byte aligned; reserved in phase a
-            uint64_t *h_lh = reinterpret_cast<uint64_t *>(ctx->h_small.as<uint8_t>() + 16 + (size_t)kUqCap * 16);
-            if (mail_enabled()) { // (the level raster is complete when the post arrives: it follows the level kernel in the stream)
+            uint64_t *h_lh = reinterpret_cast<uint64_t *>(ctx->h_small.as<uint8_t>() + 16 + (size_t)kUqCapMax * 16);
+            if (mail_enabled(ctx)) { // (the level raster is complete when the post arrives: it follows the level kernel in the stream)
                 RETCHK(mail_open(ctx));
                 uint8_t *m = mail_payload<uint8_t>(ctx);
                 PostSegs g{};
@@ -741,6 +752,7 @@ int f32_phase_d(F32Band &B) {
                 return SARPRO_HIP_OK;
             }
             queued = false; // overflow: the table route redoes the raster
+            B.idle = false; // (a copy and a kernel follow: phase e must synchronise again before the call returns)
             if (u8o) { // (the table route of the u8 form counts every level itself: start from a clean histogram)
                 HIPCHK(ctx, hipMemsetAsync(d_level_hist, 0, sizeof(uint64_t) * 256, ctx->stream));
                 a.f64_levels = 0;
@@ -756,7 +768,7 @@ int f32_phase_d(F32Band &B) {
     }
     if (B.plan->apply_rects.empty()) return SARPRO_HIP_OK;
     double *d_cdfs = reinterpret_cast<double *>(ws + kOffCdfs);
-    if (getenv("SARPRO_HIP_F32_HOST_CDFS")) { // the host twin of the kernel below (cross-check switch)
+    if (ctx->attrs.on(A_F32_HOST_CDFS)) { // the host twin of the kernel below (cross-check switch)
         uint64_t *h_tb = ctx->h_small.as<uint64_t>();
         HIPCHK(ctx, hipMemcpyAsync(h_tb, ws + kOffTileBins, sizeof(uint64_t) * 64 * 256, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -774,9 +786,10 @@ int f32_phase_d(F32Band &B) {
     a.row_w = B.plan->d_row_w.as<RowWeight>() + B.row0; // the table is indexed by the scene's row, the kernel by the stripe's
     a.col_w = B.plan->d_col_w.as<RowWeight>();
     a.level_hist = d_level_hist; a.max_val = u8o ? 255.0 : 65535.0;
-    a.est = step_estimate(B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
+    a.est = step_estimate(ctx, B.stats.low_clip, std::fmax(B.stats.high_clip - B.stats.low_clip, 1.0), 255.0, 0.5);
     a.pol = B.pol;
     KernelTimer t(ctx, "f32_clahe_apply");
+    a.no_spec = ctx->attrs.on(A_NO_SPEC) ? 1u : 0u;
     HIPCHK(ctx, launch_f32_clahe_apply(a, (int)B.plan->apply_rects.size(), B.vec, !u8o, ctx->stream));
     return SARPRO_HIP_OK;
 }
@@ -795,7 +808,7 @@ int f32_phase_e(F32Band &B) {
             std::memcpy(lh, B.level_hist_host, sizeof(lh));
         } else {
             uint64_t *h_lh = ctx->h_small.as<uint64_t>();
-            if (mail_enabled()) { // (everything before the post in the stream, the level raster included, is complete when it arrives)
+            if (mail_enabled(ctx)) { // (everything before the post in the stream, the level raster included, is complete when it arrives)
                 RETCHK(mail_open(ctx));
                 h_lh = mail_payload<uint64_t>(ctx);
                 PostSegs g{};
@@ -829,7 +842,7 @@ int f32_direct_stats(F32Band &B) {
     uint64_t *h_hist = reinterpret_cast<uint64_t *>(h);
     uint32_t nq = 0;
     std::memcpy(&nq, h + 32768, 4);
-    if (nq > direct_queue_cap()) { B.direct = false; return SARPRO_HIP_OK; }
+    if (nq > direct_queue_cap(ctx)) { B.direct = false; return SARPRO_HIP_OK; }
     B.mean = G.sum_db / (double)G.count;
     const double var = G.sumsq_db / (double)G.count - B.mean * B.mean;
     B.std_db = G.count > 1 ? std::sqrt(std::fmax(var, 0.0)) : 0.0;
@@ -859,8 +872,8 @@ int f32_direct_stats(F32Band &B) {
 }
 
 static bool f32_direct_wanted(const F32Band &B) {
-    if (const char *e = getenv("SARPRO_HIP_F32_DIRECT")) return atoi(e) != 0; // 0: never, 1: at every size (tests)
-    return (uint64_t)B.rows * B.cols <= kDirectMaxPx && !getenv("SARPRO_HIP_NO_STEP_ESTIMATE");
+    if (B.ctx->attrs.is_set(A_F32_DIRECT)) return B.ctx->attrs.val(A_F32_DIRECT, 0) != 0; // 0: never, 1: at every size (tests)
+    return (uint64_t)B.rows * B.cols <= kDirectMaxPx && !B.ctx->attrs.on(A_NO_STEP_ESTIMATE);
 }
 
 int f32_band_run(F32Band &B) {
@@ -873,7 +886,7 @@ int f32_band_run(F32Band &B) {
     B.global = B.local;
     if (B.direct && !B.use_zones) RETCHK(f32_direct_stats(B)); // (may hand the band back: direct = false, no statistics yet)
     if (B.use_zones) RETCHK(f32_zone_resolve(B));
-    if (getenv("SARPRO_HIP_F32_ZONES_DEBUG")) std::fprintf(stderr, "[zones] answered=%d note='%s'\n", (int)B.have_stats, B.zone_note);
+    if (B.ctx->attrs.on(A_F32_ZONES_DEBUG)) std::fprintf(stderr, "[zones] answered=%d note='%s'\n", (int)B.have_stats, B.zone_note);
     if (B.have_stats) { B.empty = false; }
     else RETCHK(f32_phase_b(B));
     RETCHK(f32_phase_c(B));
@@ -1278,14 +1291,24 @@ static int dualpol_f32_impl(sarpro_hip_ctx *ctx, const DualF32Src &src, size_t r
     // while this thread runs the first -- at the reference's usual 2048^2 a band is a chain of short kernels and two host turns,
     // and two of them side by side take little longer than one.  (A timing context keeps one stream: its kernel table is per
     // context.  SARPRO_HIP_NO_BAND_TWIN=1: one band after the other, as host-resident bands go.)
-    const bool twin = src.dev[0] && src.dev[1] && !ctx->timing && !ctx->f32_stripe_open && !getenv("SARPRO_HIP_NO_BAND_TWIN");
-    if (twin) {
-        if (!ctx->twin) {
-            if (sarpro_hip_ctx_create(ctx->device, ctx->flags & ~(unsigned)SARPRO_HIP_CTX_TIMING, &ctx->twin) != SARPRO_HIP_OK)
-                return fail(ctx, SARPRO_HIP_ERR_HIP, "dual-pol f32: the second band's context could not be created");
-            ctx->band_worker = new BandWorker();
-            ctx->band_worker->start();
+    bool twin = src.dev[0] && src.dev[1] && !ctx->timing && !ctx->f32_stripe_open && !ctx->attrs.on(A_NO_BAND_TWIN);
+    if (twin && !ctx->twin) { // first use.  No twin (or no thread) is not an error: one band after the other gives the same raster
+        sarpro_hip_ctx *t = nullptr;
+        BandWorker *w = nullptr;
+        if (sarpro_hip_ctx_create(ctx->device, ctx->flags & ~(unsigned)SARPRO_HIP_CTX_TIMING, &t) == SARPRO_HIP_OK) {
+            t->attrs = ctx->attrs; // the twin follows its parent's switches (sarpro_hip_ctx_set_attr keeps it so)
+            try {
+                w = new BandWorker();
+                w->start();
+            } catch (...) { // std::bad_alloc, std::system_error (no thread to be had): nothing may unwind across the C ABI
+                delete w;
+                w = nullptr;
+            }
         }
+        if (t && w) { ctx->twin = t; ctx->band_worker = w; }
+        else { if (t) sarpro_hip_ctx_destroy(t); twin = false; }
+    }
+    if (twin) {
         sarpro_hip_ctx *t = ctx->twin;
         for (int b = 0; b < 2; ++b) {
             if (!resized) HIPCHK(ctx, ctx->levels[b].reserve(r1 * lpitch_b));
@@ -1348,7 +1371,7 @@ static int dualpol_f32_impl(sarpro_hip_ctx *ctx, const DualF32Src &src, size_t r
     for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
     fold_compose_tables(luts.data(), fwc, ident, ident, tables.data());
     HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
-    if (mail_enabled() && mail_open(ctx) == SARPRO_HIP_OK) { // the tables through the mailbox's big-payload area (both bands' turns are over): a kernel, not a copy command
+    if (mail_enabled(ctx) && mail_open(ctx) == SARPRO_HIP_OK) { // the tables through the mailbox's big-payload area (both bands' turns are over): a kernel, not a copy command
         uint8_t *tstage = ctx->mailbox.as<uint8_t>() + kMailBigOff;
         std::memcpy(tstage, tables.data(), 66048);
         Prep pr;

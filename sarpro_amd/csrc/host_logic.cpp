@@ -269,6 +269,40 @@ void build_clahe_bin_lut_u16(const sarpro_hip_stats &s, DnLut *out) {
     fill_windowed(lo, hi, [=](double d) { return (uint16_t)clahe_bin_of_db(d, lo, hi); }, out);
 }
 
+bool clahe_saturated_levels(const ClaheGeometry &g, std::vector<uint8_t> *col_class, std::vector<uint8_t> *row_bits) {
+    std::vector<double> tvals;
+    std::vector<uint8_t> cc(g.col_w.size());
+    for (size_t c = 0; c < g.col_w.size(); ++c) {
+        const double dx = g.col_w[c].d;
+        const double t = 1.0 * (1.0 - dx) + 1.0 * dx; // c00 * (1.0 - dx) + c01 * dx with both CDFs 1.0
+        size_t k = 0;
+        while (k < tvals.size() && tvals[k] != t) ++k;
+        if (k == tvals.size()) {
+            if (tvals.size() == 3) return false;
+            tvals.push_back(t);
+        }
+        cc[c] = (uint8_t)k;
+    }
+    std::vector<uint8_t> rb(g.row_w.size());
+    for (size_t r = 0; r < g.row_w.size(); ++r) {
+        const double dy = g.row_w[r].d;
+        uint8_t bits = 0;
+        for (size_t k = 0; k < 3; ++k) {
+            const double t = k < tvals.size() ? tvals[k] : 1.0;
+            double o = t * (1.0 - dy) + t * dy; // top * (1.0 - dy) + bottom * dy
+            o = o < 0.0 ? 0.0 : (o > 1.0 ? 1.0 : o);
+            const double lv = o * 255.0;
+            const unsigned level = (unsigned)lv;
+            if (level != 254u && level != 255u) return false;
+            if (level == 255u) bits |= (uint8_t)(1u << k);
+        }
+        rb[r] = bits;
+    }
+    col_class->swap(cc);
+    row_bits->swap(rb);
+    return true;
+}
+
 bool clahe_shape_ok(size_t rows, size_t cols) {
     if (rows == 0 || cols == 0) return true; // early-out clone (autoscale.rs:231-233)
     size_t tile_h = (rows + kTiles - 1) / kTiles, tile_w = (cols + kTiles - 1) / kTiles;
@@ -570,6 +604,16 @@ int sarpro_hip_host_synrgb_luts(int strategy, const uint64_t combined_hist[256],
 }
 
 int sarpro_hip_host_clahe_shape_ok(size_t rows, size_t cols) { return clahe_shape_ok(rows, cols) ? 1 : 0; }
+int sarpro_hip_host_clahe_saturated_levels(size_t rows, size_t cols, uint8_t *col_class, uint8_t *row_bits) {
+    if (!clahe_shape_ok(rows, cols) || !col_class || !row_bits) return SARPRO_HIP_ERR_INVALID_ARG;
+    ClaheGeometry g;
+    build_clahe_geometry(rows, cols, &g);
+    std::vector<uint8_t> cc, rb;
+    if (!clahe_saturated_levels(g, &cc, &rb)) return SARPRO_HIP_ERR_UNSUPPORTED_SHAPE;
+    std::memcpy(col_class, cc.data(), cols);
+    std::memcpy(row_bits, rb.data(), rows);
+    return SARPRO_HIP_OK;
+}
 
 int sarpro_hip_host_stripe_plan(size_t rows, int nranks, size_t *row0_out, size_t *nrows_out) {
     if (!row0_out || !nrows_out) return SARPRO_HIP_ERR_INVALID_ARG;

@@ -54,6 +54,12 @@ struct ClaheGeometry {
     std::vector<size_t> row_cell_start, col_cell_start; // size = ncells+1
 };
 bool clahe_shape_ok(size_t rows, size_t cols);
+// A bin whose four tile CDFs are all 1.0, blended as autoscale.rs:327-329 does: top = bottom = T = fl(fl(1 - dx) + dx), out =
+// fl(fl(T (1 - dy)) + fl(T dy)), level = (out clamped to [0, 1]) * 255 truncated -- 255 or, where the roundings fall short of 1.0 (they
+// can in the first half tile row / column, where a weight is negative), 254: a function of the pixel's row and column alone.
+// col_class[c] in {0, 1, 2} names the value T of column c; bit k of row_bits[r] is set when a pixel of row r whose column is of class
+// k gets level 255.  False (tables untouched) when the geometry yields more than three values of T or a level outside {254, 255}.
+bool clahe_saturated_levels(const ClaheGeometry &g, std::vector<uint8_t> *col_class, std::vector<uint8_t> *row_bits);
 void build_clahe_geometry(size_t rows, size_t cols, ClaheGeometry *g);
 void clahe_tile_cdf(uint64_t *hist /*[256], clobbered*/, size_t tile_rows, size_t tile_cols,
                     double *cdf /*[256]*/);

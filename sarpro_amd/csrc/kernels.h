@@ -100,7 +100,7 @@ struct ChainSpecState {
     unsigned long long sample_valid_rep[kSampleReplicas * 2]; // [replica][band]: what the workgroups of the sampling pass add to
     double est_lt[2];              // the sample's estimate of n_lt (diagnostics)
     uint32_t force;                // test switches (kSpecForce*)
-    uint32_t pad;
+    uint32_t pool_overflow;        // the fused CLAHE -> RGB pass stepped aside: the bands' DN windows do not fit its LDS pool
 };
 constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it
 constexpr uint32_t kSpecForceNoSpec = 2u;     // "level 0 or 255 missing": no speculative composition at all
@@ -120,6 +120,12 @@ struct ClaheRgbArgs {
     const struct ChainBandState *dev_state; // win_hi per band
     struct ChainSpecState *spec;        // spec_ok / floor_pred in, counts and verdict out
     const uint8_t *tables;              // R2[256] | G2[256] | B2[65536] for the predicted floor
+    // Saturated bins (all four CDFs 1.0) in extrapolating cells: the reference's level is 254 or 255 by how (1 - d) + d rounds in
+    // f64 -- a function of the pixel's row and column alone.  sat_col[c]: which of the (at most three) values T = fl((1 - dx) + dx)
+    // column c produces; sat_row[r]: bit k set = a saturated pixel of row r in a column of class k gets level 255 (else 254).
+    const uint8_t *sat_col, *sat_row;   // [cols rounded up to the pitch], [rows]; host-built with the plan (api.cpp)
+    uint32_t sat_cols;                  // entries of sat_col
+    uint32_t sat_ok;                    // 0: tables absent (the geometry produced more than three classes): such pixels take the exact path
 };
 bool clahe_rgb_fused_supported(const ClaheRgbArgs &a);
 hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid /* persistent workgroups: one per CU */, hipStream_t s);
@@ -167,7 +173,7 @@ hipError_t launch_lut_compose_u16(const LutComposeArgs &a, hipStream_t s);
 hipError_t launch_polop_f32(int op, const float *a, const float *b, size_t n, float *out, hipStream_t s);
 hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q /*[4][65536]*/,
                                   size_t rows_total, size_t cols, size_t row0, size_t rows_local,
-                                  uint16_t *d_out, size_t pitch, hipStream_t s);
+                                  uint16_t *d_out, size_t pitch, uint32_t flags, hipStream_t s);
 hipError_t launch_remap_u8(uint8_t *buf, size_t pitch, uint32_t rows, uint32_t cols, const uint8_t *d_map256,
                            hipStream_t s);
 hipError_t launch_hist256_u8(const uint8_t *in, size_t pitch, uint32_t rows, uint32_t cols,

@@ -54,6 +54,12 @@ __device__ __forceinline__ void store_stream16(uint4 *p, const uint4 &t) {
     __builtin_nontemporal_store(tv, reinterpret_cast<v4u *>(p));
 }
 
+__device__ __forceinline__ void store_stream8(uint2 *p, const uint2 &t) {
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    v2u tv; tv.x = t.x; tv.y = t.y;
+    __builtin_nontemporal_store(tv, reinterpret_cast<v2u *>(p));
+}
+
 // Per-lane keep-mask for an 8-sample vector whose columns [col, col+8) may straddle [c0, c1).
 struct EdgeMask {
     uint32_t m[4];
@@ -481,7 +487,29 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     Level 0 goes to a per-lane dummy histogram word (bin 0 = pixels - other bins): a shared word would
 //     serialise the no-data wedge (measured: +7 % on the whole kernel).
 // ------------------------------------------------------------------------------------
+//     Round 4: the margins went from 1.8x to 1.17x what the bound requires (6.2e-4 / 1.6e-4 against 5.3e-4 / 1.37e-4; the largest
+//     error ever measured is 0.13 / 0.28 of them; bias = fl(-0.5 - delta) and fl(2 delta) add < 1e-7): a third fewer samples on the
+//     exact path, whose block sits in the row loop of every wave-row that holds one.  -DSARPRO_SPEC_DELTA_R3 restores 2^-10 / 2^-12.
+//     Cells that extrapolate along ONE axis only (every cell of the first half tile row or column but the corner) get their own
+//     margins.  dy in [-0.5, 0), x interior: |top|, |bottom| <= 1 with |dtop| <= 4u as in interior cells; 255 (1.5 (4u + 2u) +
+//     0.5 (4u + 2u)) for the two products, u |inner| <= 383u and u |y| <= 510u for the two fma roundings: 3953u = 2.36e-4, and yb's own
+//     rounding 510u: delta > 2.66e-4.  dx in [-0.5, 0), y interior: |top| <= 2, |dtop| <= 5u: 255 (5u + 2 * 2u) + 511u + 510u = 3316u =
+//     1.98e-4, + 510u: delta > 2.28e-4.  (Rect::pad[0] bit 1: dy < 0, bit 2: dx < 0.)
+constexpr float kSpecDeltaEdgeY = 3.0e-4f, kSpecDeltaEdgeX = 2.6e-4f;
+#ifdef SARPRO_SPEC_DELTA_R3
 constexpr float kSpecDeltaEdge = 1.0f / 1024.0f, kSpecDeltaInner = 1.0f / 4096.0f;
+#elif defined(SARPRO_ABL_SPEC_DELTA_SMALL) // timing experiment only (the bound does not cover it)
+constexpr float kSpecDeltaEdge = 7.0e-5f, kSpecDeltaInner = 6.4e-5f;
+#else
+constexpr float kSpecDeltaEdge = 6.2e-4f, kSpecDeltaInner = 1.6e-4f;
+#endif
+__device__ __forceinline__ float spec_delta(int pad0) { // the f32 blend's margin for a work item of this kind of cell
+#ifdef SARPRO_SPEC_DELTA_R3
+    return (pad0 & 1) ? kSpecDeltaEdge : kSpecDeltaInner;
+#else
+    return !(pad0 & 1) ? kSpecDeltaInner : (pad0 & 6) == 2 ? kSpecDeltaEdgeY : (pad0 & 6) == 4 ? kSpecDeltaEdgeX : kSpecDeltaEdge;
+#endif
+}
 #ifdef SARPRO_SPEC_MEASURE // instrumented build (tools/spec_margin.py): the largest |y32 - y| the speculative blend produced, per margin class
 __device__ uint32_t g_spec_max_err[2]; // float bits; [0] interior cells, [1] extrapolating cells
 #endif
@@ -529,6 +557,15 @@ struct SpecLds { // byte offsets into dynamic LDS
 __device__ __forceinline__ float to_sgpr(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
+// (b3 << 24) | (b2 << 16) | (b1 << 8) | b0 of four values < 256 in three v_lshl_or_b32 (as plain shifts and ors the compiler
+// re-associates them into five instructions per dword, masks of already zero-extended bytes included)
+__device__ __forceinline__ uint32_t lshl_or(uint32_t hi, uint32_t sh, uint32_t lo) {
+    uint32_t d;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi), "n"(sh), "v"(lo));
+    return d;
+}
+#define pack4(b0, b1, b2, b3) lshl_or(lshl_or((b3), 8, (b2)), 16, lshl_or((b1), 8, (b0)))
+__device__ __forceinline__ uint32_t to_sgpr_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ double to_sgpr(double x) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
@@ -583,7 +620,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dxf[j] = (float)*reinterpret_cast<const double *>(lds + SpecLds::colw + (lane_id() * VEC + j) * 8);
     const uint32_t copy_off = ((uint32_t)lane_id() & (kCdfCopies - 1)) * 16u; // this lane's copy of the f32 CDF table
-    const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner; // pad[0] bit 0: extrapolating cell
+    const float near_delta = spec_delta(rc.pad[0]); // pad[0] bit 0: extrapolating cell (bit 1: in y, bit 2: in x)
     const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
     const uint32_t win_hi2 = win_hi | (win_hi << 16);
     constexpr bool PARTIAL_HIST = HIST != 0;
@@ -1205,7 +1242,10 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
     ChainSpecState *sp = a.spec;
     if (!sp->spec_ok) return;
     const uint32_t win_hi[2] = {a.dev_state[0].win_hi, a.dev_state[1].win_hi};
-    if ((uint64_t)win_hi[0] + win_hi[1] + 2u > kRgbPoolEntries) return; // windows do not fit: the verdict stays "refuted", the gated kernels run
+    if ((uint64_t)win_hi[0] + win_hi[1] + 2u > kRgbPoolEntries) { // windows do not fit: the verdict stays "refuted", the gated kernels run
+        if (blockIdx.x == 0 && threadIdx.x == 0) sp->pool_overflow = 1u;
+        return;
+    }
     const uint32_t kb[2] = {0u, win_hi[0] + 1u}; // first pool entry of each band
     const int lane = lane_id(), wave = wave_id();
     {   // compose tables, once per workgroup
@@ -1222,6 +1262,13 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
     for (int item = blockIdx.x; item < a.nrects; item += gridDim.x) {
         const Rect rc = a.rects[item];
         __syncthreads(); // the previous item's rows are done (its tables may go; the compose tables have landed)
+#ifdef SARPRO_ABL_RGB_PROLOGUE2 // timing ablation: every item builds its tables twice (the difference to the default build = what the prologues cost)
+        for (int rep = 0; rep < 2; ++rep)
+#endif
+        {
+#ifdef SARPRO_ABL_RGB_PROLOGUE2
+        __syncthreads();
+#endif
         // ---- this item's tables: bin-indexed (f64 for the exact path, biased f32 for staging), then expanded by DN
         for (int t = threadIdx.x; t < 2 * 257; t += kRgbBlock) {
             const int b = t / 257, bin = t - b * 257;
@@ -1232,7 +1279,12 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
             }
             *reinterpret_cast<double4 *>(lds + RgbLds::cdf64 + (b * 257 + bin) * 32) = make_double4(c[0], c[1], c[2], c[3]);
             // the f32 entry: as kernel 4b stages it (saturated interior bins -> 1.001, all-zero bins and the invalid entry -> 0.5 / 255)
-            const bool saturated = bin < 256 && c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0 && !(rc.pad[0] & 1);
+#ifdef SARPRO_ABL_RGB_EDGESAT // timing ablation (wrong levels where a saturated bin of an extrapolating cell rounds to 254)
+            const bool saturated = bin < 256 && c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0;
+#else
+            // (extrapolating cells: only with the saturation tables -- the entry then yields 255 and the row loop takes the 254s from them)
+            const bool saturated = bin < 256 && c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0 && (!(rc.pad[0] & 1) || a.sat_ok);
+#endif
             const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
             const float kz = 0.5f / 255.0f;
             const float c00 = (float)c[0], c01 = (float)c[1], c10 = (float)c[2], c11 = (float)c[3];
@@ -1247,6 +1299,8 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
         }
         // DN -> bin of both windows, FOUR DNs per thread and load: the whole pool in one pass of the workgroup, i.e. one round trip
         // to L2, issued with the CDF loads above (a byte per thread and pass made three dependent round trips per item)
+        uint32_t *const s_dnsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 2; // per band: the first DN of a saturated bin (0xFFFF: none)
+        if (threadIdx.x < 2) s_dnsat[threadIdx.x] = 0xFFFFu;
         uint32_t q4 = 0u, qdn = 0u;
         int qb = -1;
         {
@@ -1267,11 +1321,38 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                     const uint32_t i = kb[qb] + dn;
                     *reinterpret_cast<float4 *>(lds + RgbLds::pool + i * 16) = *reinterpret_cast<const float4 *>(lds + RgbLds::stage + (qb * 257 + bin) * 16);
                     lds[RgbLds::binof + i] = (uint8_t)bin; // (DN = 0 never reaches the exact path: its biased entry is never "near")
+                    if ((rc.pad[0] & 1) && reinterpret_cast<const float *>(lds + RgbLds::stage + (qb * 257 + bin) * 16)[0] > 1.0005f)
+                        atomicMin(&s_dnsat[qb], dn); // (bins and CDFs are monotone: every DN from here on is saturated too)
                 }
             }
         }
         __syncthreads();
+        }
 
+        // The rows of the item, compiled twice and chosen per item by a wave-uniform branch: items of extrapolating cells (EDGE) and
+        // the others.
+        auto item_rows = [&](auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        // EDGE: the lane's eight columns by saturation class (byte j = 1: column j is of class k), the bands' first saturated DN
+        uint32_t satM[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+        uint32_t dnsat2[2] = {0xFFFEFFFEu, 0xFFFEFFFEu}; // (first saturated DN - 1) in both halves
+        if (EDGE && a.sat_ok) {
+            const int scol = min(rc.cstart + lane * VEC, (int)a.sat_cols - VEC);
+            const uint2 tc = *reinterpret_cast<const uint2 *>(a.sat_col + scol);
+            const uint32_t tcw[2] = {tc.x, tc.y};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const uint32_t x = tcw[g] ^ (0x01010101u * (uint32_t)k); // classes are 0..2: a byte is zero iff its two low bits are
+                    satM[k][g] = ((x | (x >> 1)) & 0x01010101u) ^ 0x01010101u;
+                }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const uint32_t d = to_sgpr_u32(reinterpret_cast<const uint32_t *>(lds + RgbLds::misc)[2 + b]) - 1u;
+                dnsat2[b] = (d & 0xFFFFu) | (d << 16);
+            }
+        }
         // ---- per-lane geometry of the strip
         const int col = rc.cstart + lane * VEC;
         uint32_t keep[2] = {0u, 0u};
@@ -1294,27 +1375,51 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
             const bool kept = col + j >= rc.c0 && col + j < rc.c1;
             if (kept && !(chunk_safe((3 * pr) / 16) && chunk_safe((3 * pr + 2) / 16))) bytewise |= 1u << j;
         }
+#ifndef SARPRO_RGB_OLDSTORE
+        // The two chunk stores of a row go through a buffer descriptor over the item's rows: a lane whose chunk is not stored passes
+        // an out-of-range offset and the hardware drops its write.  EVERY path through a row therefore holds the same two store
+        // instructions, and the wait for the prefetched row at the loop top is vmcnt(2) instead of vmcnt(0) -- with the stores inside
+        // divergent branches the compiler must assume the row issued none, and vmcnt(0) also waits for the write acknowledgements
+        // of the row just stored.  (Sending those lanes' chunks to a scratch line instead cost 13 %: a fifth of the pass's stores.)
+        const size_t item_off = ((size_t)rc.r0 * a.rgb_pitch_px + (size_t)rc.cstart) * 3;
+        const uint32_t row_bytes = (uint32_t)a.rgb_pitch_px * 3u;
+        const __amdgpu_buffer_rsrc_t rgb_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rgb + item_off, 0, (int)((uint32_t)(rc.r1 - rc.r0) * row_bytes), 0x00020000);
+        const uint32_t voff1 = safe1 ? (uint32_t)lane * 16u : 0xFFFFFFFFu, voff2 = safe2 ? 1024u + (uint32_t)lane * 16u : 0xFFFFFFFFu;
+#endif
         float dxf[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) dxf[j] = (float)*reinterpret_cast<const double *>(lds + RgbLds::colw + (lane * VEC + j) * 8);
-        const float near_delta = (rc.pad[0] & 1) ? kSpecDeltaEdge : kSpecDeltaInner;
+        const float near_delta = spec_delta(rc.pad[0]);
         const float bias = -0.5f - near_delta, two_delta = 2.0f * near_delta;
 
         // the levels of one band's 8 samples, packed as bytes; masked to 0 outside the item
-        auto band_levels = [&](int b, const uint4 &v, const double dy, const double omdy, const float wy1, const float wy2, uint32_t (&pk)[2]) {
+        auto band_levels = [&](int b, const uint4 &v, const double dy, const double omdy, const float wy1, const float wy2, const uint32_t (&satN)[2],
+                               uint32_t (&pk)[2]) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const uint32_t hi2 = win_hi[b] | (win_hi[b] << 16);
-            const uint32_t pbase = RgbLds::pool + kb[b] * 16u;
+            const uint32_t pbase = to_sgpr_u32(RgbLds::pool + kb[b] * 16u);
             uint32_t off[VEC];
+            uint32_t sat01[4] = {0u, 0u, 0u, 0u}; // EDGE: per sample 1 (in its 16-bit half) when its bin is saturated
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
                 const v2us c = __builtin_elementwise_min(__builtin_bit_cast(v2us, w[k]), __builtin_bit_cast(v2us, hi2));
                 const uint32_t cw = __builtin_bit_cast(uint32_t, c);
+                if (EDGE) { // min(sat_sub(DN, first saturated DN - 1), 1), both samples of the dword at once
+                    const v2us one = {1, 1};
+                    sat01[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_sub_sat(c, __builtin_bit_cast(v2us, dnsat2[b])), one));
+                }
                 uint32_t a0, a1;
+#ifdef SARPRO_RGB_OLDADDR
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(4u), "v"(cw));
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(4u), "v"(cw));
-                off[2 * k] = a0; off[2 * k + 1] = a1; // clamped DN x 16
+                off[2 * k] = pbase + a0; off[2 * k + 1] = pbase + a1; // LDS address of the entry: pool + (first entry + clamped DN) x 16
+#else
+                // one instruction per sample: (16-bit half of the clamped pair) x 16 + the band's base in the pool
+                asm("v_mad_u32_u16 %0, %1, 16, %2" : "=v"(a0) : "v"(cw), "s"(pbase));
+                asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(cw), "s"(pbase));
+                off[2 * k] = a0; off[2 * k + 1] = a1;
+#endif
             }
             uint32_t pb[2] = {0u, 0u};
             pk[0] = 0u; pk[1] = 0u;
@@ -1324,10 +1429,10 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
             constexpr int kAhead = SARPRO_RGB_AHEAD;
             v4f cq[VEC];
 #pragma unroll
-            for (int j = 0; j < kAhead; ++j) cq[j] = LDS_AT(v4f, pbase + off[j]);
+            for (int j = 0; j < kAhead; ++j) cq[j] = LDS_AT(v4f, off[j]);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                if (j + kAhead < VEC) cq[j + kAhead] = LDS_AT(v4f, pbase + off[j + kAhead]);
+                if (j + kAhead < VEC) cq[j + kAhead] = LDS_AT(v4f, off[j + kAhead]);
                 const v4f c4 = cq[j];
                 const float top = fmaf(c4.z, dxf[j], c4.x);
                 const float bottom = fmaf(c4.w, dxf[j], c4.y);
@@ -1345,7 +1450,7 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     if (((j < 4 ? d0 : d1) >> (8 * (j & 3))) & 0xFFu) {
-                        const uint32_t bin = lds[RgbLds::binof + kb[b] + (off[j] >> 4)];
+                        const uint32_t bin = lds[RgbLds::binof + ((off[j] - RgbLds::pool) >> 4)];
                         const double4 c4 = *reinterpret_cast<const double4 *>(lds + RgbLds::cdf64 + (b * 257 + bin) * 32);
                         const double dx = *reinterpret_cast<const double *>(lds + RgbLds::colw + (lane * VEC + j) * 8);
                         const double top = c4.x * (1.0 - dx) + c4.y * dx;
@@ -1357,6 +1462,10 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                         pk[j >> 2] = (pk[j >> 2] & ~(0xFFu << sh)) | (level << sh);
                     }
                 }
+            }
+            if (EDGE) { // saturated samples came out as 255 (biased entry): those whose (row, column class) rounds below 1.0 are 254
+                pk[0] -= __builtin_amdgcn_perm(sat01[1], sat01[0], to_sgpr_u32(0x06040200u)) & satN[0];
+                pk[1] -= __builtin_amdgcn_perm(sat01[3], sat01[2], to_sgpr_u32(0x06040200u)) & satN[1];
             }
             pk[0] &= keep[0];
             pk[1] &= keep[1];
@@ -1371,15 +1480,34 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
             if (r < rc.r1) {
                 uint4 c0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)r * a.in_pitch), c1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)r * a.in_pitch);
                 double dyv = row_w[r].d;
+                uint32_t srv = (EDGE && a.sat_ok) ? (uint32_t)a.sat_row[r] : 7u;
+#ifndef SARPRO_RGB_OLDSTORE
+                // (two stores behind the first row's loads, as every later row has them behind its own: the loop is entered in its
+                // steady state and its top waits with vmcnt(2))
+                {
+                    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                    const v4u z = {0u, 0u, 0u, 0u};
+                    __builtin_amdgcn_raw_buffer_store_b128(z, rgb_rsrc, 0xFFFFFFFFu, 0, 2); // (out of range in every lane: nothing is written)
+                    __builtin_amdgcn_raw_buffer_store_b128(z, rgb_rsrc, 0xFFFFFFF0u, 0, 2); // (another offset: two identical stores would be merged)
+                }
+#endif
                 for (; r < rc.r1; r += step) {
                     const int rn = min(r + step, rc.r1 - 1); // the next row of both bands is always in flight
                     const uint4 n0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)rn * a.in_pitch), n1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)rn * a.in_pitch);
                     const double dyn = row_w[rn].d;
+                    const uint32_t srn = (EDGE && a.sat_ok) ? (uint32_t)a.sat_row[rn] : 7u;
+                    uint32_t satN[2] = {0u, 0u}; // bytes of the lane's samples that get 254 when saturated, in this row
+                    if (EDGE) {
+                        const uint32_t rb = to_sgpr_u32(srv);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            if (!((rb >> k) & 1u)) { satN[0] |= satM[k][0]; satN[1] |= satM[k][1]; }
+                    }
                     const double dy = to_sgpr(dyv), omdy = to_sgpr(1.0 - dy);
                     const float wy1 = to_sgpr((float)omdy * 255.0f), wy2 = to_sgpr((float)dy * 255.0f);
                     uint32_t l1[2], l2[2];
-                    band_levels(0, c0, dy, omdy, wy1, wy2, l1);
-                    band_levels(1, c1, dy, omdy, wy1, wy2, l2);
+                    band_levels(0, c0, dy, omdy, wy1, wy2, satN, l1);
+                    band_levels(1, c1, dy, omdy, wy1, wy2, satN, l2);
                     // verification counts (kernel 6, SPEC): |x - T| over the 16 level bytes
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
@@ -1390,6 +1518,7 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         uint32_t px[4][3];
+#ifdef SARPRO_RGB_OLDCOMPOSE
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const uint32_t v1 = (l1[g] >> (8 * j)) & 0xFFu, v2 = (l2[g] >> (8 * j)) & 0xFFu;
@@ -1402,6 +1531,28 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                         o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
                         o[3 * g + 1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
                         o[3 * g + 2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+#else
+                        // Table addresses straight from the packed level bytes: one bit-field extract per R2 / G2 index, ONE v_perm_b32 per
+                        // B2 index ((level1 << 8) | level2 from the two packed registers), the table bases in the instructions' offset
+                        // fields; the 12 bytes are packed by v_lshl_or pairs (left to the compiler the same lines cost twice the VALU
+                        // instructions: byte masks after zero-extending loads, multiply-adds for the pair index, three-step packing).
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t v1 = j == 0 ? (l1[g] & 0xFFu) : j == 3 ? (l1[g] >> 24) : __builtin_amdgcn_ubfe(l1[g], 8 * j, 8);
+                            const uint32_t v2 = j == 0 ? (l2[g] & 0xFFu) : j == 3 ? (l2[g] >> 24) : __builtin_amdgcn_ubfe(l2[g], 8 * j, 8);
+                            const uint32_t pair = __builtin_amdgcn_perm(l1[g], l2[g], to_sgpr_u32(0x0c0c0400u + 0x0101u * (uint32_t)j)); // (0, 0, level1, level2)
+#ifdef SARPRO_ABL_RGB_NOLOOKUP // timing ablation (garbage raster)
+                            px[j][0] = v1; px[j][1] = v2; px[j][2] = pair & 0xFFu;
+#else
+                            px[j][0] = LDS_AT(uint8_t, RgbLds::tables + v1);
+                            px[j][1] = LDS_AT(uint8_t, RgbLds::tables + 256 + v2);
+                            px[j][2] = LDS_AT(uint8_t, RgbLds::tables + 512 + pair);
+#endif
+                        }
+                        o[3 * g + 0] = pack4(px[0][0], px[0][1], px[0][2], px[1][0]);
+                        o[3 * g + 1] = pack4(px[1][1], px[1][2], px[2][0], px[2][1]);
+                        o[3 * g + 2] = pack4(px[2][2], px[3][0], px[3][1], px[3][2]);
+#endif
                     }
                     uint8_t *rowp = a.rgb + ((size_t)r * a.rgb_pitch_px + (size_t)rc.cstart) * 3;
                     // (same wave writes and reads its stage: program order inside a wave, no barrier)
@@ -1410,9 +1561,24 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                     *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24 + 16) = make_uint2(o[4], o[5]);
 #ifdef SARPRO_ABL_RGB_NOSTORE
                     if (safe1 && o[0] == 0x12345678u) store_stream16(reinterpret_cast<uint4 *>(rowp) + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + lane * 16));
-#else
+#elif defined(SARPRO_RGB_OLDSTORE)
                     if (safe1) store_stream16(reinterpret_cast<uint4 *>(rowp) + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + lane * 16));
                     if (safe2) store_stream16(reinterpret_cast<uint4 *>(rowp) + 64 + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + 1024 + lane * 16));
+#else
+                    {
+                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                        const uint32_t soff = (uint32_t)(r - rc.r0) * row_bytes;
+                        // gfx950 corrupts the first dword of a 128-bit buffer store's data when a VALU instruction writes that VGPR
+                        // in the very next issue slot; the compiler only guards the form WITHOUT an SGPR offset (and, left alone,
+                        // put the next chunk's address computation into the data register right behind the store: one pixel pair per
+                        // chunk boundary came out wrong, at 36 MP and up).  Both chunks are read first, and an s_nop that names the
+                        // data registers follows each store: they stay live, and two wait states pass, before anything may touch them.
+                        const v4u d1 = LDS_AT(v4u, stage_w + lane * 16), d2 = LDS_AT(v4u, stage_w + 1024 + lane * 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(d1, rgb_rsrc, voff1, soff, 2 /* nt */);
+                        asm volatile("s_nop 1" : : "v"(d1) : "memory");
+                        __builtin_amdgcn_raw_buffer_store_b128(d2, rgb_rsrc, voff2, soff, 2);
+                        asm volatile("s_nop 1" : : "v"(d2) : "memory");
+                    }
 #endif
                     if (bytewise) {
                         uint8_t *po = rowp + (size_t)lane * 24;
@@ -1425,10 +1591,13 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                                 po[b0 + 2] = (uint8_t)(o[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3)));
                             }
                     }
-                    c0 = n0; c1 = n1; dyv = dyn;
+                    c0 = n0; c1 = n1; dyv = dyn; srv = srn;
                 }
             }
         }
+        };
+        if (rc.pad[0] & 1) item_rows(std::true_type{});
+        else item_rows(std::false_type{});
     }
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
     uint32_t ge0 = fpred ? (n_all + sad[0] - sad[1]) >> 1 : n_kept, ge1 = (n_all + sad[1] - sad[2]) >> 1;
@@ -1642,17 +1811,19 @@ __device__ inline uint64_t splitmix64(uint64_t x) {
 __global__ __launch_bounds__(kBlock) void k_synth_scene_u16(uint64_t key, const uint16_t *__restrict__ q,
                                                             uint64_t rows_total, uint64_t cols, uint64_t row0,
                                                             uint64_t rows_local, uint64_t block,
-                                                            uint16_t *__restrict__ out, size_t pitch) {
+                                                            uint16_t *__restrict__ out, size_t pitch, uint32_t flags) {
     const uint64_t total = rows_local * cols;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
         const uint64_t rl = i / cols, c = i - rl * cols, r = row0 + rl;
         const uint64_t h = splitmix64((r * cols + c) ^ key);
-        const uint64_t cls = ((r / block) + 3 * (c / block)) & 3;
+        const uint32_t map = (flags >> 4) & 15u; // sarpro_hip.h: SARPRO_HIP_SYNTH_* (class map, wedges, bright targets)
+        const uint64_t cls = map == 0 ? ((r / block) + 3 * (c / block)) & 3 : map == 1 ? ((r / block) ^ (c / block)) & 3
+                             : map == 2 ? ((r + c) / block) & 3 : 1;
         uint32_t dn = q[cls * 65536 + (h >> 48)];
-        if (((h >> 20) % 10000ull) == 0) dn = (uint32_t)((20000ull + (h & 0x7FFFull)) & 0xFFFFull);
+        if (!(flags & 2u) && ((h >> 20) % 10000ull) == 0) dn = (uint32_t)((20000ull + (h & 0x7FFFull)) & 0xFFFFull);
         const bool left = c * rows_total * 100ull < 3ull * cols * (rows_total - r);
         const bool right = (cols - 1 - c) * rows_total * 100ull < 3ull * cols * r;
-        if (left || right) dn = 0;
+        if (!(flags & 1u) && (left || right)) dn = 0;
         out[rl * pitch + c] = (uint16_t)dn;
     }
 }
@@ -1848,13 +2019,14 @@ hipError_t launch_hist256_u8(const uint8_t *in, size_t pitch, uint32_t rows, uin
 }
 
 hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q, size_t rows_total, size_t cols,
-                                  size_t row0, size_t rows_local, uint16_t *d_out, size_t pitch, hipStream_t s) {
+                                  size_t row0, size_t rows_local, uint16_t *d_out, size_t pitch, uint32_t flags, hipStream_t s) {
     if (rows_local == 0 || cols == 0) return hipSuccess;
     const uint64_t key = seed ^ ((uint64_t)band << 60);
-    const uint64_t block = std::max<uint64_t>((rows_total + 15) / 16, 1);
+    const uint64_t per_side = ((flags >> 8) & 255u) ? ((flags >> 8) & 255u) : 16u;
+    const uint64_t block = std::max<uint64_t>((rows_total + per_side - 1) / per_side, 1);
     hipLaunchKernelGGL(k_synth_scene_u16, dim3(stream_grid((uint64_t)rows_local * cols, kBlock)), dim3(kBlock), 0, s,
                        key, d_q, (uint64_t)rows_total, (uint64_t)cols, (uint64_t)row0, (uint64_t)rows_local, block,
-                       d_out, pitch);
+                       d_out, pitch, flags);
     return hipGetLastError();
 }
 

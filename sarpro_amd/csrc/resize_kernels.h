@@ -16,6 +16,7 @@ struct ResizePassArgs {
     const int32_t *k;             // [window][out_size]
     uint32_t window;              // largest tap count
     uint32_t block_span;          // horizontal pass: max over groups of kResizeHBlock consecutive outputs of start[last] - start[first]
+    uint32_t generic;             // context attribute RESIZE_GENERIC: the tap-by-tap kernels (cross-check twin of the register-resident forms)
 };
 constexpr uint32_t kResizeHBlock = 256;
 

@@ -254,8 +254,7 @@ static hipError_t launch_resize_h_dot(const ResizePassArgs &a, const ResizeLutSr
         return hipErrorNotSupported;
     const uint32_t gx = (a.out_size + kResizeHBlock - 1) / kResizeHBlock;
     const uint32_t steps = (rows + kResizeHRows - 1) / kResizeHRows;
-    uint32_t blocks = 2048; // ~2048 blocks, each walks its share of the rows
-    if (const char *e = getenv("SARPRO_HIP_RESIZE_BLOCKS")) blocks = (uint32_t)std::max(1, atoi(e));
+    const uint32_t blocks = 2048; // ~2048 blocks, each walks its share of the rows
     const uint32_t gy = std::min<uint32_t>(steps, std::max<uint32_t>(1, blocks / gx));
     const dim3 grid(gx, gy), block(kResizeHBlock);
     const size_t lds = (size_t)span * kResizeHRows * 2 + (SRC16 ? l.lut_cap : 0u);
@@ -275,13 +274,13 @@ static hipError_t launch_resize_h_dot(const ResizePassArgs &a, const ResizeLutSr
 
 hipError_t launch_resize_h_lut(const ResizePassArgs &a, const ResizeLutSrc &l, uint32_t rows, hipStream_t s) {
     if (!rows || !a.out_size) return hipSuccess;
-    if (!l.lut || !l.dev_state || l.lut_cap % 16 != 0 || getenv("SARPRO_HIP_RESIZE_GENERIC")) return hipErrorNotSupported;
+    if (!l.lut || !l.dev_state || l.lut_cap % 16 != 0 || a.generic) return hipErrorNotSupported;
     return launch_resize_h_dot<true>(a, l, rows, s);
 }
 
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s) {
     if (!rows || !a.out_size) return hipSuccess;
-    if (elem_size == 1 && a.window && !getenv("SARPRO_HIP_RESIZE_GENERIC")) { // the register-resident form where its window fits
+    if (elem_size == 1 && a.window && !a.generic) { // the register-resident form where its window fits
         const hipError_t e = launch_resize_h_dot<false>(a, ResizeLutSrc{}, rows, s);
         if (e != hipErrorNotSupported) return e;
     }
@@ -302,7 +301,7 @@ hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size
 hipError_t launch_resize_v(const ResizePassArgs &a, int elem_size, hipStream_t s) {
     if (!a.width || !a.out_size) return hipSuccess;
     dim3 grid((a.width + kBlock - 1) / kBlock, a.out_size);
-    if (elem_size == 1 && !getenv("SARPRO_HIP_RESIZE_GENERIC")) {
+    if (elem_size == 1 && !a.generic) {
         hipLaunchKernelGGL(k_resize_v_u8_x8, dim3((a.width + kBlock * 8 - 1) / (kBlock * 8), a.out_size), dim3(kBlock), 0, s, a);
         return hipGetLastError();
     }

@@ -102,12 +102,13 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     if (lut_src && !do_resize) return kResizeLutUnsupported; // (a copy, not a pass: the caller materialises the levels)
     if (lut_src && (!nc || !nr)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "target size collapses a dimension to zero");
     ResizePassArgs ah{}, av{};
+    ah.generic = av.generic = ctx->attrs.on(A_RESIZE_GENERIC) ? 1u : 0u;
     if (lut_src) { // probe BEFORE anything is enqueued: the register-resident horizontal pass must take this shape
         RETCHK(get_coeffs(ctx, 0, (uint32_t)cols, (uint32_t)nc, elem_size, &ah));
         const uint32_t nchunk = (15 + ah.window + 15) / 16;
         const size_t span = ((size_t)ah.block_span + 15 + nchunk * 16 + 15) / 16 * 16;
         if (!ah.window || nchunk > 8 || span * 2 > 2 * (size_t)kResizeHBlock * 16 || (reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || in_pitch % 16 != 0 ||
-            span * 4 + lut_src->lut_cap > 64 * 1024 || getenv("SARPRO_HIP_RESIZE_GENERIC"))
+            span * 4 + lut_src->lut_cap > 64 * 1024 || ctx->attrs.on(A_RESIZE_GENERIC))
             return kResizeLutUnsupported;
     }
     uint8_t *out = reinterpret_cast<uint8_t *>(d_out);
@@ -231,7 +232,7 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
     // synchronisation instead of two of each), then the two horizontal passes through them
     ResizeLutSrc both[2]{};
     bool both_done[2] = {false, false};
-    if (dev_bands && !getenv("SARPRO_HIP_NO_RESIZE_LUT") && rows && cols) {
+    if (dev_bands && !ctx->attrs.on(A_NO_RESIZE_LUT) && rows && cols) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         RETCHK(bands_u8_table_dev(ctx, dev_bands, 2, rows, cols, dev_pitch, strategy, 0, both));
         if (both[0].lut && both[1].lut) {
@@ -270,7 +271,7 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
         // native-resolution level raster (1 B/px written, 1 B/px read again) never exists.  CLAHE, shapes the register-resident pass
         // does not take, SARPRO_HIP_NO_RESIZE_LUT=1: the level raster, then the u8 passes.
         bool done = false;
-        if (!getenv("SARPRO_HIP_NO_RESIZE_LUT")) {
+        if (!ctx->attrs.on(A_NO_RESIZE_LUT)) {
             ResizeLutSrc ls{};
             RETCHK(band_u8_table_dev(ctx, d_in, rows, cols, pitch, strategy, tamed, &ls));
             if (ls.lut) {

@@ -302,8 +302,13 @@ def test_f32_level_queue_overflow_takes_the_table_route_and_still_returns_comple
     with S.Context(0) as c:
         _, _, st = c.process_scalar_data_pipeline(x, bit_depth, St.Robust, want_stats=True)
     thr = S.host_f32_level_thresholds(st, bit_depth)
-    inner = thr[np.isfinite(thr) & (thr > 0)][5:-5]
-    picks = inner[:: max(1, len(inner) // 40)]
+    inner = thr[np.isfinite(thr) & (thr > 0)][5:-5].astype(np.float64)
+    # a threshold is the first f32 sample AT OR ABOVE a level boundary, up to one f32 step (1e-3 of a u16 level) beyond it: keep those
+    # that land within 5e-7 levels of the boundary (the kernel queues what lies within 1e-6)
+    nlev = 255.0 if bit_depth == Bd.U8 else 65535.0
+    y = (np.clip(10.0 * np.log10(inner), st.low_clip, st.high_clip) - st.low_clip) / max(st.high_clip - st.low_clip, 1.0) * nlev
+    picks = inner[np.abs(y - np.rint(y)) < 5e-7].astype(np.float32)[:60]
+    assert len(picks) >= 3, len(picks)
     flat = x.ravel()
     order = np.argsort(flat)
     for t in picks:  # each threshold value replaces the sample closest to it: the distribution (and with it the window) stays put

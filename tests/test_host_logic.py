@@ -118,3 +118,21 @@ def test_parse_cpulist_of_the_batch_workers_numa_binding():
     assert parse("") == []
     assert parse("0-127", cap=4) == [0, 1, 2, 3]  # truncated to the caller's capacity
     assert parse("3-1") == -1 and parse("a") == -1 and parse("1-") == -1
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (250, 177), (48, 56), (400, 520)])
+def test_saturated_bin_levels_by_row_and_column_equal_the_oracles_blend(shape):
+    """A bin whose four tile CDFs are all 1.0 does not always blend to 1.0: in the first half tile row / column a weight is negative
+    and (1 - d) + d can round below 1.0, so the level is 254 there for some rows and columns (autoscale.rs:327-329, 602).  The
+    product takes those levels from two host-built tables (class of the column, bits of the row) instead of the f64 blend; here every
+    pixel of a raster that lies entirely in the last bin -- every tile's CDF is 1.0 there -- is compared with the oracle's CLAHE."""
+    rows, cols = shape
+    norm = np.ones((rows, cols))
+    mask = np.ones((rows, cols), np.uint8)
+    rc, out, cdfs = oracle.clahe(norm, mask, want_cdfs=True)
+    assert rc == 0 and np.all(cdfs[:, 255] == 1.0)
+    want = (np.clip(out, 0.0, 1.0) * 255.0).astype(np.uint16)  # autoscale.rs:602 at max_val 255
+    cc, rb = S.host_clahe_saturated_levels(rows, cols)
+    got = np.where((rb[:, None] >> cc[None, :]) & 1, 255, 254)
+    assert np.array_equal(got, want)
+    assert set(np.unique(want)) <= {254, 255} and (want[rows // 2:, cols // 2:] == 255).all()  # interior cells always reach 1.0

@@ -16,7 +16,7 @@ HEADER = os.path.join(ROOT, "include", "sarpro_hip.h")
 SYS_RS = os.path.join(ROOT, "rust", "sarpro-hip-sys", "src", "lib.rs")
 SAFE_RS = os.path.join(ROOT, "rust", "sarpro-hip", "src", "lib.rs")
 
-C2RUST = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint16_t": "u16",
+C2RUST = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "int64_t": "i64", "uint32_t": "u32", "uint16_t": "u16",
           "uint8_t": "u8", "int32_t": "i32", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void"}
 
 
