@@ -462,6 +462,15 @@ int sarpro_hip_stripe_run_polop(sarpro_hip_ctx *ctx, int op, const void *d_a, co
 int sarpro_hip_comm_unique_id(uint8_t uid_out[128]);
 int sarpro_hip_comm_init(sarpro_hip_ctx *ctx, int nranks, int rank, const uint8_t uid[128]);
 int sarpro_hip_comm_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);
+/* The same communicator for the contexts of ONE process (one context and one host thread per rank -- several GPUs of a node driven by
+ * threads as sarpro_hip_batch_* does, or several contexts on one GPU): no RCCL, no rendezvous.  An all-reduce is a barrier, a sum kernel
+ * over the ranks' device buffers (they must be mutually accessible: one device, or peer access enabled by the caller) and a second
+ * barrier; every rank's thread must be inside the collective for it to complete.  Create the group once, join it from every context,
+ * destroy it after the contexts.  The stripe entry points (sarpro_hip_stripe_run_*) use whichever communicator the context has. */
+typedef struct sarpro_hip_local_group sarpro_hip_local_group;
+int sarpro_hip_local_group_create(int nranks, sarpro_hip_local_group **out);
+void sarpro_hip_local_group_destroy(sarpro_hip_local_group *group);
+int sarpro_hip_comm_init_local(sarpro_hip_ctx *ctx, sarpro_hip_local_group *group, int rank);
 void sarpro_hip_comm_destroy(sarpro_hip_ctx *ctx);
 
 /* ================= host half of the path (no GPU needed) ================= */
@@ -520,11 +529,12 @@ int sarpro_hip_synth_scene_u16_dev(sarpro_hip_ctx *ctx, uint64_t seed, int band,
                                    const uint16_t *q_tables_host, size_t rows_total, size_t cols,
                                    size_t row0, size_t rows_local, uint16_t *d_out, size_t pitch);
 /* The same generator with the scene's structure selectable (bench.py cycles its timed steps over scenes that differ in
- * distribution, not only in seed).  flags: bit 0 no no-data wedges (no invalid pixel anywhere), bit 1 no bright targets,
+ * distribution, not only in seed).  flags: bit 0 no no-data wedges (no invalid pixel anywhere), bit 1 no bright targets, bit 2 an all-invalid second band,
  * bits 4-7 class map (0: (r/b + 3 c/b) mod 4, the generator above; 1: (r/b xor c/b) mod 4; 2: diagonal bands ((r + c) / b) mod 4;
  * 3: one class -- table 1 -- everywhere), bits 8-15 class blocks per side (0 = 16: b = ceil(rows / 16)). */
 #define SARPRO_HIP_SYNTH_NO_WEDGE 1u
 #define SARPRO_HIP_SYNTH_NO_BRIGHT 2u
+#define SARPRO_HIP_SYNTH_NO_BAND2 4u   /* band 1 (the second) is no-data everywhere */
 #define SARPRO_HIP_SYNTH_MAP(m) (((unsigned)(m) & 15u) << 4)
 #define SARPRO_HIP_SYNTH_BLOCKS(n) (((unsigned)(n) & 255u) << 8)
 int sarpro_hip_synth_scene_u16_dev_ex(sarpro_hip_ctx *ctx, uint64_t seed, int band,

@@ -97,7 +97,7 @@ SYMBOLS = [
     "sarpro_hip_dualpol_synrgb_resized_f32", "sarpro_hip_dualpol_synrgb_resized_f32_dev", "sarpro_hip_batch_dualpol_synrgb_resized_f32", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
     "sarpro_hip_batch_dualpol_synrgb_resized_u16",
     "sarpro_hip_synth_scene_u16_dev", "sarpro_hip_synth_scene_u16_dev_ex",
-    "sarpro_hip_host_clahe_saturated_levels", "sarpro_hip_ctx_set_attr", "sarpro_hip_ctx_reset_attr", "sarpro_hip_ctx_get_attr", "sarpro_hip_attr_name",
+    "sarpro_hip_local_group_create", "sarpro_hip_local_group_destroy", "sarpro_hip_comm_init_local", "sarpro_hip_host_clahe_saturated_levels", "sarpro_hip_ctx_set_attr", "sarpro_hip_ctx_reset_attr", "sarpro_hip_ctx_get_attr", "sarpro_hip_attr_name",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -199,6 +199,9 @@ _proto("sarpro_hip_host_f32_merge_partials", _i, _vp, _sz, C.POINTER(F32Partial)
 _proto("sarpro_hip_comm_unique_id", _i, _vp)
 _proto("sarpro_hip_comm_init", _i, _vp, _i, _i, _vp)
 _proto("sarpro_hip_comm_allreduce_sum_u64", _i, _vp, _vp, _sz)
+_proto("sarpro_hip_local_group_create", _i, _i, C.POINTER(_vp))
+_proto("sarpro_hip_local_group_destroy", None, _vp)
+_proto("sarpro_hip_comm_init_local", _i, _vp, _vp, _i)
 _proto("sarpro_hip_comm_destroy", None, _vp)
 _proto("sarpro_hip_host_stats_from_dn_hist", _i, _vp, _S)
 _proto("sarpro_hip_host_window", _i, _S, _i, _i)

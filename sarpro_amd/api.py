@@ -511,8 +511,35 @@ class Context:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._chk(lib.sarpro_hip_comm_init(self._h, nranks, rank, buf))
 
+    def comm_init_local(self, group: "LocalGroup", rank: int):
+        """Join the in-process communicator `group` as `rank` (sarpro_hip_comm_init_local): one context and one host thread per rank."""
+        self._chk(lib.sarpro_hip_comm_init_local(self._h, group._h, rank))
+        self._group = group  # (keeps the group alive as long as the context)
+
     def comm_allreduce_sum_u64(self, d_buf: int, count: int):
         self._chk(lib.sarpro_hip_comm_allreduce_sum_u64(self._h, _vp(d_buf), count))
+
+
+class LocalGroup:
+    """sarpro_hip_local_group: the communicator of `nranks` contexts of this process (one thread each); no RCCL, no rendezvous."""
+
+    def __init__(self, nranks: int):
+        h = C.c_void_p()
+        rc = lib.sarpro_hip_local_group_create(nranks, C.byref(h))
+        if rc != _lib.OK:
+            raise SarproHipError(rc, "sarpro_hip_local_group_create failed")
+        self._h, self.nranks = h, nranks
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sarpro_hip_local_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Stripe:

@@ -472,7 +472,7 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
             const bool neg = rw.d < 0.0 || cw.d < 0.0;
             const int cell_flags = (neg ? 1 : 0) | (rw.d < 0.0 ? 2 : 0) | (cw.d < 0.0 ? 4 : 0); // bit 1 / 2: which weight is negative (the margin depends on it)
             add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw, cell_flags);
-            if (vecw == 8 && row0 == 0 && rows_local == rows_total) { // the fused CLAHE -> RGB pass: 16 waves walk an item, so items are taller
+            if (vecw == 8) { // the fused CLAHE -> RGB pass (whole scenes and row stripes): 16 waves walk an item, so items are taller
                 size_t frows = kRgbItemRows;
                 if (at.is_set(A_RGB_ITEM_ROWS)) frows = (size_t)std::max<long long>(16, at.val(A_RGB_ITEM_ROWS, 0));
                 add_rects(P->rgb_rects, nullptr, *P, r0, r1, c0, c1, ids, frows, vecw, cell_flags);
@@ -1084,6 +1084,9 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         KernelTimer t(ctx, "clahe_sample");
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->sample_rects.size(), 2, ctx->stream));
     }
+    // row stripes: the sample of the SCENE (every replica of the sampled histogram, the valid counts beside them)
+    RETCHK(chain_reduce(J, sample_hist, (size_t)256 * kMaxBands * kSampleReplicas, "allreduce_sample_hist"));
+    RETCHK(chain_reduce(J, d_spec->sample_valid_rep, (size_t)kSampleReplicas * 2, "allreduce_sample_valid"));
     {
         ChainPredictArgs pa{};
         pa.sample_hist = sample_hist; pa.exact_hist = exact_hist; pa.spec = d_spec; pa.state = d_state;
@@ -1100,6 +1103,10 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         KernelTimer t(ctx, "clahe_rgb_fused");
         HIPCHK(ctx, launch_clahe_rgb_fused(fa, std::max(ctx->cu_count, 1), ctx->stream));
     }
+    if (J.reduce) { // the verification counts of all stripes, then the verdict every rank shares
+        RETCHK(chain_reduce(J, &d_spec->n_lt[0], 2, "allreduce_spec_counts"));
+        HIPCHK(ctx, launch_spec_verdict(d_spec, ctx->stream));
+    }
     {   // gated on the verdict: levels of every pixel with the full histogram -> exact tables -> composition
         KernelTimer t(ctx, "spec_fallback_apply");
         a.hist_mode = 0u; a.gate = d_spec;
@@ -1107,6 +1114,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         for (int b = 0; b < 2; ++b) a.level_hist[b] = exact_hist + (size_t)b * 256;
         HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), 2, ctx->stream));
     }
+    RETCHK(chain_reduce(J, exact_hist, (size_t)256 * kMaxBands, "allreduce_level_hist")); // (all zero when the fused RGB stood: the gated recount did not run)
     {
         ChainFinishArgs f{};
         f.level_hist = exact_hist; f.gate = d_spec;
@@ -1149,8 +1157,13 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     // (k_chain_predict); SARPRO_HIP_NO_SAMPLED_HIST=1 keeps the partial histogram of every row and the unconditional tail.
     const bool exact_only = ctx->attrs.on(A_NO_SPEC); // cross-check: every pixel through the exact f64 blend
     const size_t rgb_pitch_ok = rgb_pitch_px % 16 == 0 && ptr_aligned16(d_rgb);
-    bool sampled = J.synrgb && J.nbands == 2 && J.u8_out() && !J.reduce && !exact_only && !ctx->attrs.on(A_FULL_LEVEL_HIST) &&
-                   !ctx->attrs.on(A_NO_SAMPLED_HIST) && d_rgb && rgb_pitch_ok && J.row0 == 0 && J.rows_local == J.rows_total;
+    // (a row stripe takes the speculative route in its fused form only -- the sampled histogram, the valid counts and the pass's
+    // verification counts are summed over the ranks, so every rank proves, predicts and decides the same; decided below from
+    // what all ranks share: an empty stripe still joins every reduction)
+    const bool whole = J.row0 == 0 && J.rows_local == J.rows_total;
+    const bool fused_wanted = !d_out[0] && !d_out[1] && !ctx->attrs.on(A_NO_FUSED_RGB) && J.in_pitch % 8 == 0;
+    bool sampled = J.synrgb && J.nbands == 2 && J.u8_out() && !exact_only && !ctx->attrs.on(A_FULL_LEVEL_HIST) &&
+                   !ctx->attrs.on(A_NO_SAMPLED_HIST) && rgb_pitch_px % 16 == 0 && (J.reduce ? fused_wanted : (d_rgb && rgb_pitch_ok && whole));
     uint32_t sample_stride = 17; // sampled rows cost the apply pass ~0.4 % each ninth: 9 -> 17 -> 33 measured 0.540 / 0.535 / 0.529 ms; the estimate's sigma grows with sqrt(stride)
     if (sampled) {
         size_t min_px = kSampledHistMinPx;
@@ -1204,7 +1217,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     // Whole dual-pol u8 scene, RGB only: the fused pass (kernels.hip 6a) -- sample-only pass -> identity proof + predicted floor +
     // tables -> ONE sweep DN, DN -> RGB that verifies the floor; refuted (or unproven, or windows beyond the pass's LDS pool), the
     // gated apply -> finish -> compose kernels below produce the raster.  SARPRO_HIP_NO_FUSED_RGB=1: the apply + compose route.
-    if (sampled && !d_out[0] && !d_out[1] && !J.plan->rgb_rects.empty() && !ctx->attrs.on(A_NO_FUSED_RGB)) {
+    if (sampled && fused_wanted && (J.reduce || !J.plan->rgb_rects.empty())) {
         ClaheRgbArgs fa{};
         for (int b = 0; b < 2; ++b) {
             fa.in[b] = J.d_in[b];
@@ -1215,12 +1228,14 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         fa.rects = J.plan->d_rgb_rects.as<Rect>(); fa.nrects = (int)J.plan->rgb_rects.size();
         fa.row_w = J.plan->d_row_w.as<RowWeight>(); fa.col_w = J.plan->d_col_w.as<RowWeight>(); fa.row_off = (int32_t)J.row0;
         fa.dev_state = d_state; fa.spec = d_spec; fa.tables = ctx->tables.as<uint8_t>();
-        fa.sat_ok = J.plan->sat_ok ? 1u : 0u; fa.sat_col = J.plan->d_sat_col.as<uint8_t>(); fa.sat_row = J.plan->d_sat_row.as<uint8_t>();
+        fa.sat_ok = J.plan->sat_ok ? 1u : 0u; fa.sat_col = J.plan->d_sat_col.as<uint8_t>(); fa.sat_row = J.plan->d_sat_row.as<uint8_t>() + J.row0; // (the table is indexed by the scene's row, the kernel by the stripe's)
         fa.sat_cols = (uint32_t)(round_up(J.cols, 64) + 64);
         // the sample-only pass costs ~0.025 ms + (apply pass) / stride: 0.056 ms at 17, 0.033 at 33; the wider stride's larger sigma (x 1.4: ~2.4 %
         // of scenes refuted instead of ~1.7 %, 1 ms each) costs 0.007 ms in expectation
         const uint32_t fused_stride = ctx->attrs.is_set(A_SAMPLE_STRIDE) ? sample_stride : 33u;
+        fa.no_verdict = J.reduce ? 1u : 0u;
         if (clahe_rgb_fused_supported(fa)) return job_run_fused_rgb(J, fa, d_rgb, rgb_pitch_px, fused_stride, stats_out);
+        if (J.reduce) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "row stripe: the rasters of every rank must be 16-byte aligned (pitches % 8 / % 16)");
     }
     // apply: levels into the internal rasters (dual-pol) or straight into the caller's raster (single band)
     const bool direct = !J.synrgb;
@@ -2042,7 +2057,7 @@ extern "C" int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_
                                          size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
                                          uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
     if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
-    if (!ctx->comm) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "sarpro_hip_comm_init has not been called on this context");
+    if (!ctx->comm && !ctx->local_group) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no communicator on this context (sarpro_hip_comm_init / _init_local)");
     if ((!d_band1 || !d_band2 || !d_rgb) && rows_local * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
     if (rgb_pitch_px < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "rgb_pitch_px < cols");
     U16Job J;

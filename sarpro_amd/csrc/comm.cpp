@@ -4,8 +4,11 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and enums from RCCL's own header (the library itself is dlopen'ed: no link dependency)
 
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "internal.h"
 
@@ -81,10 +84,85 @@ extern "C" int sarpro_hip_comm_init(sarpro_hip_ctx *ctx, int nranks, int rank, c
     return SARPRO_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// the in-process communicator: contexts of one process, one host thread per rank
+// ---------------------------------------------------------------------------------------
+struct sarpro_hip_local_group {
+    int nranks = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    std::vector<const uint64_t *> bufs; // the ranks' device buffers of the collective in flight
+    std::vector<size_t> counts;
+    bool mismatch = false;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long long g = generation;
+        if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
+extern "C" int sarpro_hip_local_group_create(int nranks, sarpro_hip_local_group **out) {
+    if (!out || nranks <= 0 || nranks > 64) return SARPRO_HIP_ERR_INVALID_ARG;
+    sarpro_hip_local_group *g = new (std::nothrow) sarpro_hip_local_group();
+    if (!g) return SARPRO_HIP_ERR_OOM;
+    g->nranks = nranks;
+    g->bufs.assign((size_t)nranks, nullptr);
+    g->counts.assign((size_t)nranks, 0);
+    *out = g;
+    return SARPRO_HIP_OK;
+}
+extern "C" void sarpro_hip_local_group_destroy(sarpro_hip_local_group *group) { delete group; }
+
+extern "C" int sarpro_hip_comm_init_local(sarpro_hip_ctx *ctx, sarpro_hip_local_group *group, int rank) {
+    if (!ctx || !group || rank < 0 || rank >= group->nranks) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (ctx->comm || ctx->local_group) { ctx->err = "communicator already initialised"; return SARPRO_HIP_ERR_INVALID_ARG; }
+    ctx->local_group = group; ctx->comm_nranks = group->nranks; ctx->comm_rank = rank;
+    return SARPRO_HIP_OK;
+}
+
 namespace sarpro {
+hipError_t launch_sum_rank_buffers(const uint64_t *const *d_ptrs, int nranks, uint64_t *out, size_t count, hipStream_t s); // kernels.hip
+
+// The in-process all-reduce: synchronous (the ranks meet at two barriers), and the stream is complete when it returns.
+static int local_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count) {
+    sarpro_hip_local_group *g = ctx->local_group;
+    // (a rank that fails still walks through both barriers: its peers must not be left waiting)
+    const bool stream_ok = hipSetDevice(ctx->device) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    g->bufs[(size_t)ctx->comm_rank] = d_buf;
+    g->counts[(size_t)ctx->comm_rank] = stream_ok ? count : (size_t)-1;
+    g->barrier(); // every rank's buffer is complete and published
+    bool same = true;
+    for (int r = 0; r < g->nranks; ++r) same = same && g->counts[(size_t)r] == count;
+    int rc = SARPRO_HIP_OK;
+    if (same && count) {
+        const size_t table = sizeof(uint64_t *) * (size_t)g->nranks;
+        if (ctx->local_tmp.reserve(count * sizeof(uint64_t) + table) != hipSuccess) { ctx->err = "local all-reduce: out of device memory"; rc = SARPRO_HIP_ERR_OOM; }
+        else {
+            uint8_t *tmp = ctx->local_tmp.as<uint8_t>();
+            const uint64_t **d_tab = reinterpret_cast<const uint64_t **>(tmp + count * sizeof(uint64_t));
+            hipError_t e = hipMemcpyAsync(d_tab, g->bufs.data(), table, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // (the table is host memory of the group: copied before anyone may change it)
+            if (e == hipSuccess) e = launch_sum_rank_buffers(d_tab, g->nranks, reinterpret_cast<uint64_t *>(tmp), count, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->err = std::string("local all-reduce: ") + hipGetErrorString(e); rc = SARPRO_HIP_ERR_HIP; }
+        }
+    }
+    g->barrier(); // every rank has read every buffer
+    if (!stream_ok) { ctx->err = "local all-reduce: the stream failed"; return SARPRO_HIP_ERR_HIP; }
+    if (!same) { ctx->err = "local all-reduce: a rank failed or the ranks disagree on the element count"; return SARPRO_HIP_ERR_INVALID_ARG; }
+    if (rc == SARPRO_HIP_OK && count) {
+        if (hipMemcpyAsync(d_buf, ctx->local_tmp.p, count * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = "local all-reduce: copy failed"; rc = SARPRO_HIP_ERR_HIP; }
+    }
+    return rc;
+}
+
 // all-reduce(sum, u64) enqueued on the context's stream, no host synchronisation (the stripe chain keeps
 // running on the stream behind it)
 int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count) {
+    if (ctx->local_group) return (d_buf || !count) ? local_allreduce_sum_u64(ctx, d_buf, count) : SARPRO_HIP_ERR_INVALID_ARG;
     if (!ctx->comm) { ctx->err = "communicator not initialised"; return SARPRO_HIP_ERR_INVALID_ARG; }
     if (!count) return SARPRO_HIP_OK;
     if (!d_buf) return SARPRO_HIP_ERR_INVALID_ARG;
@@ -108,6 +186,7 @@ extern "C" int sarpro_hip_comm_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *
 }
 
 extern "C" void sarpro_hip_comm_destroy(sarpro_hip_ctx *ctx) {
+    if (ctx) ctx->local_group = nullptr; // (the group belongs to the caller)
     if (!ctx || !ctx->comm) return;
     Rccl r;
     std::string err;

@@ -251,4 +251,6 @@ struct sarpro_hip_ctx {
     void *rccl_lib = nullptr;
     void *comm = nullptr;
     int comm_nranks = 0, comm_rank = 0;
+    struct sarpro_hip_local_group *local_group = nullptr; // the in-process communicator (comm.cpp), instead of RCCL: `comm` stays null
+    sarpro::DevBuf local_tmp;                              // ... its rank-private sum buffer
 };

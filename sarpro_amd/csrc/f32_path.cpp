@@ -1063,7 +1063,7 @@ extern "C" void sarpro_hip_stripe_f32_end(sarpro_hip_stripe_f32 *s) {
 static int stripe_f32_run(sarpro_hip_stripe_f32 *s, sarpro_hip_stats *stats_out) {
     F32Band &B = s->B;
     sarpro_hip_ctx *ctx = B.ctx;
-    if (!ctx->comm) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "communicator not initialised");
+    if (!ctx->comm && !ctx->local_group) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "communicator not initialised");
     const int n = ctx->comm_nranks, me = ctx->comm_rank;
     if (n > 1024) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "more than 1024 ranks");
     // A rank that fails locally (bad pitch, a HIP error in its first pass, no plan) must not leave its peers waiting in a

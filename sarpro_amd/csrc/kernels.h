@@ -124,11 +124,13 @@ struct ClaheRgbArgs {
     // f64 -- a function of the pixel's row and column alone.  sat_col[c]: which of the (at most three) values T = fl((1 - dx) + dx)
     // column c produces; sat_row[r]: bit k set = a saturated pixel of row r in a column of class k gets level 255 (else 254).
     const uint8_t *sat_col, *sat_row;   // [cols rounded up to the pitch], [rows]; host-built with the plan (api.cpp)
+    uint32_t no_verdict;                // a row stripe: the counts are summed over the ranks first, launch_spec_verdict takes the verdict
     uint32_t sat_cols;                  // entries of sat_col
     uint32_t sat_ok;                    // 0: tables absent (the geometry produced more than three classes): such pixels take the exact path
 };
 bool clahe_rgb_fused_supported(const ClaheRgbArgs &a);
 hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid /* persistent workgroups: one per CU */, hipStream_t s);
+hipError_t launch_spec_verdict(struct ChainSpecState *spec, hipStream_t s); // the fused pass's verdict from counts that were all-reduced
 
 constexpr size_t kSpecDumpBytes = 256 * 1024;
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);

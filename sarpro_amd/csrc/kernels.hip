@@ -1614,13 +1614,20 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
         atomicAdd(&sp->n_lt[0], (unsigned long long)s_lt[0]);
         atomicAdd(&sp->n_lt[1], (unsigned long long)s_lt[1]);
         __threadfence();
-        if (atomicAdd(&sp->done, 1u) == gridDim.x - 1u) {
+        if (!a.no_verdict && atomicAdd(&sp->done, 1u) == gridDim.x - 1u) {
             __threadfence();
             const unsigned long long c0 = atomicAdd(&sp->n_lt[0], 0ull), c1 = atomicAdd(&sp->n_lt[1], 0ull), target = sp->target;
             const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
             sp->verdict = ok ? 0u : 1u;
         }
     }
+}
+// Row stripes: every rank's pass has added its counts, the ranks have summed them; the same verdict on every rank.
+__global__ void k_spec_verdict(ChainSpecState *sp) {
+    if (!sp->spec_ok || sp->pool_overflow) return; // the passes did not run: "refuted" stands
+    const unsigned long long c0 = sp->n_lt[0], c1 = sp->n_lt[1], target = sp->target;
+    const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
+    sp->verdict = ok ? 0u : 1u;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1824,6 +1831,7 @@ __global__ __launch_bounds__(kBlock) void k_synth_scene_u16(uint64_t key, const 
         const bool left = c * rows_total * 100ull < 3ull * cols * (rows_total - r);
         const bool right = (cols - 1 - c) * rows_total * 100ull < 3ull * cols * r;
         if (!(flags & 1u) && (left || right)) dn = 0;
+        if ((flags & 4u) && (key >> 60)) dn = 0; // SARPRO_HIP_SYNTH_NO_BAND2: the second band holds no valid sample
         out[rl * pitch + c] = (uint16_t)dn;
     }
 }
@@ -1954,14 +1962,34 @@ hipError_t opt_in_dynamic_lds(const void *kernel) {
     return e;
 }
 
-bool clahe_rgb_fused_supported(const ClaheRgbArgs &a) {
-    return a.nrects > 0 && a.spec && a.dev_state && a.in_pitch % 8 == 0 && a.rgb_pitch_px % 16 == 0 && (reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 &&
-           (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.rgb) & 15) == 0;
+bool clahe_rgb_fused_supported(const ClaheRgbArgs &a) { // (nrects == 0: a rank whose stripe is empty -- nothing to launch, nothing to align)
+    return a.nrects >= 0 && a.spec && a.dev_state && a.in_pitch % 8 == 0 && a.rgb_pitch_px % 16 == 0 &&
+           (a.nrects == 0 || ((reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 &&
+                              (reinterpret_cast<uintptr_t>(a.rgb) & 15) == 0));
+}
+hipError_t launch_spec_verdict(ChainSpecState *spec, hipStream_t s) {
+    hipLaunchKernelGGL(k_spec_verdict, dim3(1), dim3(1), 0, s, spec);
+    return hipGetLastError();
 }
 hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s) {
     if (!clahe_rgb_fused_supported(a) || grid <= 0) return hipErrorInvalidValue;
+    if (a.nrects == 0) return hipSuccess;
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused))) return e;
     hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
+    return hipGetLastError();
+}
+
+// the in-process communicator's all-reduce (comm.cpp): out[i] = sum over the ranks' buffers
+__global__ __launch_bounds__(kBlock) void k_sum_rank_buffers(const uint64_t *const *ptrs, int nranks, uint64_t *out, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) {
+        uint64_t acc = 0;
+        for (int r = 0; r < nranks; ++r) acc += ptrs[r][i];
+        out[i] = acc;
+    }
+}
+hipError_t launch_sum_rank_buffers(const uint64_t *const *d_ptrs, int nranks, uint64_t *out, size_t count, hipStream_t s) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_sum_rank_buffers, dim3((unsigned)std::min<size_t>((count + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, s, d_ptrs, nranks, out, count);
     return hipGetLastError();
 }
 

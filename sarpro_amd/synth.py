@@ -26,7 +26,7 @@ CLASS_SCALE = (0.25, 1.0, 2.0, 4.0)
 M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-NO_WEDGE, NO_BRIGHT = 1, 2
+NO_WEDGE, NO_BRIGHT, NO_BAND2 = 1, 2, 4
 
 
 def class_map(m: int) -> int:
@@ -52,7 +52,7 @@ def q_tables(flat: bool = False, sigma=SIGMA, scales=CLASS_SCALE) -> np.ndarray:
 # The scenes bench.py cycles its timed steps over: (name, seed offset, flags, q_tables keyword arguments, what it is there for).
 # Scene A first (the scene of rounds 1-3, so that rounds stay comparable).  Three of them are there to MISS the speculative fused
 # route: no invalid pixel (level 0 absent: the u8 rescale of autoscale.rs:348-364 is not provably the identity), amplitude windows
-# beyond the fused pass's LDS pool, a constant band (no level 255).
+# beyond the fused pass's LDS pool, a band without a valid sample (no level 255).
 BENCH_SCENES = (
     ("A", 0, 0, {}, "scene A of rounds 1-3: four sigma classes in 16 x 16 blocks, no-data wedges, bright targets"),
     ("B-xor-map", 1, class_map(1), {"sigma": (140.0, 55.0)}, "other class map and sigma set"),
@@ -62,7 +62,7 @@ BENCH_SCENES = (
     ("F-flat", 5, class_map(3), {"sigma": (160.0, 60.0)}, "one class everywhere (single-Rayleigh scene: IQR < 5 dB)"),
     ("G-no-bright", 6, class_map(1) | blocks(7) | NO_BRIGHT, {"sigma": (120.0, 80.0), "scales": (0.3, 1.0, 2.5, 5.0)}, "large blocks, no bright targets"),
     ("H-quantised-VH", 7, 0, {"sigma": (180.0, 2.5)}, "VH amplitudes of a few DN: heavily quantised band, a dozen occupied CLAHE bins"),
-    ("I-constant-VH", 8, NO_BRIGHT, {"sigma": (180.0, 0.0)}, "VH band constant (DN 1 on every valid pixel): one occupied CLAHE bin, no level 255 in the band -> exact route"),
+    ("I-no-VH", 8, NO_BAND2, {}, "VH band without a valid sample (a missing polarisation): no level 255 in the band, nothing proven -> exact route"),
 )
 
 
@@ -106,4 +106,6 @@ def scene_u16(rows: int, cols: int, band: int, seed: int = SEED_SCENE_A, q: np.n
         left = c * R * np.uint64(100) < np.uint64(3) * C * (R - r)
         right = (C - np.uint64(1) - c) * R * np.uint64(100) < np.uint64(3) * C * r
         dn = np.where(left | right, np.uint16(0), dn)
+    if flags & NO_BAND2 and band == 1:
+        dn = np.zeros_like(dn)
     return np.ascontiguousarray(dn.astype(np.uint16))

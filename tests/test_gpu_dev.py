@@ -31,6 +31,14 @@ def test_synth_generator_device_equals_numpy(ctx):
         ctx.dev_synth_scene_u16(synth.SEED_SCENE_A, band, q, rows, cols, row0, nloc, t.data_ptr(), 448)
         got = t[:, :cols].cpu().numpy().view(np.uint16)
         assert np.array_equal(got, synth.scene_u16(rows, cols, band, row0=row0, rows_local=nloc))
+    # the scenes bench.py cycles over (other class maps, block sizes, sigma sets, no wedge, no bright targets, a missing band)
+    for name, off, flags, qkw, _ in synth.BENCH_SCENES:
+        qs = synth.q_tables(**qkw)
+        for band in (0, 1):
+            t = torch.zeros((nloc, 448), dtype=torch.int16, device="cuda")
+            ctx.dev_synth_scene_u16(synth.SEED_SCENE_A + off, band, qs, rows, cols, row0, nloc, t.data_ptr(), 448, flags)
+            got = t[:, :cols].cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, synth.scene_u16(rows, cols, band, seed=synth.SEED_SCENE_A + off, q=qs, row0=row0, rows_local=nloc, flags=flags)), name
 
 
 @pytest.mark.parametrize("strategy", [St.Clahe, St.Robust, St.Standard])

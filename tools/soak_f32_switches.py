@@ -8,6 +8,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+import sw
 import torch
 import sarpro_amd as S
 from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, PolarizationOperation as Op
@@ -18,7 +19,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = runs = 0
 t0 = time.time()
-os.environ["SARPRO_HIP_F32_DIRECT"] = "0"
+sw.set("SARPRO_HIP_F32_DIRECT", "0")
 with S.Context(0) as c:
     for seed in range(first, first + n):
         g = torch.Generator(device="cuda"); g.manual_seed(9100 + seed)
@@ -44,14 +45,14 @@ with S.Context(0) as c:
         outs = []
         for env in [{}] + SWITCHES:
             saved = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)
+            sw.update(env)
             o = torch.zeros((rows, pitch), dtype=dt, device="cuda")
             torch.cuda.synchronize()
             call(o)
             outs.append(o[:, :cols].clone())
             for k, v in saved.items():
-                if v is None: os.environ.pop(k, None)
-                else: os.environ[k] = v
+                if v is None: sw.pop(k)
+                else: sw.set(k, v)
             runs += 1
         if int(torch.unique(outs[0][::7, ::5]).numel()) < 8:
             print(f"SUSPICIOUS seed {seed}: the default raster holds fewer than 8 distinct levels", flush=True); bad += 1

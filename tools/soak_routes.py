@@ -4,6 +4,7 @@ vs SARPRO_HIP_NO_FUSED=1 (table pass + compose), rasters compared byte for byte 
 usage: python tools/soak_routes.py [n_scenes] [rows] [cols]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sw
 import torch
 import sarpro_amd as S
 from sarpro_amd import synth
@@ -21,17 +22,17 @@ for k in range(n):
     for b in range(2):
         ctx.dev_synth_scene_u16(synth.SEED_SCENE_A + 2000 + k, b, q, rows, cols, 0, rows, band[b].data_ptr(), pitch)
     for strategy in S.AutoscaleStrategy:
-        for sw in SWITCHES: os.environ.pop(sw, None)
+        for name in SWITCHES: sw.pop(name)
         ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, strategy, S.SyntheticRgbMode.Default, rgb[0].data_ptr(), pitch)
-        for sw in SWITCHES:
-            os.environ[sw] = "1"
+        for name in SWITCHES:
+            sw.set(name, "1")
             rgb[1].zero_()
             ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, strategy, S.SyntheticRgbMode.Default, rgb[1].data_ptr(), pitch)
-            os.environ.pop(sw)
+            sw.pop(name)
             diff = int((rgb[0].view(rows, pitch, 3)[:, :cols] != rgb[1].view(rows, pitch, 3)[:, :cols]).sum().item())
             if diff:
                 bad += 1
-                print(f"scene {k} {strategy.name} {sw}: {diff} bytes differ", flush=True)
+                print(f"scene {k} {strategy.name} {name}: {diff} bytes differ", flush=True)
     print(f"scene {k}: done, {time.time() - t0:.0f} s", flush=True)
 print(f"{n} scenes x {len(list(S.AutoscaleStrategy))} strategies x {len(SWITCHES)} switches at {rows}x{cols}: {bad} differences")
 sys.exit(1 if bad else 0)

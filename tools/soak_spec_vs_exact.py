@@ -5,6 +5,7 @@ blend (SARPRO_HIP_NO_SPEC=1) -- and the RGB rasters compared byte for byte on th
 usage: python tools/soak_spec_vs_exact.py [n_scenes] [rows] [cols]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sw
 import torch
 import sarpro_amd as S
 from sarpro_amd import synth
@@ -23,11 +24,11 @@ for k in range(n):
     for b in range(2):
         ctx.dev_synth_scene_u16(synth.SEED_SCENE_A + 1000 + k, b, q, rows, cols, 0, rows, band[b].data_ptr(), pitch)
     for which, env in ((0, None), (1, "SARPRO_HIP_NO_SPEC"), (2, "SARPRO_HIP_NO_FUSED_RGB")):
-        for k2 in SW: os.environ.pop(k2, None)
-        if env: os.environ[env] = "1"
+        for k2 in SW: sw.pop(k2)
+        if env: sw.set(env, "1")
         ctx.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, S.AutoscaleStrategy.Clahe,
                                    S.SyntheticRgbMode.Default, rgb[which].data_ptr(), pitch)
-    for k2 in SW: os.environ.pop(k2, None)
+    for k2 in SW: sw.pop(k2)
     diff = int((rgb[0].view(rows, pitch, 3)[:, :cols] != rgb[1].view(rows, pitch, 3)[:, :cols]).sum().item())
     diff += int((rgb[2].view(rows, pitch, 3)[:, :cols] != rgb[1].view(rows, pitch, 3)[:, :cols]).sum().item())
     bad += diff != 0

@@ -4,6 +4,7 @@ estimate of the two cumulative counts against the exact ones the compose pass co
 target from the nearest boundary (what the estimate's error has to stay under).  usage: spec_accuracy.py [nseeds] [side]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sw
 import torch
 import sarpro_amd as S
 from sarpro_amd import AutoscaleStrategy as St, SyntheticRgbMode as Mode, synth
@@ -11,7 +12,7 @@ nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rows = cols = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 pitch = (cols + 63) // 64 * 64
 q = synth.q_tables()
-os.environ["SARPRO_HIP_SAMPLED_HIST_MIN_PX"] = "0"
+sw.set("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
 with S.Context(0, timing=True) as c:
     d = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
     rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
@@ -19,7 +20,7 @@ with S.Context(0, timing=True) as c:
         for k in range(2):
             c.dev_synth_scene_u16(synth.SEED_SCENE_A + seed, k, q, rows, cols, 0, rows, d[k].data_ptr(), pitch)
         for stride in (9, 17, 33, 65):
-            os.environ["SARPRO_HIP_SAMPLE_STRIDE"] = str(stride)
+            sw.set("SARPRO_HIP_SAMPLE_STRIDE", str(stride))
             c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
             r = c.spec_report()
             err = [r["est_lt"][i] - r["n_lt"][i] for i in range(2)] if r["spec_ok"] else None

@@ -3,6 +3,7 @@
 unfused (k_polop_f32 + f32 flavour), fused, fused without the zone route, fused with the 65535-entry level table."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sw
 import torch
 import sarpro_amd as S
 from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, PolarizationOperation as Op, synth
@@ -40,8 +41,8 @@ with S.Context(0, timing=True) as c:
                               ("fused, zone route, level table", {"SARPRO_HIP_F32_LEVEL_TABLE": "1"}, fused),
                               ("fused, zone route, queued levels (default)", {}, fused)):
             for k in ("SARPRO_HIP_F32_ZONES", "SARPRO_HIP_F32_LEVEL_TABLE"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+                sw.pop(k)
+            sw.update(env)
             ms = timed(fn)
             kern = {k: round(v, 3) for k, v in c.last_kernel_times() if not k.startswith("host:")}
             print(f"{strategy.name:9s} {bd.name:4s} {name:66s} {ms:6.3f} ms  {kern}", flush=True)

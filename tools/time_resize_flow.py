@@ -4,6 +4,7 @@ time per scene and every kernel of the composite call, with the horizontal pass 
 register-resident resize kernels (SARPRO_HIP_NO_RESIZE_LUT=1), and with the generic kernels (SARPRO_HIP_RESIZE_GENERIC=1)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sw
 import torch
 import sarpro_amd as S
 from sarpro_amd import AutoscaleStrategy as St, synth, resize_output_dims
@@ -13,9 +14,9 @@ pitch = (cols + 63) // 64 * 64
 q = synth.q_tables()
 for env in ("", "nolut", "1"):
     if env == "nolut":
-        os.environ["SARPRO_HIP_NO_RESIZE_LUT"] = "1"
+        sw.set("SARPRO_HIP_NO_RESIZE_LUT", "1")
     if env == "1":
-        os.environ["SARPRO_HIP_RESIZE_GENERIC"] = "1"
+        sw.set("SARPRO_HIP_RESIZE_GENERIC", "1")
     with S.Context(0, timing=True) as c:
         band = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
         for b in range(2):

@@ -1,5 +1,6 @@
 import os, sys, time
 sys.path.insert(0, "/root/repo")
+import sw
 import torch, numpy as np
 import sarpro_amd as S
 from sarpro_amd import AutoscaleStrategy as St, BitDepth as Bd, synth
@@ -15,7 +16,7 @@ with S.Context(0, timing=True) as c:
         for strategy in (St.Standard, St.Clahe):
             res = []
             for env in ("0", "force"):
-                os.environ["SARPRO_HIP_F32_ZONES"] = env
+                sw.set("SARPRO_HIP_F32_ZONES", env)
                 fn = lambda: c.dev_autoscale_band_f32(f.data_ptr(), rows, cols, pitch, strategy, Bd.U8, out.data_ptr(), pitch, want_stats=False)
                 fn(); fn(); torch.cuda.synchronize()
                 t = time.perf_counter()
