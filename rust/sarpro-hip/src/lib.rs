@@ -112,6 +112,22 @@ pub struct ProcessedImage {
 fn zeroed_stats() -> HistogramStats { unsafe { std::mem::zeroed() } }
 fn zeroed_meta() -> ResizeMeta { unsafe { std::mem::zeroed() } }
 
+/// The communicator of the contexts of ONE process (`sarpro_hip_local_group`): threads instead of ranks of an RCCL job.
+pub struct LocalGroup { raw: *mut sys::sarpro_hip_local_group }
+unsafe impl Send for LocalGroup {}
+unsafe impl Sync for LocalGroup {}
+impl LocalGroup {
+    pub fn new(nranks: i32) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { sys::sarpro_hip_local_group_create(nranks as c_int, &mut raw) };
+        if rc != sys::SARPRO_HIP_OK { return Err(HipError { code: rc, message: "sarpro_hip_local_group_create failed".into() }); }
+        Ok(Self { raw })
+    }
+}
+impl Drop for LocalGroup {
+    fn drop(&mut self) { unsafe { sys::sarpro_hip_local_group_destroy(self.raw) } }
+}
+
 /// One library context (one HIP stream, its workspaces).  One per host thread; contexts are independent.
 pub struct RasterCore { ctx: *mut sys::sarpro_hip_ctx }
 unsafe impl Send for RasterCore {}
@@ -459,6 +475,11 @@ impl RasterCore {
         self.chk(sys::sarpro_hip_comm_allreduce_sum_u64(self.ctx, d_buf, count))
     }
     pub fn comm_destroy(&self) { unsafe { sys::sarpro_hip_comm_destroy(self.ctx) } }
+    /// Join the in-process communicator `group` as `rank`: one `RasterCore` and one thread per rank, no RCCL (the ranks' device
+    /// buffers must be mutually accessible: one device, or peer access enabled).  The group must outlive the contexts that joined it.
+    pub fn comm_init_local(&self, group: &LocalGroup, rank: i32) -> Result<()> {
+        self.chk(unsafe { sys::sarpro_hip_comm_init_local(self.ctx, group.raw, rank as c_int) })
+    }
 
     /// tile-aligned row stripes of a `rows`-row scene for `nranks` ranks: `(row0, nrows)` per rank
     pub fn stripe_plan(rows: usize, nranks: usize) -> Result<Vec<(usize, usize)>> {
