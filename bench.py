@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (N = 1: end-to-end over PCIe, BASELINE configs 1-3, resize; "
                                                                "N > 1: row-stripe mode over RCCL and the PCIe-inclusive leg on all ranks)")
     ap.add_argument("--secondary-only", action="store_true", help=argparse.SUPPRESS)  # the child process that measures the N = 1 secondary records
+    ap.add_argument("--traffic-only", action="store_true", help=argparse.SUPPRESS)    # the child process that measures roofline.traffic under rocprofv3
+    ap.add_argument("--no-traffic", action="store_true", help="roofline.traffic from the committed PMC passes (profiles/) instead of two rocprofv3 --pmc passes "
+                                                               "started by this run after the timed region (~1 min)")
     ap.add_argument("--pitch-align", type=int, default=64, help="row pitch of the resident rasters, rounded up to this many elements")
     ap.add_argument("--scenes", type=int, default=0, help="how many of sarpro_amd.synth.BENCH_SCENES the timed steps cycle over (0 = all of them; 1 = scene A only, "
                                                           "the workload of rounds 1-3)")
@@ -62,9 +65,15 @@ def main():
         sys.exit(self_launch(args))
     if args.secondary_only:
         sys.exit(secondary_child(args))
+    if args.traffic_only:
+        sys.exit(traffic_child(args))
     # N = 1: the secondary records are measured by a CHILD process, started here -- before this process touches a GPU runtime --
     # and parked on its stdin until the headline is done (see secondary_start)
     sec_child = secondary_start(args) if (args.gpus == 1 and not args.no_secondary) else None
+    # roofline.traffic is MEASURED by this run: a second child, parked like the first, runs the headline scene under
+    # rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes) once the timed region is over
+    traffic_proc = traffic_start(args) if (args.gpus == 1 and not args.no_traffic and args.strategy.lower() == "clahe"
+                                           and (args.rows, args.cols) == (20000, 20000)) else None
 
     import torch
     import torch.distributed as dist
@@ -147,6 +156,8 @@ def main():
     # refuted / unproven / pool_overflow -- a property of the scene, the chain is deterministic) and what one synchronous call costs.
     # Rank 0 keeps scene A's RGB raster on the host: the CPU baseline below compares it with the oracle's, pixel by pixel.
     outcomes, scene_sync_ms, rgb_a_host = [], [], None
+    step(0)  # (the first call of a shape builds its plan and sizes the workspaces: not what "one synchronous call" is meant to show)
+    ctx.synchronize()
     for i in range(K):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -293,6 +304,12 @@ def main():
     ctx.close()
     parity_failed = False
     if rank == 0:
+        if traffic_proc is not None and out.get("roofline"):
+            live = traffic_collect(traffic_proc, out["roofline"]["kernel"])
+            if live and "value" in live:
+                out["roofline"]["traffic"] = live
+            elif live:
+                out["roofline"]["traffic_live_error"] = live.get("error")
         if sec_child is not None:
             out["secondary"] = secondary_collect(sec_child)
         print(json.dumps(out), flush=True)
@@ -322,6 +339,82 @@ def self_launch(args):
         cmd = [sys.executable, launcher] + cmd[3:]
     proc = subprocess.run(cmd, env=env)
     return proc.returncode
+
+
+def traffic_start(args):
+    """A child that has loaded no GPU runtime, parked on its stdin: on "go" it runs tools/profile_one.py (three headline scenes, nothing
+    else in the process) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (the two do not fit one
+    pass; no other trace domain) and prints the per-kernel means."""
+    import subprocess
+    try:
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--traffic-only"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+    except Exception as e:
+        return e
+
+
+def traffic_child(args):
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if sys.stdin.readline().strip() != "go":
+        return 0
+    out = {}
+    try:
+        if not shutil.which("rocprofv3"):
+            raise RuntimeError("rocprofv3 is not on PATH")
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="sarpro_pmc_", dir="/tmp")
+            try:
+                subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "profile_one.py"), "3", "4"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                acc, n = {}, {}
+                for r in csv.DictReader(open(files[0])):
+                    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].split("::")[-1]
+                    acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+                    n[k] = n.get(k, 0) + 1
+                out[counter] = {k: acc[k] / n[k] for k in acc}
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:
+        out = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def traffic_collect(child, kernel):
+    """-> roofline.traffic of `kernel` (bench's name for it) from the child's two PMC passes, with the gfx950 corrections of
+    MI355X_MICROARCH.md (HBM section): the counters are KiB; FETCH_SIZE reports half the bytes of a 16-B-per-lane streaming read (x 2),
+    WRITE_SIZE is exact for 16-B-per-lane streaming stores."""
+    names = {"clahe_rgb_fused": "k_clahe_rgb_fused", "clahe_apply_u8_spec": "k_clahe_apply_u8_spec", "dn_hist_u16": "k_dn_hist_pieces",
+             "compose_u8": "k_compose_u8", "lut_compose_u16": "k_lut_compose_u16"}
+    if isinstance(child, Exception):
+        return {"error": f"{type(child).__name__}: {child}"}
+    try:
+        stdout, stderr = child.communicate("go\n", timeout=600)
+        lines = [l for l in stdout.splitlines() if l.startswith("{")]
+        raw = json.loads(lines[-1]) if lines else {"error": f"no output (exit {child.returncode}): {stderr[-200:]}"}
+        if "error" in raw:
+            return raw
+        k = names.get(kernel)
+        if not k or k not in raw.get("FETCH_SIZE", {}) or k not in raw.get("WRITE_SIZE", {}):
+            return {"error": f"no counters for {kernel}"}
+        rd, wr = raw["FETCH_SIZE"][k] * 1024 * 2 / 1e9, raw["WRITE_SIZE"][k] * 1024 / 1e9
+        return {"value": round(rd + wr, 3), "read": round(rd, 3), "write": round(wr, 3), "unit": "GB",
+                "source": "measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE over three headline "
+                          "scenes (scene A) after the timed region, same box and build; KiB counters, FETCH_SIZE x 2 (gfx950 reports half of a 16-B-per-lane "
+                          "streaming read), WRITE_SIZE as is"}
+    except Exception as e:
+        try:
+            child.kill()
+        except Exception:
+            pass
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def secondary_start(args):

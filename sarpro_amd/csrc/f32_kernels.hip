@@ -1056,14 +1056,14 @@ __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
 // ------------------------------------------------------------------------------------
 template <int VEC, bool OUT16>
 __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a) {
-    __shared__ __align__(16) double cdf4[256 * 4];
+    __shared__ __align__(16) double2 cdf2[2 * 256]; // (c00, c01) at [bin], (c10, c11) at [256 + bin]: two 16-byte arrays, every bank in use (kernels.hip 4)
     __shared__ float thr[256 + 1];
     __shared__ uint32_t hist[256];
     const Rect rc = a.rects[blockIdx.x];
     {
         const int b = threadIdx.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cdf4[b * 4 + k] = a.cdfs[(size_t)rc.id[k] * 256 + b];
+        cdf2[b] = make_double2(a.cdfs[(size_t)rc.id[0] * 256 + b], a.cdfs[(size_t)rc.id[1] * 256 + b]);
+        cdf2[256 + b] = make_double2(a.cdfs[(size_t)rc.id[2] * 256 + b], a.cdfs[(size_t)rc.id[3] * 256 + b]);
         thr[b] = b ? a.thr[b] : -INFINITY;
         if (b == 0) thr[256] = INFINITY;
         hist[b] = 0;
@@ -1127,9 +1127,9 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a)
 #pragma unroll
             for (int i = 0; i < M; ++i) {
                 const int k = i / VEC, j = i % VEC;
-                const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bins[i] * 4]);
-                const double top = c4.x * omdx[j] + c4.y * dx[j];
-                const double bottom = c4.z * omdx[j] + c4.w * dx[j];
+                const double2 ct = cdf2[bins[i]], cb = cdf2[256 + bins[i]];
+                const double top = ct.x * omdx[j] + ct.y * dx[j];
+                const double bottom = cb.x * omdx[j] + cb.y * dx[j];
                 double o = top * rw[k].omd + bottom * rw[k].d;
                 o = fmin(fmax(o, 0.0), 1.0);
                 lvs[i] = ok[i] ? (uint32_t)(o * a.max_val) : 0u;
@@ -1173,7 +1173,7 @@ constexpr float kF32SpecDeltaEdge = 6.2e-4f, kF32SpecDeltaInner = 1.6e-4f; // (k
 constexpr float kF32SpecDeltaEdgeY = 3.0e-4f, kF32SpecDeltaEdgeX = 2.6e-4f; // cells that extrapolate along one axis only (kernels.hip 4b)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyArgs a) {
-    __shared__ __align__(16) double cdf4[256 * 4];
+    __shared__ __align__(16) double2 cdf2[2 * 256]; // (c00, c01) at [bin], (c10, c11) at [256 + bin]: two 16-byte arrays, every bank in use (kernels.hip 4)
     __shared__ __align__(16) float4 e32[256 + 1];
     __shared__ float thr[256 + 1];
     __shared__ uint32_t hist[256];
@@ -1183,7 +1183,9 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyAr
         const int b = threadIdx.x;
         double c[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { c[k] = a.cdfs[(size_t)rc.id[k] * 256 + b]; cdf4[b * 4 + k] = c[k]; }
+        for (int k = 0; k < 4; ++k) c[k] = a.cdfs[(size_t)rc.id[k] * 256 + b];
+        cdf2[b] = make_double2(c[0], c[1]);
+        cdf2[256 + b] = make_double2(c[2], c[3]);
         const bool saturated = c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0 && !edge;
         const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
         const float kz = 0.5f / 255.0f;
@@ -1253,9 +1255,9 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyAr
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     if (!((flagged >> j) & 1u)) continue;
-                    const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bins[j] * 4]); // (a flagged sample is valid: entry 256 is never near)
-                    const double top = c4.x * omdx[j] + c4.y * dx[j];
-                    const double bottom = c4.z * omdx[j] + c4.w * dx[j];
+                    const double2 ct = cdf2[bins[j]], cb = cdf2[256 + bins[j]]; // (a flagged sample is valid: entry 256 is never near)
+                    const double top = ct.x * omdx[j] + ct.y * dx[j];
+                    const double bottom = cb.x * omdx[j] + cb.y * dx[j];
                     double o = top * rw.omd + bottom * rw.d;
                     o = fmin(fmax(o, 0.0), 1.0);
                     lvs[j] = (uint32_t)(o * 255.0);

@@ -337,12 +337,21 @@ __global__ __launch_bounds__(kTileBinBlock) void k_tile_bin_hist(TileBinHistArgs
 //    the per-row weights (dy, 1-dy) are wave-uniform.
 //    Algorithmic traffic: 2 B/px read + 1 (u8) or 2 (u16) B/px written.
 // ------------------------------------------------------------------------------------
+#ifndef SARPRO_U16_CDF_COPIES
+#define SARPRO_U16_CDF_COPIES 2
+#endif
 template <int VEC, bool OUT16>
 __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    double *cdf4 = reinterpret_cast<double *>(lds_raw);                        // [256][4]
-    uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_raw + 256 * 4 * 8);  // [256]
-    uint8_t *lds_lut = lds_raw + 256 * 4 * 8 + 256 * 4;                        // window
+    // the four CDFs of a bin as TWO 16-byte halves in two arrays, (c00, c01) at [bin] and (c10, c11) at [256 + bin]: with one 32-byte
+    // entry per bin each of the two 16-byte reads of a sample could only ever land on half of the LDS banks (entry stride 32 B: the
+    // first halves on bank quads 0, 2, 4, 6, the second halves on the odd ones) -- 70 % of the pass's LDS cycles were bank conflicts
+    // ... and kCopies copies of both arrays, chosen by lane: the eight lanes a 16-byte LDS read serves per cycle pick among eight bank
+    // quads at random -- half of them on each copy collide less
+    constexpr int kCopies = SARPRO_U16_CDF_COPIES;
+    double2 *cdf2 = reinterpret_cast<double2 *>(lds_raw) + (kCopies > 1 ? ((threadIdx.x >> 2) & (kCopies - 1)) * 512 : 0); // [copy][2][256]
+    uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_raw + kCopies * 256 * 4 * 8);  // [256]
+    uint8_t *lds_lut = lds_raw + kCopies * 256 * 4 * 8 + 256 * 4;                        // window
 
     const Rect rc = a.rects[blockIdx.x];
     const int band = blockIdx.y;
@@ -354,10 +363,15 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
     const bool lut_lds = a.dev_state ? win_hi < a.lut_cap : a.lut_in_lds != 0;
     unsigned long long *ghist = a.level_hist[band];
 
-    {   // stage the four CDFs interleaved per bin: one pixel gathers 32 contiguous bytes
+    {   // stage the four CDFs of every bin
         const int b = threadIdx.x; // kBlock == 256 bins
+        const double2 ct = make_double2(cdfs[(size_t)rc.id[0] * 256 + b], cdfs[(size_t)rc.id[1] * 256 + b]);
+        const double2 cb = make_double2(cdfs[(size_t)rc.id[2] * 256 + b], cdfs[(size_t)rc.id[3] * 256 + b]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cdf4[b * 4 + k] = cdfs[(size_t)rc.id[k] * 256 + b];
+        for (int k = 0; k < kCopies; ++k) {
+            reinterpret_cast<double2 *>(lds_raw)[k * 512 + b] = ct;
+            reinterpret_cast<double2 *>(lds_raw)[k * 512 + 256 + b] = cb;
+        }
         lds_hist[b] = 0;
         if (lut_lds)
             for (uint32_t i = threadIdx.x; i <= win_hi - win_lo; i += kBlock) lds_lut[i] = glut[win_lo + i];
@@ -388,9 +402,9 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
             const uint32_t d = v.get(j);
             const uint32_t dc = min(max(d, win_lo), win_hi);
             const uint32_t bin = lut_lds ? (uint32_t)lds_lut[dc - win_lo] : (uint32_t)glut[dc];
-            const double4 c4 = *reinterpret_cast<const double4 *>(&cdf4[bin * 4]);
-            const double top = c4.x * omdx[j] + c4.y * dx[j];
-            const double bottom = c4.z * omdx[j] + c4.w * dx[j];
+            const double2 ct = cdf2[bin], cb = cdf2[256 + bin];
+            const double top = ct.x * omdx[j] + ct.y * dx[j];
+            const double bottom = cb.x * omdx[j] + cb.y * dx[j];
             double o = top * omdy + bottom * dy;
             o = fmin(fmax(o, 0.0), 1.0);
             const uint32_t level = (uint32_t)(o * a.max_val); // truncation, o*max_val in [0, max_val]
@@ -1232,6 +1246,11 @@ struct RgbLds {
     static constexpr uint32_t misc = pool + kRgbPoolEntries * 16;           // scratch words of the epilogue
     static constexpr uint32_t total = misc + 64;
 };
+// WIDE form (DN windows that do not fit the pool): the region [binof, misc) holds the DN -> bin bytes of both windows (loaded once per
+// workgroup) and, at its end, the item's 2 x 257 bin-indexed 16-byte entries; a sample costs one more LDS byte read (its bin).
+constexpr uint32_t kWideEnt = RgbLds::misc - 2u * 257u * 16u;    // [2][257] float4
+constexpr uint32_t kWideBytes = kWideEnt - RgbLds::binof;         // capacity: win_hi[0] + win_hi[1] + 2 bytes
+static_assert(kWideEnt % 16 == 0, "alignment");
 static_assert(RgbLds::total <= 160 * 1024, "fused pass: LDS budget");
 static_assert(RgbLds::stage % 16 == 0 && RgbLds::pool % 16 == 0 && RgbLds::cdf64 % 16 == 0, "alignment");
 static_assert(kRgbPoolEntries / 4 + 2 <= kRgbBlock, "one pass of the workgroup expands the whole pool");
@@ -1242,12 +1261,18 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
     ChainSpecState *sp = a.spec;
     if (!sp->spec_ok) return;
     const uint32_t win_hi[2] = {a.dev_state[0].win_hi, a.dev_state[1].win_hi};
-    if ((uint64_t)win_hi[0] + win_hi[1] + 2u > kRgbPoolEntries) { // windows do not fit: the verdict stays "refuted", the gated kernels run
+    const uint64_t nwin = (uint64_t)win_hi[0] + win_hi[1] + 2u;
+    const bool wide = nwin > kRgbPoolEntries; // the windows do not fit the DN-indexed pool: bin-indexed entries behind a DN -> bin byte table
+    if (wide && nwin > kWideBytes) { // ... nor the byte table: the verdict stays "refuted", the gated kernels run
         if (blockIdx.x == 0 && threadIdx.x == 0) sp->pool_overflow = 1u;
         return;
     }
-    const uint32_t kb[2] = {0u, win_hi[0] + 1u}; // first pool entry of each band
+    const uint32_t kb[2] = {0u, win_hi[0] + 1u}; // first pool entry (WIDE: first table byte) of each band
     const int lane = lane_id(), wave = wave_id();
+    if (wide) { // the DN -> bin bytes of both windows, once per workgroup (the item loop's first barrier publishes them)
+        for (int b = 0; b < 2; ++b)
+            for (uint32_t i = threadIdx.x; i <= win_hi[b]; i += kRgbBlock) lds[RgbLds::binof + kb[b] + i] = a.binlut[b][i];
+    }
     {   // compose tables, once per workgroup
         const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
         uint4 *dst = reinterpret_cast<uint4 *>(lds + RgbLds::tables);
@@ -1261,6 +1286,8 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 
     for (int item = blockIdx.x; item < a.nrects; item += gridDim.x) {
         const Rect rc = a.rects[item];
+        uint32_t *const s_bsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 4; // WIDE: per band the first saturated bin (256: none)
+        if (wide && threadIdx.x < 2) s_bsat[threadIdx.x] = 256u; // (only the prologue reads it: no wave of the previous item does)
         __syncthreads(); // the previous item's rows are done (its tables may go; the compose tables have landed)
 #ifdef SARPRO_ABL_RGB_PROLOGUE2 // timing ablation: every item builds its tables twice (the difference to the default build = what the prologues cost)
         for (int rep = 0; rep < 2; ++rep)
@@ -1292,6 +1319,7 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                                : zero    ? make_float4(kz, kz, 0.0f, 0.0f)
                                          : make_float4(c00, c10, c01 - c00, c11 - c10);
             *reinterpret_cast<float4 *>(lds + RgbLds::stage + (b * 257 + bin) * 16) = e32;
+            if (wide && saturated && (rc.pad[0] & 1)) atomicMin(&s_bsat[b], (uint32_t)bin);
         }
         for (int i = threadIdx.x; i < 512; i += kRgbBlock) {
             const int c2 = rc.cstart + i;
@@ -1305,14 +1333,26 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
         int qb = -1;
         {
             const uint32_t n0q = (win_hi[0] >> 2) + 1u, n1q = (win_hi[1] >> 2) + 1u; // n0q + n1q <= kRgbPoolEntries / 4 + 2 <= kRgbBlock
-            if (threadIdx.x < n0q + n1q) {
+            if (!wide && threadIdx.x < n0q + n1q) {
                 qb = threadIdx.x >= n0q ? 1 : 0;
                 qdn = (threadIdx.x - (qb ? n0q : 0u)) * 4u;
                 q4 = *reinterpret_cast<const uint32_t *>(a.binlut[qb] + qdn);
             }
         }
         __syncthreads();
-        if (qb >= 0) {
+        if (wide) { // the item's bin-indexed entries to their place; the first DN of a saturated bin by bisection of the (monotone) byte table
+            for (int t = threadIdx.x; t < 2 * 257; t += kRgbBlock)
+                *reinterpret_cast<float4 *>(lds + kWideEnt + t * 16) = *reinterpret_cast<const float4 *>(lds + RgbLds::stage + t * 16);
+            if (threadIdx.x < 2 && (rc.pad[0] & 1)) {
+                const uint32_t b = threadIdx.x, bs = s_bsat[b];
+                uint32_t lo = 1u, hi = win_hi[b] + 1u; // first dn in [1, win_hi] whose bin >= bs; win_hi + 1: none
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint32_t)lds[RgbLds::binof + kb[b] + mid] >= bs) hi = mid; else lo = mid + 1u;
+                }
+                s_dnsat[b] = (bs < 256u && lo <= win_hi[b]) ? lo : 0xFFFFu;
+            }
+        } else if (qb >= 0) {
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t dn = qdn + k;
@@ -1331,8 +1371,8 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 
         // The rows of the item, compiled twice and chosen per item by a wave-uniform branch: items of extrapolating cells (EDGE) and
         // the others.
-        auto item_rows = [&](auto edge_tag) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
+        auto item_rows = [&](auto edge_tag, auto wide_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value, WIDE = decltype(wide_tag)::value;
         // EDGE: the lane's eight columns by saturation class (byte j = 1: column j is of class k), the bands' first saturated DN
         uint32_t satM[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
         uint32_t dnsat2[2] = {0xFFFEFFFEu, 0xFFFEFFFEu}; // (first saturated DN - 1) in both halves
@@ -1400,6 +1440,8 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
             const uint32_t pbase = to_sgpr_u32(RgbLds::pool + kb[b] * 16u);
             uint32_t off[VEC];
             uint32_t sat01[4] = {0u, 0u, 0u, 0u}; // EDGE: per sample 1 (in its 16-bit half) when its bin is saturated
+            uint32_t nz01[4] = {0u, 0u, 0u, 0u};  // WIDE: per sample 1 when it is valid (DN != 0): the byte table has no entry for "invalid"
+            const uint32_t bbase = to_sgpr_u32(RgbLds::binof + kb[b]), ebase = to_sgpr_u32(kWideEnt + (uint32_t)b * 257u * 16u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
@@ -1410,6 +1452,14 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                     sat01[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_sub_sat(c, __builtin_bit_cast(v2us, dnsat2[b])), one));
                 }
                 uint32_t a0, a1;
+                if (WIDE) { // the samples' bins first: byte address = table base + clamped DN
+                    const v2us one = {1, 1};
+                    nz01[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(c, one));
+                    asm("v_mad_u32_u16 %0, %1, 1, %2" : "=v"(a0) : "v"(cw), "s"(bbase));
+                    asm("v_mad_u32_u16 %0, %1, 1, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(cw), "s"(bbase));
+                    off[2 * k] = a0; off[2 * k + 1] = a1;
+                    continue;
+                }
 #ifdef SARPRO_RGB_OLDADDR
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(4u), "v"(cw));
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(4u), "v"(cw));
@@ -1420,6 +1470,13 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                 asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(cw), "s"(pbase));
                 off[2 * k] = a0; off[2 * k + 1] = a1;
 #endif
+            }
+            if (WIDE) { // bin -> entry address, all eight byte reads in flight before the first is used
+                uint32_t bq[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) bq[j] = LDS_AT(uint8_t, off[j]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) off[j] = ebase + (bq[j] << 4);
             }
             uint32_t pb[2] = {0u, 0u};
             pk[0] = 0u; pk[1] = 0u;
@@ -1450,7 +1507,7 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     if (((j < 4 ? d0 : d1) >> (8 * (j & 3))) & 0xFFu) {
-                        const uint32_t bin = lds[RgbLds::binof + ((off[j] - RgbLds::pool) >> 4)];
+                        const uint32_t bin = WIDE ? (off[j] - ebase) >> 4 : (uint32_t)lds[RgbLds::binof + ((off[j] - RgbLds::pool) >> 4)];
                         const double4 c4 = *reinterpret_cast<const double4 *>(lds + RgbLds::cdf64 + (b * 257 + bin) * 32);
                         const double dx = *reinterpret_cast<const double *>(lds + RgbLds::colw + (lane * VEC + j) * 8);
                         const double top = c4.x * (1.0 - dx) + c4.y * dx;
@@ -1466,6 +1523,10 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
             if (EDGE) { // saturated samples came out as 255 (biased entry): those whose (row, column class) rounds below 1.0 are 254
                 pk[0] -= __builtin_amdgcn_perm(sat01[1], sat01[0], to_sgpr_u32(0x06040200u)) & satN[0];
                 pk[1] -= __builtin_amdgcn_perm(sat01[3], sat01[2], to_sgpr_u32(0x06040200u)) & satN[1];
+            }
+            if (WIDE) { // invalid samples (DN = 0) went through some bin's entry: their level is 0
+                pk[0] &= __builtin_amdgcn_perm(nz01[1], nz01[0], to_sgpr_u32(0x06040200u)) * 0xFFu;
+                pk[1] &= __builtin_amdgcn_perm(nz01[3], nz01[2], to_sgpr_u32(0x06040200u)) * 0xFFu;
             }
             pk[0] &= keep[0];
             pk[1] &= keep[1];
@@ -1596,8 +1657,13 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
             }
         }
         };
-        if (rc.pad[0] & 1) item_rows(std::true_type{});
-        else item_rows(std::false_type{});
+        if (!wide) {
+            if (rc.pad[0] & 1) item_rows(std::true_type{}, std::false_type{});
+            else item_rows(std::false_type{}, std::false_type{});
+        } else {
+            if (rc.pad[0] & 1) item_rows(std::true_type{}, std::true_type{});
+            else item_rows(std::false_type{}, std::true_type{});
+        }
     }
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
     uint32_t ge0 = fpred ? (n_all + sad[0] - sad[1]) >> 1 : n_kept, ge1 = (n_all + sad[1] - sad[2]) >> 1;
@@ -1886,7 +1952,7 @@ size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands) {
     if (a.dev_state) win = a.lut_cap; // window read from device memory: capacity chosen by the caller
     else if (a.lut_in_lds)
         for (int b = 0; b < nbands; ++b) win = std::max<size_t>(win, a.win_hi[b] - a.win_lo[b] + 1);
-    return 256 * 4 * 8 + 256 * 4 + ((win + 15) & ~(size_t)15);
+    return (size_t)SARPRO_U16_CDF_COPIES * 256 * 4 * 8 + 256 * 4 + ((win + 15) & ~(size_t)15);
 }
 
 bool clahe_apply_spec_ok(const ClaheApplyArgs &, int) { return true; }

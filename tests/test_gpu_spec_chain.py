@@ -261,3 +261,34 @@ def test_fused_rgb_route_equals_the_other_routes_at_36mp(monkeypatch):
         assert int(out[0].max().item()) > 0
         for o in out[1:]:
             assert torch.equal(out[0], o)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "scene", "edge_bright"])
+def test_fused_rgb_pass_wide_windows_take_the_byte_table_form(kind, monkeypatch):
+    """DN windows beyond the pass's pool of DN-indexed entries but within its DN -> bin byte table (3072 < windows <= 44000 DNs in
+    total): the pass runs in its WIDE form -- a byte read per sample for the bin, bin-indexed entries -- instead of stepping aside."""
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
+    rng = np.random.default_rng(5)
+    rows, cols = 520, 1100
+    if kind == "uniform":
+        b1 = rng.integers(1, 9000, (rows, cols)).astype(np.uint16); b2 = rng.integers(1, 6000, (rows, cols)).astype(np.uint16)
+        b1[:30] = 0; b2[:30] = 0
+    elif kind == "scene":
+        q = synth.q_tables(sigma=(420.0, 260.0))
+        b1, b2 = synth.scene_u16(rows, cols, 0, q=q), synth.scene_u16(rows, cols, 1, q=q)
+    else:  # saturated stretches in the extrapolating border cells, invalid pixels inside them
+        q = synth.q_tables(sigma=(600.0, 300.0))
+        b1, b2 = synth.scene_u16(rows, cols, 0, q=q), synth.scene_u16(rows, cols, 1, q=q)
+        b1[:25, :] = 14000; b2[:, :60] = 9000; b1[5:9, 100:400] = 0; b2[200:260, 10:30] = 0
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        for _ in range(2):  # (twice: the second scene finds the context's state of the first)
+            rgb, names = run_rgb_only(c, b1, b2)
+            rep = c.spec_report()
+            assert "clahe_rgb_fused" in names and rep["pool_overflow"] == 0, rep
+            assert np.array_equal(rgb, rrgb), (kind, rep, int((rgb != rrgb).sum()))
+            if rep["spec_ok"] and rep["verdict"] == 0:
+                f = rep["floor_pred"]
+                lv = np.concatenate([r1.ravel(), r2.ravel()])
+                assert rep["n_lt"][0] == int((lv < f).sum()) and (f == 37 or rep["n_lt"][1] == int((lv <= f).sum()))
