@@ -57,8 +57,8 @@ BENCH_SCENES = (
     ("A", 0, 0, {}, "scene A of rounds 1-3: four sigma classes in 16 x 16 blocks, no-data wedges, bright targets"),
     ("B-xor-map", 1, class_map(1), {"sigma": (140.0, 55.0)}, "other class map and sigma set"),
     ("C-diagonal", 2, class_map(2) | blocks(11), {"sigma": (220.0, 90.0), "scales": (0.5, 1.0, 1.5, 3.0)}, "diagonal class bands, other scales"),
-    ("D-no-wedge", 3, NO_WEDGE, {}, "no invalid pixel anywhere: level 0 absent, the identity of the u8 rescale cannot be proven -> exact route"),
-    ("E-wide-windows", 4, class_map(1), {"sigma": (420.0, 260.0)}, "p99 windows of VV + VH beyond the fused pass's 3072-entry pool -> exact route"),
+    ("D-no-wedge", 3, NO_WEDGE, {}, "no invalid pixel anywhere: level 0 has to come from the darkest valid samples for the identity of the u8 rescale to be proven"),
+    ("E-wide-windows", 4, class_map(1), {"sigma": (420.0, 260.0)}, "p99 windows of VV + VH beyond the fused pass's 3072-entry pool: the pass's WIDE form (DN -> bin byte table)"),
     ("F-flat", 5, class_map(3), {"sigma": (160.0, 60.0)}, "one class everywhere (single-Rayleigh scene: IQR < 5 dB)"),
     ("G-no-bright", 6, class_map(1) | blocks(7) | NO_BRIGHT, {"sigma": (120.0, 80.0), "scales": (0.3, 1.0, 2.5, 5.0)}, "large blocks, no bright targets"),
     ("H-quantised-VH", 7, 0, {"sigma": (180.0, 2.5)}, "VH amplitudes of a few DN: heavily quantised band, a dozen occupied CLAHE bins"),
