@@ -272,7 +272,7 @@ namespace sarpro {
 // levels it writes cover 4.5 instead of 5.  Cells and tiles start at multiples of tile_w / 2 (1250 px on the headline scene),
 // so with the vector width alone (8) nearly every segment straddled a line at both ends: +13 % of HBM traffic on the apply
 // pass by the PMC counters (profiles/r2_traffic.json).  The leading lanes of a cell's first strip are masked instead.
-constexpr size_t kRgbItemRows = 256, kSampleItemRows = 1024;
+constexpr size_t kRgbItemRows = 256, kSampleItemRows = 1024, kU16ItemRows = 1024;
 static size_t strip_align(const StripePlan &P, int vecw) { // (STRIP_ALIGN: planner tuning, read when the plan is built)
     if (vecw != 8 && vecw != 4) return (size_t)vecw;
     return std::max<size_t>(vecw, P.strip_align_px / vecw * vecw);
@@ -406,6 +406,38 @@ static void build_pieces(StripePlan *P, int grid) {
     for (int i = 1; i <= grid; ++i) P->piece_first[(size_t)i] = std::max(P->piece_first[(size_t)i], P->piece_first[(size_t)i - 1]);
 }
 
+// The exact u16 kernel's work: the cell-major item list cut into `nwg` contiguous shares of equal rows (a share boundary falls
+// inside an item: the item is cut there, at a multiple of the 16 waves' step).  A workgroup walks its share top to bottom, strip
+// after strip: it rebuilds its tables only where the cell changes (three or four times per launch).
+static void build_u16_shares(const StripePlan &P, int nwg, std::vector<Rect> *items, std::vector<int32_t> *first) {
+    items->clear();
+    first->assign((size_t)nwg + 1, 0);
+    double total = 0.0;
+    for (const Rect &r : P.u16_rects) total += (double)(r.r1 - r.r0);
+    const double share = total / (double)nwg;
+    double acc = 0.0;
+    int k = 0;
+    for (const Rect &src : P.u16_rects) {
+        int r = src.r0;
+        while (r < src.r1) {
+            int take = src.r1 - r;
+            if (k < nwg - 1) {
+                const double room = share * (double)(k + 1) - acc;
+                const int rows = std::max(16, ((int)std::ceil(room) + 15) / 16 * 16);
+                take = std::min(take, rows);
+            }
+            Rect it = src;
+            it.r0 = r; it.r1 = r + take;
+            items->push_back(it);
+            (*first)[(size_t)k + 1] = (int32_t)items->size();
+            acc += (double)take;
+            r += take;
+            if (k < nwg - 1 && acc >= share * (double)(k + 1) - 1e-9) ++k;
+        }
+    }
+    for (int i = 1; i <= nwg; ++i) (*first)[(size_t)i] = std::max((*first)[(size_t)i], (*first)[(size_t)i - 1]);
+}
+
 int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, size_t rows_local, int vecw,
              StripePlan **out) {
     auto key = std::make_tuple(rows_total, cols, row0, rows_local, vecw);
@@ -479,6 +511,10 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
                 size_t srows = kSampleItemRows;
                 if (at.is_set(A_SAMPLE_ITEM_ROWS)) srows = (size_t)std::max<long long>(16, at.val(A_SAMPLE_ITEM_ROWS, 0));
                 add_rects(P->sample_rects, nullptr, *P, r0, r1, c0, c1, ids, srows, vecw, cell_flags);
+                size_t urows = kU16ItemRows;
+                if (at.is_set(A_U16_ITEM_ROWS)) urows = (size_t)std::min<long long>(1024, std::max<long long>(16, at.val(A_U16_ITEM_ROWS, 0)));
+                P->u16_item_rows = urows;
+                add_rects(P->u16_rects, nullptr, *P, r0, r1, c0, c1, ids, urows, vecw, cell_flags);
             }
         }
     }
@@ -514,6 +550,12 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
         }
     }
     if (!rc) rc = upload_vec(ctx, P->d_sample_rects, P->sample_rects.data(), P->sample_rects.size() * sizeof(Rect));
+    for (int nb = 1; nb <= kMaxBands && !rc && !P->u16_rects.empty() && ctx->cu_count > 0; ++nb) { // the exact u16 kernel's shares, per band count of a launch
+        build_u16_shares(*P, std::max(1, ctx->cu_count / nb), &P->u16_items[nb - 1], &P->u16_first[nb - 1]);
+        P->u16_nwg[nb - 1] = (int)P->u16_first[nb - 1].size() - 1;
+        rc = upload_vec(ctx, P->d_u16_items[nb - 1], P->u16_items[nb - 1].data(), P->u16_items[nb - 1].size() * sizeof(Rect));
+        if (!rc) rc = upload_vec(ctx, P->d_u16_first[nb - 1], P->u16_first[nb - 1].data(), P->u16_first[nb - 1].size() * sizeof(int32_t));
+    }
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_tiled, P->hist_sliver_tiled.data(), P->hist_sliver_tiled.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_hist_sliver_flat, P->hist_sliver_flat.data(), P->hist_sliver_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_sliver, P->apply_sliver.data(), P->apply_sliver.size() * sizeof(Rect));
@@ -1264,7 +1306,13 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         for (int b = 0; b < J.nbands; ++b) a.level_hist[b] = nullptr;
         {
             KernelTimer t(ctx, "clahe_apply_u16");
-            HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, true, true, ctx->stream));
+            if (!ctx->attrs.on(A_NO_U16_CF) && J.nbands <= kMaxBands && J.plan->u16_nwg[J.nbands - 1] > 0 &&
+                clahe_apply_u16_cf_supported(a, J.nbands, J.plan->u16_item_rows)) { // the conflict-free form: one persistent workgroup per share
+                a.rects = J.plan->d_u16_items[J.nbands - 1].as<Rect>();
+                HIPCHK(ctx, launch_clahe_apply_u16_cf(a, J.plan->d_u16_first[J.nbands - 1].as<int32_t>(), J.plan->u16_nwg[J.nbands - 1], J.nbands, ctx->stream));
+            } else {
+                HIPCHK(ctx, launch_clahe_apply_u16(a, (int)J.plan->apply_rects.size(), J.nbands, true, true, ctx->stream));
+            }
         }
         ChainBandState *h_state = ctx->h_small.as<ChainBandState>();
         HIPCHK(ctx, hipMemcpyAsync(h_state, d_state, sizeof(ChainBandState) * (size_t)J.nbands, hipMemcpyDeviceToHost, ctx->stream));

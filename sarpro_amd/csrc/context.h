@@ -68,6 +68,15 @@ struct StripePlan {
     size_t strip_align_px = 64, piece_align = 4;           // planner tuning (attributes STRIP_ALIGN, PIECE_ALIGN), fixed when the plan is built
     std::vector<Rect> rgb_rects, sample_rects;             // whole scene, vecw == 8: taller cell items of the fused CLAHE -> RGB pass (256 rows) and of its sample-only pre-pass (1024 rows)
     DevBuf d_rgb_rects, d_sample_rects;
+    // vecw == 8: the conflict-free exact u16 kernel (kernels.hip 4a).  u16_rects = items of <= u16_item_rows rows in cell-major order
+    // (cell, 512-column strip, rows top to bottom: vertical neighbours share their tables); u16_items[n - 1] = the same list cut
+    // into u16_nwg[n - 1] contiguous shares of equal rows, one per workgroup of an n-band launch (u16_first: share k = items
+    // [first[k], first[k + 1]))
+    std::vector<Rect> u16_rects, u16_items[kMaxBands];
+    std::vector<int32_t> u16_first[kMaxBands];
+    int u16_nwg[kMaxBands] = {0, 0};
+    DevBuf d_u16_items[kMaxBands], d_u16_first[kMaxBands];
+    size_t u16_item_rows = 0;
     DevBuf d_sat_col, d_sat_row;                           // fused pass: saturation classes of the columns / level bits of the rows (ClaheRgbArgs)
     bool sat_ok = false;
     DevBuf d_hist_rects_tiled, d_hist_rects_flat, d_apply_rects, d_row_w, d_col_w;
@@ -79,7 +88,7 @@ struct StripePlan {
     DevBuf d_piece_items, d_piece_first;
     int refs = 0; // open stripe handles that hold this plan (the cache never evicts those)
     void release_all() {
-        d_piece_items.release(); d_piece_first.release(); d_rgb_rects.release(); d_sample_rects.release(); d_sat_col.release(); d_sat_row.release();
+        d_piece_items.release(); d_piece_first.release(); d_rgb_rects.release(); d_sample_rects.release(); for (int b = 0; b < kMaxBands; ++b) { d_u16_items[b].release(); d_u16_first[b].release(); } d_sat_col.release(); d_sat_row.release();
         d_hist_rects_tiled.release(); d_hist_rects_flat.release(); d_apply_rects.release();
         d_hist_sliver_tiled.release(); d_hist_sliver_flat.release(); d_apply_sliver.release();
         d_row_w.release(); d_col_w.release();
@@ -166,7 +175,8 @@ struct BandWorker {
     X(SAMPLED_HIST_MIN_PX) X(SAMPLE_STRIDE) X(SEPARATE_CDFS) X(NO_FUSED_RGB) X(SPEC_FORCE) X(FORCE_UNCERTAIN) \
     X(STRIP_ALIGN) X(PIECE_ALIGN) X(CHUNK_ROWS) X(RGB_ITEM_ROWS) X(SAMPLE_ITEM_ROWS) \
     X(NO_MAILBOX) X(NO_STEP_ESTIMATE) X(F32_ZONES) X(F32_ZONES_DEBUG) X(F32_DIRECT) X(F32_DIRECT_QCAP) X(F32_LEVEL_GENERAL) \
-    X(F32_LEVEL_TABLE) X(F32_LEVEL_QCAP) X(F32_HOST_CDFS) X(F32_NO_VEC8) X(NO_BAND_TWIN) X(RESIZE_GENERIC) X(NO_RESIZE_LUT)
+    X(F32_LEVEL_TABLE) X(F32_LEVEL_QCAP) X(F32_HOST_CDFS) X(F32_NO_VEC8) X(NO_BAND_TWIN) X(RESIZE_GENERIC) X(NO_RESIZE_LUT) \
+    X(NO_U16_CF) X(U16_ITEM_ROWS)
 namespace sarpro {
 enum Attr : int {
 #define X(n) A_##n,

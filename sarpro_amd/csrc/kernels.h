@@ -182,6 +182,9 @@ hipError_t launch_hist256_u8(const uint8_t *in, size_t pitch, uint32_t rows, uin
                              unsigned long long *hist, hipStream_t s);
 
 size_t clahe_apply_lds_bytes(const ClaheApplyArgs &a, int nbands);
+// the conflict-free exact kernel with u16 levels out (kernels.hip 4a): persistent 1024-thread workgroups over items of <= 1024 rows
+bool clahe_apply_u16_cf_supported(const ClaheApplyArgs &a, int nbands, size_t max_item_rows);
+hipError_t launch_clahe_apply_u16_cf(const ClaheApplyArgs &a, const int32_t *first, int nwg, int nbands, hipStream_t s); // workgroup k of a band: items [first[k], first[k + 1]) of a.rects
 // more than the default 64 KiB of dynamic LDS for `kernel` on the CURRENT device: once per (device, kernel), thread-safe, checked
 hipError_t opt_in_dynamic_lds(const void *kernel);
 constexpr uint32_t kLutLdsMaxBytes = 48 * 1024; // per-band window budget in LDS

@@ -74,6 +74,11 @@ struct EdgeMask {
     __device__ bool keep(int j) const { return (m[j >> 1] >> (16 * (j & 1))) & 1u; }
 };
 
+// The dynamic LDS block of this kernel starts at LDS address 0 (it holds no static __shared__), so a byte offset
+// IS the address: going through the `extern __shared__` symbol makes the compiler add its (zero) link-time
+// address to every computed LDS address, one VALU instruction per access.
+#define LDS_AT(T, off) (*reinterpret_cast<__attribute__((address_space(3))) T *>((uint32_t)(off)))
+
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
@@ -468,6 +473,197 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// 4a. CLAHE apply, exact, u16 levels out: the conflict-free form (config 3).
+//     Kernel 4 spends two thirds of its LDS cycles in bank conflicts: a ds_read_b128 is served in four groups of 16 lanes, each
+//     group one cycle when its 16 addresses fall into 16 different 16-byte slots of the 256-byte bank row, and a gather of random
+//     bins puts three lanes on the busiest slot on average.  Here every bin holds SIXTEEN copies of its (c00, c01) pair side by
+//     side -- one whole bank row -- and of its (c10, c11) pair in the row after it; a lane reads copy (lane & 15), and the lanes of
+//     each of the instruction's four groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32) have sixteen different
+//     values of lane & 15: every gather is conflict-free whatever the bins are.  128 KiB of tables: one persistent 1024-thread
+//     workgroup per CU walks items of up to 1024 rows (16 waves x 64 rows: lane l of a wave holds dy of the wave's l-th row), the
+//     DN -> bin bytes of the band's window stay in LDS for the whole launch, rows are loaded and stored through buffer
+//     descriptors (rows past the item's end and lanes outside it pass an out-of-range offset: no branch around a load or a
+//     store, so the wait for the rows prefetched one step ahead does not wait for the stores issued after them).
+//     Interior cells skip the clamp of the blend to [0, 1]: with weights in [0, 1] that sum to exactly 1 (dx is a multiple of
+//     2^-53 below 1, so 1 - dx is exact) and CDFs in [0, 1] every rounded product is <= its weight and the rounded sums <= 1.
+//     Algorithmic traffic: 2 B/px read + 2 B/px written.
+// ------------------------------------------------------------------------------------
+constexpr int kCfBlock = 1024, kCfWaves = 16;
+#ifndef SARPRO_CF_ROWS_AHEAD
+#define SARPRO_CF_ROWS_AHEAD 2
+#endif
+struct CfLds {
+    static constexpr uint32_t lut = 0;                  // DN -> bin bytes of the window [0, win_hi]: the clamped DN IS the byte's address
+    static constexpr uint32_t lut_cap = 32768;
+    static constexpr uint32_t cdf = lut_cap;            // [256 bins][2][16 copies] double2: 512 B per bin
+    static constexpr uint32_t total = cdf + 256 * 512;  // 160 KiB
+};
+__global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs a, const int32_t *__restrict__ first, int nbands) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int VEC = 8, NR = SARPRO_CF_ROWS_AHEAD;
+    const int band = (int)blockIdx.x % nbands, wg = (int)blockIdx.x / nbands;
+    const int lane = lane_id(), wave = wave_id();
+    const uint16_t *__restrict__ in = a.in[band];
+    uint16_t *__restrict__ out = reinterpret_cast<uint16_t *>(a.out[band]);
+    const double *__restrict__ cdfs = a.cdfs[band];
+    const uint8_t *__restrict__ glut = a.binlut[band];
+    const uint32_t win_hi = a.dev_state[band].win_hi; // (chain mode: the window is [0, win_hi], known on the device only)
+    const bool lut_lds = win_hi < CfLds::lut_cap;      // (else: the bins are gathered from the global table)
+    if (lut_lds)
+        for (uint32_t i = threadIdx.x; i <= win_hi; i += kCfBlock) lds[CfLds::lut + i] = glut[i];
+    const uint32_t k16 = CfLds::cdf + (uint32_t)(lane & 15) * 16u;
+    const double max_val = a.max_val;
+    const uint32_t in_row_bytes = (uint32_t)a.in_pitch * 2u, out_row_bytes = (uint32_t)a.out_pitch * 2u;
+
+    int have[4] = {-1, -1, -1, -1}; // the tiles whose CDFs the tables hold
+    for (int item = first[wg]; item < first[wg + 1]; ++item) {
+        const Rect rc = a.rects[item];
+        // a workgroup's items are vertical neighbours, strip after strip of a cell: the tables change three or four times per launch,
+        // and only then do the waves meet -- otherwise each runs on into the next item on its own
+        if (rc.id[0] != have[0] || rc.id[1] != have[1] || rc.id[2] != have[2] || rc.id[3] != have[3]) {
+        have[0] = rc.id[0]; have[1] = rc.id[1]; have[2] = rc.id[2]; have[3] = rc.id[3];
+        __syncthreads(); // the previous item's rows are done (first item: the byte table has landed once the next barrier is passed)
+        {   // sixteen copies of both halves of every bin: thread = (bin mod 64, copy), four bins each; a wave's stores are contiguous
+            const uint32_t copy = threadIdx.x & 15u, b0 = threadIdx.x >> 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t b = b0 + 64u * (uint32_t)i;
+                v2d ct, cb;
+                ct.x = cdfs[(size_t)rc.id[0] * 256 + b]; ct.y = cdfs[(size_t)rc.id[1] * 256 + b];
+                cb.x = cdfs[(size_t)rc.id[2] * 256 + b]; cb.y = cdfs[(size_t)rc.id[3] * 256 + b];
+                LDS_AT(v2d, CfLds::cdf + b * 512u + copy * 16u) = ct;
+                LDS_AT(v2d, CfLds::cdf + b * 512u + 256u + copy * 16u) = cb;
+            }
+        }
+        __syncthreads();
+        }
+
+        const int col = rc.cstart + lane * VEC;
+        const bool lane_on = col < rc.c1 && col + VEC > rc.c0;
+        const bool full = col >= rc.c0 && col + VEC <= rc.c1;
+        double dx[VEC], omdx[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = col + j;
+            const RowWeight w = a.col_w[(c >= rc.c0 && c < rc.c1) ? c : rc.c0];
+            dx[j] = w.d;
+            omdx[j] = w.omd;
+        }
+        // lane l: dy of this wave's l-th row of the item (rows r0 + wave + 16 l)
+        const int nrows_w = (rc.r1 - rc.r0 - wave + kCfWaves - 1) / kCfWaves; // <= 64
+        const double dyl = a.row_w[a.row_off + min(rc.r0 + wave + kCfWaves * lane, rc.r1 - 1)].d;
+        const uint32_t dyl_lo = (uint32_t)__double_as_longlong(dyl), dyl_hi = (uint32_t)(__double_as_longlong(dyl) >> 32);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(in) + (size_t)rc.r0 * a.in_pitch + rc.cstart, 0,
+                                                                               (int)((uint32_t)(rc.r1 - rc.r0) * in_row_bytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)rc.r0 * a.out_pitch + rc.cstart, 0,
+                                                                                (int)((uint32_t)(rc.r1 - rc.r0) * out_row_bytes), 0x00020000);
+        const uint32_t voff_ld = lane_on ? (uint32_t)lane * 16u : 0xFFFFFFFFu, voff_st = full ? (uint32_t)lane * 16u : 0xFFFFFFFFu;
+
+        auto item_rows = [&](auto edge_tag, auto lds_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value, LUTLDS = decltype(lds_tag)::value;
+            auto load_rows = [&](v4u (&dst)[NR], int k) { // rows k .. k + NR - 1 of this wave (k counts the wave's rows)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const bool on = k + i < nrows_w; // wave-uniform
+#ifdef SARPRO_ABL_CF_NOLOAD // timing ablation: no row is read (every sample invalid)
+                    dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, 0xFFFFFFFFu, 0u, 0);
+#else
+                    dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, on ? voff_ld : 0xFFFFFFFFu, on ? (uint32_t)(wave + kCfWaves * (k + i)) * in_row_bytes : 0u, 0);
+#endif
+                }
+            };
+            v4u cur[NR], nxt[NR];
+            load_rows(cur, 0);
+            // NR dropped stores behind the first rows' loads: the loop is entered in its steady state (NR loads, then NR stores in
+            // flight), so the wait for a turn's rows at the loop top is vmcnt(NR) on both edges -- without them the entry edge asks
+            // for vmcnt(NR - 1), which in every later turn also waits for the write acknowledgement of the turn's first store
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                v4u z; z.x = z.y = z.z = z.w = 0u;
+                __builtin_amdgcn_raw_buffer_store_b128(z, rs_out, 0xFFFFFFFFu - 16u * (uint32_t)i, 0u, 2);
+            }
+            for (int k = 0; k < nrows_w; k += NR) {
+                load_rows(nxt, k + NR);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int kr = min(k + i, nrows_w - 1);
+                    const bool on = k + i < nrows_w;
+                    const double dy = __longlong_as_double(((long long)(uint32_t)__builtin_amdgcn_readlane((int)dyl_hi, kr) << 32) |
+                                                           (long long)(uint32_t)__builtin_amdgcn_readlane((int)dyl_lo, kr));
+                    const double omdy = 1.0 - dy;
+                    const uint32_t w[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+                    uint32_t lv[VEC];
+                    // Three phases with nothing moved across: the row's eight bin bytes, its sixteen gathers, the blends.  (Left to the
+                    // scheduler every sample's byte read -> gather -> blend chain ran behind the previous sample's: two LDS round
+                    // trips per sample, sixteen per row, and four waves per SIMD do not hide that.)
+                    uint32_t bin[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const uint32_t d = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu);
+                        const uint32_t dc = min(d, win_hi);
+                        bin[j] = LUTLDS ? (uint32_t)LDS_AT(uint8_t, CfLds::lut + dc) : (uint32_t)glut[dc];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    v2d ct[VEC], cb[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const uint32_t ea = (bin[j] << 9) + k16;
+                        ct[j] = LDS_AT(v2d, ea);
+                        cb[j] = LDS_AT(v2d, 256u + ea);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const double top = ct[j].x * omdx[j] + ct[j].y * dx[j];
+                        const double bottom = cb[j].x * omdx[j] + cb[j].y * dx[j];
+                        double o = top * omdy + bottom * dy;
+                        if (EDGE) o = fmin(fmax(o, 0.0), 1.0);
+                        lv[j] = (uint32_t)(o * max_val); // truncation, o * max_val in [0, max_val]
+                    }
+                    // invalid samples (DN = 0) -> level 0: the packed pair times min(DN, 1) per half (two packed 16-bit operations per pair)
+                    uint32_t pw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t nz; // (written out: the compiler turns the vector form into compares and selects per half)
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(w[q]), "s"(0x00010001u));
+                        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(pw[q]) : "v"(lv[2 * q] | (lv[2 * q + 1] << 16)), "v"(nz));
+                        lv[2 * q] = pw[q] & 0xFFFFu; lv[2 * q + 1] = pw[q] >> 16; // (only the straddling lanes below read these)
+                    }
+                    v4u pk;
+                    pk.x = pw[0]; pk.y = pw[1]; pk.z = pw[2]; pk.w = pw[3];
+                    const uint32_t soff = on ? (uint32_t)(wave + kCfWaves * (k + i)) * out_row_bytes : 0u;
+                    // (gfx950: the data registers of a 128-bit buffer store with an SGPR offset must not be written in the next issue
+                    // slots -- see the fused CLAHE -> RGB pass)
+#ifdef SARPRO_ABL_CF_NOSTORE // timing ablation: nothing is written
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, 0xFFFFFFFFu, soff, 2);
+#else
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, on ? voff_st : 0xFFFFFFFFu, soff, 2 /* nt */);
+#endif
+                    asm volatile("s_nop 1" : : "v"(pk) : "memory");
+                    if (on && lane_on && !full) { // a lane that straddles the item's edge: sample by sample
+                        uint16_t *o16 = out + (size_t)(rc.r0 + wave + kCfWaves * (k + i)) * a.out_pitch + col;
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j)
+                            if (col + j >= rc.c0 && col + j < rc.c1) o16[j] = (uint16_t)lv[j];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NR; ++i) cur[i] = nxt[i];
+            }
+        };
+        if (lut_lds) {
+            if (rc.pad[0] & 1) item_rows(std::true_type{}, std::true_type{});
+            else item_rows(std::false_type{}, std::true_type{});
+        } else {
+            if (rc.pad[0] & 1) item_rows(std::true_type{}, std::false_type{});
+            else item_rows(std::false_type{}, std::false_type{});
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // 4b. CLAHE apply, u8 output, speculative form (the headline kernel).
 //     PMC profiling of kernel 4 showed it bound by VALU issue and LDS latency (38 VALU + 13 SALU
 //     instructions and 32 B of conflicting LDS gathers per pixel, waves waiting 50 % of the time),
@@ -562,10 +758,6 @@ struct SpecLds { // byte offsets into dynamic LDS
 // The row weights stay in global memory: one wave-uniform load per row, prefetched with the row.
 // (1 - dx) and (1 - dy) are recomputed as 1.0 - d: the reference's own expression (autoscale.rs:327-329)
 
-// The dynamic LDS block of this kernel starts at LDS address 0 (it holds no static __shared__), so a byte offset
-// IS the address: going through the `extern __shared__` symbol makes the compiler add its (zero) link-time
-// address to every computed LDS address, one VALU instruction per access.
-#define LDS_AT(T, off) (*reinterpret_cast<__attribute__((address_space(3))) T *>((uint32_t)(off)))
 
 // wave-uniform values moved to SGPRs (the row weights: they would otherwise hold VGPRs across the whole row)
 __device__ __forceinline__ float to_sgpr(float x) {
@@ -1994,6 +2186,24 @@ hipError_t launch_clahe_apply_u16(const ClaheApplyArgs &a, int nrects, int nband
         if (out16) hipLaunchKernelGGL((k_clahe_apply_u16<1, true>), grid, dim3(kBlock), lds, s, a);
         else hipLaunchKernelGGL((k_clahe_apply_u16<1, false>), grid, dim3(kBlock), lds, s, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t opt_in_dynamic_lds(const void *kernel);
+
+bool clahe_apply_u16_cf_supported(const ClaheApplyArgs &a, int nbands, size_t max_item_rows) {
+    if (!a.dev_state || a.in_pitch % 8 != 0 || a.out_pitch % 8 != 0 || max_item_rows == 0 || max_item_rows > (size_t)kCfWaves * 64) return false;
+    if (max_item_rows * std::max(a.in_pitch, a.out_pitch) * 2 >= (size_t)1 << 31) return false; // one buffer descriptor per item
+    for (int b = 0; b < nbands; ++b)
+        if ((reinterpret_cast<uintptr_t>(a.in[b]) & 15) || (reinterpret_cast<uintptr_t>(a.out[b]) & 15)) return false;
+    return true;
+}
+
+hipError_t launch_clahe_apply_u16_cf(const ClaheApplyArgs &a, const int32_t *first, int nwg, int nbands, hipStream_t s) {
+    if (nwg <= 0) return hipSuccess;
+    hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_apply_u16_cf));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_clahe_apply_u16_cf, dim3(nwg * nbands), dim3(kCfBlock), CfLds::total, s, a, first, nbands); // workgroup i: band i % nbands, share i / nbands
     return hipGetLastError();
 }
 
