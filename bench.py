@@ -827,6 +827,36 @@ def secondary_records(torch, dev, rows, cols):
                       "scene_ms": round(2 * ms_band + ms_fused, 3), "scene_unfused_ms": round(2 * ms_band + ms_op + ms_f32, 3),
                       "value": round(px / (2 * ms_band + ms_fused) / 1e3, 1), "unit": "Mpix/s"}
     ctx.close()
+    del o16, ratio
+    # (4) several scenes in flight on the one GPU: one context (own stream, own workspaces) and one host thread per scene, as the batch
+    # driver runs when a device is listed more than once -- the short dependent kernels of one scene's chain run beside another
+    # scene's sweeps.  Beside the headline, which keeps ONE context and stream.
+    try:
+        import threading
+        nmax = 3
+        ctxs = [sarpro_amd.Context(dev.index) for _ in range(nmax)]
+        rgbs = [torch.empty((rows, pitch * 3), dtype=torch.uint8, device=dev) for _ in range(nmax)]
+        torch.cuda.synchronize()
+
+        def worker(i, n):
+            for _ in range(n):
+                ctxs[i].dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgbs[i].data_ptr(), pitch)
+        rec = {}
+        for nw in range(1, nmax + 1):
+            for n in (3, 20):  # (warm, timed)
+                ths = [threading.Thread(target=worker, args=(i, n)) for i in range(nw)]
+                t = time.perf_counter()
+                [x.start() for x in ths]
+                [x.join() for x in ths]
+                dt = time.perf_counter() - t
+            rec[str(nw)] = {"ms_per_scene": round(dt / (nw * 20) * 1e3, 3), "value": round(px * nw * 20 / dt / 1e6, 1)}
+        same = all(bool(torch.equal(rgbs[0], r)) for r in rgbs[1:])
+        out["scenes_in_flight"] = {"what": "scene A (CLAHE -> synRGB, resident in HBM) by 1, 2, 3 contexts at once on this GPU, one synchronous call per scene and thread; "
+                                           "20 scenes per context", "unit": "Mpix/s", "by_contexts": rec, "rasters_equal": same}
+        for c in ctxs:
+            c.close()
+    except Exception as e:
+        out["scenes_in_flight"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

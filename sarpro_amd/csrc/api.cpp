@@ -504,6 +504,12 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
             const bool neg = rw.d < 0.0 || cw.d < 0.0;
             const int cell_flags = (neg ? 1 : 0) | (rw.d < 0.0 ? 2 : 0) | (cw.d < 0.0 ? 4 : 0); // bit 1 / 2: which weight is negative (the margin depends on it)
             add_rects(P->apply_rects, split ? &P->apply_sliver : nullptr, *P, r0, r1, c0, c1, ids, chunk_rows, vecw, cell_flags);
+            if (vecw == 8) { // the conflict-free exact kernel with u16 levels out (kernels.hip 4a)
+                size_t urows = kU16ItemRows;
+                if (at.is_set(A_U16_ITEM_ROWS)) urows = (size_t)std::min<long long>(1024, std::max<long long>(16, at.val(A_U16_ITEM_ROWS, 0)));
+                P->u16_item_rows = urows;
+                add_rects(P->u16_rects, nullptr, *P, r0, r1, c0, c1, ids, urows, vecw, cell_flags);
+            }
             if (vecw == 8) { // the fused CLAHE -> RGB pass (whole scenes and row stripes): 16 waves walk an item, so items are taller
                 size_t frows = kRgbItemRows;
                 if (at.is_set(A_RGB_ITEM_ROWS)) frows = (size_t)std::max<long long>(16, at.val(A_RGB_ITEM_ROWS, 0));
@@ -511,10 +517,6 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
                 size_t srows = kSampleItemRows;
                 if (at.is_set(A_SAMPLE_ITEM_ROWS)) srows = (size_t)std::max<long long>(16, at.val(A_SAMPLE_ITEM_ROWS, 0));
                 add_rects(P->sample_rects, nullptr, *P, r0, r1, c0, c1, ids, srows, vecw, cell_flags);
-                size_t urows = kU16ItemRows;
-                if (at.is_set(A_U16_ITEM_ROWS)) urows = (size_t)std::min<long long>(1024, std::max<long long>(16, at.val(A_U16_ITEM_ROWS, 0)));
-                P->u16_item_rows = urows;
-                add_rects(P->u16_rects, nullptr, *P, r0, r1, c0, c1, ids, urows, vecw, cell_flags);
             }
         }
     }

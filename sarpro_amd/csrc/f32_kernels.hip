@@ -19,9 +19,24 @@ constexpr int kWavesPerBlock = 4;
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
+// A threshold table as PAIRS (thr[k], thr[k + 1]) at [k]: the verification of an estimate reads both bounds of its step with ONE
+// 8-byte LDS read.  (As two 4-byte reads -- a ds_read2_b32 -- the 32 lanes of a group pick among 32 banks twice, ~3.5 lanes on the
+// busiest one each time: 14 LDS cycles per wave against 7 for the ds_read_b64 of a pair; the kernels that search per sample are
+// bound by exactly these cycles.)
+struct ThrPairs {
+    const float2 *p;
+    __device__ float operator[](uint32_t i) const { return p[i].x; }
+};
+__device__ inline void thr_bounds(const float *thr, uint32_t k, float *t0, float *t1) { *t0 = thr[k]; *t1 = thr[k + 1]; }
+__device__ inline void thr_bounds(const ThrPairs &thr, uint32_t k, float *t0, float *t1) { const float2 t = thr.p[k]; *t0 = t.x; *t1 = t.y; }
+// fills pairs[0 .. n - 1] from thr[1 .. n - 1] (global), thr[0] = -inf, thr[n] = +inf; n threads of the workgroup call it with i = their index
+__device__ inline void thr_pairs_fill(float2 *pairs, const float *g_thr, int n, int i) {
+    if (i < n) pairs[i] = make_float2(i ? g_thr[i] : -INFINITY, i + 1 < n ? g_thr[i + 1] : INFINITY);
+}
+
 // number of k in 1..N with v >= thr[k]  (thr sorted ascending, N = 2^m - 1, NaN compares false)
-template <int N>
-__device__ inline uint32_t step_search(const float *thr, float v) {
+template <int N, typename Tab>
+__device__ inline uint32_t step_search(const Tab &thr, float v) {
     uint32_t idx = 0;
 #pragma unroll
     for (uint32_t step = (N + 1) / 2; step; step >>= 1)
@@ -31,8 +46,8 @@ __device__ inline uint32_t step_search(const float *thr, float v) {
 
 // The same count by estimate + verification: thr[0] = -inf and thr[N + 1] = +inf must be readable.  k is right iff
 // thr[k] <= v < thr[k + 1] (ascending table), whatever produced k; otherwise the binary search decides.
-template <int N>
-__device__ inline uint32_t est_search(const float *thr, float v, const F32StepEstimate &e) {
+template <int N, typename Tab>
+__device__ inline uint32_t est_search(const Tab &thr, float v, const F32StepEstimate &e) {
     uint32_t k;
     if (e.gamma == 1.0f) { // the common case, folded: the estimate only has to be right often, the two reads below decide
         k = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_logf(v), e.a_mul, e.b_add), 0.0f, (float)N); // NaN -> 0
@@ -41,21 +56,22 @@ __device__ inline uint32_t est_search(const float *thr, float v, const F32StepEs
         t = __builtin_amdgcn_exp2f(e.gamma * __builtin_amdgcn_logf(t)); // t^gamma (t = 0: exp2(-inf) = 0)
         k = (uint32_t)fminf(fmaxf(t * e.nsteps + e.bias, 0.0f), (float)N);
     }
-    const float t0 = thr[k], t1 = thr[k + 1];
+    float t0, t1;
+    thr_bounds(thr, k, &t0, &t1);
     if (t0 <= v && v < t1) return k;
     return step_search<N>(thr, v);
 }
 
 // est_search for M samples at once: all estimates, then all table reads, then all verifications -- no branch between the samples,
 // so their chains (v_log_f32, two dependent LDS reads) overlap; ONE branch for the samples whose estimate failed.
-template <int N, int M>
-__device__ inline void est_search_m(const float *thr, const float (&v)[M], const F32StepEstimate &e, uint32_t (&k)[M]) {
+template <int N, int M, typename Tab>
+__device__ inline void est_search_m(const Tab &thr, const float (&v)[M], const F32StepEstimate &e, uint32_t (&k)[M]) {
     if (e.gamma == 1.0f) {
         float t0[M], t1[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) k[j] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_logf(v[j]), e.a_mul, e.b_add), 0.0f, (float)N);
 #pragma unroll
-        for (int j = 0; j < M; ++j) { t0[j] = thr[k[j]]; t1[j] = thr[k[j] + 1]; }
+        for (int j = 0; j < M; ++j) thr_bounds(thr, k[j], &t0[j], &t1[j]);
         uint32_t bad = 0;
 #pragma unroll
         for (int j = 0; j < M; ++j) bad |= (t0[j] <= v[j] && v[j] < t1[j]) ? 0u : (1u << j);
@@ -925,10 +941,14 @@ __global__ __launch_bounds__(kBlock) void k_f32_hist4096(const float *__restrict
 template <int VEC, bool OUT16, int MODE>
 __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
     constexpr bool F64 = MODE != 0;
-    __shared__ float thr[256 + 1];
+    __shared__ __align__(8) float2 thr_p[256]; // (thr[k], thr[k + 1]) at [k]: one 8-byte read verifies an estimate
     __shared__ uint32_t hist[256];
-    if (!OUT16) { thr[threadIdx.x] = (threadIdx.x && a.thr) ? a.thr[threadIdx.x] : -INFINITY; hist[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) thr[256] = INFINITY;
+    const ThrPairs thr{thr_p};
+    if (!OUT16) {
+        if (a.thr) thr_pairs_fill(thr_p, a.thr, 256, threadIdx.x);
+        else thr_p[threadIdx.x] = make_float2(-INFINITY, threadIdx.x == 255 ? INFINITY : -INFINITY);
+        hist[threadIdx.x] = 0;
+    }
     __shared__ double logc[F64 ? 256 : 1], invc[F64 ? 256 : 1]; // table of db_of_f32_fast (f64 levels)
     if (F64) {
         const double c = 1.0 + ((double)threadIdx.x + 0.5) / 256.0;
@@ -1001,10 +1021,10 @@ __global__ __launch_bounds__(kBlock) void k_f32_level(F32LevelArgs a) {
 // ------------------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
-    __shared__ float thr[256 + 1];
+    __shared__ __align__(8) float2 thr_p[256]; // (thr[k], thr[k + 1]) at [k]: one 8-byte read verifies an estimate
     __shared__ uint32_t hist[256];
-    thr[threadIdx.x] = threadIdx.x ? a.thr[threadIdx.x] : -INFINITY;
-    if (threadIdx.x == 0) thr[256] = INFINITY;
+    thr_pairs_fill(thr_p, a.thr, 256, threadIdx.x);
+    const ThrPairs thr{thr_p};
     hist[threadIdx.x] = 0;
     __syncthreads();
     const Rect rc = a.rects[blockIdx.x];
@@ -1057,15 +1077,15 @@ __global__ __launch_bounds__(kBlock) void k_f32_tile_hist(F32TileHistArgs a) {
 template <int VEC, bool OUT16>
 __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply(F32ClaheApplyArgs a) {
     __shared__ __align__(16) double2 cdf2[2 * 256]; // (c00, c01) at [bin], (c10, c11) at [256 + bin]: two 16-byte arrays, every bank in use (kernels.hip 4)
-    __shared__ float thr[256 + 1];
+    __shared__ __align__(8) float2 thr_p[256]; // (thr[k], thr[k + 1]) at [k]: one 8-byte read verifies an estimate
     __shared__ uint32_t hist[256];
+    const ThrPairs thr{thr_p};
     const Rect rc = a.rects[blockIdx.x];
     {
         const int b = threadIdx.x;
         cdf2[b] = make_double2(a.cdfs[(size_t)rc.id[0] * 256 + b], a.cdfs[(size_t)rc.id[1] * 256 + b]);
         cdf2[256 + b] = make_double2(a.cdfs[(size_t)rc.id[2] * 256 + b], a.cdfs[(size_t)rc.id[3] * 256 + b]);
-        thr[b] = b ? a.thr[b] : -INFINITY;
-        if (b == 0) thr[256] = INFINITY;
+        thr_pairs_fill(thr_p, a.thr, 256, b);
         hist[b] = 0;
     }
     __syncthreads();
@@ -1175,8 +1195,9 @@ template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyArgs a) {
     __shared__ __align__(16) double2 cdf2[2 * 256]; // (c00, c01) at [bin], (c10, c11) at [256 + bin]: two 16-byte arrays, every bank in use (kernels.hip 4)
     __shared__ __align__(16) float4 e32[256 + 1];
-    __shared__ float thr[256 + 1];
+    __shared__ __align__(8) float2 thr_p[256]; // (thr[k], thr[k + 1]) at [k]: one 8-byte read verifies an estimate
     __shared__ uint32_t hist[256];
+    const ThrPairs thr{thr_p};
     const Rect rc = a.rects[blockIdx.x];
     const bool edge = (rc.pad[0] & 1) != 0;
     {
@@ -1192,8 +1213,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_clahe_apply_spec(F32ClaheApplyAr
         const float c00 = (float)c[0], c01 = (float)c[1], c10 = (float)c[2], c11 = (float)c[3];
         e32[b] = saturated ? make_float4(1.001f, 1.001f, 0.0f, 0.0f) : zero ? make_float4(kz, kz, 0.0f, 0.0f) : make_float4(c00, c10, c01 - c00, c11 - c10);
         if (b == 0) e32[256] = make_float4(kz, kz, 0.0f, 0.0f);
-        thr[b] = b ? a.thr[b] : -INFINITY;
-        if (b == 0) thr[256] = INFINITY;
+        thr_pairs_fill(thr_p, a.thr, 256, b);
         hist[b] = 0;
     }
     __syncthreads();

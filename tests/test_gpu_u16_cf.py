@@ -90,3 +90,4 @@ def test_cf_kernel_band_by_band():
             host = bands[b][:, :cols].cpu().numpy().view(np.uint16).astype(np.float32)
             rc, ref = oracle.pipeline(host, int(Bd.U16), int(St.Clahe))
             assert rc == 0 and np.array_equal(outs[b][:, :cols].cpu().numpy().view(np.uint16), ref)
+
