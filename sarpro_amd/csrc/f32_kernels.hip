@@ -28,7 +28,14 @@ struct ThrPairs {
     __device__ float operator[](uint32_t i) const { return p[i].x; }
 };
 __device__ inline void thr_bounds(const float *thr, uint32_t k, float *t0, float *t1) { *t0 = thr[k]; *t1 = thr[k + 1]; }
+#ifdef SARPRO_ABL_F32_THR_SPLIT // timing ablation: the two bounds as two 4-byte reads (what the plain thr[] table of rounds 1-3 cost)
+__device__ inline void thr_bounds(const ThrPairs &thr, uint32_t k, float *t0, float *t1) {
+    *t0 = *reinterpret_cast<const volatile float *>(&thr.p[k].x);
+    *t1 = *reinterpret_cast<const volatile float *>(&thr.p[k].y);
+}
+#else
 __device__ inline void thr_bounds(const ThrPairs &thr, uint32_t k, float *t0, float *t1) { const float2 t = thr.p[k]; *t0 = t.x; *t1 = t.y; }
+#endif
 // fills pairs[0 .. n - 1] from thr[1 .. n - 1] (global), thr[0] = -inf, thr[n] = +inf; n threads of the workgroup call it with i = their index
 __device__ inline void thr_pairs_fill(float2 *pairs, const float *g_thr, int n, int i) {
     if (i < n) pairs[i] = make_float2(i ? g_thr[i] : -INFINITY, i + 1 < n ? g_thr[i + 1] : INFINITY);
