@@ -355,16 +355,17 @@ static void build_pieces(StripePlan *P, int grid) {
             const bool neg = rw.d < 0.0 || cw.d < 0.0; // constant sign inside the cut cell
             const size_t palign = P->piece_align; // (pieces: 64-px alignment measured 5 % SLOWER on the histogram pass, unlike the strips of the apply pass)
             const size_t cstart = c0 / palign * palign;
-            size_t nch = (c1 - cstart + 255) / 256, off = 0;
+            constexpr size_t kCh = (size_t)kPieceChunk; // px per wave column
+            size_t nch = (c1 - cstart + kCh - 1) / kCh, off = 0;
             while (nch > 0) {
                 int lg = 4;
                 while ((size_t(1) << lg) > nch) --lg;
                 const size_t gw = size_t(1) << lg;
                 Strip st{};
                 st.it.r0 = (int32_t)r0; st.it.r1 = (int32_t)r1;
-                st.it.cstart = (int32_t)(cstart + off * 256);
-                st.it.c0 = (int32_t)std::max(c0, cstart + off * 256);
-                st.it.c1 = (int32_t)std::min(c1, cstart + (off + gw) * 256);
+                st.it.cstart = (int32_t)(cstart + off * kCh);
+                st.it.c0 = (int32_t)std::max(c0, cstart + off * kCh);
+                st.it.c1 = (int32_t)std::min(c1, cstart + (off + gw) * kCh);
                 st.it.gx_log2 = lg;
                 st.it.flags = neg ? 1 : 0;
                 st.it.id[0] = rw.t0 * kTiles + cw.t0; st.it.id[1] = rw.t0 * kTiles + cw.t1;
@@ -454,7 +455,8 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     StripePlan *P = new StripePlan();
     P->rows_total = rows_total; P->cols = cols; P->row0 = row0; P->rows_local = rows_local; P->vecw = vecw;
     if (ctx->attrs.is_set(A_STRIP_ALIGN)) P->strip_align_px = (size_t)std::max<long long>(1, ctx->attrs.val(A_STRIP_ALIGN, 64));
-    if (ctx->attrs.is_set(A_PIECE_ALIGN)) P->piece_align = (size_t)std::max<long long>(4, ctx->attrs.val(A_PIECE_ALIGN, 4) / 4 * 4);
+    P->piece_align = (size_t)kPieceVec;
+    if (ctx->attrs.is_set(A_PIECE_ALIGN)) P->piece_align = (size_t)std::max<long long>(kPieceVec, ctx->attrs.val(A_PIECE_ALIGN, kPieceVec) / kPieceVec * kPieceVec);
     build_clahe_geometry(rows_total, cols, &P->geom);
     const size_t strips_across = (cols + 64 * vecw - 1) / (64 * vecw) + kTiles;
     const size_t target_items = 4096;

@@ -10,7 +10,7 @@ namespace sarpro {
 struct PieceItem {
     int32_t r0, r1;   // local rows [r0, r1)
     int32_t c0, c1;   // columns this piece owns
-    int32_t cstart;   // column of lane 0 of wave column 0: a multiple of 4, <= c0
+    int32_t cstart;   // column of lane 0 of wave column 0: a multiple of kPieceVec, <= c0
     int32_t gx_log2;
     int32_t flags;    // bit 0: the cell extrapolates (negative blend weights)
     int32_t id[4];    // tiles t00, t01, t10, t11
@@ -18,6 +18,16 @@ struct PieceItem {
 };
 static_assert(sizeof(PieceItem) == 48, "PieceItem layout");
 constexpr int kPieceMaxGrid = 1024;
+// samples per lane and band-row of the piece histogram; a wave column is 64 x kPieceVec px wide.  4 (8-byte loads) is the default:
+// the read-only piece traversal streams faster with 16 bytes per lane (6.1-6.3 TB/s against 5.6: profiles/r2/stream_bench.txt), but
+// the histogram pass with 8 samples per lane -- sixteen LDS adds per lane and row behind two loads -- ran at 0.39 ms against 0.32
+// (round 4, one call, alternating builds: profiles/r4/variants_piece_vec.txt).  -DSARPRO_PIECE_VEC=8 (api.cpp and piece_kernels.hip).
+#ifndef SARPRO_PIECE_VEC
+#define SARPRO_PIECE_VEC 4
+#endif
+constexpr int kPieceVec = SARPRO_PIECE_VEC;
+constexpr int kPieceChunk = 64 * kPieceVec;
+static_assert(kPieceVec == 4 || kPieceVec == 8, "piece histogram: 8- or 16-byte loads");
 
 struct DnHistPiecesArgs { // per-tile DN histograms of both bands (k_dn_hist_pieces)
     const uint16_t *in[kMaxBands];

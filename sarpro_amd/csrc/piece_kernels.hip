@@ -15,16 +15,19 @@ constexpr int kPBlock = 1024, kPWaves = 16;
 constexpr uint32_t kLowBins = 256, kLowReps = 8;
 // LDS atomics through the address-space-3 pointer (the HIP overloads take generic pointers)
 #define LDS_ADD(off, v) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)(off)), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#ifdef SARPRO_NT_PIECE
-__device__ __forceinline__ uint2 piece_load_nt(const uint16_t *p) {
-    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-    const v2u t = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p));
-    return make_uint2(t.x, t.y);
+struct PieceRow { uint32_t w[kPieceVec / 2]; }; // kPieceVec samples of a band-row, two per dword
+__device__ __forceinline__ PieceRow piece_load(const uint16_t *p) {
+    PieceRow r;
+    if (kPieceVec == 8) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        r.w[0] = t.x; r.w[1] = t.y; r.w[kPieceVec / 2 - 2] = t.z; r.w[kPieceVec / 2 - 1] = t.w;
+    } else {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        r.w[0] = t.x; r.w[1] = t.y;
+    }
+    return r;
 }
-#define PIECE_LOAD(p) piece_load_nt(p)
-#else
-#define PIECE_LOAD(p) (*reinterpret_cast<const uint2 *>(p))
-#endif
+#define PIECE_LOAD(p) piece_load(p)
 __device__ __forceinline__ int p_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int p_lane() { return (int)(threadIdx.x & 63); }
 
@@ -79,19 +82,24 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
         }
         const int gx = 1 << I.gx_log2, gy = kPWaves >> I.gx_log2;
         const int wx = wave & (gx - 1), wy = wave >> I.gx_log2;
-        const int col = I.cstart + (wx * 64 + lane) * 4;
-        if (col >= I.c1 || col + 4 <= I.c0) continue;
+        constexpr int V = kPieceVec;
+        const int col = I.cstart + (wx * 64 + lane) * V;
+        if (col >= I.c1 || col + V <= I.c0) continue;
         // samples outside the piece's columns become DN = 0 (never counted)
-        uint32_t m[2] = {0u, 0u};
+        uint32_t m[V / 2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < V / 2; ++k) m[k] = 0u;
+#pragma unroll
+        for (int j = 0; j < V; ++j)
             if (col + j >= I.c0 && col + j < I.c1) m[j >> 1] |= 0xFFFFu << (16 * (j & 1));
         uint32_t *const gt[2] = {a.tile_hist[0] + (size_t)I.tile * 65536u, a.tile_hist[1] + (size_t)I.tile * 65536u};
-        auto consume = [&](int b, uint2 w) {
-            const uint32_t ww[2] = {w.x & m[0], w.y & m[1]};
+        auto consume = [&](int b, const PieceRow &w) {
+            uint32_t ww[V / 2];
+#pragma unroll
+            for (int k = 0; k < V / 2; ++k) ww[k] = w.w[k] & m[k];
             uint32_t big = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < V; ++j) {
                 const uint32_t d = (j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu);
                 const bool in_lds = d - 1u < W - 1u; // 1 <= d < W
                 big |= (d >= W ? 1u : 0u) << j;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
 #else
             if (big) { // bright tail: rare
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < V; ++j)
                     if ((big >> j) & 1u) atomicAdd(&gt[b][(j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu)], 1u);
             }
 #endif
@@ -117,9 +125,9 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
         int r = I.r0 + wy;
         if (r < I.r1) { // two rows in flight per wave: the next row's loads are issued before this row is counted
             const int lastr = I.r1 - 1;
-            uint2 n1 = PIECE_LOAD(p1 + (size_t)r * a.pitch), n2 = PIECE_LOAD(p2 + (size_t)r * a.pitch);
+            PieceRow n1 = PIECE_LOAD(p1 + (size_t)r * a.pitch), n2 = PIECE_LOAD(p2 + (size_t)r * a.pitch);
             for (; r < I.r1; r += gy) {
-                const uint2 c1 = n1, c2 = n2;
+                const PieceRow c1 = n1, c2 = n2;
                 const int rn = min(r + gy, lastr);
                 n1 = PIECE_LOAD(p1 + (size_t)rn * a.pitch);
                 n2 = PIECE_LOAD(p2 + (size_t)rn * a.pitch);
