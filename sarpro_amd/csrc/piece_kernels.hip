@@ -9,10 +9,12 @@ namespace sarpro {
 namespace {
 
 constexpr int kPBlock = 1024, kPWaves = 16;
-// DN 1..255 are counted in one of kLowReps lane-selected copies of those bins: a band of a few distinct low amplitudes (cross-pol
-// over open water: most samples on five or ten DN values) otherwise sends a whole wave's adds to a handful of LDS words, which
-// serialise -- 1.34 ms instead of 0.31 for the pass on a scene whose VH band holds DN 1..10 only.  The copies are summed on publish.
-constexpr uint32_t kLowBins = 256, kLowReps = 8;
+// DN 1..kLowBins-1 are counted in the LANE'S OWN copy of those bins ([band][DN][64 lanes]: the word of lane l lies on bank l mod 32, and
+// lanes l and l + 32 belong to different halves of a ds_add_u32 -- no two lanes of an instruction ever meet, neither on a bank nor on
+// an address).  A band of a few distinct low amplitudes (cross-pol over open water: most samples on five or ten DN values) otherwise
+// sends a whole wave's adds to a handful of LDS words, which serialise: 1.34 ms instead of 0.31 for the pass on a scene whose VH
+// band holds DN 1..10 only; eight lane-selected copies (the first form of this) left 0.72.  The copies are summed on publish.
+constexpr uint32_t kLowBins = 128, kLowReps = 64;
 // LDS atomics through the address-space-3 pointer (the HIP overloads take generic pointers)
 #define LDS_ADD(off, v) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)(off)), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 struct PieceRow { uint32_t w[kPieceVec / 2]; }; // kPieceVec samples of a band-row, two per dword
@@ -49,26 +51,28 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
     __syncthreads();
     const int wave = p_wave(), lane = p_lane();
     const uint32_t dummy[2] = {(W + (uint32_t)lane) * 4u, (S + W + (uint32_t)lane) * 4u};
-    // byte offset of this lane's copy of the low bins, per band: behind the two histograms, [band][copy][kLowBins]
-    const uint32_t low_off[2] = {(2u * S + ((uint32_t)lane & (kLowReps - 1u)) * kLowBins) * 4u,
-                                 (2u * S + (kLowReps + ((uint32_t)lane & (kLowReps - 1u))) * kLowBins) * 4u};
+    // byte offset of this lane's word of low bin 0, per band: behind the two histograms, [band][kLowBins][64 lanes]
+    const uint32_t low_off[2] = {(2u * S + (uint32_t)lane) * 4u, (2u * S + kLowReps * kLowBins + (uint32_t)lane) * 4u};
     int cur_tile = -1;
     auto publish = [&]() { // all threads, between barriers
         if (cur_tile < 0) return;
+        // the lanes' own words of the low bins first, folded into the shared bins by all threads (16 bytes each, four turns)
+        for (uint32_t q = threadIdx.x; q < 2u * kLowBins * kLowReps / 4u; q += kPBlock) {
+            uint4 *p = reinterpret_cast<uint4 *>(&h[2u * S]) + q;
+            const uint4 v = *p;
+            const uint32_t n = v.x + v.y + v.z + v.w;
+            if (n) {
+                *p = make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t b = q / (kLowBins * kLowReps / 4u), dn = (q / (kLowReps / 4u)) % kLowBins;
+                LDS_ADD((b * S + dn) * 4u, n);
+            }
+        }
+        __syncthreads();
         for (int b = 0; b < 2; ++b) {
             uint32_t *g = a.tile_hist[b] + (size_t)cur_tile * 65536u;
             for (uint32_t i = threadIdx.x + 1; i < W; i += kPBlock) {
-                uint32_t n = h[b * S + i];
-                if (n) h[b * S + i] = 0u;
-                if (i < kLowBins) {
-#pragma unroll
-                    for (uint32_t rep = 0; rep < kLowReps; ++rep) {
-                        uint32_t *p = &h[2u * S + ((uint32_t)b * kLowReps + rep) * kLowBins + i];
-                        n += *p;
-                        *p = 0u;
-                    }
-                }
-                if (n) atomicAdd(&g[i], n);
+                const uint32_t n = h[b * S + i];
+                if (n) { h[b * S + i] = 0u; atomicAdd(&g[i], n); }
             }
         }
     };
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
                 const bool in_lds = d - 1u < W - 1u; // 1 <= d < W
                 big |= (d >= W ? 1u : 0u) << j;
                 const bool low = d - 1u < kLowBins - 1u; // 1 <= d < kLowBins: this lane's copy
-                const uint32_t off = low ? low_off[b] + d * 4u : in_lds ? (b ? S * 4u : 0u) + d * 4u : dummy[b];
+                const uint32_t off = low ? low_off[b] + d * (kLowReps * 4u) : in_lds ? (b ? S * 4u : 0u) + d * 4u : dummy[b];
 #ifdef PIECE_HIST_NO_ATOMICS // timing experiment: the traversal and the address arithmetic without the LDS atomics
                 big += off;
 #else
