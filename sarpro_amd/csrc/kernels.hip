@@ -480,7 +480,9 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     side -- one whole bank row -- and of its (c10, c11) pair in the row after it; a lane reads copy (lane & 15), and the lanes of
 //     each of the instruction's four groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32) have sixteen different
 //     values of lane & 15: every gather is conflict-free whatever the bins are.  128 KiB of tables: one persistent 1024-thread
-//     workgroup per CU walks items of up to 1024 rows (16 waves x 64 rows: lane l of a wave holds dy of the wave's l-th row), the
+//     workgroup per CU walks its share of the cell-major item list (equal rows per workgroup; vertical neighbours, strip after strip
+//     of a cell: the tables are rebuilt, and the waves meet, only where the cell changes), items of up to 1024 rows (16 waves x 64
+//     rows: lane l of a wave holds dy of the wave's l-th row), the
 //     DN -> bin bytes of the band's window stay in LDS for the whole launch, rows are loaded and stored through buffer
 //     descriptors (rows past the item's end and lanes outside it pass an out-of-range offset: no branch around a load or a
 //     store, so the wait for the rows prefetched one step ahead does not wait for the stores issued after them).
