@@ -704,8 +704,8 @@ def secondary_records(torch, dev, rows, cols):
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
 
-    # (first, while this process holds no other context: the call overlaps its two bands on two streams, and a process's streams share a
-    # few hardware queues -- with the two measurement contexts below alive as well the bands serialise and the call reads 0.26 instead of 0.21 ms)
+    # (first: a 0.2-ms call reads 0.21-0.23 ms in a quiet process and 0.25-0.27 right after the 400 MP records below -- tools/dbg_ctx_count.py:
+    # neither the number of live contexts nor of streams explains it, what ran just before does)
     # The reference's DEFAULT flow at its usual size (`--size 2048` resamples on read: the raster core sees two non-integer f32 bands):
     # per-band autoscale -> synRGB, device-resident, one synchronous call.  A context without the timing table: the second band runs on
     # the context's twin (own stream) from its helper thread.
