@@ -1,5 +1,6 @@
 """The dual-pol 2048^2 f32 call of a fresh context after various things happened in the process (allocations, other contexts, their
 use): the 0.2-ms figure moves by 10 % with what ran just before it, not with the number of contexts or streams."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sarpro_amd as S
