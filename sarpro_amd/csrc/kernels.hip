@@ -1424,15 +1424,25 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
 //     Per pixel and band: v_pk_min_u16 (clamp, 2 px) -> SDWA shift -> one 16-B gather -> 4 FMA + add -> 2 v_cvt_pk_u8_f32,
 //     margin test and exact f64 path exactly as in kernel 4b (same bounds: the entry values and operation order are the same).
 // ------------------------------------------------------------------------------------
+// The blue table in LDS has rows of 260 bytes, not 256: the bank of B2[level1][level2] is then (level1 + level2 / 4) mod 32 instead of
+// (level2 / 4) mod 32.  With 256-byte rows a band whose levels sit on a handful of values (a quantised cross-pol band: a dozen
+// occupied CLAHE bins) sends all 32 lanes of a byte read to the two or three banks of those level2 values, in different rows:
+// the pass ran 0.70 ms on such a scene against 0.64 on the others.  The index costs what it cost: one v_mad_u32_u24 (level1 x 260 +
+// level2) instead of one v_perm_b32; the 1 KiB comes out of the pool (3008 DN-indexed entries instead of 3072).
+#ifndef SARPRO_RGB_B2_STRIDE
+#define SARPRO_RGB_B2_STRIDE 260
+#endif
+constexpr uint32_t kRgbB2Stride = SARPRO_RGB_B2_STRIDE;
+static_assert(kRgbB2Stride == 256 || kRgbB2Stride == 260, "blue table rows: 256 (as in global memory) or 260 bytes");
 #ifndef SARPRO_RGB_BLOCK // (occupancy experiment: -DSARPRO_RGB_BLOCK=512 -DSARPRO_RGB_POOL=2040)
 #define SARPRO_RGB_BLOCK 1024
-#define SARPRO_RGB_POOL 3072
+#define SARPRO_RGB_POOL (SARPRO_RGB_B2_STRIDE == 256 ? 3072 : 3008)
 #endif
 constexpr int kRgbBlock = SARPRO_RGB_BLOCK, kRgbWaves = kRgbBlock / kWave;
 constexpr uint32_t kRgbPoolEntries = SARPRO_RGB_POOL;
 struct RgbLds {
-    static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[65536]
-    static constexpr uint32_t stage = kComposeTableBytes;                   // [16][1536] RGB of a wave-row | tmp32 [2][257] float4 while staging
+    static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[256][kRgbB2Stride]
+    static constexpr uint32_t stage = 512 + 256 * kRgbB2Stride;             // [16][1536] RGB of a wave-row | tmp32 [2][257] float4 while staging
     static constexpr uint32_t cdf64 = stage + kRgbWaves * 1536;             // [2][257][4] double
     static constexpr uint32_t colw = cdf64 + 2 * 257 * 32;                  // [512] double
     static constexpr uint32_t binof = colw + 512 * 8;                       // [kRgbPoolEntries] u8: CLAHE bin of the entry's DN
@@ -1467,10 +1477,11 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
         for (int b = 0; b < 2; ++b)
             for (uint32_t i = threadIdx.x; i <= win_hi[b]; i += kRgbBlock) lds[RgbLds::binof + kb[b] + i] = a.binlut[b][i];
     }
-    {   // compose tables, once per workgroup
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds + RgbLds::tables);
-        for (int i = threadIdx.x; i < kComposeTableBytes / 16; i += kRgbBlock) dst[i] = src[i];
+    {   // compose tables, once per workgroup: R2 | G2 as they are, the blue table's 256-byte rows at their LDS stride
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables);
+        for (int i = threadIdx.x; i < 512 / 4; i += kRgbBlock) LDS_AT(uint32_t, RgbLds::tables + 4 * i) = src[i];
+        for (int i = threadIdx.x; i < 65536 / 4; i += kRgbBlock)
+            LDS_AT(uint32_t, RgbLds::tables + 512 + (uint32_t)(i >> 6) * kRgbB2Stride + (uint32_t)(i & 63) * 4u) = src[128 + i];
     }
     const uint32_t fpred = (uint32_t)sp->floor_pred;
     const uint32_t t4[3] = {(fpred ? fpred - 1u : 0u) * 0x01010101u, fpred * 0x01010101u, (fpred + 1u) * 0x01010101u};
@@ -1780,7 +1791,7 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 #ifdef SARPRO_ABL_RGB_NOLOOKUP // timing ablation (garbage raster)
                             px[j][0] = v1; px[j][1] = v2; px[j][2] = v1 ^ v2;
 #else
-                            px[j][0] = lds[RgbLds::tables + v1]; px[j][1] = lds[RgbLds::tables + 256 + v2]; px[j][2] = lds[RgbLds::tables + 512 + ((v1 << 8) | v2)];
+                            px[j][0] = lds[RgbLds::tables + v1]; px[j][1] = lds[RgbLds::tables + 256 + v2]; px[j][2] = lds[RgbLds::tables + 512 + v1 * kRgbB2Stride + v2];
 #endif
                         }
                         o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
@@ -1795,7 +1806,9 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                         for (int j = 0; j < 4; ++j) {
                             const uint32_t v1 = j == 0 ? (l1[g] & 0xFFu) : j == 3 ? (l1[g] >> 24) : __builtin_amdgcn_ubfe(l1[g], 8 * j, 8);
                             const uint32_t v2 = j == 0 ? (l2[g] & 0xFFu) : j == 3 ? (l2[g] >> 24) : __builtin_amdgcn_ubfe(l2[g], 8 * j, 8);
-                            const uint32_t pair = __builtin_amdgcn_perm(l1[g], l2[g], to_sgpr_u32(0x0c0c0400u + 0x0101u * (uint32_t)j)); // (0, 0, level1, level2)
+                            uint32_t pair; // byte offset of B2[level1][level2]
+                            if (kRgbB2Stride == 256) pair = __builtin_amdgcn_perm(l1[g], l2[g], to_sgpr_u32(0x0c0c0400u + 0x0101u * (uint32_t)j)); // (0, 0, level1, level2)
+                            else asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair) : "v"(v1), "s"(kRgbB2Stride), "v"(v2));
 #ifdef SARPRO_ABL_RGB_NOLOOKUP // timing ablation (garbage raster)
                             px[j][0] = v1; px[j][1] = v2; px[j][2] = pair & 0xFFu;
 #else
