@@ -37,9 +37,10 @@ __device__ __forceinline__ int p_lane() { return (int)(threadIdx.x & 63); }
 // The per-tile DN histograms of BOTH bands over balanced pieces of the scene: persistent workgroups of 1024 threads, each on its
 // static share of the scene (strips of 2^k wave columns x row ranges inside one tile), reading the two rasters at the rate the
 // piece traversal streams them (tools/stream_bench.hip: 5.6-6.2 TB/s against 4.6 for the 256-thread strip items of
-// kernels.hip 1b).  Counting as there: one unconditional ds_add_u32 per pixel -- DN in [1, W) to its bin, DN = 0 and the
-// bright tail to a per-lane dummy word, tail pixels to the tile's global histogram -- and DN = 0 is not accumulated at all
-// (bin 0 is what is left of the tile, restored by the consumer).  The LDS histograms are published when the tile changes.
+// kernels.hip 1b).  Counting: one unconditional ds_add_u32 per pixel -- DN in [kLowBins, W) to its shared bin, DN below kLowBins (0, the
+// invalid sample, included) to the lane's own word of that bin, the bright tail to a per-lane dummy word and, by a rare branch, to
+// the tile's global histogram -- ; bin 0 is not published (it is what is left of the tile, restored by the consumer).  The LDS
+// histograms are published when the tile changes.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -50,7 +51,6 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
     for (uint32_t i = threadIdx.x; i < 2u * S + 2u * kLowReps * kLowBins; i += kPBlock) h[i] = 0u;
     __syncthreads();
     const int wave = p_wave(), lane = p_lane();
-    const uint32_t dummy[2] = {(W + (uint32_t)lane) * 4u, (S + W + (uint32_t)lane) * 4u};
     // byte offset of this lane's word of low bin 0, per band: behind the two histograms, [band][kLowBins][64 lanes]
     const uint32_t low_off[2] = {(2u * S + (uint32_t)lane) * 4u, (2u * S + kLowReps * kLowBins + (uint32_t)lane) * 4u};
     int cur_tile = -1;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
             if (n) {
                 *p = make_uint4(0u, 0u, 0u, 0u);
                 const uint32_t b = q / (kLowBins * kLowReps / 4u), dn = (q / (kLowReps / 4u)) % kLowBins;
-                LDS_ADD((b * S + dn) * 4u, n);
+                if (dn) LDS_ADD((b * S + dn) * 4u, n); // (low bin 0 holds the invalid samples: bin 0 is what is left of the tile, restored by the consumer)
             }
         }
         __syncthreads();
@@ -97,31 +97,43 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
         for (int j = 0; j < V; ++j)
             if (col + j >= I.c0 && col + j < I.c1) m[j >> 1] |= 0xFFFFu << (16 * (j & 1));
         uint32_t *const gt[2] = {a.tile_hist[0] + (size_t)I.tile * 65536u, a.tile_hist[1] + (size_t)I.tile * 65536u};
+        // Per sample: min(DN, W + lane) straight from its 16-bit half (a tail sample lands on the lane's dummy word behind the bins), one
+        // compare against the low range -- DN = 0 included: it goes to the lane's own word of low bin 0, which nobody reads (the no-data
+        // wedge never meets another lane) --, stride and base by that compare, one multiply-add, one ds_add_u32: five VALU
+        // instructions.  The bright tail is found by ONE packed max per dword and a wave-level test per band-row; its samples then go
+        // to the tile's global histogram one by one (rare).
+        const uint32_t Wl = W + (uint32_t)lane;
+        const uint32_t tail_mask = ~(W - 1u) & 0xFFFFu; // (W is a power of two: a half >= W has one of these bits)
         auto consume = [&](int b, const PieceRow &w) {
-            uint32_t ww[V / 2];
+            uint32_t ww[V / 2], mx = 0u;
+            typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int k = 0; k < V / 2; ++k) ww[k] = w.w[k] & m[k];
-            uint32_t big = 0;
+            for (int k = 0; k < V / 2; ++k) {
+                ww[k] = w.w[k] & m[k];
+                mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2us, mx), __builtin_bit_cast(v2us, ww[k])));
+            }
+            const uint32_t band_base = b ? S * 4u : 0u;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const uint32_t d = (j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu);
-                const bool in_lds = d - 1u < W - 1u; // 1 <= d < W
-                big |= (d >= W ? 1u : 0u) << j;
-                const bool low = d - 1u < kLowBins - 1u; // 1 <= d < kLowBins: this lane's copy
-                const uint32_t off = low ? low_off[b] + d * (kLowReps * 4u) : in_lds ? (b ? S * 4u : 0u) + d * 4u : dummy[b];
+                const uint32_t dc = min(d, Wl);
+                const bool low = dc < kLowBins; // 0 <= DN < kLowBins: this lane's own words
+                const uint32_t off = dc * (low ? kLowReps * 4u : 4u) + (low ? low_off[b] : band_base);
 #ifdef PIECE_HIST_NO_ATOMICS // timing experiment: the traversal and the address arithmetic without the LDS atomics
-                big += off;
+                mx += off;
 #else
                 LDS_ADD(off, 1u);
 #endif
             }
 #ifdef PIECE_HIST_NO_ATOMICS
-            if (big == 0xFFFFFFFFu) atomicAdd(&gt[b][0], 1u);
+            if (mx == 0xFFFFFFFFu) atomicAdd(&gt[b][0], 1u);
 #else
-            if (big) { // bright tail: rare
+            if ((mx | (mx >> 16)) & tail_mask) { // bright tail: rare
 #pragma unroll
-                for (int j = 0; j < V; ++j)
-                    if ((big >> j) & 1u) atomicAdd(&gt[b][(j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu)], 1u);
+                for (int j = 0; j < V; ++j) {
+                    const uint32_t d = (j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu);
+                    if (d >= W) atomicAdd(&gt[b][d], 1u);
+                }
             }
 #endif
         };
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
 hipError_t launch_dn_hist_pieces(const DnHistPiecesArgs &a, int grid, hipStream_t s) {
     if (grid <= 0 || grid > kPieceMaxGrid) return hipErrorInvalidValue;
     const size_t lds = (2 * ((size_t)a.lds_bins + 64) + 2 * (size_t)kLowReps * kLowBins) * sizeof(uint32_t);
-    if (lds > 160 * 1024 || a.lds_bins < kLowBins) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 || a.lds_bins < kLowBins || (a.lds_bins & (a.lds_bins - 1)) != 0) return hipErrorInvalidValue; // (a power of two: the tail test is a mask)
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_dn_hist_pieces))) return e;
     hipLaunchKernelGGL(k_dn_hist_pieces, dim3(grid), dim3(kPBlock), lds, s, a);
     return hipGetLastError();
