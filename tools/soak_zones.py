@@ -5,7 +5,7 @@ must be the oracle's whether the route answered or stepped aside.  usage: python
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["SARPRO_HIP_F32_ZONES"] = "force"
+os.environ["SARPRO_HIP_F32_DIRECT"] = "0"  # rasters this small take the direct route otherwise: the zone route is what is soaked here
 import numpy as np
 import oracle
 import sarpro_amd as S
