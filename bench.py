@@ -180,6 +180,7 @@ def main():
     dom_warm = max(wtimes, key=wtimes.get) if wtimes else None
     if dom_warm is None:  # --warmup 0: no measurement to choose by; the kernel that dominates this strategy's chain in every profile
         dom_warm = "clahe_rgb_fused" if strategy == AutoscaleStrategy.Clahe else "lut_compose_u16"
+    ctx.last_kernel_times()  # (drained: with --warmup 0 the classification pass's event pairs would otherwise count as timed launches)
     if dom_warm:
         ctx.time_only(dom_warm)
     dtimes: list[float] = []  # the dominant kernel's launches inside the timed region
