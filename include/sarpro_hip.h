@@ -262,6 +262,31 @@ int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices
                                                 size_t nscenes, int strategy, int mode, unsigned flags, size_t target_size, int pad,
                                                 int continue_on_error, sarpro_hip_batch_report *report);
 
+/* Resident batch: the batch loop of api/mod.rs:484-533 for scenes whose bands are ALREADY in device memory (decoded and uploaded by
+ * the caller, or produced on the device), all of one shape -- the save.rs:317-367 product at native resolution per scene:
+ * d_band1, d_band2 -> per-band autoscale -> synRGB -> d_rgb (rgb_pitch_px pixels per row).  One context, `lanes` internal lanes (each
+ * its own stream and workspace set, created on first use; 0 = the library's default): scene i runs on lane i mod lanes, so scene
+ * i + 1's histogram sweep and its short dependent kernels (statistics, CLAHE bins, CDFs, sample, prediction) are enqueued beside
+ * scene i's CLAHE -> RGB pass instead of behind it.  Every scene takes the route it would take alone (speculative, refuted or
+ * unproven -> exact kernels): the rasters are those of sarpro_hip_dualpol_synrgb_u16_dev, bit for bit.  The call returns when every
+ * raster is complete.  status / route are written per scene (route: SARPRO_HIP_ROUTE_*; -1 when no speculative chain ran for it);
+ * continue_on_error = 0 stops enqueuing after the first failure (the rest count as skipped), as the other batch entry points.
+ * Stream ordering: the lanes' streams are ordered against nothing of the caller's -- inputs must be complete before the call. */
+#define SARPRO_HIP_ROUTE_NONE (-1)      /* no speculative CLAHE chain ran (another strategy, a small or unaligned scene) */
+#define SARPRO_HIP_ROUTE_ACCEPTED 0     /* the fused CLAHE -> RGB pass's raster stood */
+#define SARPRO_HIP_ROUTE_REFUTED 1      /* the predicted floor / rescale range was refuted in the pass: exact kernels produced the raster */
+#define SARPRO_HIP_ROUTE_UNPROVEN 2     /* the speculation never started */
+#define SARPRO_HIP_ROUTE_POOL_OVERFLOW 3 /* DN windows beyond the fused pass's LDS pool: exact kernels */
+typedef struct {
+    const uint16_t *d_band1, *d_band2; /* device, rows x in_pitch */
+    uint8_t *d_rgb;                    /* device, rows x rgb_pitch_px x 3 */
+    int status;                        /* out */
+    int route;                         /* out */
+} sarpro_hip_resident_scene;
+int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarpro_hip_resident_scene *scenes, size_t nscenes, size_t rows,
+                                            size_t cols, size_t in_pitch, int strategy, int mode, size_t rgb_pitch_px, int lanes,
+                                            int continue_on_error, sarpro_hip_batch_report *report);
+
 /* ================= device-pointer entry points ================= */
 /* Same operations on rasters already resident in HBM.  pitch = row stride in elements
  * (>= cols).  The vectorised kernels need base pointers aligned to 16 bytes and

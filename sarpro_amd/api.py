@@ -393,6 +393,26 @@ class Context:
                                                         _vp(d_u8_1), _vp(d_u8_2), u8_pitch, st))
         return [st[0], st[1]] if want_stats else None
 
+    ROUTES = {-1: "n/a", 0: "accepted", 1: "refuted", 2: "unproven", 3: "pool_overflow"}
+
+    def dev_batch_dualpol_synrgb_u16(self, scenes, rows: int, cols: int, in_pitch: int, strategy, mode, rgb_pitch_px: int,
+                                     lanes: int = 0, continue_on_error: bool = True, check: bool = True):
+        """sarpro_hip_batch_dualpol_synrgb_u16_dev: `scenes` = [(d_band1, d_band2, d_rgb), ...] device pointers of one shape; the
+        batch loop of api/mod.rs:484-533 for resident scenes, pipelined over `lanes` internal lanes.  Returns (report dict,
+        per-scene statuses, per-scene routes); raises on a failed batch unless check=False."""
+        from ._lib import BatchReport, ResidentScene
+        arr = (ResidentScene * max(len(scenes), 1))()
+        for i, (b1, b2, rgb) in enumerate(scenes):
+            arr[i].d_band1, arr[i].d_band2, arr[i].d_rgb = b1, b2, rgb
+        rep = BatchReport()
+        rc = lib.sarpro_hip_batch_dualpol_synrgb_u16_dev(self._h, arr, len(scenes), rows, cols, in_pitch, int(strategy), int(mode), rgb_pitch_px,
+                                                         int(lanes), 1 if continue_on_error else 0, C.byref(rep))
+        if check:
+            self._chk(rc)
+        n = len(scenes)
+        return ({"processed": int(rep.processed), "skipped": int(rep.skipped), "errors": int(rep.errors), "rc": int(rc)},
+                [int(arr[i].status) for i in range(n)], [self.ROUTES.get(int(arr[i].route), "n/a") for i in range(n)])
+
     def dev_polop_f32(self, op, d_a: int, d_b: int, n: int, d_out: int):
         self._chk(lib.sarpro_hip_polop_f32_dev(self._h, int(op), _vp(d_a), _vp(d_b), n, _vp(d_out)))
 

@@ -135,6 +135,7 @@ extern "C" int sarpro_hip_ctx_set_attr(sarpro_hip_ctx *ctx, const char *name, in
     if (a < 0) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "unknown context attribute");
     ctx->attrs.set[a] = true; ctx->attrs.v[a] = value;
     if (ctx->twin) { ctx->twin->attrs.set[a] = true; ctx->twin->attrs.v[a] = value; }
+    for (sarpro_hip_ctx *l : ctx->lanes) { l->attrs.set[a] = true; l->attrs.v[a] = value; }
     return SARPRO_HIP_OK;
 }
 extern "C" int sarpro_hip_ctx_reset_attr(sarpro_hip_ctx *ctx, const char *name) {
@@ -143,6 +144,7 @@ extern "C" int sarpro_hip_ctx_reset_attr(sarpro_hip_ctx *ctx, const char *name) 
     if (a < 0) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "unknown context attribute");
     ctx->attrs.set[a] = false; ctx->attrs.v[a] = 0;
     if (ctx->twin) { ctx->twin->attrs.set[a] = false; ctx->twin->attrs.v[a] = 0; }
+    for (sarpro_hip_ctx *l : ctx->lanes) { l->attrs.set[a] = false; l->attrs.v[a] = 0; }
     return SARPRO_HIP_OK;
 }
 extern "C" int sarpro_hip_ctx_get_attr(const sarpro_hip_ctx *ctx, const char *name, int64_t *value, int *is_set) {
@@ -194,7 +196,10 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     if (!ctx) return;
     if (ctx->band_worker) { ctx->band_worker->stop(); delete ctx->band_worker; ctx->band_worker = nullptr; }
     if (ctx->twin) { sarpro_hip_ctx_destroy(ctx->twin); ctx->twin = nullptr; }
+    for (sarpro_hip_ctx *l : ctx->lanes) sarpro_hip_ctx_destroy(l);
+    ctx->lanes.clear();
     (void)hipSetDevice(ctx->device);
+    for (hipEvent_t ev : ctx->pipe_events) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     sarpro_hip_comm_destroy(ctx);
     for (auto &kv : ctx->plans) {
@@ -258,6 +263,13 @@ extern "C" int sarpro_hip_last_kernel_times(sarpro_hip_ctx *ctx, const char **na
         if (ms) ms[n] = h.second;
         ++n;
     }
+    for (const auto &h : ctx->lane_times) { // the kernels of the last resident batch, lane after lane (pipeline.cpp)
+        if (n >= max_entries) break;
+        if (names) names[n] = h.first;
+        if (ms) ms[n] = h.second;
+        ++n;
+    }
+    ctx->lane_times.clear();
     ctx->async_pending = false; // read: the next call starts a fresh list
     return n;
 }
@@ -537,7 +549,11 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
         sweep_order(P->rgb_rects);
         sweep_order(P->sample_rects);
     }
-    if (vecw == 8 && row0 == 0 && rows_local == rows_total && ctx->cu_count > 0) build_pieces(P, std::min(ctx->cu_count, kPieceMaxGrid));
+    if (vecw == 8 && row0 == 0 && rows_local == rows_total && ctx->cu_count > 0) {
+        long long pg = ctx->cu_count; // PIECE_GRID: planner tuning (how many persistent workgroups share the histogram sweep)
+        if (at.is_set(A_PIECE_GRID)) pg = std::max<long long>(1, at.val(A_PIECE_GRID, pg));
+        build_pieces(P, (int)std::min<long long>(pg, kPieceMaxGrid));
+    }
     int rc = upload_vec(ctx, P->d_hist_rects_tiled, P->hist_rects_tiled.data(), P->hist_rects_tiled.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_piece_items, P->piece_items.data(), P->piece_items.size() * sizeof(PieceItem));
     if (!rc) rc = upload_vec(ctx, P->d_piece_first, P->piece_first.data(), P->piece_first.size() * sizeof(int32_t));
@@ -1146,12 +1162,23 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
     }
     {
-        KernelTimer t(ctx, "clahe_rgb_fused");
-        HIPCHK(ctx, launch_clahe_rgb_fused(fa, std::max(ctx->cu_count, 1), ctx->stream));
+        // resident batch (pipeline.cpp): this scene's pass behind the previous scene's pass (another lane's stream), its own completion
+        // published for the next one -- the passes own whole compute units (160 KiB of LDS each), two of them at once only split the chip
+        if (ctx->pipe_wait_before_fused) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_wait_before_fused, 0));
+        int grid = std::max(ctx->cu_count, 1);
+        if (ctx->attrs.is_set(A_RGB_GRID)) grid = (int)std::min<long long>(1024, std::max<long long>(1, ctx->attrs.val(A_RGB_GRID, grid)));
+        {
+            KernelTimer t(ctx, "clahe_rgb_fused");
+            HIPCHK(ctx, launch_clahe_rgb_fused(fa, grid, ctx->stream));
+        }
+        if (ctx->pipe_record_after_fused) {
+            HIPCHK(ctx, hipEventRecord(ctx->pipe_record_after_fused, ctx->stream));
+            ctx->pipe_record_after_fused = nullptr; // recorded (the batch records it itself behind a chain that never got here)
+        }
     }
     if (J.reduce) { // the verification counts of all stripes, then the verdict every rank shares
         RETCHK(chain_reduce(J, &d_spec->n_lt[0], 2, "allreduce_spec_counts"));
-        HIPCHK(ctx, launch_spec_verdict(d_spec, ctx->stream));
+        HIPCHK(ctx, launch_spec_verdict(d_spec, d_state, ctx->stream));
     }
     {   // gated on the verdict: levels of every pixel with the full histogram -> exact tables -> composition
         KernelTimer t(ctx, "spec_fallback_apply");
@@ -1218,6 +1245,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         if ((size_t)J.rows_total * J.cols < min_px) sampled = false;
     }
     ChainSpecState *d_spec = nullptr;
+    ctx->spec_ran = sampled;
     if (sampled) {
         HIPCHK(ctx, ctx->spec_state.reserve(sizeof(ChainSpecState)));
         d_spec = ctx->spec_state.as<ChainSpecState>();
@@ -1556,6 +1584,7 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
 static int job_run_all(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch, uint8_t *d_rgb, size_t rgb_pitch_px,
                        sarpro_hip_stats *stats_out) {
     timing_reset(J.ctx);
+    J.ctx->spec_ran = false;
     RETCHK(job_init(J));
     if ((J.rows_local == 0 && !J.reduce) || J.cols == 0) { // a rank with an empty stripe still joins the reductions
         if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out) * (size_t)J.nbands);

@@ -581,6 +581,10 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
         const unsigned long long valid = a.state[wb].stats.valid_count;
         if (blockIdx.x == 0 && ln == 0) a.spec->sample_valid[wb] = sv;
         const unsigned long long invalid = a.total_px - valid;
+        // A band without a valid sample is level 0 everywhere (autoscale.rs:466-468 returns the zero raster) and scale_u16_to_u8 of a
+        // constant raster has max == min, scale 1.0: the identity (autoscale.rs:356).  Nothing needs a sample to be proven; its
+        // estimate is exact (every band-pixel at level 0: `invalid` below is the whole band).
+        const bool empty_band = valid == 0ull;
         const bool consistent = sv >= others && sv > 0;
         const unsigned long long s0v = consistent ? sv - others : 0ull; // sampled valid pixels at level 0
         const bool has255 = __builtin_amdgcn_ballot_w64(ln == 63 && v[3] != 0ull) != 0ull;
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
                 est[wb][l] = l ? scale * (double)v[k] : (double)invalid + scale * (double)s0v;
             }
         }
-        if (ln == 0) s_ok[wb] = (consistent && has0 && has255) ? 1 : 0;
+        if (ln == 0) s_ok[wb] = (empty_band || (consistent && has0 && has255)) ? 1 : 0;
     }
     __syncthreads();
     if (t == 0) {

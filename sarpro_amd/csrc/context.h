@@ -176,7 +176,7 @@ struct BandWorker {
     X(STRIP_ALIGN) X(PIECE_ALIGN) X(CHUNK_ROWS) X(RGB_ITEM_ROWS) X(SAMPLE_ITEM_ROWS) \
     X(NO_MAILBOX) X(NO_STEP_ESTIMATE) X(F32_ZONES) X(F32_ZONES_DEBUG) X(F32_DIRECT) X(F32_DIRECT_QCAP) X(F32_LEVEL_GENERAL) \
     X(F32_LEVEL_TABLE) X(F32_LEVEL_QCAP) X(F32_HOST_CDFS) X(F32_NO_VEC8) X(NO_BAND_TWIN) X(RESIZE_GENERIC) X(NO_RESIZE_LUT) \
-    X(NO_U16_CF) X(U16_ITEM_ROWS)
+    X(NO_U16_CF) X(U16_ITEM_ROWS) X(PIPE_LANES) X(PIPE_ORDER) X(RGB_GRID) X(PIECE_GRID)
 namespace sarpro {
 enum Attr : int {
 #define X(n) A_##n,
@@ -246,6 +246,15 @@ struct sarpro_hip_ctx {
     // per-kernel timing of the last call
     bool timing = false;
     bool async_dev = false;                      // SARPRO_HIP_CTX_ASYNC_DEV
+    // resident batch (pipeline.cpp): the internal lanes -- contexts of their own (stream, workspaces, plans) that follow this
+    // context's attributes --, the events that order the lanes' fused passes, and the lanes' kernel times of the last batch
+    std::vector<sarpro_hip_ctx *> lanes;
+    std::vector<hipEvent_t> pipe_events;
+    hipEvent_t pipe_wait_before_fused = nullptr; // (on a lane, for ONE scene) the fused pass waits for this event ...
+    hipEvent_t pipe_record_after_fused = nullptr; // ... and records this one behind itself
+    std::vector<std::pair<const char *, float>> lane_times;
+    bool spec_ran = false;                       // the last u16 chain of this context took the speculative route (spec_state is that scene's)
+    sarpro::PinnedBuf pipe_routes;               // ChainSpecState of every scene of the last batch (host copies)
     sarpro_hip_ctx *twin = nullptr;              // a second context on the same device (own stream, own workspaces): the other band of a dual-pol f32 product
     sarpro::BandWorker *band_worker = nullptr;   // ... and the thread that drives it
     bool f32_stripe_open = false;                // an open sarpro_hip_stripe_f32 owns the f32 workspace until its _end

@@ -130,7 +130,7 @@ struct ClaheRgbArgs {
 };
 bool clahe_rgb_fused_supported(const ClaheRgbArgs &a);
 hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid /* persistent workgroups: one per CU */, hipStream_t s);
-hipError_t launch_spec_verdict(struct ChainSpecState *spec, hipStream_t s); // the fused pass's verdict from counts that were all-reduced
+hipError_t launch_spec_verdict(struct ChainSpecState *spec, const struct ChainBandState *state, hipStream_t s); // the fused pass's verdict from counts that were all-reduced
 
 constexpr size_t kSpecDumpBytes = 256 * 1024;
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);

@@ -1896,7 +1896,11 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
     }
 }
 // Row stripes: every rank's pass has added its counts, the ranks have summed them; the same verdict on every rank.
-__global__ void k_spec_verdict(ChainSpecState *sp) {
+__global__ void k_spec_verdict(ChainSpecState *sp, const ChainBandState *state) {
+    // (the windows are the same on every rank; `pool_overflow` is raised by block 0 of the pass, which a rank with an empty stripe
+    // never launches: every rank derives it here, so that verdict, floor and report agree across the ranks)
+    const uint64_t nwin = (uint64_t)state[0].win_hi + state[1].win_hi + 2u;
+    if (sp->spec_ok && nwin > kRgbPoolEntries && nwin > kWideBytes) sp->pool_overflow = 1u;
     if (!sp->spec_ok || sp->pool_overflow) return; // the passes did not run: "refuted" stands
     const unsigned long long c0 = sp->n_lt[0], c1 = sp->n_lt[1], target = sp->target;
     const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
@@ -2104,7 +2108,7 @@ __global__ __launch_bounds__(kBlock) void k_synth_scene_u16(uint64_t key, const 
         const bool left = c * rows_total * 100ull < 3ull * cols * (rows_total - r);
         const bool right = (cols - 1 - c) * rows_total * 100ull < 3ull * cols * r;
         if (!(flags & 1u) && (left || right)) dn = 0;
-        if ((flags & 4u) && (key >> 60)) dn = 0; // SARPRO_HIP_SYNTH_NO_BAND2: the second band holds no valid sample
+        if (flags & 0x80000000u) dn = 0; // SARPRO_HIP_SYNTH_NO_BAND2 on the second band (decided by the launcher from `band`, not from the key's bits): no valid sample
         out[rl * pitch + c] = (uint16_t)dn;
     }
 }
@@ -2258,8 +2262,8 @@ bool clahe_rgb_fused_supported(const ClaheRgbArgs &a) { // (nrects == 0: a rank 
            (a.nrects == 0 || ((reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 &&
                               (reinterpret_cast<uintptr_t>(a.rgb) & 15) == 0));
 }
-hipError_t launch_spec_verdict(ChainSpecState *spec, hipStream_t s) {
-    hipLaunchKernelGGL(k_spec_verdict, dim3(1), dim3(1), 0, s, spec);
+hipError_t launch_spec_verdict(ChainSpecState *spec, const ChainBandState *state, hipStream_t s) {
+    hipLaunchKernelGGL(k_spec_verdict, dim3(1), dim3(1), 0, s, spec, state);
     return hipGetLastError();
 }
 hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s) {
@@ -2345,7 +2349,7 @@ hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q, 
     const uint64_t block = std::max<uint64_t>((rows_total + per_side - 1) / per_side, 1);
     hipLaunchKernelGGL(k_synth_scene_u16, dim3(stream_grid((uint64_t)rows_local * cols, kBlock)), dim3(kBlock), 0, s,
                        key, d_q, (uint64_t)rows_total, (uint64_t)cols, (uint64_t)row0, (uint64_t)rows_local, block,
-                       d_out, pitch, flags);
+                       d_out, pitch, (flags & 0x7FFFFFFFu) | (((flags & 4u) && band == 1) ? 0x80000000u : 0u));
     return hipGetLastError();
 }
 

@@ -17,6 +17,20 @@ constexpr int kPBlock = 1024, kPWaves = 16;
 constexpr uint32_t kLowBins = 128, kLowReps = 64;
 // LDS atomics through the address-space-3 pointer (the HIP overloads take generic pointers)
 #define LDS_ADD(off, v) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)(off)), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// The bright tail (DN >= the LDS bins: point targets, one sample in 10^4 on a GRD scene) goes to the tile's GLOBAL histogram.  Round 5: not
+// from inside the row loop.  With global atomics in a divergent branch of the loop the compiler cannot count the memory operations in
+// flight and closed every iteration with s_waitcnt vmcnt(0) -- the next row's loads, issued at the top of the iteration, had to be back
+// before the iteration ended: one row in flight per wave, whatever the source said.  The tail samples are queued in LDS instead
+// ((band << 16) | DN, a slot reserved by one returning ds_add per lane and band-row) and added to the global histogram when the
+// workgroup publishes its tile; the row loop holds no vector-memory instruction but its loads and waits with counted vmcnt.  A lane
+// that finds the queue full (a raster that is mostly brighter than the LDS bins) stops queueing for the rest of the piece and
+// recounts its tail samples from that band-row on in a second loop behind the first: slower, never wrong.
+constexpr uint32_t kTailCap = 4096;
+#ifndef SARPRO_PIECE_AHEAD
+#define SARPRO_PIECE_AHEAD 2 // rows of both bands in flight per wave beyond the one being counted
+#endif
+constexpr int kPieceAhead = SARPRO_PIECE_AHEAD;
+static_assert(kPieceAhead >= 1 && kPieceAhead <= 4, "piece histogram: 1..4 rows ahead");
 struct PieceRow { uint32_t w[kPieceVec / 2]; }; // kPieceVec samples of a band-row, two per dword
 __device__ __forceinline__ PieceRow piece_load(const uint16_t *p) {
     PieceRow r;
@@ -49,6 +63,9 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
     const int first = a.wg_first[blockIdx.x], last = a.wg_first[blockIdx.x + 1];
     if (first >= last) return;
     for (uint32_t i = threadIdx.x; i < 2u * S + 2u * kLowReps * kLowBins; i += kPBlock) h[i] = 0u;
+    uint32_t *const q = h + 2u * S + 2u * kLowReps * kLowBins; // q[0]: entries reserved so far; q[1 + k]: entry k
+    if (threadIdx.x == 0) q[0] = 0u;
+    const uint32_t q_off = (2u * S + 2u * kLowReps * kLowBins) * 4u; // byte offset of q[0]
     __syncthreads();
     const int wave = p_wave(), lane = p_lane();
     // byte offset of this lane's word of low bin 0, per band: behind the two histograms, [band][kLowBins][64 lanes]
@@ -57,17 +74,25 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
     auto publish = [&]() { // all threads, between barriers
         if (cur_tile < 0) return;
         // the lanes' own words of the low bins first, folded into the shared bins by all threads (16 bytes each, four turns)
-        for (uint32_t q = threadIdx.x; q < 2u * kLowBins * kLowReps / 4u; q += kPBlock) {
-            uint4 *p = reinterpret_cast<uint4 *>(&h[2u * S]) + q;
+        for (uint32_t qq = threadIdx.x; qq < 2u * kLowBins * kLowReps / 4u; qq += kPBlock) {
+            uint4 *p = reinterpret_cast<uint4 *>(&h[2u * S]) + qq;
             const uint4 v = *p;
             const uint32_t n = v.x + v.y + v.z + v.w;
             if (n) {
                 *p = make_uint4(0u, 0u, 0u, 0u);
-                const uint32_t b = q / (kLowBins * kLowReps / 4u), dn = (q / (kLowReps / 4u)) % kLowBins;
+                const uint32_t b = qq / (kLowBins * kLowReps / 4u), dn = (qq / (kLowReps / 4u)) % kLowBins;
                 if (dn) LDS_ADD((b * S + dn) * 4u, n); // (low bin 0 holds the invalid samples: bin 0 is what is left of the tile, restored by the consumer)
             }
         }
+        {   // the queued tail samples of this tile (entry 0 = a slot reserved by a lane that then found the queue full)
+            const uint32_t nq = min(q[0], kTailCap);
+            for (uint32_t i = threadIdx.x; i < nq; i += kPBlock) {
+                const uint32_t e = q[1u + i];
+                if (e) atomicAdd(&a.tile_hist[e >> 16][(size_t)cur_tile * 65536u + (e & 0xFFFFu)], 1u);
+            }
+        }
         __syncthreads();
+        if (threadIdx.x == 0) q[0] = 0u; // (the caller's barrier stands between this and the next piece's reservations)
         for (int b = 0; b < 2; ++b) {
             uint32_t *g = a.tile_hist[b] + (size_t)cur_tile * 65536u;
             for (uint32_t i = threadIdx.x + 1; i < W; i += kPBlock) {
@@ -104,7 +129,9 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
         // to the tile's global histogram one by one (rare).
         const uint32_t Wl = W + (uint32_t)lane;
         const uint32_t tail_mask = ~(W - 1u) & 0xFFFFu; // (W is a power of two: a half >= W has one of these bits)
-        auto consume = [&](int b, const PieceRow &w) {
+        bool failed = false; // this lane found the tail queue full in this piece: from (fail_r, fail_b) on its tail samples are recounted below
+        int fail_r = 0, fail_b = 0;
+        auto consume = [&](int b, int r, const PieceRow &w) {
             uint32_t ww[V / 2], mx = 0u;
             typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -126,31 +153,79 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
 #endif
             }
 #ifdef PIECE_HIST_NO_ATOMICS
-            if (mx == 0xFFFFFFFFu) atomicAdd(&gt[b][0], 1u);
+            if (mx == 0xFFFFFFFFu) LDS_ADD(q_off, 1u);
 #else
-            if ((mx | (mx >> 16)) & tail_mask) { // bright tail: rare
+            if (((mx | (mx >> 16)) & tail_mask) && !failed) { // bright tail: rare
+                uint32_t nt = 0u;
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    const uint32_t d = (j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu);
-                    if (d >= W) atomicAdd(&gt[b][d], 1u);
+                for (int j = 0; j < V; ++j) nt += (((j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu)) >= W) ? 1u : 0u;
+                uint32_t k = LDS_ADD(q_off, nt); // (returns the old count: this lane's first slot)
+                if (k + nt <= kTailCap) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const uint32_t d = (j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu);
+                        if (d >= W) { q[1u + k] = ((uint32_t)b << 16) | d; ++k; }
+                    }
+                } else { // full: the slots this lane holds inside the queue become no-ops, the lane recounts from here on
+                    for (uint32_t e = k; e < min(k + nt, kTailCap); ++e) q[1u + e] = 0u;
+                    failed = true; fail_r = r; fail_b = b;
                 }
             }
 #endif
         };
         const uint16_t *__restrict__ p1 = a.in[0] + col, *__restrict__ p2 = a.in[1] + col;
         int r = I.r0 + wy;
-        if (r < I.r1) { // two rows in flight per wave: the next row's loads are issued before this row is counted
+        if (r < I.r1) { // kPieceAhead rows of both bands in flight per wave behind the one being counted
+            // A ring of kPieceAhead + 1 row slots with STATIC indices (the trip below is unrolled over the slots): rotating the rows
+            // through registers instead costs a v_mov of a register whose load is still in flight, i.e. a wait for that load.
             const int lastr = I.r1 - 1;
-            PieceRow n1 = PIECE_LOAD(p1 + (size_t)r * a.pitch), n2 = PIECE_LOAD(p2 + (size_t)r * a.pitch);
-            for (; r < I.r1; r += gy) {
-                const PieceRow c1 = n1, c2 = n2;
-                const int rn = min(r + gy, lastr);
-                n1 = PIECE_LOAD(p1 + (size_t)rn * a.pitch);
-                n2 = PIECE_LOAD(p2 + (size_t)rn * a.pitch);
-                consume(0, c1);
-                consume(1, c2);
+            constexpr int NS = kPieceAhead + 1;
+            PieceRow n1[NS], n2[NS];
+#pragma unroll
+            for (int k = 0; k < kPieceAhead; ++k) {
+                const int rk = min(r + k * gy, lastr);
+                n1[k] = PIECE_LOAD(p1 + (size_t)rk * a.pitch);
+                n2[k] = PIECE_LOAD(p2 + (size_t)rk * a.pitch);
+            }
+            // whole trips of NS rows without a branch between the slots (a conditional load makes the compiler wait for every load in
+            // flight at the join); the last rows of the piece one by one behind them, from the same ring
+            while (r + (NS - 1) * gy < I.r1) {
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int rn = min(r + kPieceAhead * gy, lastr);
+                    n1[(sl + kPieceAhead) % NS] = PIECE_LOAD(p1 + (size_t)rn * a.pitch);
+                    n2[(sl + kPieceAhead) % NS] = PIECE_LOAD(p2 + (size_t)rn * a.pitch);
+                    consume(0, r, n1[sl]);
+                    consume(1, r, n2[sl]);
+                    r += gy;
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < NS - 1; ++sl) { // (slot sl holds row r: the trips above end on slot 0; the rows ahead were loaded clamped to the last row)
+                if (r < I.r1) {
+                    consume(0, r, n1[sl]);
+                    consume(1, r, n2[sl]);
+                    r += gy;
+                }
             }
         }
+#ifndef PIECE_HIST_NO_ATOMICS
+        if (failed) { // the queue was full: this lane's tail samples from (fail_r, fail_b) on, straight to the tile's global histogram
+            for (int r2 = fail_r; r2 < I.r1; r2 += gy) {
+                const PieceRow wa = PIECE_LOAD(p1 + (size_t)r2 * a.pitch), wb = PIECE_LOAD(p2 + (size_t)r2 * a.pitch);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (r2 == fail_r && b < fail_b) continue;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const uint32_t wj = (b ? wb : wa).w[j >> 1] & m[j >> 1];
+                        const uint32_t d = (j & 1) ? (wj >> 16) : (wj & 0xFFFFu);
+                        if (d >= W) atomicAdd(&gt[b][d], 1u);
+                    }
+                }
+            }
+        }
+#endif
     }
     __syncthreads();
     publish();
@@ -160,7 +235,7 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
 
 hipError_t launch_dn_hist_pieces(const DnHistPiecesArgs &a, int grid, hipStream_t s) {
     if (grid <= 0 || grid > kPieceMaxGrid) return hipErrorInvalidValue;
-    const size_t lds = (2 * ((size_t)a.lds_bins + 64) + 2 * (size_t)kLowReps * kLowBins) * sizeof(uint32_t);
+    const size_t lds = (2 * ((size_t)a.lds_bins + 64) + 2 * (size_t)kLowReps * kLowBins + 1 + kTailCap) * sizeof(uint32_t);
     if (lds > 160 * 1024 || a.lds_bins < kLowBins || (a.lds_bins & (a.lds_bins - 1)) != 0) return hipErrorInvalidValue; // (a power of two: the tail test is a mask)
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_dn_hist_pieces))) return e;
     hipLaunchKernelGGL(k_dn_hist_pieces, dim3(grid), dim3(kPBlock), lds, s, a);

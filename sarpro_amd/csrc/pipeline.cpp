@@ -1,0 +1,152 @@
+// pipeline.cpp -- the resident batch: K dual-pol scenes that are already in HBM through ONE context.
+//
+// Replaces the sequential batch loop of api/mod.rs:484-533 (one scene after the other: read, process, write) for callers that keep
+// their rasters on the device; the product per scene is save.rs:317-367 at native resolution (sarpro_hip_dualpol_synrgb_u16_dev).
+//
+// Why lanes.  One scene's CLAHE chain is   H (DN histogram sweep, 4 B/px, HBM-bound)  ->  S (a dozen short dependent kernels:
+// statistics, CLAHE bins, CDFs, sample, prediction; launch- and latency-bound, a few workgroups each)  ->  F (the fused CLAHE -> RGB
+// pass, 7 B/px, bound by its LDS gathers).  On one stream the chip idles through S, through every launch gap and through the tails
+// of H and F (persistent workgroups that finish at different times).  With L lanes -- internal contexts with their own stream,
+// workspaces and plans -- scene i + 1's H and S are in the queue while scene i's F runs: its S kernels run beside F's tail and H,
+// its H fills the compute units F's workgroups leave.  Both sweeps own whole compute units (F: 160 KiB of LDS and 128 VGPRs x 1024
+// threads; H: 144 KiB), so they never share one: the lanes hide S, the launch gaps and the tails, not H behind F.  Measured on the
+// nine-scene cycle at 400 MP (profiles/r5/pipe_sweep.txt): one stream 1.034 ms per scene, 2 lanes 0.962, 3 lanes 0.958-0.963, 4 lanes
+// 1.006.  PIPE_ORDER = 1 chains the F passes by events (F of scene i + 1 waits for F of scene i): 0.969-0.974, no better than the free
+// run (default 0).  RGB_GRID / PIECE_GRID (planner attributes) size the two sweeps' persistent grids: giving F and H disjoint sets
+// of compute units (RGB_GRID + PIECE_GRID = 256) so that they run side by side was measured too and lost -- 1.12 ms at 192 + 64,
+// 1.35 at 208 + 48, 1.54 at 224 + 32: H on a quarter of the chip cannot pull its 1.6 GB in the time F needs.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "chain_kernels.h"
+#include "internal.h"
+
+using namespace sarpro;
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+            return e__ == hipErrorOutOfMemory ? SARPRO_HIP_ERR_OOM : SARPRO_HIP_ERR_HIP;          \
+        }                                                                                         \
+    } while (0)
+
+static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+constexpr int kPipeDefaultLanes = 3, kPipeMaxLanes = 8;
+
+static int ensure_lanes(sarpro_hip_ctx *ctx, int lanes) {
+    while ((int)ctx->lanes.size() < lanes) {
+        sarpro_hip_ctx *l = nullptr;
+        const int rc = sarpro_hip_ctx_create(ctx->device, SARPRO_HIP_CTX_ASYNC_DEV | (ctx->timing ? SARPRO_HIP_CTX_TIMING : 0u), &l);
+        if (rc != SARPRO_HIP_OK) { ctx->err = std::string("resident batch: lane context: ") + sarpro_hip_last_error(nullptr); return rc; }
+        ctx->lanes.push_back(l);
+    }
+    for (sarpro_hip_ctx *l : ctx->lanes) { // the lanes follow their parent's switches (sarpro_hip_ctx_set_attr keeps them so between calls)
+        l->attrs = ctx->attrs;
+        l->time_only = ctx->time_only;
+        l->pipe_wait_before_fused = nullptr;
+        l->pipe_record_after_fused = nullptr;
+    }
+    return SARPRO_HIP_OK;
+}
+
+static int route_of(const ChainSpecState &st) {
+    if (!st.spec_ok) return SARPRO_HIP_ROUTE_UNPROVEN;
+    if (st.pool_overflow) return SARPRO_HIP_ROUTE_POOL_OVERFLOW;
+    return st.verdict == 0 ? SARPRO_HIP_ROUTE_ACCEPTED : SARPRO_HIP_ROUTE_REFUTED;
+}
+
+extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarpro_hip_resident_scene *scenes, size_t nscenes, size_t rows,
+                                                       size_t cols, size_t in_pitch, int strategy, int mode, size_t rgb_pitch_px, int lanes,
+                                                       int continue_on_error, sarpro_hip_batch_report *report) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if ((!scenes && nscenes) || !report) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "resident batch: null scenes / report");
+    if (lanes < 0 || lanes > kPipeMaxLanes) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "resident batch: lanes must be 0 (default) .. 8");
+    std::memset(report, 0, sizeof(*report));
+    for (size_t i = 0; i < nscenes; ++i) { scenes[i].status = SARPRO_HIP_OK; scenes[i].route = SARPRO_HIP_ROUTE_NONE; }
+    if (!nscenes) return SARPRO_HIP_OK;
+    if (lanes == 0) lanes = (int)std::min<long long>(kPipeMaxLanes, std::max<long long>(1, ctx->attrs.val(A_PIPE_LANES, kPipeDefaultLanes)));
+    lanes = (int)std::min<size_t>((size_t)lanes, nscenes);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int rc = ensure_lanes(ctx, lanes)) return rc;
+    const bool chain_f = ctx->attrs.val(A_PIPE_ORDER, 0) != 0 && lanes > 1;
+    while (chain_f && ctx->pipe_events.size() < nscenes) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_events.push_back(e);
+    }
+    // (pinned memory is allocated in large steps: a reallocation costs about a millisecond, a batch of twenty scenes takes twenty)
+    HIPCHK(ctx, ctx->pipe_routes.reserve(sizeof(ChainSpecState) * ((nscenes + 255) / 256 * 256)));
+    ChainSpecState *routes = ctx->pipe_routes.as<ChainSpecState>();
+    std::vector<char> has_route(nscenes, 0);
+    ctx->lane_times.clear();
+
+    int first_error = SARPRO_HIP_OK;
+    size_t enq = 0;
+    for (; enq < nscenes; ++enq) {
+        sarpro_hip_resident_scene &sc = scenes[enq];
+        sarpro_hip_ctx *l = ctx->lanes[enq % (size_t)lanes];
+        if (chain_f) {
+            l->pipe_wait_before_fused = enq ? ctx->pipe_events[enq - 1] : nullptr;
+            l->pipe_record_after_fused = ctx->pipe_events[enq];
+        }
+        const void *spec_before = l->spec_state.p;
+        (void)spec_before;
+        int rc = sarpro_hip_dualpol_synrgb_u16_dev(l, sc.d_band1, sc.d_band2, rows, cols, in_pitch, strategy, mode, sc.d_rgb, rgb_pitch_px,
+                                                   nullptr, nullptr, 0, nullptr);
+        if (chain_f) {
+            // a scene whose chain never reached the fused pass (another route, an error) still releases its successor
+            if (l->pipe_record_after_fused) (void)hipEventRecord(l->pipe_record_after_fused, l->stream);
+            l->pipe_wait_before_fused = nullptr;
+            l->pipe_record_after_fused = nullptr;
+        }
+        if (rc == SARPRO_HIP_OK && strategy == SARPRO_STRATEGY_CLAHE && l->spec_state.p && l->spec_ran) {
+            // the scene's verdict, copied out in stream order (the next scene of this lane overwrites the state)
+            if (hipMemcpyAsync(&routes[enq], l->spec_state.p, sizeof(ChainSpecState), hipMemcpyDeviceToHost, l->stream) == hipSuccess) has_route[enq] = 1;
+        }
+        sc.status = rc;
+        if (rc != SARPRO_HIP_OK) {
+            ctx->err = std::string("resident batch: scene ") + std::to_string(enq) + ": " + l->err;
+            ++report->errors;
+            if (first_error == SARPRO_HIP_OK) first_error = rc;
+            if (!continue_on_error) { ++enq; break; } // api/mod.rs:518-526
+        }
+    }
+    int sync_rc = SARPRO_HIP_OK;
+    for (int k = 0; k < lanes; ++k) {
+        sarpro_hip_ctx *l = ctx->lanes[(size_t)k];
+        const hipError_t e = hipStreamSynchronize(l->stream);
+        if (e != hipSuccess && sync_rc == SARPRO_HIP_OK) {
+            ctx->err = std::string("resident batch: lane synchronisation: ") + hipGetErrorString(e);
+            sync_rc = SARPRO_HIP_ERR_HIP;
+        }
+    }
+    if (sync_rc != SARPRO_HIP_OK) { // the device failed under the batch: no raster of it can be trusted
+        for (size_t i = 0; i < enq; ++i) if (scenes[i].status == SARPRO_HIP_OK) scenes[i].status = sync_rc;
+        report->errors = enq; report->processed = 0; report->skipped = nscenes - enq;
+        return sync_rc;
+    }
+    for (size_t i = 0; i < enq; ++i) {
+        if (scenes[i].status == SARPRO_HIP_OK) ++report->processed;
+        if (has_route[i]) scenes[i].route = route_of(routes[i]);
+    }
+    report->skipped = nscenes - report->processed - report->errors;
+    if (ctx->timing) { // the lanes' event pairs, lane after lane (sarpro_hip_last_kernel_times of THIS context reports them)
+        std::vector<const char *> names(8192);
+        std::vector<float> ms(8192);
+        for (int k = 0; k < lanes; ++k) {
+            const int n = sarpro_hip_last_kernel_times(ctx->lanes[(size_t)k], names.data(), ms.data(), (int)names.size());
+            for (int j = 0; j < n; ++j)
+                if (std::strncmp(names[(size_t)j], "host:", 5) != 0) ctx->lane_times.emplace_back(names[(size_t)j], ms[(size_t)j]);
+        }
+    }
+    if (report->errors && !continue_on_error) return first_error;
+    return SARPRO_HIP_OK;
+}

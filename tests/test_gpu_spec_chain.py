@@ -79,7 +79,9 @@ def test_speculative_chain_forced_fallbacks(force, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["two_values", "high_plateau", "constant", "no_invalid", "all_invalid_band", "bright_only"])
 def test_rasters_whose_sample_lacks_level_0_or_255(kind, monkeypatch):
-    """No identity proof (a band without level 0 or without level 255) => spec_ok = 0 and the exact kernels decide the rescale."""
+    """No identity proof (a band without level 0 or without level 255) => spec_ok = 0 and the exact kernels decide the rescale.  A band
+    without a single valid sample is level 0 everywhere (autoscale.rs:466-468) and its u8 rescale is the identity by autoscale.rs:356
+    (max == min): nothing needs a sample to be proven there, the speculation stands on the other band's proof (round 5)."""
     monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
     rng = np.random.default_rng(11)
     rows, cols = 264, 512
@@ -96,6 +98,7 @@ def test_rasters_whose_sample_lacks_level_0_or_255(kind, monkeypatch):
     elif kind == "all_invalid_band":
         b1 = np.zeros((rows, cols), np.uint16)
         b2 = synth.scene_u16(rows, cols, 1)
+        lacks = False
     elif kind == "bright_only":   # wide DN range, no invalid pixel: level 0 only where a tile's first bin is nearly empty
         b1 = rng.integers(1, 60000, (rows, cols)).astype(np.uint16)
         b2 = rng.integers(200, 9000, (rows, cols)).astype(np.uint16)
@@ -110,6 +113,8 @@ def test_rasters_whose_sample_lacks_level_0_or_255(kind, monkeypatch):
     assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, rrgb), (kind, rep)
     if lacks:
         assert rep["spec_ok"] == 0 and rep["verdict"] == 1, rep
+    if kind == "all_invalid_band":
+        assert rep["spec_ok"] == 1 and rep["verdict"] == 0 and rep["floor_pred"] == 0, rep  # half of the band-pixels sit at level 0: floor 0
 
 
 @pytest.mark.parametrize("stride", [5, 7, 9, 13, 64])
