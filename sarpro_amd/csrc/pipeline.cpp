@@ -86,6 +86,7 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
     HIPCHK(ctx, ctx->pipe_routes.reserve(sizeof(ChainSpecState) * ((nscenes + 255) / 256 * 256)));
     ChainSpecState *routes = ctx->pipe_routes.as<ChainSpecState>();
     std::vector<char> has_route(nscenes, 0);
+    timing_reset(ctx); // (this context's own event pairs belong to an earlier call)
     ctx->lane_times.clear();
 
     int first_error = SARPRO_HIP_OK;

@@ -120,3 +120,38 @@ def test_resident_batch_errors_are_counted_not_fatal():
         # an empty batch is a no-op
         rep, st, _ = c.dev_batch_dualpol_synrgb_u16([], rows, cols, pitch, St.Clahe, Mode.Default, pitch)
         assert rep == {"processed": 0, "skipped": 0, "errors": 0, "rc": 0}
+
+
+def test_resident_batch_36mp_four_scenes_every_pixel(monkeypatch):
+    """The size from which the product takes the speculative fused route by itself (>= 32 MP): four different scenes at 6000 x 6000
+    through three lanes, every pixel against the oracle; then the same batch with every predicted floor shifted by one
+    (SPEC_FORCE = mispredict): refuted scenes run their exact kernels beside the other lanes' chains, same rasters."""
+    rows = cols = 6000
+    pitch = (cols + 63) // 64 * 64
+    defs = [synth.BENCH_SCENES[i] for i in (0, 3, 4, 8)]  # A, D-no-wedge, E-wide-windows (the pass's WIDE form), I-no-VH
+    q0 = synth.q_tables()
+    dev, refs = [], []
+    with S.Context(0) as c:
+        for name, off, flags, qkw, _ in defs:
+            q = synth.q_tables(**qkw) if qkw else q0
+            d = [torch.zeros((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+            for b in range(2):
+                c.dev_synth_scene_u16(synth.SEED_SCENE_A + off, b, q, rows, cols, 0, rows, d[b].data_ptr(), pitch, flags)
+            torch.cuda.synchronize()
+            hb = [t[:, :cols].cpu().numpy().view(np.uint16) for t in d]
+            dev.append(d)
+            refs.append(oracle_rgb(hb, St.Clahe))
+        outs = [torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda") for _ in defs]
+        batch = [(d[0].data_ptr(), d[1].data_ptr(), o.data_ptr()) for d, o in zip(dev, outs)]
+        rep, st, routes = c.dev_batch_dualpol_synrgb_u16(batch, rows, cols, pitch, St.Clahe, Mode.Default, pitch, lanes=3)
+        assert rep["processed"] == 4 and "n/a" not in routes and "unproven" not in routes, routes
+        for i, d in enumerate(defs):
+            assert np.array_equal(rgb_of(outs[i], rows, cols, pitch), refs[i]), (d[0], routes[i])
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        monkeypatch.setenv("SARPRO_HIP_SPEC_FORCE", "mispredict")
+        rep, st, forced = c.dev_batch_dualpol_synrgb_u16(batch, rows, cols, pitch, St.Clahe, Mode.Default, pitch, lanes=3)
+        assert rep["processed"] == 4 and "refuted" in forced, forced
+        for i, d in enumerate(defs):
+            assert np.array_equal(rgb_of(outs[i], rows, cols, pitch), refs[i]), (d[0], forced[i])

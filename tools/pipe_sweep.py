@@ -52,7 +52,9 @@ for cfg in cfgs.split(","):
     lanes, order, rgrid, pgrid = (int(x) for x in cfg.split(":"))
     for t in out:
         t.zero_()
-    with S.Context(0) as c:
+    with S.Context(0, timing=bool(os.environ.get("TIMING"))) as c:
+        if os.environ.get("TIMING") == "2":
+            c.time_only("clahe_rgb_fused")
         for k, v in min_px.items():
             c.set_attr(k, v)
         c.set_attr("PIPE_ORDER", order)
@@ -66,7 +68,9 @@ for cfg in cfgs.split(","):
         runs = []
         for _ in range(reps):
             torch.cuda.synchronize(); t = time.perf_counter()
-            c.dev_batch_dualpol_synrgb_u16(batch * 3, rows, cols, pitch, St.Clahe, Mode.Default, pitch, lanes=lanes)
-            runs.append((time.perf_counter() - t) / (3 * K) * 1e3)
+            nb = int(os.environ.get("NBATCH", str(3 * K)))
+            c.dev_batch_dualpol_synrgb_u16((batch * 3)[:nb], rows, cols, pitch, St.Clahe, Mode.Default, pitch, lanes=lanes)
+            runs.append((time.perf_counter() - t) / nb * 1e3)
+            c.last_kernel_times()
         print(json.dumps({"config": {"lanes": lanes, "order": order, "rgb_grid": rgrid, "piece_grid": pgrid}, "ms_per_scene": round(sorted(runs)[len(runs) // 2], 4),
                           "runs": [round(x, 4) for x in runs], "rasters_equal_one_stream": same, "report": rep, "routes": rt}), flush=True)
