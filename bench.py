@@ -821,6 +821,35 @@ def secondary_records(torch, dev, rows, cols):
         out["e2e"] = {"what": "pinned host u16 bands -> H2D -> calibrate + CLAHE + synRGB -> D2H of the RGB raster (sarpro_hip_dualpol_synrgb_u16)",
                       "ms_per_scene": round(ms, 2), "value": round(px / ms / 1e3, 1), "unit": "Mpix/s",
                       "pcie_gb_s": round((2 * px * 2 + px * 3) / ms / 1e6, 1), "north_star_target_mpix_s": 500}
+        # two scenes in flight through PCIe: a second context + host thread on the same device, so that scene i's D2H (RGB, 1.2 GB)
+        # crosses the link beside scene i + 1's H2D (bands, 1.6 GB) -- the link is full duplex, one synchronous call per scene uses one
+        # direction at a time.  What listing a device twice in sarpro_hip_batch_* does.
+        try:
+            import threading
+            c2 = sarpro_amd.Context(dev.index)
+            rgb_h2 = torch.empty((rows, cols, 3), dtype=torch.uint8, pin_memory=True)
+            o2 = rgb_h2.numpy()
+
+            def e2e_on(cx, oo, n):
+                for _ in range(n):
+                    rc = lib.sarpro_hip_dualpol_synrgb_u16(cx._h, b1.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p), rows, cols, int(St.Clahe), 0,
+                                                           oo.ctypes.data_as(C.c_void_p), None, None, None)
+                    assert rc == 0
+            e2e_on(c2, o2, 1)  # (plan, workspaces)
+            n2 = 3
+            ths = [threading.Thread(target=e2e_on, args=(cx, oo, n2)) for cx, oo in ((ctx, o), (c2, o2))]
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            [x.start() for x in ths]
+            [x.join() for x in ths]
+            ms2 = (time.perf_counter() - t) / (2 * n2) * 1e3
+            out["e2e_two_in_flight"] = {"what": "the same end-to-end call from two host threads on two contexts of this GPU (scene i's D2H beside scene i + 1's H2D)",
+                                        "ms_per_scene": round(ms2, 2), "value": round(px / ms2 / 1e3, 1), "unit": "Mpix/s",
+                                        "pcie_gb_s_both_directions": round((2 * px * 2 + px * 3) / ms2 / 1e6, 1), "rasters_equal": bool(np.array_equal(o, o2))}
+            c2.close()
+            del rgb_h2
+        except Exception as e:
+            out["e2e_two_in_flight"] = {"error": f"{type(e).__name__}: {e}"}
         # BASELINE config 2 as a flow: host bands -> Robust -> Lanczos3 to 2048^2 -> pad -> synRGB (small RGB back)
         ms = timed(lambda: ctx.dualpol_synrgb_resized(b1, b2, St.Robust, 2048, True), n=3, warm=1)
         out["config2_flow"] = {"what": "host u16 bands -> Robust autoscale x2 -> Lanczos3 to 2048^2 -> pad -> default synRGB -> 2048x2048x3 back",
@@ -913,6 +942,39 @@ def secondary_records(torch, dev, rows, cols):
     ctx.close()
     cp.close()
     del o16, ratio
+    # (3b) what ONE rank of an 8-rank row-stripe run executes (BASELINE config 4), minus the wire: the single-call stripe chain on an
+    # interior 2500-row stripe of scene A over a 1-rank RCCL communicator (all five all-reduces are issued; with one rank they move
+    # nothing).  The DN histogram is the stripe's only, so the raster is not the scene's -- this is a TIMING model of the serial term
+    # of DESIGN section 7; the N-rank rasters are checked in tests/test_gpu_full_size_oracle.py through the in-process communicator.
+    # No scaling curve can be measured on a one-GPU box: this record is what stands in for it.
+    try:
+        cs = sarpro_amd.Context(dev.index, timing=True)
+        try:
+            cs.comm_init(1, 0, sarpro_amd.comm_unique_id())
+            r0s, nrs = sarpro_amd.host_stripe_plan(rows, 8)
+            r0, nr = int(r0s[3]), int(nrs[3])
+            rgb_s = torch.empty((nr, pitch * 3), dtype=torch.uint8, device=dev)
+
+            def stripe_call():
+                cs.stripe_run_u16(band[0].data_ptr() + r0 * pitch * 2, band[1].data_ptr() + r0 * pitch * 2, rows, cols, r0, nr, pitch, St.Clahe, Mode.Default,
+                                  rgb_s.data_ptr(), pitch)
+            ms = timed(stripe_call, n=10, warm=3)
+            kt = {}
+            for k, v in cs.last_kernel_times():
+                if not k.startswith("host:"):
+                    kt[k] = round(kt.get(k, 0.0) + v, 4)
+            sweeps = sum(v for k, v in kt.items() if k in ("dn_hist_u16", "clahe_rgb_fused", "clahe_sample"))
+            out["stripe_rank_model"] = {"what": f"one rank of 8: rows [{r0}, {r0 + nr}) of the {rows}x{cols} scene through sarpro_hip_stripe_run_u16 over a 1-rank RCCL "
+                                                "communicator (the chain a rank of an 8-GPU stripe run executes, its five all-reduces issued but moving nothing); a timing "
+                                                "model, not a raster", "ms_per_call": round(ms, 4), "kernels_ms": kt,
+                                        "sweeps_ms": round(sweeps, 4), "serial_term_ms": round(sum(kt.values()) - sweeps, 4),
+                                        "note": "sweeps_ms scales with 1/N; serial_term_ms (statistics, tables, CDFs, prediction, verdict, all-reduce launches) does not; "
+                                                "no multi-GPU node was available to measure the curve itself"}
+            del rgb_s
+        finally:
+            cs.close()
+    except Exception as e:
+        out["stripe_rank_model"] = {"error": f"{type(e).__name__}: {e}"}
     # (4) several scenes in flight on the one GPU: one context (own stream, own workspaces) and one host thread per scene, as the batch
     # driver runs when a device is listed more than once -- the short dependent kernels of one scene's chain run beside another
     # scene's sweeps.  Beside the headline, which keeps ONE context and stream.

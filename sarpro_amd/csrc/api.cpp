@@ -2134,17 +2134,59 @@ extern "C" void sarpro_hip_stripe_end(sarpro_hip_stripe *s) {
 // (sarpro_hip_comm_init): the device-resident chains run unchanged with three (CLAHE) or one (percentile
 // strategies) small all-reduces enqueued on the stream between their kernels -- no host synchronisation
 // until the stripe's RGB is complete.
-extern "C" int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total,
-                                         size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
-                                         uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
-    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+namespace sarpro {
+// Which route a stripe takes (device-resident chain or host phases, fused pass or apply + compose) follows from the LAYOUT of its
+// rasters -- alignment of the pointers, pitches -- and a route fixes the sequence of collectives the rank joins.  Ranks with
+// different layouts would therefore join different sequences and wait for each other for ever.  The one-call stripe entry point
+// makes the layout a property of the library, not of the caller: a stripe whose rasters are not in the aligned form (16-byte
+// aligned pointers, in_pitch % 16 == 0, rgb_pitch_px % 16 == 0) is staged through library-owned rasters that are (one device copy
+// in, one out: 11 B/px on that rank only), so every rank of a scene takes the same route whatever it was handed.
+static int stripe_run_u16_impl(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total,
+                               size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
+                               uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
     if (!ctx->comm && !ctx->local_group) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no communicator on this context (sarpro_hip_comm_init / _init_local)");
     if ((!d_band1 || !d_band2 || !d_rgb) && rows_local * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
-    if (rgb_pitch_px < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "rgb_pitch_px < cols");
+    if (rgb_pitch_px < cols || in_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
+    const bool empty = rows_local == 0 || cols == 0;
+    const bool aligned = !empty && in_pitch % 16 == 0 && rgb_pitch_px % 16 == 0 && ptr_aligned16(d_band1) && ptr_aligned16(d_band2) && ptr_aligned16(d_rgb);
+    const size_t lib_pitch = round_up(std::max<size_t>(cols, 1), 64);
+    uint8_t *rgb_user = nullptr;
+    size_t rgb_user_pitch = 0;
+    if (empty) { // nothing of this rank is read or written; its pitches still decide the route: the library's
+        in_pitch = rgb_pitch_px = lib_pitch;
+    } else if (!aligned) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        const uint16_t *src[2] = {d_band1, d_band2};
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(ctx, ctx->stage_in[b].reserve(rows_local * lib_pitch * sizeof(uint16_t)));
+            HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_in[b].p, lib_pitch * sizeof(uint16_t), src[b], in_pitch * sizeof(uint16_t), cols * sizeof(uint16_t), rows_local,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        HIPCHK(ctx, ctx->stage_out[0].reserve(rows_local * lib_pitch * 3));
+        d_band1 = ctx->stage_in[0].as<uint16_t>(); d_band2 = ctx->stage_in[1].as<uint16_t>();
+        rgb_user = d_rgb; rgb_user_pitch = rgb_pitch_px;
+        d_rgb = ctx->stage_out[0].as<uint8_t>();
+        in_pitch = rgb_pitch_px = lib_pitch;
+    }
     U16Job J;
     J.ctx = ctx; J.nbands = 2; J.d_in[0] = d_band1; J.d_in[1] = d_band2;
     J.rows_total = rows_total; J.cols = cols; J.row0 = row0; J.rows_local = rows_local; J.in_pitch = in_pitch;
     J.strategy = strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.mode = mode; J.synrgb = true; J.reduce = true;
     void *outs[kMaxBands] = {nullptr, nullptr};
-    return job_run_all(J, outs, 0, d_rgb, rgb_pitch_px, stats_out);
+    RETCHK(job_run_all(J, outs, 0, d_rgb, rgb_pitch_px, stats_out));
+    if (rgb_user) {
+        HIPCHK(ctx, hipMemcpy2DAsync(rgb_user, rgb_user_pitch * 3, d_rgb, rgb_pitch_px * 3, cols * 3, rows_local, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SARPRO_HIP_OK;
+}
+} // namespace sarpro
+
+extern "C" int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total,
+                                         size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
+                                         uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const int rc = sarpro::stripe_run_u16_impl(ctx, d_band1, d_band2, rows_total, cols, row0, rows_local, in_pitch, strategy, mode, d_rgb, rgb_pitch_px, stats_out);
+    if (rc != SARPRO_HIP_OK) sarpro::comm_abort_local_group(ctx); // an in-process group: the peers of a rank that failed must not wait for it (comm.cpp)
+    return rc;
 }

@@ -96,11 +96,19 @@ struct sarpro_hip_local_group {
     std::vector<const uint64_t *> bufs; // the ranks' device buffers of the collective in flight
     std::vector<size_t> counts;
     bool mismatch = false;
-    void barrier() {
+    bool aborted = false; // a rank failed outside a collective (an argument check, an allocation, a HIP error mid-chain): nobody may wait for it
+    // false: the group was aborted (before or while this rank waited) -- the collective did not complete
+    bool barrier() {
         std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
         const unsigned long long g = generation;
-        if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g; });
+        if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != g || aborted; });
+        return generation != g; // (released by the last arrival, not by the abort)
+    }
+    void abort() {
+        { std::lock_guard<std::mutex> lk(m); aborted = true; }
+        cv.notify_all();
     }
 };
 
@@ -133,7 +141,7 @@ static int local_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t 
     const bool stream_ok = hipSetDevice(ctx->device) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
     g->bufs[(size_t)ctx->comm_rank] = d_buf;
     g->counts[(size_t)ctx->comm_rank] = stream_ok ? count : (size_t)-1;
-    g->barrier(); // every rank's buffer is complete and published
+    if (!g->barrier()) { ctx->err = "local all-reduce: the group was aborted (another rank failed)"; return SARPRO_HIP_ERR_RCCL; } // every rank's buffer is complete and published
     bool same = true;
     for (int r = 0; r < g->nranks; ++r) same = same && g->counts[(size_t)r] == count;
     int rc = SARPRO_HIP_OK;
@@ -150,13 +158,21 @@ static int local_allreduce_sum_u64(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t 
             if (e != hipSuccess) { ctx->err = std::string("local all-reduce: ") + hipGetErrorString(e); rc = SARPRO_HIP_ERR_HIP; }
         }
     }
-    g->barrier(); // every rank has read every buffer
+    if (!g->barrier()) { ctx->err = "local all-reduce: the group was aborted (another rank failed)"; return SARPRO_HIP_ERR_RCCL; } // every rank has read every buffer
     if (!stream_ok) { ctx->err = "local all-reduce: the stream failed"; return SARPRO_HIP_ERR_HIP; }
     if (!same) { ctx->err = "local all-reduce: a rank failed or the ranks disagree on the element count"; return SARPRO_HIP_ERR_INVALID_ARG; }
     if (rc == SARPRO_HIP_OK && count) {
         if (hipMemcpyAsync(d_buf, ctx->local_tmp.p, count * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = "local all-reduce: copy failed"; rc = SARPRO_HIP_ERR_HIP; }
     }
     return rc;
+}
+
+// A rank of an in-process group that fails between two collectives (the stripe entry points call this on every error return) releases
+// its peers: their pending and later barriers return an error instead of waiting for ever.  The group stays aborted -- destroy it and
+// create a new one.  (RCCL has no counterpart the library could use safely from one rank: a process whose rank failed must tear its
+// communicator down, as with any NCCL program.)
+void comm_abort_local_group(sarpro_hip_ctx *ctx) {
+    if (ctx && ctx->local_group) ctx->local_group->abort();
 }
 
 // all-reduce(sum, u64) enqueued on the context's stream, no host synchronisation (the stripe chain keeps

@@ -1117,9 +1117,12 @@ extern "C" int sarpro_hip_stripe_run_f32(sarpro_hip_ctx *ctx, const float *d_in,
                                          size_t in_pitch, int strategy, int bit_depth, void *d_out, size_t out_pitch,
                                          sarpro_hip_stats *stats_out) {
     sarpro_hip_stripe_f32 *s = nullptr;
-    RETCHK(sarpro_hip_stripe_begin_f32(ctx, d_in, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out, out_pitch, &s));
-    int rc = stripe_f32_run(s, stats_out);
-    sarpro_hip_stripe_f32_end(s);
+    int rc = sarpro_hip_stripe_begin_f32(ctx, d_in, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out, out_pitch, &s);
+    if (rc == SARPRO_HIP_OK) {
+        rc = stripe_f32_run(s, stats_out);
+        sarpro_hip_stripe_f32_end(s);
+    }
+    if (rc != SARPRO_HIP_OK) comm_abort_local_group(ctx); // (an in-process group: the peers must not wait for this rank)
     return rc;
 }
 
@@ -1127,10 +1130,13 @@ extern "C" int sarpro_hip_stripe_run_polop(sarpro_hip_ctx *ctx, int op, const vo
                                            size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int bit_depth,
                                            void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out) {
     sarpro_hip_stripe_f32 *s = nullptr;
-    RETCHK(sarpro_hip_stripe_begin_polop(ctx, op, d_a, d_b, elem_u16, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out,
-                                         out_pitch, &s));
-    int rc = stripe_f32_run(s, stats_out);
-    sarpro_hip_stripe_f32_end(s);
+    int rc = sarpro_hip_stripe_begin_polop(ctx, op, d_a, d_b, elem_u16, rows_total, cols, row0, rows_local, in_pitch, strategy, bit_depth, d_out,
+                                           out_pitch, &s);
+    if (rc == SARPRO_HIP_OK) {
+        rc = stripe_f32_run(s, stats_out);
+        sarpro_hip_stripe_f32_end(s);
+    }
+    if (rc != SARPRO_HIP_OK) comm_abort_local_group(ctx);
     return rc;
 }
 

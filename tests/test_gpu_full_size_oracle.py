@@ -35,6 +35,16 @@ def scene():
     c.close()
 
 
+@pytest.fixture(scope="module")
+def headline_ref(scene):
+    """The oracle's raster of the headline (CLAHE u8 x 2 + suppressed synRGB of scene A at 20000 x 20000): ~27 s, computed once for
+    the tests that compare against it."""
+    _, _, host = scene
+    rc, ref, r1, r2 = oracle.dualpol_synrgb(host[0], host[1], int(St.Clahe))
+    assert rc == 0
+    return ref, r1, r2
+
+
 def _same(dev_t, ref: np.ndarray, what: str):
     """dev_t: device tensor view [rows, cols(, 3)] ; ref: the oracle's raster.  Compared on the device, slab by slab."""
     step = 2500
@@ -48,12 +58,11 @@ def _same(dev_t, ref: np.ndarray, what: str):
     assert bad == 0, f"{what}: {bad} of {ref.size} raster entries differ from the oracle"
 
 
-def test_headline_400mp_clahe_synrgb_equals_oracle_every_pixel(scene):
+def test_headline_400mp_clahe_synrgb_equals_oracle_every_pixel(scene, headline_ref):
     """The metric's workload: calibrate + CLAHE u8 x 2 + suppressed synRGB (save.rs:317-367) at 20000 x 20000, both GPU routes
     (the fused CLAHE -> RGB pass that bench.py times, and the apply + compose route with its per-band u8 rasters) == oracle."""
     c, band, host = scene
-    rc, ref, r1, r2 = oracle.dualpol_synrgb(host[0], host[1], int(St.Clahe))
-    assert rc == 0
+    ref, r1, r2 = headline_ref
     rgb = torch.zeros((ROWS, PITCH * 3), dtype=torch.uint8, device="cuda")
     c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Mode.Default, rgb.data_ptr(), PITCH,
                              want_stats=False)
@@ -138,3 +147,85 @@ def test_config2_400mp_clahe_u16_bands_and_log_ratio_band_equal_oracle_every_pix
     out16.zero_()
     c.dev_autoscale_band_f32(ratio.data_ptr(), ROWS, COLS, COLS, St.Clahe, Bd.U16, out16.data_ptr(), PITCH)
     _same(out16[:, :COLS], ref, "CLAHE u16 of the materialised log-ratio raster")
+
+
+def _run_stripes(band, rgb, n, attrs=None):
+    """The headline scene as n row stripes: one context + host thread per rank on this GPU, joined by the in-process communicator,
+    every rank through the ONE-CALL stripe entry point (sarpro_hip_stripe_run_u16) on views of the resident rasters.  Returns the
+    ranks' kernel names and speculation reports."""
+    import threading
+    r0s, nrs = S.host_stripe_plan(ROWS, n)
+    group = S.LocalGroup(n)
+    ctxs = [S.Context(0, timing=True) for _ in range(n)]
+    for k, c in enumerate(ctxs):
+        c.comm_init_local(group, k)
+        for name, v in (attrs or {}).items():
+            c.set_attr(name, v)
+    names, reps, errs = [None] * n, [None] * n, []
+    torch.cuda.synchronize()
+
+    def work(k):
+        try:
+            r0, nr = int(r0s[k]), int(nrs[k])
+            ctxs[k].stripe_run_u16(band[0].data_ptr() + r0 * PITCH * 2, band[1].data_ptr() + r0 * PITCH * 2, ROWS, COLS, r0, nr, PITCH, St.Clahe,
+                                   Mode.Default, rgb.data_ptr() + r0 * PITCH * 3, PITCH)
+            names[k] = [x for x, _ in ctxs[k].last_kernel_times()]
+            reps[k] = ctxs[k].spec_report()
+        except Exception as e:
+            errs.append((k, repr(e)))
+    ths = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    alive = [t.is_alive() for t in ths]
+    assert not errs and not any(alive), (errs, alive)
+    for c in ctxs:
+        c.close()
+    group.close()
+    return list(zip(r0s, nrs)), names, reps
+
+
+@pytest.mark.parametrize("ranks,force", [(8, None), (8, "mispredict"), (4, None), (2, None)])
+def test_config3_400mp_scene_as_row_stripes_equals_oracle_every_pixel(scene, headline_ref, ranks, force):
+    """configs[3] at its stated size: ONE 400 MP scene as 8 (4, 2) row stripes of 2500 (5000, 10000) rows, each rank's single-call
+    chain with its integer all-reduces (in-process communicator: the ranks are contexts of this GPU), the fused CLAHE -> RGB route on
+    every rank -- item geometry, border strips and chunk boundaries of full-height stripes, which the 403-row rasters of
+    test_gpu_multirank_local.py never meet -- and, forced once, the refuted route.  The assembled raster == the oracle's, every pixel."""
+    c, band, host = scene
+    ref, _, _ = headline_ref
+    rgb = torch.zeros((ROWS, PITCH * 3), dtype=torch.uint8, device="cuda")
+    splits, names, reps = _run_stripes(band, rgb, ranks, {"SPEC_FORCE": force} if force else None)
+    assert [int(nr) for _, nr in splits] == [ROWS // ranks] * ranks
+    for nm in names:
+        assert "clahe_rgb_fused" in nm and "allreduce_sample_hist" in nm and "allreduce_spec_counts" in nm, nm
+    key = [(r["spec_ok"], r["verdict"], r["floor_pred"], tuple(r["n_lt"]), r["target"]) for r in reps]
+    assert all(k == key[0] for k in key), key  # every rank proved, predicted and decided the same
+    assert key[0][0] == 1 and key[0][1] == (1 if force else 0), key[0]
+    _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, f"{ranks} row stripes{' (forced refutation)' if force else ''}")
+
+
+def test_config4_batch_of_64_scenes_to_1024_padded_synrgb_equals_oracle():
+    """configs[4] at its stated size: 64 scenes dealt to four workers (device 0 listed four times: one context + host thread each, as
+    eight GPUs would be listed once each), every scene -> per-band autoscale -> Lanczos3 to 1024 on the long side -> pad to 1024^2 ->
+    synRGB (api/mod.rs:474-536 over save.rs:317-367), BatchReport{processed: 64}; every scene's raster == the oracle's flow."""
+    n = 64
+    shapes = [(3000 + 37 * (i % 7), 2600 + 53 * (i % 5)) if i % 2 else (2500 + 41 * (i % 6), 3100 + 29 * (i % 4)) for i in range(n)]
+    scenes = []
+    with S.Context(0) as c:
+        q = synth.q_tables()
+        for i, (r, cc) in enumerate(shapes):
+            pitch = (cc + 63) // 64 * 64
+            bands = []
+            for k in (0, 1):
+                t = torch.empty((r, pitch), dtype=torch.int16, device="cuda")
+                c.dev_synth_scene_u16(synth.SEED_SCENE_A + 100 + i, k, q, r, cc, 0, r, t.data_ptr(), pitch)
+                torch.cuda.synchronize()
+                bands.append(np.ascontiguousarray(t[:, :cc].cpu().numpy().view(np.uint16)))
+            scenes.append(tuple(bands))
+    outs, rep, st, rc = S.batch_dualpol_synrgb_resized([0, 0, 0, 0], scenes, St.Clahe, 1024, True)
+    assert rc == 0 and rep.processed == n and rep.errors == 0 and rep.skipped == 0 and not any(st)
+    for i, ((b1, b2), got) in enumerate(zip(scenes, outs)):
+        u8 = [oracle.resize_image_data_with_meta(oracle.pipeline(x.astype(np.float32), 0, int(St.Clahe))[1], 1024, True)[0] for x in (b1, b2)]
+        want = oracle.synrgb(0, int(St.Clahe), u8[0], u8[1])
+        assert got.shape == (1024, 1024, 3) and np.array_equal(got, want), (i, shapes[i])

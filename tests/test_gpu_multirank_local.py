@@ -151,3 +151,72 @@ def test_row_stripes_take_the_fused_clahe_rgb_route(ranks, force):
         lv = np.concatenate([u[0].ravel(), u[1].ravel()])
         f = key[0][2]
         assert key[0][3][0] == int((lv < f).sum()) and (f == 37 or key[0][3][1] == int((lv <= f).sum()))
+
+
+@pytest.mark.parametrize("strategy", [St.Clahe, St.Robust])
+def test_ranks_with_different_raster_layouts_take_the_same_route(strategy):
+    """The route (and with it the sequence of collectives) follows from the layout of the rasters; a rank whose stripe is not in the
+    aligned form is staged through library-owned rasters, so that ranks with different layouts still join the same collectives
+    (round 4 advice: a rank that alone failed the fused pass's alignment test left its peers waiting in an all-reduce)."""
+    rows, cols = 403, 520
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    rc, ref, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(strategy))
+    assert rc == 0
+    splits = list(zip(*S.host_stripe_plan(rows, 3)))
+    layouts = [(576, 576, 0), (523, 521, 1), (528, 520, 0)]  # (in_pitch, rgb_pitch_px, element offset of the first sample): aligned, odd + offset, rgb pitch % 16 != 0
+    d, rgb = [], []
+    for (r0, nr), (ip, rp, off) in zip(splits, layouts):
+        bands = []
+        for x in b:
+            t = torch.zeros((max(nr, 1) * ip + 8,), dtype=torch.int16, device="cuda")
+            t[off: off + nr * ip].view(nr, ip)[:, :cols] = torch.from_numpy(x[r0:r0 + nr].view(np.int16)).cuda()
+            bands.append(t)
+        d.append(bands)
+        rgb.append(torch.zeros((max(nr, 1) * rp * 3 + 16,), dtype=torch.uint8, device="cuda"))
+
+    def body(c, k, r0, nr):
+        ip, rp, off = layouts[k]
+        return c.stripe_run_u16(d[k][0].data_ptr() + 2 * off, d[k][1].data_ptr() + 2 * off, rows, cols, r0, nr, ip, strategy, Mode.Default,
+                                rgb[k].data_ptr() + off, rp)
+    _, names = run_ranks(splits, body, {"SAMPLED_HIST_MIN_PX": 0, "SAMPLE_STRIDE": 5})
+    got = np.concatenate([t[layouts[k][2]: layouts[k][2] + nr * layouts[k][1] * 3].cpu().numpy().reshape(nr, layouts[k][1], 3)[:, :cols]
+                          for k, (t, (_, nr)) in enumerate(zip(rgb, splits))], axis=0)
+    assert np.array_equal(got, ref), strategy
+    routes = [tuple(n for n in nm if n.startswith("allreduce_")) for nm in names]
+    assert all(r == routes[0] for r in routes) and routes[0], routes  # the same collectives, in the same order, on every rank
+    if strategy == St.Clahe:
+        assert all("clahe_rgb_fused" in nm for nm in names), names
+
+
+def test_a_failing_rank_releases_its_peers():
+    """A rank that fails outside a collective (here: a null band) aborts the in-process group: its peers' all-reduces return an error
+    instead of waiting for ever (sarpro_hip_local_group has no timeout; RCCL behaves like any NCCL program and is not covered)."""
+    rows, cols, pitch = 403, 520, 576
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    splits = list(zip(*S.host_stripe_plan(rows, 3)))
+    d = [[to_dev(x[r0:r0 + nr], pitch, torch.int16) for x in b] for r0, nr in splits]
+    rgb = [torch.zeros((max(nr, 1), pitch * 3), dtype=torch.uint8, device="cuda") for _, nr in splits]
+    group = S.LocalGroup(3)
+    ctxs = [S.Context(0) for _ in range(3)]
+    for k, c in enumerate(ctxs):
+        c.comm_init_local(group, k)
+    res = [None] * 3
+    torch.cuda.synchronize()
+
+    def work(k):
+        r0, nr = splits[k]
+        try:
+            ctxs[k].stripe_run_u16(0 if k == 1 else d[k][0].data_ptr(), d[k][1].data_ptr(), rows, cols, r0, nr, pitch, St.Clahe, Mode.Default, rgb[k].data_ptr(), pitch)
+            res[k] = "ok"
+        except S.SarproHipError as e:
+            res[k] = str(e)
+    ths = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in ths), "a peer of the failed rank is still waiting"
+    assert "null raster" in res[1] and all(r != "ok" and "aborted" in r for r in (res[0], res[2])), res
+    for c in ctxs:
+        c.close()
+    group.close()
