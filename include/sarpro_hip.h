@@ -231,9 +231,12 @@ int sarpro_hip_process_band_resized_f32(sarpro_hip_ctx *ctx, const float *in, si
                                         sarpro_hip_resize_meta *meta);
 
 /* Batch mode (api/mod.rs:474-536 process_directory_to_path; BatchReport :453-458) for scenes already
- * decoded into host memory: one worker thread + context per listed device (a device may be listed
- * more than once), scenes dealt dynamically, no collective.  continue_on_error = 0 stops handing out
- * scenes after the first failure (the rest count as skipped) and returns that failure's status. */
+ * decoded into host memory: workers_per_device worker threads (each with a context of its own) per listed
+ * device, scenes dealt dynamically, no collective.  workers_per_device = 0 picks the default, 2: a scene's
+ * call is upload -> chain -> download, one PCIe direction at a time; with two workers on a device scene i's
+ * D2H crosses the full-duplex link beside scene i + 1's H2D (50.2 -> 31.8 ms per 400 MP scene, bench.py
+ * `secondary.e2e_two_in_flight`).  continue_on_error = 0 stops handing out scenes after the first failure
+ * (the rest count as skipped) and returns that failure's status. */
 /* row-chunk callbacks of the streaming entry points (described with sarpro_hip_dualpol_synrgb_stream_u16 below) */
 typedef int (*sarpro_hip_row_reader)(void *user, int band, size_t row0, size_t nrows, uint16_t *dst, size_t dst_pitch);
 typedef int (*sarpro_hip_row_sink)(void *user, size_t row0, size_t nrows, const uint8_t *src, size_t src_pitch_bytes);
@@ -247,7 +250,7 @@ typedef struct {
     void *reader_user;
 } sarpro_hip_batch_scene;
 typedef struct { size_t processed, skipped, errors; } sarpro_hip_batch_report;
-int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, const sarpro_hip_batch_scene *scenes,
+int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, int workers_per_device, const sarpro_hip_batch_scene *scenes,
                                                 size_t nscenes, int strategy, int mode, size_t target_size, int pad,
                                                 int continue_on_error, sarpro_hip_batch_report *report);
 
@@ -258,7 +261,7 @@ typedef struct {
     uint8_t *rgb_out;           /* final_rows * final_cols * 3 */
     int *status_out;            /* optional per-scene status */
 } sarpro_hip_batch_scene_f32;
-int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices, const sarpro_hip_batch_scene_f32 *scenes,
+int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices, int workers_per_device, const sarpro_hip_batch_scene_f32 *scenes,
                                                 size_t nscenes, int strategy, int mode, unsigned flags, size_t target_size, int pad,
                                                 int continue_on_error, sarpro_hip_batch_report *report);
 

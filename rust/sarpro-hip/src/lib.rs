@@ -768,9 +768,10 @@ impl<M: ?Sized> RasterWriter<M> for PlainTiffWriter {
     }
 }
 
-/// `process_directory_to_path`'s hot loop (api/mod.rs:474-536) for scenes already decoded to u16 DN: one host thread and
-/// one context per device, scenes dealt round-robin.  `out[i]` receives scene i's RGB (`final_rows * final_cols * 3`).
-pub fn batch_dualpol_synrgb_resized_u16(devices: &[i32], scenes: &[(&Array2<u16>, &Array2<u16>)], strategy: AutoscaleStrategy,
+/// `process_directory_to_path`'s hot loop (api/mod.rs:474-536) for scenes already decoded to u16 DN: `workers_per_device` host
+/// threads (0 = the library's default, 2: scene i's download beside scene i + 1's upload), each with a context of its own, per listed
+/// device; scenes dealt dynamically.  `out[i]` receives scene i's RGB (`final_rows * final_cols * 3`).
+pub fn batch_dualpol_synrgb_resized_u16(devices: &[i32], workers_per_device: usize, scenes: &[(&Array2<u16>, &Array2<u16>)], strategy: AutoscaleStrategy,
     mode: SyntheticRgbMode, target_size: Option<usize>, pad: bool, continue_on_error: bool, out: &mut [Vec<u8>]) -> Result<(BatchReport, Vec<i32>)> {
     assert_eq!(scenes.len(), out.len());
     let ts = target_size.unwrap_or(0);
@@ -787,7 +788,7 @@ pub fn batch_dualpol_synrgb_resized_u16(devices: &[i32], scenes: &[(&Array2<u16>
     }
     let devs: Vec<c_int> = devices.iter().map(|d| *d as c_int).collect();
     let mut rep = sys::sarpro_hip_batch_report { processed: 0, skipped: 0, errors: 0 };
-    let rc = unsafe { sys::sarpro_hip_batch_dualpol_synrgb_resized_u16(devs.as_ptr(), devs.len() as c_int, descs.as_ptr(), descs.len(),
+    let rc = unsafe { sys::sarpro_hip_batch_dualpol_synrgb_resized_u16(devs.as_ptr(), devs.len() as c_int, workers_per_device as c_int, descs.as_ptr(), descs.len(),
         strategy as c_int, mode as c_int, ts, pad as c_int, continue_on_error as c_int, &mut rep) };
     let report = BatchReport { processed: rep.processed, skipped: rep.skipped, errors: rep.errors };
     if rc != sys::SARPRO_HIP_OK && !continue_on_error { return Err(HipError { code: rc, message: "batch aborted on the first failing scene".into() }); }

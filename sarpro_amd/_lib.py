@@ -235,11 +235,11 @@ _u = C.c_uint
 _proto("sarpro_hip_dualpol_synrgb_f32_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _u, _vp, _sz, _vp, _vp, _sz, C.POINTER(Stats))
 _proto("sarpro_hip_dualpol_synrgb_resized_f32", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _u, _sz, _i, _vp, _M)
 _proto("sarpro_hip_dualpol_synrgb_resized_f32_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _u, _sz, _i, _vp, _M)
-_proto("sarpro_hip_batch_dualpol_synrgb_resized_f32", _i, C.POINTER(C.c_int), _i, C.POINTER(BatchSceneF32), _sz, _i, _i, _u, _sz, _i, _i, C.POINTER(BatchReport))
+_proto("sarpro_hip_batch_dualpol_synrgb_resized_f32", _i, C.POINTER(C.c_int), _i, _i, C.POINTER(BatchSceneF32), _sz, _i, _i, _u, _sz, _i, _i, C.POINTER(BatchReport))
 _proto("sarpro_hip_dualpol_synrgb_resized_u16_dev", _i, _vp, _vp, _vp, _sz, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_process_band_resized_u16", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_process_band_resized_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
-_proto("sarpro_hip_batch_dualpol_synrgb_resized_u16", _i, C.POINTER(_i), _i, C.POINTER(BatchScene), _sz, _i, _i, _sz, _i, _i,
+_proto("sarpro_hip_batch_dualpol_synrgb_resized_u16", _i, C.POINTER(_i), _i, _i, C.POINTER(BatchScene), _sz, _i, _i, _sz, _i, _i,
        C.POINTER(BatchReport))
 _proto("sarpro_hip_batch_dualpol_synrgb_u16_dev", _i, _vp, C.POINTER(ResidentScene), _sz, _sz, _sz, _sz, _i, _i, _sz, _i, _i, C.POINTER(BatchReport))
 _proto("sarpro_hip_stripe_run_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)

@@ -782,7 +782,7 @@ def resize_output_dims(cols: int, rows: int, target_size: int | None, pad: bool)
 
 
 def batch_dualpol_synrgb_resized(devices, scenes, strategy, target_size, pad, mode=SyntheticRgbMode.Default,
-                                 continue_on_error: bool = True):
+                                 continue_on_error: bool = True, workers_per_device: int = 0):
     """process_directory_to_path semantics (api/mod.rs:474-536).
     scenes: list of (band1_u16, band2_u16) arrays, or of (reader, rows, cols) with reader a (fn_ptr, user_ptr) pair such as
     TiffPair.reader() -- the scene is then streamed from its files by the worker that picks it up.
@@ -813,14 +813,14 @@ def batch_dualpol_synrgb_resized(devices, scenes, strategy, target_size, pad, mo
                             C.cast(C.byref(stats, i * C.sizeof(C.c_int)), C.POINTER(C.c_int)), None, None)
     dev = (C.c_int * len(devices))(*devices)
     rep = BatchReport()
-    rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_u16(dev, len(devices), arr, n, int(strategy), int(mode), target_size or 0,
+    rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_u16(dev, len(devices), workers_per_device, arr, n, int(strategy), int(mode), target_size or 0,
                                                          int(pad), int(continue_on_error), C.byref(rep))
     st = [stats[i] for i in range(n)]
     return [o if s == 0 else None for o, s in zip(outs, st)], rep, st, rc
 
 
 def batch_dualpol_synrgb_resized_f32(devices, scenes, strategy, target_size, pad, mode=SyntheticRgbMode.Default, plain_pipeline: bool = False,
-                                     continue_on_error: bool = True):
+                                     continue_on_error: bool = True, workers_per_device: int = 0):
     """The batch driver for scenes with f32 bands: scenes = list of (band1_f32, band2_f32).  Returns (RGB arrays or None, BatchReport, statuses, rc)."""
     from ._lib import BatchReport, BatchSceneF32
     n = len(scenes)
@@ -838,7 +838,7 @@ def batch_dualpol_synrgb_resized_f32(devices, scenes, strategy, target_size, pad
                                C.cast(C.byref(stats, i * C.sizeof(C.c_int)), C.POINTER(C.c_int)))
     dev = (C.c_int * len(devices))(*devices)
     rep = BatchReport()
-    rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_f32(dev, len(devices), arr, n, int(strategy), int(mode), 1 if plain_pipeline else 0,
+    rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_f32(dev, len(devices), workers_per_device, arr, n, int(strategy), int(mode), 1 if plain_pipeline else 0,
                                                          target_size or 0, int(pad), int(continue_on_error), C.byref(rep))
     st = [stats[i] for i in range(n)]
     return [o if s == 0 else None for o, s in zip(outs, st)], rep, st, rc

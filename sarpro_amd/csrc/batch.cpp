@@ -2,8 +2,8 @@
 //   * sarpro_hip_process_band_resized_*: save_processed_image (save.rs:23-170) up to the raster the
 //     writer receives: pipeline -> resize -> pad, device-resident.
 //   * sarpro_hip_batch_dualpol_synrgb_resized_u16: process_directory_to_path semantics
-//     (api/mod.rs:474-536; cli/runner.rs:277-345) for in-memory scenes: scenes are dealt to one worker
-//     thread per GPU (no collective: scenes are independent), failures are counted and -- with
+//     (api/mod.rs:474-536; cli/runner.rs:277-345) for in-memory scenes: scenes are dealt to workers_per_device worker
+//     threads per GPU (no collective: scenes are independent), failures are counted and -- with
 //     continue_on_error -- do not stop the batch (BatchReport, api/mod.rs:453-458).
 #include <algorithm>
 #include <atomic>
@@ -141,8 +141,10 @@ extern "C" int sarpro_hip_process_band_resized_f32(sarpro_hip_ctx *ctx, const fl
 // The batch driver proper: one worker thread + context per listed device, scenes dealt dynamically, BatchReport semantics of
 // api/mod.rs:453-458, 518-526.  `run_scene(ctx, i)` processes scene i on the worker's context.
 template <typename RunScene, typename StatusOut>
-static int run_batch(const int *devices, int ndevices, size_t nscenes, int continue_on_error, sarpro_hip_batch_report *report,
+static int run_batch(const int *devices, int ndevices, int workers_per_device, size_t nscenes, int continue_on_error, sarpro_hip_batch_report *report,
                      RunScene run_scene, StatusOut status_out) {
+    if (workers_per_device < 0 || workers_per_device > 8) return SARPRO_HIP_ERR_INVALID_ARG;
+    if (workers_per_device == 0) workers_per_device = 2; // scene i's download beside scene i + 1's upload (PCIe is full duplex)
     std::memset(report, 0, sizeof(*report));
     std::atomic<size_t> next{0}, processed{0}, errors{0};
     std::atomic<bool> stop{false};
@@ -175,7 +177,8 @@ static int run_batch(const int *devices, int ndevices, size_t nscenes, int conti
         sarpro_hip_ctx_destroy(ctx);
     };
     std::vector<std::thread> pool;
-    for (int d = 0; d < ndevices; ++d) pool.emplace_back(worker, devices[d]);
+    for (int w = 0; w < workers_per_device; ++w) // (worker-major: with fewer scenes than workers every device still gets one first)
+        for (int d = 0; d < ndevices && pool.size() < std::max<size_t>(nscenes, 1); ++d) pool.emplace_back(worker, devices[d]);
     for (auto &t : pool) t.join();
     report->processed = processed.load();
     report->errors = errors.load();
@@ -186,11 +189,11 @@ static int run_batch(const int *devices, int ndevices, size_t nscenes, int conti
     return SARPRO_HIP_OK;
 }
 
-extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, const sarpro_hip_batch_scene *scenes,
+extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, int ndevices, int workers_per_device, const sarpro_hip_batch_scene *scenes,
                                                            size_t nscenes, int strategy, int mode, size_t target_size, int pad,
                                                            int continue_on_error, sarpro_hip_batch_report *report) {
     if (!devices || ndevices <= 0 || (!scenes && nscenes) || !report) return SARPRO_HIP_ERR_INVALID_ARG;
-    return run_batch(devices, ndevices, nscenes, continue_on_error, report,
+    return run_batch(devices, ndevices, workers_per_device, nscenes, continue_on_error, report,
                      [&](sarpro_hip_ctx *ctx, size_t i) {
                          const sarpro_hip_batch_scene &sc = scenes[i];
                          if (sc.reader) return sarpro_hip_dualpol_synrgb_resized_stream_u16(ctx, sc.reader, sc.reader_user, sc.rows, sc.cols, strategy, mode, target_size, pad, sc.rgb_out, nullptr);
@@ -201,11 +204,11 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_u16(const int *devices, i
 
 // The same batch for scenes whose bands are f32 (the reference's default flow: resampled on read, sentinel1.rs:1074-1108); flags:
 // SARPRO_HIP_DUALPOL_* (api/mod.rs:404-437 is SARPRO_HIP_DUALPOL_PLAIN_PIPELINE).
-extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices, const sarpro_hip_batch_scene_f32 *scenes,
+extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices, int workers_per_device, const sarpro_hip_batch_scene_f32 *scenes,
                                                            size_t nscenes, int strategy, int mode, unsigned flags, size_t target_size,
                                                            int pad, int continue_on_error, sarpro_hip_batch_report *report) {
     if (!devices || ndevices <= 0 || (!scenes && nscenes) || !report) return SARPRO_HIP_ERR_INVALID_ARG;
-    return run_batch(devices, ndevices, nscenes, continue_on_error, report,
+    return run_batch(devices, ndevices, workers_per_device, nscenes, continue_on_error, report,
                      [&](sarpro_hip_ctx *ctx, size_t i) {
                          const sarpro_hip_batch_scene_f32 &sc = scenes[i];
                          return sarpro_hip_dualpol_synrgb_resized_f32(ctx, sc.band1, sc.band2, sc.rows, sc.cols, strategy, mode, flags, target_size, pad, sc.rgb_out, nullptr);

@@ -53,7 +53,7 @@ int get_coeffs(sarpro_hip_ctx *ctx, int slot, uint32_t in_size, uint32_t out_siz
         a->size = buf.as<uint32_t>() + n;
         a->k = reinterpret_cast<const int32_t *>(buf.as<uint8_t>() + n * 8);
         a->in_size = in_size; a->out_size = out_size; a->precision = (int)key[3];
-        a->window = key[4]; a->block_span = key[5];
+        a->window = key[4]; a->block_span = key[5] & 0x7FFFFFFFu; a->k_small = key[5] >> 31;
         return SARPRO_HIP_OK;
     }
     ResizeCoeffs c;
@@ -74,8 +74,10 @@ int get_coeffs(sarpro_hip_ctx *ctx, int slot, uint32_t in_size, uint32_t out_siz
     a->in_size = c.in_size; a->out_size = c.out_size; a->precision = c.precision;
     uint32_t span = 0;
     for (size_t g = 0; g < n; g += kResizeHBlock) span = std::max(span, c.start[std::min(n, g + kResizeHBlock) - 1] - c.start[g]);
-    a->window = c.window; a->block_span = span;
-    key[0] = in_size; key[1] = out_size; key[2] = (uint32_t)elem_size; key[3] = (uint32_t)c.precision; key[4] = c.window; key[5] = span;
+    int32_t kmax = 0;
+    for (int32_t v : c.k) kmax = std::max(kmax, v < 0 ? -v : v);
+    a->window = c.window; a->block_span = span; a->k_small = kmax < 32768 - 128 ? 1u : 0u;
+    key[0] = in_size; key[1] = out_size; key[2] = (uint32_t)elem_size; key[3] = (uint32_t)c.precision; key[4] = c.window; key[5] = span | (a->k_small << 31);
     return SARPRO_HIP_OK;
 }
 
@@ -105,10 +107,8 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     ah.generic = av.generic = ctx->attrs.on(A_RESIZE_GENERIC) ? 1u : 0u;
     if (lut_src) { // probe BEFORE anything is enqueued: the register-resident horizontal pass must take this shape
         RETCHK(get_coeffs(ctx, 0, (uint32_t)cols, (uint32_t)nc, elem_size, &ah));
-        const uint32_t nchunk = (15 + ah.window + 15) / 16;
-        const size_t span = ((size_t)ah.block_span + 15 + nchunk * 16 + 15) / 16 * 16;
-        if (!ah.window || nchunk > 8 || span * 2 > 2 * (size_t)kResizeHBlock * 16 || (reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || in_pitch % 16 != 0 ||
-            span * 4 + lut_src->lut_cap > 64 * 1024 || ctx->attrs.on(A_RESIZE_GENERIC))
+        if (!resize_h_dot_fits(ah.block_span, ah.window, lut_src->lut_cap) || (reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || in_pitch % 16 != 0 ||
+            ctx->attrs.on(A_RESIZE_GENERIC))
             return kResizeLutUnsupported;
     }
     uint8_t *out = reinterpret_cast<uint8_t *>(d_out);
