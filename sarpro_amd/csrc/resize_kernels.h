@@ -22,7 +22,7 @@ struct ResizePassArgs {
 constexpr uint32_t kResizeHBlock = 256;
 constexpr uint32_t kResizeHMaxChunks = 16; // 8-byte chunks of taps a thread of the register-resident horizontal pass can hold (windows up to 114 taps)
 // does the register-resident horizontal pass take this (block span, window, LDS bytes reserved for a DN table)?  (the launcher's own test: callers probe with it before they enqueue anything)
-bool resize_h_dot_fits(uint32_t block_span, uint32_t window, size_t lut_cap);
+bool resize_h_dot_fits(uint32_t block_span, uint32_t window, bool src16, size_t lut_cap);
 
 hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size, hipStream_t s);
 // The horizontal u8 pass reading u16 DN through the band's DN -> u8 table (the percentile strategies' whole autoscale is that table,

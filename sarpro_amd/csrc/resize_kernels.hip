@@ -67,6 +67,12 @@ __global__ __launch_bounds__(kBlock) void k_resize_h(ResizePassArgs a) {
 #ifndef SARPRO_RESIZE_H_MINWAVES
 #define SARPRO_RESIZE_H_MINWAVES 1
 #endif
+// Bytes of a tap chunk (one LDS read): 16 (ds_read_b128: 5 reads and 40 dot products for the 59 taps of 20000 -> 2048) or 8 (ds_read_b64:
+// 9 reads, 36 dot products).  Measured both ways for both sources (profiles/r5/resize_variants.txt): the pass that turns DN into
+// levels while it stages (SRC16) is bound by its LDS cycles -- the table gathers come on top of the window reads -- and is 3 % faster
+// with the wide read (0.415 against 0.433 ms for two 400 MP bands); the pass over a u8 raster is 15 % faster with the narrow one
+// (0.257 against 0.297 ms: four dot products less per output, and its lanes' 8-byte chunks meet on LDS banks less than they cost).
+constexpr uint32_t rz_chunk(bool src16) { return src16 ? 16u : 8u; }
 template <int NC8, bool SRC16, bool BIG>
 __global__ __launch_bounds__(kResizeHBlock, SARPRO_RESIZE_H_MINWAVES) void k_resize_h_u8_dot(ResizePassArgs a, uint32_t rows, uint32_t span_bytes /* LDS bytes per staged row */, ResizeLutSrc lsrc) {
     extern __shared__ __align__(16) unsigned char lds_all[];
@@ -84,11 +90,12 @@ __global__ __launch_bounds__(kResizeHBlock, SARPRO_RESIZE_H_MINWAVES) void k_res
     const uint32_t oxc = valid ? ox : a.out_size - 1;
     const uint32_t x0 = a.start[oxc], n = a.size[oxc];
     const uint32_t bx0 = a.start[first] & ~15u;   // the block's window starts here (start[] is non-decreasing)
-    const uint32_t xb = x0 & ~7u, lead = x0 - xb; // this thread's first 8-byte chunk, and where its first tap sits in it
-    uint32_t lo[NC8 * 2], hi[NC8 * 2], ex[BIG ? NC8 * 2 : 1];
+    constexpr uint32_t kRzChunk = rz_chunk(SRC16), kRzW = kRzChunk / 4; // bytes / dwords per chunk
+    const uint32_t xb = x0 & ~(kRzChunk - 1u), lead = x0 - xb; // this thread's first chunk, and where its first tap sits in it
+    uint32_t lo[NC8 * kRzW], hi[NC8 * kRzW], ex[BIG ? NC8 * kRzW : 1];
     int32_t sumk = 0;
 #pragma unroll
-    for (int w = 0; w < NC8 * 2; ++w) {
+    for (int w = 0; w < NC8 * (int)kRzW; ++w) {
         uint32_t l = 0, h = 0, e = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -189,14 +196,19 @@ __global__ __launch_bounds__(kResizeHBlock, SARPRO_RESIZE_H_MINWAVES) void k_res
             for (int j = 0; j < R; ++j) {
 #pragma unroll
                 for (int c = 0; c < NC8; ++c) {
-                    const uint2 px2 = *reinterpret_cast<const uint2 *>(buf + (size_t)j * span_bytes + c * 8);
-                    acc_lo[j] = __builtin_amdgcn_sdot4((int32_t)px2.x, (int32_t)lo[c * 2], acc_lo[j], false);
-                    acc_hi[j] = __builtin_amdgcn_sdot4((int32_t)px2.x, (int32_t)hi[c * 2], acc_hi[j], false);
-                    acc_lo[j] = __builtin_amdgcn_sdot4((int32_t)px2.y, (int32_t)lo[c * 2 + 1], acc_lo[j], false);
-                    acc_hi[j] = __builtin_amdgcn_sdot4((int32_t)px2.y, (int32_t)hi[c * 2 + 1], acc_hi[j], false);
-                    if (BIG) {
-                        acc_hi[j] = __builtin_amdgcn_sdot4((int32_t)px2.x, (int32_t)ex[c * 2], acc_hi[j], false);
-                        acc_hi[j] = __builtin_amdgcn_sdot4((int32_t)px2.y, (int32_t)ex[c * 2 + 1], acc_hi[j], false);
+                    uint32_t px[kRzW];
+                    if (kRzChunk == 16) {
+                        const uint4 p4 = *reinterpret_cast<const uint4 *>(buf + (size_t)j * span_bytes + c * 16);
+                        px[0] = p4.x; px[1] = p4.y; px[kRzW - 2] = p4.z; px[kRzW - 1] = p4.w;
+                    } else {
+                        const uint2 p2 = *reinterpret_cast<const uint2 *>(buf + (size_t)j * span_bytes + c * 8);
+                        px[0] = p2.x; px[1] = p2.y;
+                    }
+#pragma unroll
+                    for (int w = 0; w < (int)kRzW; ++w) {
+                        acc_lo[j] = __builtin_amdgcn_sdot4((int32_t)px[w], (int32_t)lo[c * kRzW + w], acc_lo[j], false);
+                        acc_hi[j] = __builtin_amdgcn_sdot4((int32_t)px[w], (int32_t)hi[c * kRzW + w], acc_hi[j], false);
+                        if (BIG) acc_hi[j] = __builtin_amdgcn_sdot4((int32_t)px[w], (int32_t)ex[c * kRzW + w], acc_hi[j], false);
                     }
                 }
             }
@@ -295,22 +307,24 @@ __global__ __launch_bounds__(kBlock) void k_resize_v(ResizePassArgs a) {
 // the register-resident form: SRC16 = false reads u8 levels, true reads u16 DN through a table (lut_cap bytes of LDS ahead of the rows)
 template <bool SRC16, int NC8>
 static void launch_resize_h_dot_n(dim3 grid, size_t lds, hipStream_t s, const ResizePassArgs &a, uint32_t rows, uint32_t span, const ResizeLutSrc &l) {
-    if (a.k_small) hipLaunchKernelGGL((k_resize_h_u8_dot<NC8, SRC16, false>), grid, dim3(kResizeHBlock), lds, s, a, rows, span, l);
-    else hipLaunchKernelGGL((k_resize_h_u8_dot<NC8, SRC16, true>), grid, dim3(kResizeHBlock), lds, s, a, rows, span, l);
+    if constexpr (NC8 * rz_chunk(SRC16) <= kResizeHMaxChunks * 8) { // (a thread holds at most 128 bytes of taps: larger counts are never launched, nor compiled)
+        if (a.k_small) hipLaunchKernelGGL((k_resize_h_u8_dot<NC8, SRC16, false>), grid, dim3(kResizeHBlock), lds, s, a, rows, span, l);
+        else hipLaunchKernelGGL((k_resize_h_u8_dot<NC8, SRC16, true>), grid, dim3(kResizeHBlock), lds, s, a, rows, span, l);
+    }
 }
-uint32_t resize_h_dot_chunks(uint32_t window) { return (7 + window + 7) / 8; }
-uint32_t resize_h_dot_span(uint32_t block_span, uint32_t window) { return (block_span + 15 + resize_h_dot_chunks(window) * 8 + 15) / 16 * 16; } // bytes of a row that one block's 256 outputs read
-bool resize_h_dot_fits(uint32_t block_span, uint32_t window, size_t lut_cap) {
-    const uint32_t nc8 = resize_h_dot_chunks(window);
-    const size_t span = resize_h_dot_span(block_span, window);
-    return window && nc8 <= kResizeHMaxChunks && span * kResizeHRows <= (size_t)kResizeHVecs * kResizeHBlock * 16 && span * kResizeHRows * 2 + lut_cap <= 64 * 1024;
+uint32_t resize_h_dot_chunks(uint32_t window, bool src16) { return (rz_chunk(src16) - 1 + window + rz_chunk(src16) - 1) / rz_chunk(src16); }
+uint32_t resize_h_dot_span(uint32_t block_span, uint32_t window, bool src16) { return (block_span + 15 + resize_h_dot_chunks(window, src16) * rz_chunk(src16) + 15) / 16 * 16; } // bytes of a row that one block's 256 outputs read
+bool resize_h_dot_fits(uint32_t block_span, uint32_t window, bool src16, size_t lut_cap) {
+    const uint32_t nc8 = resize_h_dot_chunks(window, src16);
+    const size_t span = resize_h_dot_span(block_span, window, src16);
+    return window && nc8 <= kResizeHMaxChunks * 8 / rz_chunk(src16) && span * kResizeHRows <= (size_t)kResizeHVecs * kResizeHBlock * 16 && span * kResizeHRows * 2 + lut_cap <= 64 * 1024;
 }
 template <bool SRC16>
 static hipError_t launch_resize_h_dot(const ResizePassArgs &a, const ResizeLutSrc &l, uint32_t rows, hipStream_t s) {
     if (!a.window) return hipErrorNotSupported;
-    const uint32_t nc8 = resize_h_dot_chunks(a.window);
-    const uint32_t span = resize_h_dot_span(a.block_span, a.window);
-    if (!(resize_h_dot_fits(a.block_span, a.window, SRC16 ? l.lut_cap : 0u) && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && a.src_pitch % 16 == 0))
+    const uint32_t nc8 = resize_h_dot_chunks(a.window, SRC16);
+    const uint32_t span = resize_h_dot_span(a.block_span, a.window, SRC16);
+    if (!(resize_h_dot_fits(a.block_span, a.window, SRC16, SRC16 ? l.lut_cap : 0u) && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && a.src_pitch % 16 == 0))
         return hipErrorNotSupported;
     const uint32_t gx = (a.out_size + kResizeHBlock - 1) / kResizeHBlock;
     const uint32_t steps = (rows + kResizeHRows - 1) / kResizeHRows;

@@ -107,7 +107,7 @@ int resize_pad_dev(sarpro_hip_ctx *ctx, const void *d_in, size_t cols, size_t ro
     ah.generic = av.generic = ctx->attrs.on(A_RESIZE_GENERIC) ? 1u : 0u;
     if (lut_src) { // probe BEFORE anything is enqueued: the register-resident horizontal pass must take this shape
         RETCHK(get_coeffs(ctx, 0, (uint32_t)cols, (uint32_t)nc, elem_size, &ah));
-        if (!resize_h_dot_fits(ah.block_span, ah.window, lut_src->lut_cap) || (reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || in_pitch % 16 != 0 ||
+        if (!resize_h_dot_fits(ah.block_span, ah.window, true, lut_src->lut_cap) || (reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || in_pitch % 16 != 0 ||
             ctx->attrs.on(A_RESIZE_GENERIC))
             return kResizeLutUnsupported;
     }

@@ -160,11 +160,11 @@ def test_horizontal_pass_through_the_autoscale_table_equals_the_level_raster_rou
                 monkeypatch.delenv("SARPRO_HIP_NO_RESIZE_LUT", raising=False)
             rgb, m = c.dualpol_synrgb_resized(b1, b2, strategy, target, True)
             names = [n for n, _ in c.last_kernel_times()]
-            # the register-resident pass takes windows of up to 16 x 8 bytes (window = 2 ceil(3 scale) + 1 taps)
+            # the register-resident pass takes windows of up to 8 x 16 bytes (window = 2 ceil(3 scale) + 1 taps)
             import math
             nc, _ = resize_output_dims(cols, rows, target, False)
             window = 2 * math.ceil(3.0 * max(cols / nc, 1.0)) + 1
-            through_table = (7 + window + 7) // 8 <= 16
+            through_table = (15 + window + 15) // 16 <= 8
             if not off and strategy != St.Clahe:
                 assert ("lut_apply_u16" not in names) == through_table, (names, window)
             if strategy == St.Clahe:
