@@ -723,7 +723,8 @@ __device__ __forceinline__ float spec_delta(int pad0) { // the f32 blend's margi
 #endif
 }
 #ifdef SARPRO_SPEC_MEASURE // instrumented build (tools/spec_margin.py): the largest |y32 - y| the speculative blend produced, per margin class
-__device__ uint32_t g_spec_max_err[2]; // float bits; [0] interior cells, [1] extrapolating cells
+__device__ uint32_t g_spec_max_err[4]; // float bits, one per margin of spec_delta: [0] interior cells, [1] dy < 0 only, [2] dx < 0 only, [3] the corner (both)
+__device__ __forceinline__ int spec_class(int pad0) { return !(pad0 & 1) ? 0 : (pad0 & 6) == 2 ? 1 : (pad0 & 6) == 4 ? 2 : 3; }
 #endif
 constexpr uint32_t kPartialHistLevels = 64; // partial level histogram: levels below this are counted one by one
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1067,7 +1068,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 #ifdef SARPRO_SPEC_MEASURE
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) spec_err = fmaxf(spec_err, __shfl_xor(spec_err, m, 64));
-    if (lane_id() == 0 && spec_err > 0.0f) atomicMax(&g_spec_max_err[(rc.pad[0] & 1) ? 1 : 0], __float_as_uint(spec_err));
+    if (lane_id() == 0 && spec_err > 0.0f) atomicMax(&g_spec_max_err[spec_class(rc.pad[0])], __float_as_uint(spec_err));
 #endif
 }
 
@@ -2360,13 +2361,13 @@ hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q, 
 } // namespace sarpro
 
 #ifdef SARPRO_SPEC_MEASURE
-// instrumented build only: reads and clears the largest speculation errors seen so far (interior cells, extrapolating cells)
-extern "C" int sarpro_hip_debug_spec_max_err(float out[2]) {
-    uint32_t h[2] = {0, 0};
+// instrumented build only: reads and clears the largest speculation errors seen so far, per margin class (interior, dy < 0, dx < 0, corner)
+extern "C" int sarpro_hip_debug_spec_max_err(float out[4]) {
+    uint32_t h[4] = {0, 0, 0, 0};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(sarpro::g_spec_max_err), sizeof(h)) != hipSuccess) return -1;
-    const uint32_t z[2] = {0, 0};
+    const uint32_t z[4] = {0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(sarpro::g_spec_max_err), z, sizeof(z)) != hipSuccess) return -1;
-    for (int i = 0; i < 2; ++i) { float f; __builtin_memcpy(&f, &h[i], 4); out[i] = f; }
+    for (int i = 0; i < 4; ++i) { float f; __builtin_memcpy(&f, &h[i], 4); out[i] = f; }
     return 0;
 }
 #endif

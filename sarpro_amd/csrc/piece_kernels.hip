@@ -9,12 +9,14 @@ namespace sarpro {
 namespace {
 
 constexpr int kPBlock = 1024, kPWaves = 16;
-// DN 1..kLowBins-1 are counted in the LANE'S OWN copy of those bins ([band][DN][64 lanes]: the word of lane l lies on bank l mod 32, and
+// DN 1..kLowBins-1 are counted in the LANE'S OWN copy of those bins (round 5 layout: [band][lane][kLowStride = 129 words], so that a
+// sample's word is at DN * 4 + a per-lane constant -- the same multiply as the shared bins, one select instead of two -- and the word
+// of lane l for bin d lies on bank (l + d) mod 64: lanes that hold the same DN never meet on a bank; rounds 2-4: [band][DN][64 lanes], and
 // lanes l and l + 32 belong to different halves of a ds_add_u32 -- no two lanes of an instruction ever meet, neither on a bank nor on
 // an address).  A band of a few distinct low amplitudes (cross-pol over open water: most samples on five or ten DN values) otherwise
 // sends a whole wave's adds to a handful of LDS words, which serialise: 1.34 ms instead of 0.31 for the pass on a scene whose VH
 // band holds DN 1..10 only; eight lane-selected copies (the first form of this) left 0.72.  The copies are summed on publish.
-constexpr uint32_t kLowBins = 128, kLowReps = 64;
+constexpr uint32_t kLowBins = 128, kLowReps = 64, kLowStride = kLowBins + 1, kLowWords = kLowReps * kLowStride; // words per band
 // LDS atomics through the address-space-3 pointer (the HIP overloads take generic pointers)
 #define LDS_ADD(off, v) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)(off)), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 // The bright tail (DN >= the LDS bins: point targets, one sample in 10^4 on a GRD scene) goes to the tile's GLOBAL histogram.  Round 5: not
@@ -27,7 +29,7 @@ constexpr uint32_t kLowBins = 128, kLowReps = 64;
 // recounts its tail samples from that band-row on in a second loop behind the first: slower, never wrong.
 constexpr uint32_t kTailCap = 4096;
 #ifndef SARPRO_PIECE_AHEAD
-#define SARPRO_PIECE_AHEAD 2 // rows of both bands in flight per wave beyond the one being counted
+#define SARPRO_PIECE_AHEAD 1 // rows of both bands in flight per wave beyond the one being counted (1, 2, 3, 4 measured: 0.300, 0.312, 0.311, 0.313 ms)
 #endif
 constexpr int kPieceAhead = SARPRO_PIECE_AHEAD;
 static_assert(kPieceAhead >= 1 && kPieceAhead <= 4, "piece histogram: 1..4 rows ahead");
@@ -62,27 +64,26 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
     const uint32_t W = a.lds_bins, S = W + 64u;
     const int first = a.wg_first[blockIdx.x], last = a.wg_first[blockIdx.x + 1];
     if (first >= last) return;
-    for (uint32_t i = threadIdx.x; i < 2u * S + 2u * kLowReps * kLowBins; i += kPBlock) h[i] = 0u;
-    uint32_t *const q = h + 2u * S + 2u * kLowReps * kLowBins; // q[0]: entries reserved so far; q[1 + k]: entry k
+    for (uint32_t i = threadIdx.x; i < 2u * S + 2u * kLowWords; i += kPBlock) h[i] = 0u;
+    uint32_t *const q = h + 2u * S + 2u * kLowWords; // q[0]: entries reserved so far; q[1 + k]: entry k
     if (threadIdx.x == 0) q[0] = 0u;
-    const uint32_t q_off = (2u * S + 2u * kLowReps * kLowBins) * 4u; // byte offset of q[0]
+    const uint32_t q_off = (2u * S + 2u * kLowWords) * 4u; // byte offset of q[0]
     __syncthreads();
     const int wave = p_wave(), lane = p_lane();
-    // byte offset of this lane's word of low bin 0, per band: behind the two histograms, [band][kLowBins][64 lanes]
-    const uint32_t low_off[2] = {(2u * S + (uint32_t)lane) * 4u, (2u * S + kLowReps * kLowBins + (uint32_t)lane) * 4u};
+    // byte offset of this lane's word of low bin 0, per band: behind the two histograms, [band][lane][kLowStride]
+    const uint32_t low_off[2] = {(2u * S + (uint32_t)lane * kLowStride) * 4u, (2u * S + kLowWords + (uint32_t)lane * kLowStride) * 4u};
     int cur_tile = -1;
     auto publish = [&]() { // all threads, between barriers
         if (cur_tile < 0) return;
-        // the lanes' own words of the low bins first, folded into the shared bins by all threads (16 bytes each, four turns)
-        for (uint32_t qq = threadIdx.x; qq < 2u * kLowBins * kLowReps / 4u; qq += kPBlock) {
-            uint4 *p = reinterpret_cast<uint4 *>(&h[2u * S]) + qq;
-            const uint4 v = *p;
-            const uint32_t n = v.x + v.y + v.z + v.w;
-            if (n) {
-                *p = make_uint4(0u, 0u, 0u, 0u);
-                const uint32_t b = qq / (kLowBins * kLowReps / 4u), dn = (qq / (kLowReps / 4u)) % kLowBins;
-                if (dn) LDS_ADD((b * S + dn) * 4u, n); // (low bin 0 holds the invalid samples: bin 0 is what is left of the tile, restored by the consumer)
-            }
+        // the lanes' own words of the low bins first, folded into the shared bins: thread (band, DN) sums its bin over the 64 lanes (a wave's
+        // threads hold consecutive DN of one lane's row at a time: consecutive banks)
+        if (threadIdx.x < 2u * kLowBins) {
+            const uint32_t b = threadIdx.x / kLowBins, dn = threadIdx.x % kLowBins;
+            uint32_t *p = &h[2u * S + b * kLowWords + dn];
+            uint32_t n = 0u;
+#pragma unroll 8
+            for (uint32_t l = 0; l < kLowReps; ++l) { const uint32_t v = p[l * kLowStride]; if (v) { n += v; p[l * kLowStride] = 0u; } }
+            if (n && dn) LDS_ADD((b * S + dn) * 4u, n); // (low bin 0 holds the invalid samples: bin 0 is what is left of the tile, restored by the consumer)
         }
         {   // the queued tail samples of this tile (entry 0 = a slot reserved by a lane that then found the queue full)
             const uint32_t nq = min(q[0], kTailCap);
@@ -142,10 +143,12 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
             const uint32_t band_base = b ? S * 4u : 0u;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const uint32_t d = (j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xFFFFu);
-                const uint32_t dc = min(d, Wl);
-                const bool low = dc < kLowBins; // 0 <= DN < kLowBins: this lane's own words
-                const uint32_t off = dc * (low ? kLowReps * 4u : 4u) + (low ? low_off[b] : band_base);
+                // min(DN, W + lane) straight from the sample's 16-bit half (SDWA source select: no extract), then DN * 4 + (low ? this lane's
+                // row of low bins : the band's shared bins): four vector instructions per sample (rounds 2-4: six)
+                uint32_t dc;
+                if (j & 1) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(dc) : "v"(ww[j >> 1]), "v"(Wl));
+                else asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(dc) : "v"(ww[j >> 1]), "v"(Wl));
+                const uint32_t off = dc * 4u + (dc < kLowBins ? low_off[b] : band_base);
 #ifdef PIECE_HIST_NO_ATOMICS // timing experiment: the traversal and the address arithmetic without the LDS atomics
                 mx += off;
 #else
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
 
 hipError_t launch_dn_hist_pieces(const DnHistPiecesArgs &a, int grid, hipStream_t s) {
     if (grid <= 0 || grid > kPieceMaxGrid) return hipErrorInvalidValue;
-    const size_t lds = (2 * ((size_t)a.lds_bins + 64) + 2 * (size_t)kLowReps * kLowBins + 1 + kTailCap) * sizeof(uint32_t);
+    const size_t lds = (2 * ((size_t)a.lds_bins + 64) + 2 * (size_t)kLowWords + 1 + kTailCap) * sizeof(uint32_t);
     if (lds > 160 * 1024 || a.lds_bins < kLowBins || (a.lds_bins & (a.lds_bins - 1)) != 0) return hipErrorInvalidValue; // (a power of two: the tail test is a mask)
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_dn_hist_pieces))) return e;
     hipLaunchKernelGGL(k_dn_hist_pieces, dim3(grid), dim3(kPBlock), lds, s, a);
