@@ -768,6 +768,31 @@ impl<M: ?Sized> RasterWriter<M> for PlainTiffWriter {
     }
 }
 
+/// One scene of a resident batch: device pointers of its two u16 bands and of its RGB raster (`RasterCore::try_batch_dualpol_synrgb_u16_dev`).
+#[derive(Clone, Copy, Debug)]
+pub struct ResidentScene { pub d_band1: *const u16, pub d_band2: *const u16, pub d_rgb: *mut u8 }
+/// What a scene of a resident batch did: the fused CLAHE -> RGB pass's raster stood, or the exact kernels produced it.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum SceneRoute { NotSpeculative, Accepted, Refuted, Unproven, PoolOverflow }
+
+impl RasterCore {
+    /// The batch loop of api/mod.rs:484-533 for scenes that are already in HBM (all of one shape): save.rs:317-367 at native
+    /// resolution per scene, pipelined over `lanes` internal streams of this context (0 = the library's default).  Returns when every
+    /// raster is complete, with the report and each scene's (status, route).  The rasters are those of one
+    /// `dev_dualpol_synrgb_u16` call per scene, bit for bit.
+    pub fn try_batch_dualpol_synrgb_u16_dev(&self, scenes: &[ResidentScene], rows: usize, cols: usize, in_pitch: usize, strategy: AutoscaleStrategy,
+        mode: SyntheticRgbMode, rgb_pitch_px: usize, lanes: usize, continue_on_error: bool) -> Result<(BatchReport, Vec<(i32, SceneRoute)>)> {
+        let mut descs: Vec<sys::sarpro_hip_resident_scene> = scenes.iter().map(|s| sys::sarpro_hip_resident_scene {
+            d_band1: s.d_band1, d_band2: s.d_band2, d_rgb: s.d_rgb, status: 0, route: sys::SARPRO_HIP_ROUTE_NONE }).collect();
+        let mut rep = sys::sarpro_hip_batch_report { processed: 0, skipped: 0, errors: 0 };
+        let rc = unsafe { sys::sarpro_hip_batch_dualpol_synrgb_u16_dev(self.ctx, descs.as_mut_ptr(), descs.len(), rows, cols, in_pitch,
+            strategy as c_int, mode as c_int, rgb_pitch_px, lanes as c_int, continue_on_error as c_int, &mut rep) };
+        if rc != sys::SARPRO_HIP_OK && !continue_on_error { return Err(Self::err(self.ctx, rc)); }
+        let route = |r: c_int| match r { 0 => SceneRoute::Accepted, 1 => SceneRoute::Refuted, 2 => SceneRoute::Unproven, 3 => SceneRoute::PoolOverflow, _ => SceneRoute::NotSpeculative };
+        Ok((BatchReport { processed: rep.processed, skipped: rep.skipped, errors: rep.errors }, descs.iter().map(|d| (d.status as i32, route(d.route))).collect()))
+    }
+}
+
 /// `process_directory_to_path`'s hot loop (api/mod.rs:474-536) for scenes already decoded to u16 DN: `workers_per_device` host
 /// threads (0 = the library's default, 2: scene i's download beside scene i + 1's upload), each with a context of its own, per listed
 /// device; scenes dealt dynamically.  `out[i]` receives scene i's RGB (`final_rows * final_cols * 3`).

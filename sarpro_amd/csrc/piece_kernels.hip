@@ -16,7 +16,14 @@ constexpr int kPBlock = 1024, kPWaves = 16;
 // an address).  A band of a few distinct low amplitudes (cross-pol over open water: most samples on five or ten DN values) otherwise
 // sends a whole wave's adds to a handful of LDS words, which serialise: 1.34 ms instead of 0.31 for the pass on a scene whose VH
 // band holds DN 1..10 only; eight lane-selected copies (the first form of this) left 0.72.  The copies are summed on publish.
-constexpr uint32_t kLowBins = 128, kLowReps = 64, kLowStride = kLowBins + 1, kLowWords = kLowReps * kLowStride; // words per band
+#ifndef SARPRO_PIECE_LOWBINS
+#define SARPRO_PIECE_LOWBINS 64
+#endif
+// LDS footprint (round 5): 2 x 8256 shared bins + 2 x 64 lanes x 65 low words + the tail queue = 104 KiB (rounds 2-4: 144 KiB with 128
+// low bins per lane).  What is left of the CU's 160 KiB lets the chain's short kernels (statistics: 48 KiB, tile bins, CDFs, sample,
+// prediction) start beside this pass when another lane of a resident batch has them queued, instead of behind it.  The pass itself
+// runs the same with 32, 64 or 128 low bins per lane (0.295-0.300 ms).
+constexpr uint32_t kLowBins = SARPRO_PIECE_LOWBINS, kLowReps = 64, kLowStride = kLowBins + 1, kLowWords = kLowReps * kLowStride; // words per band
 // LDS atomics through the address-space-3 pointer (the HIP overloads take generic pointers)
 #define LDS_ADD(off, v) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)(off)), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 // The bright tail (DN >= the LDS bins: point targets, one sample in 10^4 on a GRD scene) goes to the tile's GLOBAL histogram.  Round 5: not
@@ -27,7 +34,10 @@ constexpr uint32_t kLowBins = 128, kLowReps = 64, kLowStride = kLowBins + 1, kLo
 // workgroup publishes its tile; the row loop holds no vector-memory instruction but its loads and waits with counted vmcnt.  A lane
 // that finds the queue full (a raster that is mostly brighter than the LDS bins) stops queueing for the rest of the piece and
 // recounts its tail samples from that band-row on in a second loop behind the first: slower, never wrong.
-constexpr uint32_t kTailCap = 4096;
+#ifndef SARPRO_PIECE_TAILCAP
+#define SARPRO_PIECE_TAILCAP 1024
+#endif
+constexpr uint32_t kTailCap = SARPRO_PIECE_TAILCAP;
 #ifndef SARPRO_PIECE_AHEAD
 #define SARPRO_PIECE_AHEAD 1 // rows of both bands in flight per wave beyond the one being counted (1, 2, 3, 4 measured: 0.300, 0.312, 0.311, 0.313 ms)
 #endif

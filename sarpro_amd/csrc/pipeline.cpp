@@ -11,7 +11,9 @@
 // its H fills the compute units F's workgroups leave.  Both sweeps own whole compute units (F: 160 KiB of LDS and 128 VGPRs x 1024
 // threads; H: 144 KiB), so they never share one: the lanes hide S, the launch gaps and the tails, not H behind F.  Measured on the
 // nine-scene cycle at 400 MP (profiles/r5/pipe_sweep.txt): one stream 1.034 ms per scene, 2 lanes 0.962, 3 lanes 0.958-0.963, 4 lanes
-// 1.006.  PIPE_ORDER = 1 chains the F passes by events (F of scene i + 1 waits for F of scene i): 0.969-0.974, no better than the free
+// 1.006 (round 5's last build, another box: 0.980 / 0.964 / 0.988 for 2 / 3 / 4 lanes).  Leaving eight compute units free of F
+// (RGB_GRID = 248) so that the other lanes' short kernels need not wait for F's tail measured 0.965-0.980 against 0.963-0.967: not kept.
+// PIPE_ORDER = 1 chains the F passes by events (F of scene i + 1 waits for F of scene i): 0.969-0.974, no better than the free
 // run (default 0).  RGB_GRID / PIECE_GRID (planner attributes) size the two sweeps' persistent grids: giving F and H disjoint sets
 // of compute units (RGB_GRID + PIECE_GRID = 256) so that they run side by side was measured too and lost -- 1.12 ms at 192 + 64,
 // 1.35 at 208 + 48, 1.54 at 224 + 32: H on a quarter of the chip cannot pull its 1.6 GB in the time F needs.
