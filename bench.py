@@ -944,37 +944,73 @@ def secondary_records(torch, dev, rows, cols):
     ctx.close()
     cp.close()
     del o16, ratio
-    # (3b) what ONE rank of an 8-rank row-stripe run executes (BASELINE config 4), minus the wire: the single-call stripe chain on an
-    # interior 2500-row stripe of scene A over a 1-rank RCCL communicator (all five all-reduces are issued; with one rank they move
-    # nothing).  The DN histogram is the stripe's only, so the raster is not the scene's -- this is a TIMING model of the serial term
-    # of DESIGN section 7; the N-rank rasters are checked in tests/test_gpu_full_size_oracle.py through the in-process communicator.
-    # No scaling curve can be measured on a one-GPU box: this record is what stands in for it.
+    # (3b) what ONE rank of an 8-rank row-stripe run executes (BASELINE config 4), timed alone on this GPU.  First the real thing: eight
+    # contexts + host threads joined by the in-process communicator run the single-call stripe chain on the eight 2500-row stripes of
+    # scene A (the accepted fused route, as tests/test_gpu_full_size_oracle.py checks against the oracle), with COMM_RECORD on rank 3:
+    # it keeps the RESULT of each of its six all-reduces.  Then rank 3 runs the same call ALONE with COMM_REPLAY: every all-reduce is
+    # answered from the recorded sums (one device copy), so the rank executes exactly the chain it executed among eight -- the scene's
+    # histograms, proof, prediction, verdict -- without seven neighbours sharing the GPU.  What is missing is the wire (five small
+    # xGMI all-reduces, section 7 of DESIGN.md prices them); no scaling curve can be measured on a one-GPU box.
     try:
-        cs = sarpro_amd.Context(dev.index, timing=True)
+        import threading
+        nr = 8
+        r0s, nrs = sarpro_amd.host_stripe_plan(rows, nr)
+        group = sarpro_amd.LocalGroup(nr)
+        cr = [sarpro_amd.Context(dev.index, timing=(k == 3)) for k in range(nr)]
         try:
-            cs.comm_init(1, 0, sarpro_amd.comm_unique_id())
-            r0s, nrs = sarpro_amd.host_stripe_plan(rows, 8)
-            r0, nr = int(r0s[3]), int(nrs[3])
-            rgb_s = torch.empty((nr, pitch * 3), dtype=torch.uint8, device=dev)
+            for k, c_ in enumerate(cr):
+                c_.comm_init_local(group, k)
+            rgb_s = torch.empty((rows, pitch * 3), dtype=torch.uint8, device=dev)
+            errs = []
+
+            def rank_call(k):
+                try:
+                    r0, nrw = int(r0s[k]), int(nrs[k])
+                    cr[k].stripe_run_u16(band[0].data_ptr() + r0 * pitch * 2, band[1].data_ptr() + r0 * pitch * 2, rows, cols, r0, nrw, pitch, St.Clahe, Mode.Default,
+                                         rgb_s.data_ptr() + r0 * pitch * 3, pitch)
+                except Exception as e:
+                    errs.append(f"rank {k}: {e}")
+
+            def all_ranks():
+                ths = [threading.Thread(target=rank_call, args=(k,)) for k in range(nr)]
+                [x.start() for x in ths]
+                [x.join() for x in ths]
+            torch.cuda.synchronize()
+            all_ranks()                      # plans, workspaces
+            cr[3].set_attr("COMM_RECORD", 1)
+            all_ranks()                      # the recorded run
+            if errs:
+                raise RuntimeError("; ".join(errs))
+            route8 = cr[3].spec_report()["outcome"]
+            cr[3].reset_attr("COMM_RECORD")
+            for c_ in cr:
+                c_.comm_destroy()
+            cs = cr[3]
+            cs.set_attr("COMM_REPLAY", 1)
+            r0, nrw = int(r0s[3]), int(nrs[3])
 
             def stripe_call():
-                cs.stripe_run_u16(band[0].data_ptr() + r0 * pitch * 2, band[1].data_ptr() + r0 * pitch * 2, rows, cols, r0, nr, pitch, St.Clahe, Mode.Default,
-                                  rgb_s.data_ptr(), pitch)
+                cs.stripe_run_u16(band[0].data_ptr() + r0 * pitch * 2, band[1].data_ptr() + r0 * pitch * 2, rows, cols, r0, nrw, pitch, St.Clahe, Mode.Default,
+                                  rgb_s.data_ptr() + r0 * pitch * 3, pitch)
             ms = timed(stripe_call, n=10, warm=3)
             kt = {}
             for k, v in cs.last_kernel_times():
                 if not k.startswith("host:"):
                     kt[k] = round(kt.get(k, 0.0) + v, 4)
             sweeps = sum(v for k, v in kt.items() if k in ("dn_hist_u16", "clahe_rgb_fused", "clahe_sample"))
-            out["stripe_rank_model"] = {"what": f"one rank of 8: rows [{r0}, {r0 + nr}) of the {rows}x{cols} scene through sarpro_hip_stripe_run_u16 over a 1-rank RCCL "
-                                                "communicator (the chain a rank of an 8-GPU stripe run executes, its five all-reduces issued but moving nothing); a timing "
-                                                "model, not a raster", "ms_per_call": round(ms, 4), "kernels_ms": kt,
+            out["stripe_rank_model"] = {"what": f"one rank of 8, alone on the GPU: rows [{r0}, {r0 + nrw}) of the {rows}x{cols} scene through sarpro_hip_stripe_run_u16, its six all-reduces "
+                                                "answered from the sums recorded in a real 8-rank run of the same scene (COMM_RECORD / COMM_REPLAY, in-process communicator): the chain a "
+                                                "rank of an 8-GPU stripe run executes, minus the wire",
+                                        "route_in_the_8_rank_run": route8, "route_replayed": cs.spec_report()["outcome"],
+                                        "ms_per_call_with_timing_events": round(ms, 4), "kernels_ms": kt,
                                         "sweeps_ms": round(sweeps, 4), "serial_term_ms": round(sum(kt.values()) - sweeps, 4),
-                                        "note": "sweeps_ms scales with 1/N; serial_term_ms (statistics, tables, CDFs, prediction, verdict, all-reduce launches) does not; "
-                                                "no multi-GPU node was available to measure the curve itself"}
+                                        "note": "sweeps_ms scales with 1/N; serial_term_ms (statistics, tables, CDFs, prediction, verdict, the replayed all-reduces' copies, gated launches) does "
+                                                "not; an event pair per kernel adds ~10 us each to ms_per_call; no multi-GPU node was available to measure the curve itself"}
             del rgb_s
         finally:
-            cs.close()
+            for c_ in cr:
+                c_.close()
+            group.close()
     except Exception as e:
         out["stripe_rank_model"] = {"error": f"{type(e).__name__}: {e}"}
     # (4) several scenes in flight on the one GPU: one context (own stream, own workspaces) and one host thread per scene, as the batch

@@ -536,6 +536,11 @@ class Context:
         self._chk(lib.sarpro_hip_comm_init_local(self._h, group._h, rank))
         self._group = group  # (keeps the group alive as long as the context)
 
+    def comm_destroy(self):
+        """Leave the communicator (sarpro_hip_comm_destroy); an in-process group itself belongs to its creator."""
+        lib.sarpro_hip_comm_destroy(self._h)
+        self._group = None
+
     def comm_allreduce_sum_u64(self, d_buf: int, count: int):
         self._chk(lib.sarpro_hip_comm_allreduce_sum_u64(self._h, _vp(d_buf), count))
 

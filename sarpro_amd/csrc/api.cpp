@@ -200,6 +200,7 @@ extern "C" void sarpro_hip_ctx_destroy(sarpro_hip_ctx *ctx) {
     ctx->lanes.clear();
     (void)hipSetDevice(ctx->device);
     for (hipEvent_t ev : ctx->pipe_events) (void)hipEventDestroy(ev);
+    sarpro::comm_saved_release(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     sarpro_hip_comm_destroy(ctx);
     for (auto &kv : ctx->plans) {
@@ -2144,7 +2145,8 @@ namespace sarpro {
 static int stripe_run_u16_impl(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total,
                                size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
                                uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out) {
-    if (!ctx->comm && !ctx->local_group) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no communicator on this context (sarpro_hip_comm_init / _init_local)");
+    if (!ctx->comm && !ctx->local_group && !ctx->attrs.on(A_COMM_REPLAY)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no communicator on this context (sarpro_hip_comm_init / _init_local)");
+    comm_replay_rewind(ctx);
     if ((!d_band1 || !d_band2 || !d_rgb) && rows_local * cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster");
     if (rgb_pitch_px < cols || in_pitch < cols) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "pitch < cols");
     const bool empty = rows_local == 0 || cols == 0;

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and enums from RCCL's own header (the library itself is dlopen'ed: no link dependency)
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -175,9 +176,44 @@ void comm_abort_local_group(sarpro_hip_ctx *ctx) {
     if (ctx && ctx->local_group) ctx->local_group->abort();
 }
 
+// Record / replay (a measurement aid, bench.py `stripe_rank_model`).  COMM_RECORD = 1 on a rank of a real N-rank run keeps a copy of
+// every all-reduce RESULT of its stripe call; COMM_REPLAY = 1 on the same context afterwards answers the all-reduces of an identical
+// call from those copies (one device copy each, no communicator involved).  The context then executes, alone on its GPU, exactly the
+// chain a rank of the N-rank run executed -- the scene's histograms, proofs, predictions and verdicts -- so that the per-rank cost of
+// stripe mode can be timed where no second GPU exists.
+void comm_replay_rewind(sarpro_hip_ctx *ctx) {
+    ctx->comm_replay_pos = 0;
+    if (ctx->attrs.on(A_COMM_RECORD)) { for (DevBuf *b : ctx->comm_saved) delete b; ctx->comm_saved.clear(); }
+}
+void comm_saved_release(sarpro_hip_ctx *ctx) { for (DevBuf *b : ctx->comm_saved) delete b; ctx->comm_saved.clear(); }
+
 // all-reduce(sum, u64) enqueued on the context's stream, no host synchronisation (the stripe chain keeps
 // running on the stream behind it)
+static int comm_allreduce_sum_u64_async_raw(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);
 int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count) {
+    const size_t bytes = count * sizeof(uint64_t);
+    if (ctx->attrs.on(A_COMM_REPLAY)) {
+        if (ctx->comm_replay_pos >= ctx->comm_saved.size() || ctx->comm_saved[ctx->comm_replay_pos]->cap != std::max<size_t>(bytes, 8)) {
+            ctx->err = "COMM_REPLAY: this call's all-reduces differ from the recorded ones";
+            return SARPRO_HIP_ERR_INVALID_ARG;
+        }
+        DevBuf *b = ctx->comm_saved[ctx->comm_replay_pos++];
+        if (bytes && hipMemcpyAsync(d_buf, b->p, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = "COMM_REPLAY: copy failed"; return SARPRO_HIP_ERR_HIP; }
+        return SARPRO_HIP_OK;
+    }
+    const int rc = comm_allreduce_sum_u64_async_raw(ctx, d_buf, count);
+    if (rc == SARPRO_HIP_OK && ctx->attrs.on(A_COMM_RECORD)) {
+        DevBuf *b = new DevBuf();
+        if (b->reserve(std::max<size_t>(bytes, 8)) != hipSuccess || (bytes && hipMemcpyAsync(b->p, d_buf, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)) {
+            delete b;
+            ctx->err = "COMM_RECORD: out of device memory";
+            return SARPRO_HIP_ERR_OOM;
+        }
+        ctx->comm_saved.push_back(b);
+    }
+    return rc;
+}
+static int comm_allreduce_sum_u64_async_raw(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count) {
     if (ctx->local_group) return (d_buf || !count) ? local_allreduce_sum_u64(ctx, d_buf, count) : SARPRO_HIP_ERR_INVALID_ARG;
     if (!ctx->comm) { ctx->err = "communicator not initialised"; return SARPRO_HIP_ERR_INVALID_ARG; }
     if (!count) return SARPRO_HIP_OK;

@@ -176,7 +176,7 @@ struct BandWorker {
     X(STRIP_ALIGN) X(PIECE_ALIGN) X(CHUNK_ROWS) X(RGB_ITEM_ROWS) X(SAMPLE_ITEM_ROWS) \
     X(NO_MAILBOX) X(NO_STEP_ESTIMATE) X(F32_ZONES) X(F32_ZONES_DEBUG) X(F32_DIRECT) X(F32_DIRECT_QCAP) X(F32_LEVEL_GENERAL) \
     X(F32_LEVEL_TABLE) X(F32_LEVEL_QCAP) X(F32_HOST_CDFS) X(F32_NO_VEC8) X(NO_BAND_TWIN) X(RESIZE_GENERIC) X(NO_RESIZE_LUT) \
-    X(NO_U16_CF) X(U16_ITEM_ROWS) X(PIPE_LANES) X(PIPE_ORDER) X(RGB_GRID) X(PIECE_GRID)
+    X(NO_U16_CF) X(U16_ITEM_ROWS) X(PIPE_LANES) X(PIPE_ORDER) X(RGB_GRID) X(PIECE_GRID) X(COMM_RECORD) X(COMM_REPLAY)
 namespace sarpro {
 enum Attr : int {
 #define X(n) A_##n,
@@ -272,4 +272,8 @@ struct sarpro_hip_ctx {
     int comm_nranks = 0, comm_rank = 0;
     struct sarpro_hip_local_group *local_group = nullptr; // the in-process communicator (comm.cpp), instead of RCCL: `comm` stays null
     sarpro::DevBuf local_tmp;                              // ... its rank-private sum buffer
+    // measurement aid (bench.py `stripe_rank_model`, comm.cpp): the summed buffers of a stripe call's all-reduces, recorded on a rank of a
+    // real N-rank run (COMM_RECORD) and played back to the same context running alone (COMM_REPLAY)
+    std::vector<sarpro::DevBuf *> comm_saved;
+    size_t comm_replay_pos = 0;
 };

@@ -50,6 +50,8 @@ int band_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, si
 int bands_u8_table_dev(sarpro_hip_ctx *ctx, const uint16_t *const d_in[], int nb, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
                        ResizeLutSrc *out);
 int comm_allreduce_sum_u64_async(sarpro_hip_ctx *ctx, uint64_t *d_buf, size_t count);
+void comm_replay_rewind(sarpro_hip_ctx *ctx);   // start of a stripe call: COMM_REPLAY answers from the first recorded buffer again (COMM_RECORD: forget the old ones)
+void comm_saved_release(sarpro_hip_ctx *ctx);
 void comm_abort_local_group(sarpro_hip_ctx *ctx); // a rank of an in-process group failed outside a collective: release its peers (comm.cpp)
 // lut_src != nullptr: d_in is the u16 DN raster (in_pitch in u16 elements, elem_size 1 = the output's) and the horizontal pass reads
 // it through the table; returns kResizeLutUnsupported (nothing enqueued) when that form does not apply to this shape
