@@ -371,7 +371,7 @@ static void build_pieces(StripePlan *P, int grid) {
             constexpr size_t kCh = (size_t)kPieceChunk; // px per wave column
             size_t nch = (c1 - cstart + kCh - 1) / kCh, off = 0;
             while (nch > 0) {
-                int lg = 4;
+                int lg = kPieceWavesLog2;
                 while ((size_t(1) << lg) > nch) --lg;
                 const size_t gw = size_t(1) << lg;
                 Strip st{};
@@ -398,7 +398,7 @@ static void build_pieces(StripePlan *P, int grid) {
     double acc = 0.0;
     int k = 0;
     for (const Strip &st : strips) {
-        const int gy = 16 >> st.it.gx_log2;
+        const int gy = kPieceWaves >> st.it.gx_log2;
         int r = st.it.r0;
         while (r < st.it.r1) {
             int take = st.it.r1 - r;
@@ -675,6 +675,10 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
     // both bands' tile histograms in one allocation (band b at tile_hist_of(ctx, b, ntiles)): one fill instead of two
     const size_t band_bytes = sizeof(uint32_t) * 65536 * (size_t)ntiles;
     HIPCHK(ctx, ctx->tile_hist[0].reserve(band_bytes * kMaxBands));
+    if (begin && ctx->pipe_wait_before_hist) { // resident batch, PIPE_ORDER = 2: this scene's sweep beside the previous scene's fused pass, not before it
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_wait_before_hist, 0));
+        ctx->pipe_wait_before_hist = nullptr;
+    }
     if (begin) {
         // the chain's last reader of the tile histograms zeroes what it read: a scene that follows one of the same or a
         // larger footprint on this context starts on clean bins (the fill of 32 MiB and its launch: ~12 us)
@@ -699,7 +703,7 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
         DnHistPiecesArgs pa{};
         for (int b = 0; b < 2; ++b) { pa.in[b] = a.in[b]; pa.tile_hist[b] = a.tile_hist[b]; }
         pa.pitch = a.pitch; pa.items = J.plan->d_piece_items.as<PieceItem>(); pa.wg_first = J.plan->d_piece_first.as<int32_t>();
-        pa.lds_bins = a.lds_bins;
+        pa.lds_bins = kPieceLdsBins;
         KernelTimer t(ctx, "dn_hist_u16");
         HIPCHK(ctx, launch_dn_hist_pieces(pa, J.plan->piece_grid, ctx->stream));
     } else if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !ctx->attrs.on(A_NO_LINEAR_HIST)) {
@@ -1043,7 +1047,8 @@ static int job_phase4(U16Job &J, void *const d_out[kMaxBands], size_t out_pitch,
 // ---------------------------------------------------------------------------------------
 constexpr size_t kChainOffDb = 0, kChainOffSupp = 65536 * 8, kChainOffBlue = kChainOffSupp + 21504;
 constexpr size_t kChainOffBlueDef = kChainOffBlue + 65536, kChainOffDefRg = kChainOffBlueDef + 65536;
-constexpr size_t kChainOffGamma = kChainOffDefRg + 512, kChainConstBytes = kChainOffGamma + 3 * 256 * 8;
+constexpr size_t kChainOffGamma = kChainOffDefRg + 512, kChainOffBluePQ = kChainOffGamma + 3 * 256 * 8, kChainConstBytes = kChainOffBluePQ + 512 * 4;
+constexpr size_t kTablesOffPQ = 66048 + 512, kTablesBytes = kTablesOffPQ + 2 * 256 * 4; // compose tables | per-band maps | Pv[256] f32 | Qv[256] f32 (the blue factors by LEVEL)
 constexpr size_t kStateOffResc = 2 * sizeof(ChainBandState), kStateOffIdent = kStateOffResc + 512,
                  kStateOffFloor = kStateOffIdent + 16, kStateBytes = kStateOffFloor + 16;
 
@@ -1060,6 +1065,10 @@ static int chain_prepare(sarpro_hip_ctx *ctx) {
     synrgb_luts_default(dflt.data());
     HIPCHK(ctx, hipMemcpyAsync(d + kChainOffDefRg, dflt.data(), 512, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d + kChainOffGamma, gamma_level_thresholds_u8(), 3 * 256 * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (const float *pq = synrgb_blue_factors_supp()) { // the suppressed blue as a product of two factors (verified against the pair table for all pairs)
+        HIPCHK(ctx, hipMemcpyAsync(d + kChainOffBluePQ, pq, 512 * 4, hipMemcpyHostToDevice, ctx->stream));
+        ctx->blue_factors_ok = true;
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->chain_ready = true;
     return SARPRO_HIP_OK;
@@ -1159,6 +1168,8 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         pa.tables = ctx->tables.as<uint8_t>();
         pa.supp_rg = consts + kChainOffSupp; pa.blue_pair_supp = consts + kChainOffBlue;
         pa.force = spec_force_flags(ctx);
+        pa.blue_pq = ctx->blue_factors_ok ? reinterpret_cast<const float *>(consts + kChainOffBluePQ) : nullptr;
+        pa.blue_by_level = reinterpret_cast<float *>(ctx->tables.as<uint8_t>() + kTablesOffPQ);
         KernelTimer t(ctx, "chain_predict");
         HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
     }
@@ -1166,6 +1177,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         // resident batch (pipeline.cpp): this scene's pass behind the previous scene's pass (another lane's stream), its own completion
         // published for the next one -- the passes own whole compute units (160 KiB of LDS each), two of them at once only split the chip
         if (ctx->pipe_wait_before_fused) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_wait_before_fused, 0));
+        if (ctx->pipe_record_before_fused) { HIPCHK(ctx, hipEventRecord(ctx->pipe_record_before_fused, ctx->stream)); ctx->pipe_record_before_fused = nullptr; }
         int grid = std::max(ctx->cu_count, 1);
         if (ctx->attrs.is_set(A_RGB_GRID)) grid = (int)std::min<long long>(1024, std::max<long long>(1, ctx->attrs.val(A_RGB_GRID, grid)));
         {
@@ -1223,7 +1235,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     HIPCHK(ctx, ctx->cdfs.reserve(sizeof(double) * 64 * 256 * kMaxBands));
     // [kSampleReplicas][2][256]: the apply / sampling pass's histogram (replica 0 alone unless it is sampled); then [2][256]: the gated recount
     HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands * (kSampleReplicas + 1)));
-    HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
+    HIPCHK(ctx, ctx->tables.reserve(kTablesBytes));
     HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
     uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
     ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);
@@ -1303,6 +1315,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         fa.rects = J.plan->d_rgb_rects.as<Rect>(); fa.nrects = (int)J.plan->rgb_rects.size();
         fa.row_w = J.plan->d_row_w.as<RowWeight>(); fa.col_w = J.plan->d_col_w.as<RowWeight>(); fa.row_off = (int32_t)J.row0;
         fa.dev_state = d_state; fa.spec = d_spec; fa.tables = ctx->tables.as<uint8_t>();
+        fa.blue_by_level = ctx->blue_factors_ok ? reinterpret_cast<const float *>(ctx->tables.as<uint8_t>() + kTablesOffPQ) : nullptr;
         fa.sat_ok = J.plan->sat_ok ? 1u : 0u; fa.sat_col = J.plan->d_sat_col.as<uint8_t>(); fa.sat_row = J.plan->d_sat_row.as<uint8_t>() + J.row0; // (the table is indexed by the scene's row, the kernel by the stripe's)
         fa.sat_cols = (uint32_t)(round_up(J.cols, 64) + 64);
         // the sample-only pass costs ~0.025 ms + (apply pass) / stride: 0.056 ms at 17, 0.033 at 33; the wider stride's larger sigma (x 1.4: ~2.4 %
@@ -1491,7 +1504,7 @@ static int job_run_chain_levels(U16Job &J, void *const d_out[kMaxBands], size_t 
     RETCHK(chain_prepare(ctx));
     HIPCHK(ctx, ctx->luts.reserve(2 * 131072));
     HIPCHK(ctx, ctx->level_hist.reserve(sizeof(uint64_t) * 256 * kMaxBands));
-    HIPCHK(ctx, ctx->tables.reserve(66048 + 512));
+    HIPCHK(ctx, ctx->tables.reserve(kTablesBytes));
     HIPCHK(ctx, ctx->h_small.reserve(sizeof(uint64_t) * 64 * 256 * kMaxBands + sizeof(uint64_t) * 256 * kMaxBands));
     uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
     ChainBandState *d_state = reinterpret_cast<ChainBandState *>(state);

@@ -88,6 +88,8 @@ struct ChainPredictArgs {
     const uint8_t *supp_rg;                // [41][512]
     const uint8_t *blue_pair_supp;         // [256][256]
     uint32_t force;                        // kSpecForce*
+    const float *blue_pq;                  // P[256] | Q[256] (host-built, verified) or null
+    float *blue_by_level;                  // out: Pv[256] | Qv[256] with Pv[v] = P[R2[v]], Qv[v] = Q[G2[v]] (the fused pass's LITE form reads these instead of B2)
 };
 hipError_t launch_chain_predict(const ChainPredictArgs &a, hipStream_t s);
 hipError_t launch_level_hist_if_flagged(const LevelRecountArgs &a, int nbands, hipStream_t s);

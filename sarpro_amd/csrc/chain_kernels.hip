@@ -638,8 +638,10 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
     const uint8_t *lut_r = a.supp_rg + (size_t)fwc * 512, *lut_g = lut_r + 256;
     uint8_t *R2 = a.tables, *G2 = a.tables + 256, *B2 = a.tables + 512;
     if (blockIdx.x == 0 && t < 256) {
-        R2[t] = t <= fwc ? 0 : lut_r[t];
-        G2[t] = t <= fwc ? 0 : lut_g[t];
+        const uint8_t r = t <= fwc ? 0 : lut_r[t], g = t <= fwc ? 0 : lut_g[t];
+        R2[t] = r;
+        G2[t] = g;
+        if (a.blue_pq && a.blue_by_level) { a.blue_by_level[t] = a.blue_pq[r]; a.blue_by_level[256 + t] = a.blue_pq[256 + g]; }
     }
     for (int i = blockIdx.x * kStatsBlock + t; i < 65536; i += gridDim.x * kStatsBlock) {
         const int r1 = i >> 8, r2 = i & 255;

@@ -229,6 +229,7 @@ struct sarpro_hip_ctx {
     sarpro::DevBuf chain_scratch;               // statistics step: per-slice partials | 4096 bins per band
     sarpro::DevBuf chain_state;                  // ChainBandState[2] | resc[2][256] | identity[2] | floor
     bool chain_ready = false;
+    bool blue_factors_ok = false;                // chain_consts holds the verified blue factor tables (host_logic: synrgb_blue_factors_supp)
     uint32_t chain_levels_cap = 4096;            // LDS bytes per band of the fused pass's DN tables (percentile chain)
     uint32_t chain_lut_cap = 4096;               // LDS capacity (entries) of the apply kernel's offset table
     // pinned host mirrors
@@ -252,6 +253,8 @@ struct sarpro_hip_ctx {
     std::vector<hipEvent_t> pipe_events;
     hipEvent_t pipe_wait_before_fused = nullptr; // (on a lane, for ONE scene) the fused pass waits for this event ...
     hipEvent_t pipe_record_after_fused = nullptr; // ... and records this one behind itself
+    hipEvent_t pipe_wait_before_hist = nullptr;   // PIPE_ORDER = 2: the scene's histogram pass waits for this event (the previous scene's fused pass is about to start) ...
+    hipEvent_t pipe_record_before_fused = nullptr; // ... and the scene records this one in front of its own fused pass
     std::vector<std::pair<const char *, float>> lane_times;
     bool spec_ran = false;                       // the last u16 chain of this context took the speculative route (spec_state is that scene's)
     sarpro::PinnedBuf pipe_routes;               // ChainSpecState of every scene of the last batch (host copies)

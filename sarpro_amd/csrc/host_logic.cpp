@@ -464,6 +464,31 @@ void synrgb_luts_suppressed(int fwc, uint8_t *luts) {
 }
 
 const uint8_t *synrgb_blue_pair_supp() { return blue_pair_table(false); }
+
+// The suppressed variant's blue as a PRODUCT (synthetic_rgb.rs:139-151): round(powf((r + 8) / (g + 8), 0.1) * 255 * 0.18) takes the values
+// 32..65 only, and round-to-nearest of the f32 product P[r] * Q[g] with P[r] = f32(45.9 (r + 8)^0.1), Q[g] = f32((g + 8)^-0.1) equals the
+// reference's table entry for ALL 65 536 (r, g) pairs -- checked here against blue_pair_table, entry by entry, every time the tables
+// are built (the nearest a product comes to a rounding boundary is 1.4e-6, three f32 steps).  Returns nullptr when the check fails
+// (another libm): the fused pass then keeps its 64-KB pair table.  out: P[256] | Q[256].
+const float *synrgb_blue_factors_supp() {
+    static float tab[512];
+    static bool ok = false;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (unsigned i = 0; i < 256; ++i) {
+            tab[i] = (float)(45.9 * std::pow((double)i + 8.0, 0.1));
+            tab[256 + i] = (float)std::pow((double)i + 8.0, -0.1);
+        }
+        const uint8_t *pair = blue_pair_table(false);
+        ok = true;
+        for (unsigned r = 0; r < 256 && ok; ++r)
+            for (unsigned g = 0; g < 256; ++g) {
+                const float prod = tab[r] * tab[256 + g];
+                if ((unsigned)std::nearbyintf(prod) != pair[(r << 8) | g]) { ok = false; break; } // (default rounding mode: to nearest even, as v_cvt_pk_u8_f32)
+            }
+    });
+    return ok ? tab : nullptr;
+}
 const uint8_t *synrgb_blue_pair_default() { return blue_pair_table(true); }
 
 const double *gamma_level_thresholds_u8() {

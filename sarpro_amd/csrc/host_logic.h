@@ -86,6 +86,7 @@ int stripe_plan(size_t rows, int nranks, size_t *row0, size_t *nrows);
 // constant tables the device-resident chain uploads once (chain_kernels.hip)
 const uint8_t *synrgb_supp_rg_tables(); // [41][512]: suppressed lut_r | lut_g for floor_with_cushion = 0..40
 const uint8_t *synrgb_blue_pair_supp(); // [256][256]: blue of the suppressed variant per (r, g) pair
+const float *synrgb_blue_factors_supp(); // P[256] | Q[256]: that table as rne(P[r] * Q[g]), verified for all pairs; nullptr when the check fails
 const uint8_t *synrgb_blue_pair_default(); // [256][256]: blue of the default variant per (r, g) pair
 // [3][256] doubles for gamma = 0.8, 0.9, 1.1: thr[k] = smallest x in [0,1] with trunc(clamp(pow(x, gamma) * 255)) >= k
 // (autoscale.rs:441-442 / 650-651 at max_val 255); thr[0] = 0.  Found with glibc pow by bisection over doubles.

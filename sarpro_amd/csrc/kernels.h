@@ -124,6 +124,7 @@ struct ClaheRgbArgs {
     // f64 -- a function of the pixel's row and column alone.  sat_col[c]: which of the (at most three) values T = fl((1 - dx) + dx)
     // column c produces; sat_row[r]: bit k set = a saturated pixel of row r in a column of class k gets level 255 (else 254).
     const uint8_t *sat_col, *sat_row;   // [cols rounded up to the pitch], [rows]; host-built with the plan (api.cpp)
+    const float *blue_by_level;         // Pv[256] | Qv[256] (k_chain_predict) or null: the LITE form's blue = rne(Pv[level1] * Qv[level2]), 0 for water
     uint32_t no_verdict;                // a row stripe: the counts are summed over the ranks first, launch_spec_verdict takes the verdict
     uint32_t sat_cols;                  // entries of sat_col
     uint32_t sat_ok;                    // 0: tables absent (the geometry produced more than three classes): such pixels take the exact path

@@ -1441,9 +1441,18 @@ static_assert(kRgbB2Stride == 256 || kRgbB2Stride == 260, "blue table rows: 256 
 #endif
 constexpr int kRgbBlock = SARPRO_RGB_BLOCK, kRgbWaves = kRgbBlock / kWave;
 constexpr uint32_t kRgbPoolEntries = SARPRO_RGB_POOL;
+// SARPRO_RGB_LITE (round 5 experiment): no blue table in LDS.  The suppressed variant's blue is rne(Pv[level1] * Qv[level2]) -- two
+// 256-entry f32 tables by LEVEL that k_chain_predict derives from the host's verified factors (host_logic: synrgb_blue_factors_supp) --
+// and 0 for water (both levels <= floor + cushion): 2.5 KB of tables instead of 67, so that the pass leaves LDS for other workgroups
+// on its compute unit.
+#ifdef SARPRO_RGB_LITE
+constexpr uint32_t kRgbTableBytes = 512 + 2048;                             // R2[256] | G2[256] | Pv[256] f32 | Qv[256] f32
+#else
+constexpr uint32_t kRgbTableBytes = 512 + 256 * kRgbB2Stride;
+#endif
 struct RgbLds {
-    static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[256][kRgbB2Stride]
-    static constexpr uint32_t stage = 512 + 256 * kRgbB2Stride;             // [16][1536] RGB of a wave-row | tmp32 [2][257] float4 while staging
+    static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[256][kRgbB2Stride]  (LITE: | Pv | Qv)
+    static constexpr uint32_t stage = kRgbTableBytes;                       // [16][1536] RGB of a wave-row | tmp32 [2][257] float4 while staging
     static constexpr uint32_t cdf64 = stage + kRgbWaves * 1536;             // [2][257][4] double
     static constexpr uint32_t colw = cdf64 + 2 * 257 * 32;                  // [512] double
     static constexpr uint32_t binof = colw + 512 * 8;                       // [kRgbPoolEntries] u8: CLAHE bin of the entry's DN
@@ -1481,10 +1490,18 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
     {   // compose tables, once per workgroup: R2 | G2 as they are, the blue table's 256-byte rows at their LDS stride
         const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables);
         for (int i = threadIdx.x; i < 512 / 4; i += kRgbBlock) LDS_AT(uint32_t, RgbLds::tables + 4 * i) = src[i];
+#ifdef SARPRO_RGB_LITE
+        const uint32_t *pq = reinterpret_cast<const uint32_t *>(a.blue_by_level);
+        for (int i = threadIdx.x; i < 512; i += kRgbBlock) LDS_AT(uint32_t, RgbLds::tables + 512 + 4 * i) = pq[i];
+#else
         for (int i = threadIdx.x; i < 65536 / 4; i += kRgbBlock)
             LDS_AT(uint32_t, RgbLds::tables + 512 + (uint32_t)(i >> 6) * kRgbB2Stride + (uint32_t)(i & 63) * 4u) = src[128 + i];
+#endif
     }
     const uint32_t fpred = (uint32_t)sp->floor_pred;
+#ifdef SARPRO_RGB_LITE
+    const uint32_t fwc_lite = fpred + 3u < 40u ? fpred + 3u : 40u; // floor_with_cushion of the prediction (k_chain_predict's s_fwc)
+#endif
     const uint32_t t4[3] = {(fpred ? fpred - 1u : 0u) * 0x01010101u, fpred * 0x01010101u, (fpred + 1u) * 0x01010101u};
     uint32_t sad[3] = {0u, 0u, 0u}, n_all = 0u, n_kept = 0u; // this lane's |x - T| sums, level bytes seen (8 per band-row), kept ones
     const RowWeight *__restrict__ row_w = a.row_w + a.row_off;
@@ -1803,6 +1820,21 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                         // B2 index ((level1 << 8) | level2 from the two packed registers), the table bases in the instructions' offset
                         // fields; the 12 bytes are packed by v_lshl_or pairs (left to the compiler the same lines cost twice the VALU
                         // instructions: byte masks after zero-extending loads, multiply-adds for the pair index, three-step packing).
+#ifdef SARPRO_RGB_LITE
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t v1 = j == 0 ? (l1[g] & 0xFFu) : j == 3 ? (l1[g] >> 24) : __builtin_amdgcn_ubfe(l1[g], 8 * j, 8);
+                            const uint32_t v2 = j == 0 ? (l2[g] & 0xFFu) : j == 3 ? (l2[g] >> 24) : __builtin_amdgcn_ubfe(l2[g], 8 * j, 8);
+                            px[j][0] = LDS_AT(uint8_t, RgbLds::tables + v1);
+                            px[j][1] = LDS_AT(uint8_t, RgbLds::tables + 256 + v2);
+                            const float pv = LDS_AT(float, RgbLds::tables + 512 + 4u * v1), qv = LDS_AT(float, RgbLds::tables + 1536 + 4u * v2);
+                            const uint32_t blue = __builtin_amdgcn_cvt_pk_u8_f32(pv * qv, 0, 0u); // round to nearest even, as the host's check of the factors
+                            px[j][2] = max(v1, v2) <= fwc_lite ? 0u : blue;                       // water: both levels at or below floor + cushion (synthetic_rgb.rs:158-164)
+                        }
+                        o[3 * g + 0] = pack4(px[0][0], px[0][1], px[0][2], px[1][0]);
+                        o[3 * g + 1] = pack4(px[1][1], px[1][2], px[2][0], px[2][1]);
+                        o[3 * g + 2] = pack4(px[2][2], px[3][0], px[3][1], px[3][2]);
+#else
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const uint32_t v1 = j == 0 ? (l1[g] & 0xFFu) : j == 3 ? (l1[g] >> 24) : __builtin_amdgcn_ubfe(l1[g], 8 * j, 8);
@@ -1821,6 +1853,7 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                         o[3 * g + 0] = pack4(px[0][0], px[0][1], px[0][2], px[1][0]);
                         o[3 * g + 1] = pack4(px[1][1], px[1][2], px[2][0], px[2][1]);
                         o[3 * g + 2] = pack4(px[2][2], px[3][0], px[3][1], px[3][2]);
+#endif
 #endif
                     }
                     uint8_t *rowp = a.rgb + ((size_t)r * a.rgb_pitch_px + (size_t)rc.cstart) * 3;
@@ -2263,6 +2296,9 @@ hipError_t opt_in_dynamic_lds(const void *kernel) {
 }
 
 bool clahe_rgb_fused_supported(const ClaheRgbArgs &a) { // (nrects == 0: a rank whose stripe is empty -- nothing to launch, nothing to align)
+#ifdef SARPRO_RGB_LITE
+    if (!a.blue_by_level) return false;
+#endif
     return a.nrects >= 0 && a.spec && a.dev_state && a.in_pitch % 8 == 0 && a.rgb_pitch_px % 16 == 0 &&
            (a.nrects == 0 || ((reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 &&
                               (reinterpret_cast<uintptr_t>(a.rgb) & 15) == 0));

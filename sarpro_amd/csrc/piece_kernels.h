@@ -18,6 +18,18 @@ struct PieceItem {
 };
 static_assert(sizeof(PieceItem) == 48, "PieceItem layout");
 constexpr int kPieceMaxGrid = 1024;
+// threads of a workgroup of the piece histogram (1024: sixteen waves, one workgroup per CU; 512: eight waves, so that another
+// workgroup -- the fused pass of the previous scene -- fits beside it) and the DN range it keeps in LDS
+#ifndef SARPRO_PIECE_BLOCK
+#define SARPRO_PIECE_BLOCK 1024
+#endif
+#ifndef SARPRO_PIECE_BINS
+#define SARPRO_PIECE_BINS 8192
+#endif
+constexpr int kPieceBlock = SARPRO_PIECE_BLOCK, kPieceWaves = kPieceBlock / 64;
+constexpr int kPieceWavesLog2 = kPieceWaves == 16 ? 4 : 3;
+static_assert(kPieceWaves == 16 || kPieceWaves == 8, "piece histogram: 1024 or 512 threads");
+constexpr uint32_t kPieceLdsBins = SARPRO_PIECE_BINS;
 // samples per lane and band-row of the piece histogram; a wave column is 64 x kPieceVec px wide.  4 (8-byte loads) is the default:
 // the read-only piece traversal streams faster with 16 bytes per lane (6.1-6.3 TB/s against 5.6: profiles/r2/stream_bench.txt), but
 // the histogram pass with 8 samples per lane -- sixteen LDS adds per lane and row behind two loads -- ran at 0.39 ms against 0.32

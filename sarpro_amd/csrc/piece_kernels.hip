@@ -8,7 +8,7 @@ namespace sarpro {
 
 namespace {
 
-constexpr int kPBlock = 1024, kPWaves = 16;
+constexpr int kPBlock = kPieceBlock, kPWaves = kPieceWaves;
 // DN 1..kLowBins-1 are counted in the LANE'S OWN copy of those bins (round 5 layout: [band][lane][kLowStride = 129 words], so that a
 // sample's word is at DN * 4 + a per-lane constant -- the same multiply as the shared bins, one select instead of two -- and the word
 // of lane l for bin d lies on bank (l + d) mod 64: lanes that hold the same DN never meet on a bank; rounds 2-4: [band][DN][64 lanes], and

@@ -55,6 +55,8 @@ static int ensure_lanes(sarpro_hip_ctx *ctx, int lanes) {
         l->time_only = ctx->time_only;
         l->pipe_wait_before_fused = nullptr;
         l->pipe_record_after_fused = nullptr;
+        l->pipe_wait_before_hist = nullptr;
+        l->pipe_record_before_fused = nullptr;
     }
     return SARPRO_HIP_OK;
 }
@@ -78,8 +80,10 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
     lanes = (int)std::min<size_t>((size_t)lanes, nscenes);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (int rc = ensure_lanes(ctx, lanes)) return rc;
-    const bool chain_f = ctx->attrs.val(A_PIPE_ORDER, 0) != 0 && lanes > 1;
-    while (chain_f && ctx->pipe_events.size() < nscenes) {
+    const long long order = ctx->attrs.val(A_PIPE_ORDER, 0);
+    const bool chain_f = order != 0 && lanes > 1;
+    const bool pair_fh = order == 2 && lanes > 1; // scene i + 1's histogram pass starts when scene i's fused pass starts (and the fused passes follow each other)
+    while (chain_f && ctx->pipe_events.size() < (pair_fh ? 2 : 1) * nscenes) {
         hipEvent_t e;
         HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->pipe_events.push_back(e);
@@ -100,6 +104,10 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
             l->pipe_wait_before_fused = enq ? ctx->pipe_events[enq - 1] : nullptr;
             l->pipe_record_after_fused = ctx->pipe_events[enq];
         }
+        if (pair_fh) {
+            l->pipe_wait_before_hist = enq >= 2 ? ctx->pipe_events[nscenes + enq - 1] : nullptr; // (scene 1 starts at once: it has scene 0's whole chain to hide behind)
+            l->pipe_record_before_fused = ctx->pipe_events[nscenes + enq];
+        }
         const void *spec_before = l->spec_state.p;
         (void)spec_before;
         int rc = sarpro_hip_dualpol_synrgb_u16_dev(l, sc.d_band1, sc.d_band2, rows, cols, in_pitch, strategy, mode, sc.d_rgb, rgb_pitch_px,
@@ -107,8 +115,11 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
         if (chain_f) {
             // a scene whose chain never reached the fused pass (another route, an error) still releases its successor
             if (l->pipe_record_after_fused) (void)hipEventRecord(l->pipe_record_after_fused, l->stream);
+            if (l->pipe_record_before_fused) (void)hipEventRecord(l->pipe_record_before_fused, l->stream);
             l->pipe_wait_before_fused = nullptr;
             l->pipe_record_after_fused = nullptr;
+            l->pipe_wait_before_hist = nullptr;
+            l->pipe_record_before_fused = nullptr;
         }
         if (rc == SARPRO_HIP_OK && strategy == SARPRO_STRATEGY_CLAHE && l->spec_state.p && l->spec_ran) {
             // the scene's verdict, copied out in stream order (the next scene of this lane overwrites the state)
