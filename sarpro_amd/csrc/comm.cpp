@@ -94,6 +94,7 @@ struct sarpro_hip_local_group {
     std::condition_variable cv;
     int arrived = 0;
     unsigned long long generation = 0;
+    std::vector<int> devices;           // the device of each rank that has joined (-1: not yet)
     std::vector<const uint64_t *> bufs; // the ranks' device buffers of the collective in flight
     std::vector<size_t> counts;
     bool mismatch = false;
@@ -118,6 +119,7 @@ extern "C" int sarpro_hip_local_group_create(int nranks, sarpro_hip_local_group 
     sarpro_hip_local_group *g = new (std::nothrow) sarpro_hip_local_group();
     if (!g) return SARPRO_HIP_ERR_OOM;
     g->nranks = nranks;
+    g->devices.assign((size_t)nranks, -1);
     g->bufs.assign((size_t)nranks, nullptr);
     g->counts.assign((size_t)nranks, 0);
     *out = g;
@@ -128,6 +130,24 @@ extern "C" void sarpro_hip_local_group_destroy(sarpro_hip_local_group *group) { 
 extern "C" int sarpro_hip_comm_init_local(sarpro_hip_ctx *ctx, sarpro_hip_local_group *group, int rank) {
     if (!ctx || !group || rank < 0 || rank >= group->nranks) return SARPRO_HIP_ERR_INVALID_ARG;
     if (ctx->comm || ctx->local_group) { ctx->err = "communicator already initialised"; return SARPRO_HIP_ERR_INVALID_ARG; }
+    {   // the sum kernel of a rank reads every other rank's buffer: ranks on different devices need peer access both ways (round 4
+        // advice: a mixed-device group without it faulted inside the first collective instead of failing here)
+        std::lock_guard<std::mutex> lk(group->m);
+        for (int r = 0; r < group->nranks; ++r) {
+            const int other = group->devices[(size_t)r];
+            if (other < 0 || other == ctx->device || r == rank) continue;
+            int a = 0, b = 0;
+            if (hipDeviceCanAccessPeer(&a, ctx->device, other) != hipSuccess || hipDeviceCanAccessPeer(&b, other, ctx->device) != hipSuccess || !a || !b) {
+                ctx->err = "in-process communicator: ranks on devices " + std::to_string(ctx->device) + " and " + std::to_string(other) + " cannot access each other's memory";
+                return SARPRO_HIP_ERR_INVALID_ARG;
+            }
+            (void)hipSetDevice(ctx->device);
+            const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { ctx->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return SARPRO_HIP_ERR_HIP; }
+            (void)hipGetLastError();
+        }
+        group->devices[(size_t)rank] = ctx->device;
+    }
     ctx->local_group = group; ctx->comm_nranks = group->nranks; ctx->comm_rank = rank;
     return SARPRO_HIP_OK;
 }

@@ -220,3 +220,53 @@ def test_a_failing_rank_releases_its_peers():
     for c in ctxs:
         c.close()
     group.close()
+
+
+def test_recorded_all_reduces_replay_the_rank_alone():
+    """COMM_RECORD / COMM_REPLAY (the measurement aid behind bench.py's `stripe_rank_model`): a rank of a real 3-rank run keeps the
+    results of its all-reduces; the same context then runs the same stripe ALONE, its all-reduces answered from the recorded sums --
+    the same chain, the same route, the same stripe of the oracle's raster."""
+    rows, cols, pitch = 403, 520, 576
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    rc, ref, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(St.Clahe))
+    assert rc == 0
+    splits = list(zip(*S.host_stripe_plan(rows, 3)))
+    d = [[to_dev(x[r0:r0 + nr], pitch, torch.int16) for x in b] for r0, nr in splits]
+    rgb = [torch.zeros((max(n_, 1), pitch * 3), dtype=torch.uint8, device="cuda") for _, n_ in splits]
+    group = S.LocalGroup(3)
+    ctxs = [S.Context(0, timing=True) for _ in range(3)]
+    for k, c in enumerate(ctxs):
+        c.comm_init_local(group, k)
+        c.set_attr("SAMPLED_HIST_MIN_PX", 0)
+        c.set_attr("SAMPLE_STRIDE", 5)
+    ctxs[1].set_attr("COMM_RECORD", 1)
+    torch.cuda.synchronize()
+
+    def work(k):
+        r0, nr = splits[k]
+        ctxs[k].stripe_run_u16(d[k][0].data_ptr(), d[k][1].data_ptr(), rows, cols, r0, nr, pitch, St.Clahe, Mode.Default, rgb[k].data_ptr(), pitch)
+    ths = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths)
+    r0, nr = splits[1]
+    want = ref[r0:r0 + nr]
+    assert np.array_equal(rgb[1].cpu().numpy().reshape(-1, pitch, 3)[:nr, :cols], want)
+    names3 = [n for n, _ in ctxs[1].last_kernel_times()]
+    rep3 = ctxs[1].spec_report()
+    c = ctxs[1]
+    c.reset_attr("COMM_RECORD")
+    for x in ctxs:
+        x.comm_destroy()
+    c.set_attr("COMM_REPLAY", 1)
+    rgb[1].zero_()
+    c.stripe_run_u16(d[1][0].data_ptr(), d[1][1].data_ptr(), rows, cols, r0, nr, pitch, St.Clahe, Mode.Default, rgb[1].data_ptr(), pitch)
+    assert np.array_equal(rgb[1].cpu().numpy().reshape(-1, pitch, 3)[:nr, :cols], want)
+    assert [n for n, _ in c.last_kernel_times()] == names3 and "clahe_rgb_fused" in names3
+    rep1 = c.spec_report()
+    assert (rep1["spec_ok"], rep1["verdict"], rep1["floor_pred"], rep1["n_lt"]) == (rep3["spec_ok"], rep3["verdict"], rep3["floor_pred"], rep3["n_lt"])
+    for x in ctxs:
+        x.close()
+    group.close()
