@@ -290,3 +290,32 @@ def test_tile_histograms_left_clean_by_the_previous_scene():
             else:
                 rc, ref = oracle.pipeline(b[0].astype(np.float32), int(Bd.U8), int(strategy))
                 assert rc == 0 and np.array_equal(c.process_scalar_data_pipeline(b[0], Bd.U8, strategy)[0], ref), (k, strategy)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "bright_plateau", "half_dark"])
+def test_piece_histogram_tail_queue_and_its_overflow_route(kind):
+    """The piece histogram (whole dual-pol scenes, csrc/piece_kernels.hip) keeps DN < 8192 in LDS bins and queues brighter samples in
+    LDS (1024 entries per workgroup and tile visit) for the tile's global histogram; a lane that finds the queue full recounts its
+    tail samples in a second loop behind the row loop.  Rasters that are mostly brighter than the LDS bins drive every workgroup
+    through that route, across several tiles and pieces; statistics and rasters must be the oracle's."""
+    rng = np.random.default_rng(17)
+    rows, cols = 1500, 2100
+    if kind == "uniform":            # 87 % of the samples beyond the LDS bins, every 65536-bin counter in use
+        b = [rng.integers(1, 65536, (rows, cols)).astype(np.uint16) for _ in range(2)]
+    elif kind == "bright_plateau":   # every sample in the tail, a few thousand distinct DNs, an invalid stripe
+        b = [(20000 + rng.integers(0, 3000, (rows, cols))).astype(np.uint16) for _ in range(2)]
+        b[0][:, :97] = 0
+    else:                            # rows alternate between dark (LDS bins) and bright (queue): the queue fills and drains per tile
+        b = []
+        for k in range(2):
+            x = rng.integers(1, 4000, (rows, cols)).astype(np.uint16)
+            x[::2] = (9000 + rng.integers(0, 50000, (rows // 2 + rows % 2, cols))).astype(np.uint16)
+            b.append(x)
+    for strategy in (St.Clahe, St.Robust):
+        rc, ref, r1, r2 = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(strategy))
+        assert rc == 0
+        with S.Context(0, timing=True) as c:
+            rgb, u1, u2 = c.dualpol_synrgb(b[0], b[1], strategy, want_u8=True)
+            names = [n for n, _ in c.last_kernel_times()]
+        assert "dn_hist_u16" in names
+        assert np.array_equal(u1, r1) and np.array_equal(u2, r2) and np.array_equal(rgb, ref), (kind, strategy)
