@@ -348,8 +348,10 @@ const char *sarpro_hip_attr_name(int index);
  * histogram on sampled rows only; from the sample the chain PROVES that the u8 rescale of autoscale.rs:348-364 is the
  * identity (levels 0 and 255 occur) and PREDICTS the suppressed-synRGB floor (synthetic_rgb.rs:99-113), composes with the
  * prediction, and verifies it exactly inside the compose pass (csrc/chain_kernels.hip, k_chain_predict).  Synchronises the
- * context's stream.  spec_ok: the proof held and the speculative composition ran; verdict 0: its RGB stood, 1: refuted (or
- * never ran) and the exact recount + composition ran; the raster is the reference's either way. */
+ * context's stream.  spec_ok: 1 = the proof held and the speculative composition ran; 2 = a band holds no level 0 (a crop
+ * without invalid pixels), its lowest level min_pred is a PREDICTION too, the rescale (min_pred, 255) is folded into the tables and
+ * the fused pass counts the level bytes below min_pred (n_below_min: any refutes); 0 = no speculation.  verdict 0: the speculative
+ * RGB stood, 1: refuted (or never ran) and the exact recount + composition ran; the raster is the reference's either way. */
 typedef struct {
     uint32_t spec_ok, verdict;
     int32_t floor_pred;       /* predicted floor before the +3 cushion; 37 stands for "37 or more" (the cushion caps at 40) */
@@ -358,8 +360,23 @@ typedef struct {
     uint64_t target;          /* synthetic_rgb.rs:99-100 */
     double est_lt[2];         /* the sample's estimate of n_lt */
     uint64_t sample_valid[2]; /* per band: valid pixels on the sampled rows, each work item weighted by rows / sampled rows, 4096 = 1.0 */
+    uint64_t n_below_min;     /* spec_ok 2: band-pixels whose level lies below their band's min_pred (exact; 0 or refuted) */
+    uint32_t min_pred[2];     /* spec_ok 2: predicted lowest level per band (0: proven) */
 } sarpro_hip_spec_report;
 int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_report *out);
+
+/* Diagnostics of the last device-resident CLAHE chain of this context (u16 flavour): what stood between the CLAHE levels and the
+ * composition.  rescale[b]: the u8 rescale of band b's levels (autoscale.rs:348-364) as a table; floor_with_cushion: synthetic_rgb.rs:
+ * 110-113 (-1: none, no synRGB was composed); level_hist[b]: the exact level histogram the exact kernels built them from (bin 0 implied:
+ * pixels - sum of the others) -- all zero when the speculative composition stood (nothing was recounted).  Synchronises the stream. */
+typedef struct {
+    int32_t floor_with_cushion;
+    uint8_t identity[2];      /* 1: band b's rescale is the identity on the levels that occur */
+    uint8_t reserved[2];
+    uint8_t rescale[512];     /* [band][256] */
+    uint64_t level_hist[512]; /* [band][256] */
+} sarpro_hip_chain_report;
+int sarpro_hip_ctx_chain_report(sarpro_hip_ctx *ctx, sarpro_hip_chain_report *out);
 
 /* ================= row-stripe (multi-GPU) protocol ================= */
 /* One scene split into row stripes, one per rank.  Each phase

@@ -80,7 +80,7 @@ SYMBOLS = [
     "sarpro_hip_polop_autoscale_band_f32", "sarpro_hip_polop_autoscale_band_u16", "sarpro_hip_polop_autoscale_band_f32_dev", "sarpro_hip_polop_autoscale_band_u16_dev",
     "sarpro_hip_dualpol_synrgb_u16_dev", "sarpro_hip_polop_f32_dev", "sarpro_hip_synrgb_u8_dev",
     "sarpro_hip_last_kernel_times",
-    "sarpro_hip_ctx_time_only", "sarpro_hip_ctx_spec_report",
+    "sarpro_hip_ctx_time_only", "sarpro_hip_ctx_spec_report", "sarpro_hip_ctx_chain_report",
     "sarpro_hip_stripe_begin_u16", "sarpro_hip_stripe_phase1", "sarpro_hip_stripe_phase2",
     "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end", "sarpro_hip_stripe_run_u16",
     "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_dualpol_synrgb_resized_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
@@ -175,10 +175,19 @@ _proto("sarpro_hip_ctx_time_only", _i, _vp, C.c_char_p)
 
 class SpecReport(C.Structure):
     _fields_ = [("spec_ok", C.c_uint32), ("verdict", C.c_uint32), ("floor_pred", C.c_int32), ("pool_overflow", C.c_uint32),
-                ("n_lt", C.c_uint64 * 2), ("target", C.c_uint64), ("est_lt", C.c_double * 2), ("sample_valid", C.c_uint64 * 2)]
+                ("n_lt", C.c_uint64 * 2), ("target", C.c_uint64), ("est_lt", C.c_double * 2), ("sample_valid", C.c_uint64 * 2),
+                ("n_below_min", C.c_uint64), ("min_pred", C.c_uint32 * 2)]
 
 
 _proto("sarpro_hip_ctx_spec_report", _i, _vp, C.POINTER(SpecReport))
+
+
+class ChainReport(C.Structure):
+    _fields_ = [("floor_with_cushion", C.c_int32), ("identity", C.c_uint8 * 2), ("reserved", C.c_uint8 * 2),
+                ("rescale", C.c_uint8 * 512), ("level_hist", C.c_uint64 * 512)]
+
+
+_proto("sarpro_hip_ctx_chain_report", _i, _vp, C.POINTER(ChainReport))
 _proto("sarpro_hip_ctx_set_attr", _i, _vp, C.c_char_p, C.c_int64)
 _proto("sarpro_hip_ctx_reset_attr", _i, _vp, C.c_char_p)
 _proto("sarpro_hip_ctx_get_attr", _i, _vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int))

@@ -101,19 +101,30 @@ class Context:
         self._chk(lib.sarpro_hip_ctx_spec_report(self._h, C.byref(r)))
         return {"spec_ok": int(r.spec_ok), "verdict": int(r.verdict), "floor_pred": int(r.floor_pred), "n_lt": [int(x) for x in r.n_lt],
                 "target": int(r.target), "est_lt": [float(x) for x in r.est_lt], "sample_valid": [int(x) for x in r.sample_valid], "pool_overflow": int(r.pool_overflow),
+                "n_below_min": int(r.n_below_min), "min_pred": [int(x) for x in r.min_pred],
                 "outcome": ("unproven" if not r.spec_ok else "pool_overflow" if r.pool_overflow else "refuted" if r.verdict else "accepted")}
+
+    def chain_report(self) -> dict:
+        """What stood between the CLAHE levels and the composition in the last u16 chain (sarpro_hip_ctx_chain_report): the u8 rescale
+        tables, the synRGB floor + cushion, the exact kernels' level histogram; synchronises the stream."""
+        import numpy as np
+        from ._lib import ChainReport
+        r = ChainReport()
+        self._chk(lib.sarpro_hip_ctx_chain_report(self._h, C.byref(r)))
+        return {"floor_with_cushion": int(r.floor_with_cushion), "identity": [int(x) for x in r.identity],
+                "rescale": np.ctypeslib.as_array(r.rescale).reshape(2, 256).copy(), "level_hist": np.ctypeslib.as_array(r.level_hist).reshape(2, 256).copy()}
 
     # ------------------------------------------------------------------ context attributes (route switches)
     def set_attr(self, name: str, value=1):
         """sarpro_hip_ctx_set_attr: `name` as in DESIGN.md's list of cross-check switches ("NO_SPEC", "SAMPLE_STRIDE", ...; the
         SARPRO_HIP_ prefix is optional).  value None resets the attribute to "unset"; the two word-valued attributes also take their
-        words (SPEC_FORCE: "mispredict", "nospec", "mispredict,nospec"; F32_ZONES: "tiny")."""
+        words (SPEC_FORCE: "mispredict", "nospec", "lowmin", comma-joined; F32_ZONES: "tiny")."""
         if value is None:
             return self.reset_attr(name)
         if isinstance(value, str):
-            words = {"mispredict": 1, "nospec": 2, "mispredict,nospec": 3, "nospec,mispredict": 3, "tiny": 2}
+            words = {"mispredict": 1, "nospec": 2, "lowmin": 4, "tiny": 2}
             try:
-                value = words[value] if value in words else int(value)
+                value = sum(words[w] for w in value.split(",")) if all(w in words for w in value.split(",")) else int(value)
             except ValueError:
                 value = 1  # any other word switches the attribute on, as a bare environment variable does at creation
         self._chk(lib.sarpro_hip_ctx_set_attr(self._h, name.encode(), int(value)))

@@ -112,10 +112,11 @@ int attr_index(const char *name) {
     return -1;
 }
 // The value of a switch as the environment (or a caller) spells it: a number; "" or any other word = 1 (the variable's presence
-// used to be the switch); the two word-valued ones: SPEC_FORCE = "mispredict" (1) and / or "nospec" (2), F32_ZONES = "tiny" (2).
+// used to be the switch); the two word-valued ones: SPEC_FORCE = "mispredict" (1), "nospec" (2), "lowmin" (4) in any combination, F32_ZONES = "tiny" (2).
 static long long attr_parse(int a, const char *e) {
     if (a == A_SPEC_FORCE && !(e[0] >= '0' && e[0] <= '9'))
-        return (strstr(e, "mispredict") ? (long long)kSpecForceMispredict : 0) | (strstr(e, "nospec") ? (long long)kSpecForceNoSpec : 0);
+        return (strstr(e, "mispredict") ? (long long)kSpecForceMispredict : 0) | (strstr(e, "nospec") ? (long long)kSpecForceNoSpec : 0) |
+               (strstr(e, "lowmin") ? (long long)kSpecForceMinMispredict : 0);
     if (a == A_F32_ZONES && !strcmp(e, "tiny")) return 2;
     char *end = nullptr;
     const long long v = strtoll(e, &end, 10);
@@ -244,6 +245,7 @@ extern "C" int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_r
     out->est_lt[0] = st.est_lt[0]; out->est_lt[1] = st.est_lt[1];
     out->sample_valid[0] = st.sample_valid[0]; out->sample_valid[1] = st.sample_valid[1];
     out->pool_overflow = st.pool_overflow;
+    out->n_below_min = st.n_below_min; out->min_pred[0] = st.min_pred[0]; out->min_pred[1] = st.min_pred[1];
     return SARPRO_HIP_OK;
 }
 
@@ -1052,6 +1054,22 @@ constexpr size_t kTablesOffPQ = 66048 + 512, kTablesBytes = kTablesOffPQ + 2 * 2
 constexpr size_t kStateOffResc = 2 * sizeof(ChainBandState), kStateOffIdent = kStateOffResc + 512,
                  kStateOffFloor = kStateOffIdent + 16, kStateBytes = kStateOffFloor + 16;
 
+extern "C" int sarpro_hip_ctx_chain_report(sarpro_hip_ctx *ctx, sarpro_hip_chain_report *out) {
+    if (!ctx || !out) return SARPRO_HIP_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    out->floor_with_cushion = -1;
+    if (!ctx->chain_state.p || !ctx->last_final_hist) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no CLAHE chain has run on this context");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint8_t *state = ctx->chain_state.as<uint8_t>();
+    HIPCHK(ctx, hipMemcpy(out->rescale, state + kStateOffResc, 512, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out->identity, state + kStateOffIdent, 2, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&out->floor_with_cushion, state + kStateOffFloor, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out->level_hist, ctx->last_final_hist, sizeof(out->level_hist), hipMemcpyDeviceToHost));
+    return SARPRO_HIP_OK;
+}
+
+
 static int chain_prepare(sarpro_hip_ctx *ctx) {
     if (ctx->chain_ready) return SARPRO_HIP_OK;
     HIPCHK(ctx, ctx->chain_consts.reserve(kChainConstBytes));
@@ -1120,8 +1138,8 @@ static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_
 // Scenes below this size keep the exact partial histogram: their chain is launch-bound, the gated kernels would cost more than
 // the sampled histogram saves.  SARPRO_HIP_SAMPLED_HIST_MIN_PX overrides (the tests run the speculative chain on small rasters).
 constexpr size_t kSampledHistMinPx = 32u << 20;
-static uint32_t spec_force_flags(const sarpro_hip_ctx *ctx) { // SPEC_FORCE = mispredict (1) | nospec (2): every rare branch of the speculative chain is testable
-    return (uint32_t)ctx->attrs.val(A_SPEC_FORCE, 0) & (kSpecForceMispredict | kSpecForceNoSpec);
+static uint32_t spec_force_flags(const sarpro_hip_ctx *ctx) { // SPEC_FORCE = mispredict (1) | nospec (2) | predicted lowest level + 1 (4): every rare branch of the speculative chain is testable
+    return (uint32_t)ctx->attrs.val(A_SPEC_FORCE, 0) & (kSpecForceMispredict | kSpecForceNoSpec | kSpecForceMinMispredict);
 }
 
 static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_state);
@@ -1137,6 +1155,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
     RETCHK(ensure_levels(J)); // the fallback's level rasters (allocated once per shape; untouched when the fused RGB stands)
     HIPCHK(ctx, ctx->spec_dump.reserve(kSpecDumpBytes));
     unsigned long long *sample_hist = ctx->level_hist.as<unsigned long long>(), *exact_hist = sample_hist + 256 * kMaxBands * kSampleReplicas;
+    ctx->last_final_hist = exact_hist;
     ClaheApplyArgs a{};
     for (int b = 0; b < 2; ++b) {
         a.in[b] = J.d_in[b];
@@ -1168,6 +1187,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         pa.tables = ctx->tables.as<uint8_t>();
         pa.supp_rg = consts + kChainOffSupp; pa.blue_pair_supp = consts + kChainOffBlue;
         pa.force = spec_force_flags(ctx);
+        pa.allow_rescaled = ctx->attrs.on(A_NO_SPEC_RESCALE) ? 0u : 1u; // the fused pass verifies a predicted lowest level
         pa.blue_pq = ctx->blue_factors_ok ? reinterpret_cast<const float *>(consts + kChainOffBluePQ) : nullptr;
         pa.blue_by_level = reinterpret_cast<float *>(ctx->tables.as<uint8_t>() + kTablesOffPQ);
         KernelTimer t(ctx, "chain_predict");
@@ -1190,7 +1210,8 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         }
     }
     if (J.reduce) { // the verification counts of all stripes, then the verdict every rank shares
-        RETCHK(chain_reduce(J, &d_spec->n_lt[0], 2, "allreduce_spec_counts"));
+        static_assert(offsetof(ChainSpecState, n_below_min) == offsetof(ChainSpecState, n_lt) + 16, "the verification counts are one buffer");
+        RETCHK(chain_reduce(J, &d_spec->n_lt[0], 3, "allreduce_spec_counts"));
         HIPCHK(ctx, launch_spec_verdict(d_spec, d_state, ctx->stream));
     }
     {   // gated on the verdict: levels of every pixel with the full histogram -> exact tables -> composition
@@ -1447,6 +1468,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     {
         ChainFinishArgs fa{};
         fa.level_hist = final_hist;
+        ctx->last_final_hist = final_hist;
         fa.gate = d_spec;
         fa.total_px = (unsigned long long)J.rows_total * J.cols;
         fa.nbands = J.nbands;

@@ -88,6 +88,7 @@ struct ChainPredictArgs {
     const uint8_t *supp_rg;                // [41][512]
     const uint8_t *blue_pair_supp;         // [256][256]
     uint32_t force;                        // kSpecForce*
+    uint32_t allow_rescaled;               // the consumer verifies a predicted lowest level (the fused CLAHE -> RGB pass does)
     const float *blue_pq;                  // P[256] | Q[256] (host-built, verified) or null
     float *blue_by_level;                  // out: Pv[256] | Qv[256] with Pv[v] = P[R2[v]], Qv[v] = Q[G2[v]] (the fused pass's LITE form reads these instead of B2)
 };

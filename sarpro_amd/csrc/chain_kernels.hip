@@ -561,11 +561,18 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
 // exact kernels run: level recount -> k_chain_finish -> composition.  The raster is the reference's either way; the
 // prediction only decides which kernels produce it.  Every block computes the (tiny) prediction and builds its slice of the
 // blue table; block 0 publishes the state.
+//   A band WITHOUT level 0 (a crop with no invalid pixel whose darkest cells start above the CDF's foot) used to have no proof and
+// took the exact kernels.  With allow_rescaled its lowest sampled level becomes a third prediction: the rescale (min_pred, 255) is
+// folded into the tables, the floor is predicted on the rescaled levels, and the fused pass also counts the level bytes below
+// min_pred -- any such byte refutes (spec_ok = kSpecRescaled; kernels.hip, clahe_rgb_fused_body<true>).  Level 255 stays a proof.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs a) {
-    __shared__ double est[2][64];
-    __shared__ int s_ok[2], s_fwc;
+    __shared__ double est[2][256], fin[2][256]; // per band: estimated pixels per level, per FINAL level (after the predicted rescale)
+    __shared__ uint8_t resc[2][256];
+    __shared__ int s_ok[2], s_fwc, s_f;
+    __shared__ unsigned s_mn[2];
     const int t = threadIdx.x, wb = t >> 6, ln = t & 63;
+    if (t < 512) (&fin[0][0])[t] = 0.0;
     if (wb < 2) {
         const unsigned long long *sh = a.sample_hist + (size_t)wb * 256;
         unsigned long long v[4], others = 0, sv = 0;
@@ -589,15 +596,42 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
         const unsigned long long s0v = consistent ? sv - others : 0ull; // sampled valid pixels at level 0
         const bool has255 = __builtin_amdgcn_ballot_w64(ln == 63 && v[3] != 0ull) != 0ull;
         const bool has0 = invalid > 0ull || s0v > 0ull;
-        const double scale = consistent ? (double)valid / (double)sv : 0.0;
-        if (ln < 16) {
+        // the band's lowest level: 0 is PROVEN by has0 (a level of the sample is a level of the raster); without it the lowest
+        // sampled level is a PREDICTION that the fused pass verifies (no byte below it) -- a.allow_rescaled
+        unsigned mn = 256u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int l = ln * 4 + k;
-                est[wb][l] = l ? scale * (double)v[k] : (double)invalid + scale * (double)s0v;
-            }
+        for (int k = 3; k >= 0; --k) if (v[k] && (ln * 4 + k)) mn = (unsigned)(ln * 4 + k);
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, m, 64));
+        if (has0 || empty_band || mn == 256u) mn = 0u;
+        if ((a.force & kSpecForceMinMispredict) && mn && mn < 255u) mn += 1u; // (a level the raster undercuts: the verification must refute it)
+        const double scale = consistent ? (double)valid / (double)sv : 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = ln * 4 + k;
+            est[wb][l] = l ? scale * (double)v[k] : (double)invalid + scale * (double)s0v;
         }
-        if (ln == 0) s_ok[wb] = (empty_band || (consistent && has0 && has255)) ? 1 : 0;
+        // autoscale.rs:348-364 with (min, max) = (mn, 255), as k_chain_finish computes it from the exact histogram
+        const float fmn = (float)mn, fmx = 255.0f;
+        const float rs = fmx > fmn ? 255.0f / (fmx - fmn) : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned x = ln * 4 + k;
+            float val = roundf(((float)x - fmn) * rs);
+            val = val < 0.0f ? 0.0f : (val > 255.0f ? 255.0f : val);
+            resc[wb][x] = (uint8_t)val;
+        }
+        if (ln == 0) {
+            s_mn[wb] = mn;
+            s_ok[wb] = (empty_band || (consistent && has255 && (mn == 0u ? has0 : a.allow_rescaled != 0u))) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // final-level estimates: from mn on the rescale is strictly increasing (its slope is >= 1), so every final level has ONE source
+    // per band -- plain stores, no order of additions that could differ between two ranks of a stripe group
+    if (t < 512) {
+        const int b = t >> 8, x = t & 255;
+        if ((unsigned)x >= s_mn[b]) fin[b][resc[b][x]] = est[b][x];
     }
     __syncthreads();
     if (t == 0) {
@@ -607,44 +641,62 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
         double cum = 0.0, lt0 = 0.0, lt1 = 0.0;
         int f = kSpecFloorCap;
         for (int i = 0; i < kSpecFloorCap; ++i) {
-            cum += est[0][i] + est[1][i];
+            cum += fin[0][i] + fin[1][i];
             if (cum >= (double)target) { f = i; break; }
         }
         bool ok = s_ok[0] && s_ok[1];
         if (a.force & kSpecForceNoSpec) ok = false;
         if (a.force & kSpecForceMispredict) f = f < kSpecFloorCap ? f + 1 : kSpecFloorCap - 1;
-        for (int i = 0; i <= f && i < 64; ++i) { if (i < f) lt0 += est[0][i] + est[1][i]; lt1 += est[0][i] + est[1][i]; }
+        for (int i = 0; i <= f && i < 64; ++i) { if (i < f) lt0 += fin[0][i] + fin[1][i]; lt1 += fin[0][i] + fin[1][i]; }
         s_fwc = f + 3 < 40 ? f + 3 : 40;
+        s_f = f;
         if (blockIdx.x == 0) {
             ChainSpecState *sp = a.spec;
-            sp->spec_ok = ok ? 1u : 0u;
+            sp->spec_ok = !ok ? 0u : (s_mn[0] | s_mn[1]) ? kSpecRescaled : kSpecIdentity;
             sp->verdict = 1u; // until the speculative composition has verified the floor
             sp->floor_pred = f;
             sp->done = 0u;
-            sp->n_lt[0] = 0ull; sp->n_lt[1] = 0ull;
+            sp->n_lt[0] = 0ull; sp->n_lt[1] = 0ull; sp->n_below_min = 0ull;
             sp->target = target;
+            sp->min_pred[0] = s_mn[0]; sp->min_pred[1] = s_mn[1];
             sp->est_lt[0] = lt0; sp->est_lt[1] = lt1;
             sp->force = a.force;
             sp->pool_overflow = 0u;
             if (a.floor_out) *a.floor_out = s_fwc; // stands iff the verdict accepts; k_chain_finish rewrites it otherwise
         }
     }
-    if (blockIdx.x == 0) {
-        if (t < 512) { a.exact_hist[t] = 0ull; if (a.resc_out) a.resc_out[t] = (uint8_t)(t & 255); }
-        if (t < 2 && a.identity_out) a.identity_out[t] = 1;
-    }
     __syncthreads();
+    if (blockIdx.x == 0 && wb < 2) { // per band the lowest level (from mn on) whose final value reaches F, F + 1: what the fused pass counts against
+        const unsigned mn = s_mn[wb];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            unsigned thr = 256u;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const unsigned x = ln * 4 + k;
+                if (x >= mn && (int)resc[wb][x] >= s_f + q) thr = x;
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) thr = min(thr, (unsigned)__shfl_xor((int)thr, m, 64));
+            if (ln == 0) a.spec->thr[wb][q] = thr;
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (t < 512) { a.exact_hist[t] = 0ull; if (a.resc_out) a.resc_out[t] = resc[t >> 8][t & 255]; }
+        if (t < 2 && a.identity_out) a.identity_out[t] = s_mn[t] == 0u ? 1 : 0;
+    }
     const int fwc = s_fwc;
     const uint8_t *lut_r = a.supp_rg + (size_t)fwc * 512, *lut_g = lut_r + 256;
     uint8_t *R2 = a.tables, *G2 = a.tables + 256, *B2 = a.tables + 512;
     if (blockIdx.x == 0 && t < 256) {
-        const uint8_t r = t <= fwc ? 0 : lut_r[t], g = t <= fwc ? 0 : lut_g[t];
+        const int r1 = resc[0][t], r2 = resc[1][t];
+        const uint8_t r = r1 <= fwc ? 0 : lut_r[r1], g = r2 <= fwc ? 0 : lut_g[r2];
         R2[t] = r;
         G2[t] = g;
         if (a.blue_pq && a.blue_by_level) { a.blue_by_level[t] = a.blue_pq[r]; a.blue_by_level[256 + t] = a.blue_pq[256 + g]; }
     }
     for (int i = blockIdx.x * kStatsBlock + t; i < 65536; i += gridDim.x * kStatsBlock) {
-        const int r1 = i >> 8, r2 = i & 255;
+        const int r1 = resc[0][i >> 8], r2 = resc[1][i & 255];
         B2[i] = (r1 <= fwc && r2 <= fwc) ? 0 : a.blue_pair_supp[((size_t)lut_r[r1] << 8) | lut_g[r2]];
     }
 }

@@ -176,7 +176,7 @@ struct BandWorker {
     X(STRIP_ALIGN) X(PIECE_ALIGN) X(CHUNK_ROWS) X(RGB_ITEM_ROWS) X(SAMPLE_ITEM_ROWS) \
     X(NO_MAILBOX) X(NO_STEP_ESTIMATE) X(F32_ZONES) X(F32_ZONES_DEBUG) X(F32_DIRECT) X(F32_DIRECT_QCAP) X(F32_LEVEL_GENERAL) \
     X(F32_LEVEL_TABLE) X(F32_LEVEL_QCAP) X(F32_HOST_CDFS) X(F32_NO_VEC8) X(NO_BAND_TWIN) X(RESIZE_GENERIC) X(NO_RESIZE_LUT) \
-    X(NO_U16_CF) X(U16_ITEM_ROWS) X(PIPE_LANES) X(PIPE_ORDER) X(RGB_GRID) X(PIECE_GRID) X(COMM_RECORD) X(COMM_REPLAY)
+    X(NO_U16_CF) X(U16_ITEM_ROWS) X(PIPE_LANES) X(PIPE_ORDER) X(RGB_GRID) X(PIECE_GRID) X(COMM_RECORD) X(COMM_REPLAY) X(NO_SPEC_RESCALE)
 namespace sarpro {
 enum Attr : int {
 #define X(n) A_##n,
@@ -256,6 +256,7 @@ struct sarpro_hip_ctx {
     hipEvent_t pipe_wait_before_hist = nullptr;   // PIPE_ORDER = 2: the scene's histogram pass waits for this event (the previous scene's fused pass is about to start) ...
     hipEvent_t pipe_record_before_fused = nullptr; // ... and the scene records this one in front of its own fused pass
     std::vector<std::pair<const char *, float>> lane_times;
+    const void *last_final_hist = nullptr;       // the level histogram of the last CLAHE chain's exact kernels (device; sarpro_hip_ctx_chain_report)
     bool spec_ran = false;                       // the last u16 chain of this context took the speculative route (spec_state is that scene's)
     sarpro::PinnedBuf pipe_routes;               // ChainSpecState of every scene of the last batch (host copies)
     sarpro_hip_ctx *twin = nullptr;              // a second context on the same device (own stream, own workspaces): the other band of a dual-pol f32 product

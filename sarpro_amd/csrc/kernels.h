@@ -90,20 +90,27 @@ constexpr unsigned long long kSampleWeightOne = 4096;
 constexpr int kSampleReplicas = 16; // fixed-point 1.0 of the sampled histogram's per-item weights
 constexpr int kSpecFloorCap = 37; // synthetic_rgb.rs:110-113: floor + 3 is capped at 40, so every floor >= 37 is the same floor
 struct ChainSpecState {
-    uint32_t spec_ok;              // both bands hold level 0 and level 255 (=> the u8 rescale is the identity) and a floor was predicted
+    uint32_t spec_ok;              // kSpecIdentity: both bands hold level 0 and level 255 (=> the u8 rescale is the identity) and a floor was
+                                   // predicted; kSpecRescaled: a band's lowest level is PREDICTED (min_pred > 0), its rescale folded into the
+                                   // tables, and the fused pass verifies that too; 0: no speculation
     uint32_t verdict;              // 0: the speculative RGB is final; 1: refuted (or never composed): the exact kernels run
     int32_t floor_pred;            // predicted floor F (before the +3 cushion), kSpecFloorCap = "at least that"
     uint32_t done;                 // workgroups of the speculative compose pass that have added their counts
-    unsigned long long n_lt[2];    // band-pixels with level < F, < F + 1, counted by the speculative compose pass
+    unsigned long long n_lt[2];    // band-pixels with final level < F, < F + 1, counted by the speculative compose pass
+    unsigned long long n_below_min; // kSpecRescaled: valid-raster band-pixels with level < min_pred of their band (0 or the prediction is refuted); follows n_lt (one all-reduce)
     unsigned long long target;     // synthetic_rgb.rs:99-100
+    uint32_t min_pred[2];          // kSpecRescaled: predicted lowest level of each band (the highest is 255: proven from the sample)
+    uint32_t thr[2][2];            // kSpecRescaled: per band the lowest LEVEL whose final value is >= F, >= F + 1 (256: none)
     unsigned long long sample_valid[2]; // valid pixels on the sampled rows, per band, weighted like the histogram (summed by k_chain_predict)
     unsigned long long sample_valid_rep[kSampleReplicas * 2]; // [replica][band]: what the workgroups of the sampling pass add to
     double est_lt[2];              // the sample's estimate of n_lt (diagnostics)
     uint32_t force;                // test switches (kSpecForce*)
     uint32_t pool_overflow;        // the fused CLAHE -> RGB pass stepped aside: the bands' DN windows do not fit its LDS pool
 };
+constexpr uint32_t kSpecIdentity = 1u, kSpecRescaled = 2u;
 constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it
 constexpr uint32_t kSpecForceNoSpec = 2u;     // "level 0 or 255 missing": no speculative composition at all
+constexpr uint32_t kSpecForceMinMispredict = 4u; // a predicted lowest level + 1: the verification must refute it
 
 // The fused CLAHE -> RGB pass (kernels.hip 6a): both DN rasters in, interleaved RGB out.
 struct ClaheRgbArgs {

@@ -1144,6 +1144,10 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u8_spec(ClaheApplyArgs a
     if (lut_lds) clahe_spec_rows<true, HIST>(a, rc, band, lds, win_hi);
     else clahe_spec_rows<false, HIST>(a, rc, band, lds, win_hi);
     if (ghist) {
+        // The rows' ds_add_u32 are inline assembly: the compiler's wait-count pass does not see them and emitted a bare s_barrier here, so a
+        // wave could pass the barrier with its last adds still in flight and the flush below missed them (round 5: 162 of 36 M band-pixels at
+        // 36 MP -- enough to leave bin 0 = pixels - others above zero on a raster WITHOUT level 0, where it decides the u8 rescale).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t n = reinterpret_cast<const uint32_t *>(lds + SpecLds::hist)[threadIdx.x];
         // HIST == 2: the item's sampled rows stand for all its rows: counts are added with the weight rows / sampled rows (fixed
@@ -1248,7 +1252,7 @@ constexpr int kComposeStageBytes = (kComposeBlock / kWave) * 3072; // per-wave 3
 template <int VEC, bool SPEC>
 __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    if (SPEC) { if (!a.spec->spec_ok) return; }
+    if (SPEC) { if (a.spec->spec_ok != kSpecIdentity) return; } // (a predicted rescale is verified by the fused pass only)
     else if (a.spec && a.spec->verdict == 0) return; // fallback composition: the speculative RGB stands
     // SPEC: thresholds F - 1 (F when F = 0: unused), F, F + 1 in every byte; this lane's |x - T| sums over its vectors, its
     // pixel count, and the direct counts of the ragged row tails
@@ -1469,11 +1473,14 @@ static_assert(RgbLds::total <= 160 * 1024, "fused pass: LDS budget");
 static_assert(RgbLds::stage % 16 == 0 && RgbLds::pool % 16 == 0 && RgbLds::cdf64 % 16 == 0, "alignment");
 static_assert(kRgbPoolEntries / 4 + 2 <= kRgbBlock, "one pass of the workgroup expands the whole pool");
 
-__global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
+// GENERAL (ChainSpecState::spec_ok == kSpecRescaled): a band's lowest level is a prediction too.  The compose tables hold that band's
+// u8 rescale folded in (k_chain_predict), the floor counts compare each band's level bytes with ITS thresholds (the lowest levels whose
+// final values reach F and F + 1: the rescale is strictly increasing from min_pred on), and a fourth count -- level bytes below
+// min_pred -- must be zero.  Eight more v_sad_u8 per lane and row pair than the identity form, which is why it is its own body.
+template <bool GENERAL>
+__device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a, unsigned char *lds) {
     constexpr int VEC = 8;
     ChainSpecState *sp = a.spec;
-    if (!sp->spec_ok) return;
     const uint32_t win_hi[2] = {a.dev_state[0].win_hi, a.dev_state[1].win_hi};
     const uint64_t nwin = (uint64_t)win_hi[0] + win_hi[1] + 2u;
     const bool wide = nwin > kRgbPoolEntries; // the windows do not fit the DN-indexed pool: bin-indexed entries behind a DN -> bin byte table
@@ -1504,6 +1511,16 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 #endif
     const uint32_t t4[3] = {(fpred ? fpred - 1u : 0u) * 0x01010101u, fpred * 0x01010101u, (fpred + 1u) * 0x01010101u};
     uint32_t sad[3] = {0u, 0u, 0u}, n_all = 0u, n_kept = 0u; // this lane's |x - T| sums, level bytes seen (8 per band-row), kept ones
+    // GENERAL: per band |x - T| sums at T0 - 1, T0, T0 + 1 (T0 = thr[b][0]; thr[b][1] is T0 or T0 + 1) and at min_pred - 1, min_pred
+    uint32_t tg[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}}, sadg[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}};
+    if (GENERAL) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t T0 = sp->thr[b][0], mn = sp->min_pred[b];
+            tg[b][0] = min(T0 ? T0 - 1u : 0u, 255u) * 0x01010101u; tg[b][1] = min(T0, 255u) * 0x01010101u; tg[b][2] = min(T0 + 1u, 255u) * 0x01010101u;
+            tg[b][3] = (mn ? mn - 1u : 0u) * 0x01010101u; tg[b][4] = mn * 0x01010101u;
+        }
+    }
     const RowWeight *__restrict__ row_w = a.row_w + a.row_off;
     const uint32_t stage_w = RgbLds::stage + (uint32_t)wave * 1536u;
 
@@ -1793,9 +1810,17 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
                     band_levels(0, c0, dy, omdy, wy1, wy2, satN, l1);
                     band_levels(1, c1, dy, omdy, wy1, wy2, satN, l2);
                     // verification counts (kernel 6, SPEC): |x - T| over the 16 level bytes
+                    if (GENERAL) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        sad[k] = __builtin_amdgcn_sad_u8(l2[1], t4[k], __builtin_amdgcn_sad_u8(l2[0], t4[k], __builtin_amdgcn_sad_u8(l1[1], t4[k], __builtin_amdgcn_sad_u8(l1[0], t4[k], sad[k]))));
+                        for (int k = 0; k < 5; ++k) {
+                            sadg[0][k] = __builtin_amdgcn_sad_u8(l1[1], tg[0][k], __builtin_amdgcn_sad_u8(l1[0], tg[0][k], sadg[0][k]));
+                            sadg[1][k] = __builtin_amdgcn_sad_u8(l2[1], tg[1][k], __builtin_amdgcn_sad_u8(l2[0], tg[1][k], sadg[1][k]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            sad[k] = __builtin_amdgcn_sad_u8(l2[1], t4[k], __builtin_amdgcn_sad_u8(l2[0], t4[k], __builtin_amdgcn_sad_u8(l1[1], t4[k], __builtin_amdgcn_sad_u8(l1[0], t4[k], sad[k]))));
+                    }
                     n_all += 16u; n_kept += 2u * nkeep;
                     // composition (synthetic_rgb.rs:158-175 through the folded tables): 8 px -> 24 bytes
                     uint32_t o[6];
@@ -1911,28 +1936,70 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
         }
     }
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
-    uint32_t ge0 = fpred ? (n_all + sad[0] - sad[1]) >> 1 : n_kept, ge1 = (n_all + sad[1] - sad[2]) >> 1;
-    uint32_t lt0 = n_kept - ge0, lt1 = n_kept - ge1;
+    uint32_t lt0, lt1, below = 0u;
+    if (GENERAL) {
+        lt0 = 0u; lt1 = 0u;
+        const uint32_t na = n_all >> 1, nk = n_kept >> 1; // per band
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) { lt0 += __shfl_xor(lt0, m, 64); lt1 += __shfl_xor(lt1, m, 64); }
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t T0 = sp->thr[b][0], T1 = sp->thr[b][1], mn = sp->min_pred[b];
+            // bytes >= T of this band: everything kept for T = 0 (the masked bytes are 0), nothing for T = 256
+            const uint32_t ge_t0 = T0 == 0u ? nk : T0 > 255u ? 0u : (na + sadg[b][0] - sadg[b][1]) >> 1;
+            const uint32_t ge_t0p = T0 + 1u > 255u ? 0u : (na + sadg[b][1] - sadg[b][2]) >> 1;
+            const uint32_t ge_t1 = T1 == T0 ? ge_t0 : ge_t0p;
+            const uint32_t ge_mn = mn == 0u ? nk : (na + sadg[b][3] - sadg[b][4]) >> 1;
+            lt0 += nk - ge_t0; lt1 += nk - ge_t1; below += nk - ge_mn;
+        }
+    } else {
+        const uint32_t ge0 = fpred ? (n_all + sad[0] - sad[1]) >> 1 : n_kept, ge1 = (n_all + sad[1] - sad[2]) >> 1;
+        lt0 = n_kept - ge0; lt1 = n_kept - ge1;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { lt0 += __shfl_xor(lt0, m, 64); lt1 += __shfl_xor(lt1, m, 64); if (GENERAL) below += __shfl_xor(below, m, 64); }
     uint32_t *s_lt = reinterpret_cast<uint32_t *>(lds + RgbLds::misc);
     __syncthreads();
-    if (threadIdx.x == 0) { s_lt[0] = 0u; s_lt[1] = 0u; }
+    if (threadIdx.x == 0) { s_lt[0] = 0u; s_lt[1] = 0u; s_lt[2] = 0u; }
     __syncthreads();
-    if (lane == 0) { atomicAdd(&s_lt[0], lt0); atomicAdd(&s_lt[1], lt1); }
+    if (lane == 0) { atomicAdd(&s_lt[0], lt0); atomicAdd(&s_lt[1], lt1); if (GENERAL) atomicAdd(&s_lt[2], below); }
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&sp->n_lt[0], (unsigned long long)s_lt[0]);
         atomicAdd(&sp->n_lt[1], (unsigned long long)s_lt[1]);
+        if (GENERAL) atomicAdd(&sp->n_below_min, (unsigned long long)s_lt[2]);
         __threadfence();
         if (!a.no_verdict && atomicAdd(&sp->done, 1u) == gridDim.x - 1u) {
             __threadfence();
             const unsigned long long c0 = atomicAdd(&sp->n_lt[0], 0ull), c1 = atomicAdd(&sp->n_lt[1], 0ull), target = sp->target;
-            const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
+            const unsigned long long under = GENERAL ? atomicAdd(&sp->n_below_min, 0ull) : 0ull;
+            const bool ok = (sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1)) && under == 0ull;
             sp->verdict = ok ? 0u : 1u;
         }
     }
 }
+// Two kernels, two launches (the second returns at once on all but the rare scene): with both bodies in ONE kernel the identity form ran
+// 2 % slower (0.697-0.707 ms against 0.681-0.693 on the same box, the register allocator spills for the union of the two), the extra
+// launch costs nothing measurable (host time of the chain 1.179-1.190 ms against 1.186-1.195).  -DSARPRO_RGB_ONE_KERNEL = the merged form.
+#ifndef SARPRO_RGB_ONE_KERNEL
+__global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    if (a.spec->spec_ok == kSpecIdentity) clahe_rgb_fused_body<false>(a, lds);
+}
+#ifndef SARPRO_RGB_LITE
+__global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused_rescaled(ClaheRgbArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    if (a.spec->spec_ok == kSpecRescaled) clahe_rgb_fused_body<true>(a, lds);
+}
+#endif
+#else
+__global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t how = a.spec->spec_ok;
+    if (how == kSpecIdentity) clahe_rgb_fused_body<false>(a, lds);
+#ifndef SARPRO_RGB_LITE // (the LITE form's water test reads the levels themselves: identity only)
+    else if (how == kSpecRescaled) clahe_rgb_fused_body<true>(a, lds);
+#endif
+}
+#endif
 // Row stripes: every rank's pass has added its counts, the ranks have summed them; the same verdict on every rank.
 __global__ void k_spec_verdict(ChainSpecState *sp, const ChainBandState *state) {
     // (the windows are the same on every rank; `pool_overflow` is raised by block 0 of the pass, which a rank with an empty stripe
@@ -1941,7 +2008,7 @@ __global__ void k_spec_verdict(ChainSpecState *sp, const ChainBandState *state) 
     if (sp->spec_ok && nwin > kRgbPoolEntries && nwin > kWideBytes) sp->pool_overflow = 1u;
     if (!sp->spec_ok || sp->pool_overflow) return; // the passes did not run: "refuted" stands
     const unsigned long long c0 = sp->n_lt[0], c1 = sp->n_lt[1], target = sp->target;
-    const bool ok = sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1);
+    const bool ok = (sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1)) && (sp->spec_ok != kSpecRescaled || sp->n_below_min == 0ull);
     sp->verdict = ok ? 0u : 1u;
 }
 
@@ -2312,6 +2379,10 @@ hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s
     if (a.nrects == 0) return hipSuccess;
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused))) return e;
     hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
+#if !defined(SARPRO_RGB_ONE_KERNEL) && !defined(SARPRO_RGB_LITE) // (the LITE form's water test reads the levels themselves: identity only)
+    if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused_rescaled))) return e;
+    hipLaunchKernelGGL(k_clahe_rgb_fused_rescaled, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
+#endif
     return hipGetLastError();
 }
 

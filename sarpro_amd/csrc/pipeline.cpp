@@ -108,8 +108,6 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
             l->pipe_wait_before_hist = enq >= 2 ? ctx->pipe_events[nscenes + enq - 1] : nullptr; // (scene 1 starts at once: it has scene 0's whole chain to hide behind)
             l->pipe_record_before_fused = ctx->pipe_events[nscenes + enq];
         }
-        const void *spec_before = l->spec_state.p;
-        (void)spec_before;
         int rc = sarpro_hip_dualpol_synrgb_u16_dev(l, sc.d_band1, sc.d_band2, rows, cols, in_pitch, strategy, mode, sc.d_rgb, rgb_pitch_px,
                                                    nullptr, nullptr, 0, nullptr);
         if (chain_f) {

@@ -110,7 +110,7 @@ def test_stripe_run_f32_and_polop_with_n_ranks_in_one_process(strategy, bd):
     assert np.array_equal(got, ref), (strategy, bd, "polop")
 
 
-@pytest.mark.parametrize("force", [None, "mispredict", "nospec"])
+@pytest.mark.parametrize("force", [None, "mispredict", "nospec", "few_values", "few_values+lowmin"])
 @pytest.mark.parametrize("ranks", [2, 8, "ragged+empty"])
 def test_row_stripes_take_the_fused_clahe_rgb_route(ranks, force):
     """A striped CLAHE scene above the speculative route's size threshold (lowered to zero here) runs the fused CLAHE -> RGB pass on
@@ -119,6 +119,10 @@ def test_row_stripes_take_the_fused_clahe_rgb_route(ranks, force):
     gated exact kernels run with their level histogram reduced as well.  Whatever happens: the oracle's one-piece raster."""
     rows, cols, pitch = 403, 520, 576
     b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    few = force is not None and force.startswith("few_values")
+    if few:  # band 2 without level 0: its lowest level is predicted, the count of bytes below it joins the all-reduce of the verification counts
+        b[1] = np.random.default_rng(5).choice(np.array([40, 130, 260, 500, 700, 1000], np.uint16), size=(rows, cols))
+        force = "lowmin" if force.endswith("lowmin") else None
     rc, ref, _, _ = oracle.dualpol_synrgb(b[0].astype(np.float32), b[1].astype(np.float32), int(St.Clahe))
     assert rc == 0
     splits = SPLITS[ranks] or list(zip(*S.host_stripe_plan(rows, ranks)))
@@ -140,13 +144,16 @@ def test_row_stripes_take_the_fused_clahe_rgb_route(ranks, force):
         assert "allreduce_sample_hist" in nm and "allreduce_spec_counts" in nm and "allreduce_level_hist" in nm, nm
         assert ("clahe_rgb_fused" in nm) and "clahe_apply_u8_spec" not in nm, nm  # (the gated recount is timed as spec_fallback_apply)
     # every rank holds the same state: same proof, same prediction, same (summed) counts, same verdict
-    key = [(r["spec_ok"], r["verdict"], r["floor_pred"], tuple(r["n_lt"]), r["target"]) for r in reports]
+    key = [(r["spec_ok"], r["verdict"], r["floor_pred"], tuple(r["n_lt"]), r["target"], r["n_below_min"], tuple(r["min_pred"])) for r in reports]
     assert all(k == key[0] for k in key), key
+    if few:
+        assert key[0][0] == 2 and key[0][6][0] == 0 and key[0][6][1] > 0, key[0]
+        assert (key[0][1] == 1 and key[0][5] > 0) if force == "lowmin" else key[0][5] == 0, key[0]
     if force == "nospec":
         assert key[0][0] == 0 and key[0][1] == 1
     elif force == "mispredict":
         assert key[0][1] == 1
-    if key[0][0] == 1 and force is None and key[0][1] == 0:
+    if key[0][0] and force is None and key[0][1] == 0:
         u = [oracle.pipeline(x.astype(np.float32), 0, int(St.Clahe))[1] for x in b]
         lv = np.concatenate([u[0].ravel(), u[1].ravel()])
         f = key[0][2]

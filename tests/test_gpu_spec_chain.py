@@ -242,6 +242,81 @@ def test_fused_rgb_pass_degenerate_rasters(kind, monkeypatch):
     assert np.array_equal(rgb, rrgb), kind
 
 
+def _no_level0_scene(kind, rows, cols, rng):
+    """Rasters without an invalid pixel whose CLAHE levels start above 0 in at least one band (few distinct DNs: every occupied bin
+    of every tile is clipped and the redistributed excess lifts the CDF's foot above 1/255)."""
+    few1 = np.array([90, 200, 420, 800, 1300, 1900, 2600, 3100], np.uint16)
+    few2 = np.array([40, 130, 260, 500, 700, 1000], np.uint16)
+    if kind == "few_values":
+        return rng.choice(few1, size=(rows, cols)), rng.choice(few2, size=(rows, cols))
+    if kind == "one_band":       # band 1: the natural scene with its no-data wedge (level 0 proven); band 2: no level 0
+        return synth.scene_u16(rows, cols, 0), rng.choice(few2, size=(rows, cols))
+    if kind == "two_values":     # levels ~127 and 255 only
+        return rng.choice(np.array([120, 2000], np.uint16), size=(rows, cols)), rng.choice(np.array([300, 900], np.uint16), size=(rows, cols))
+    if kind == "high_plateau":   # 80 % of the pixels in the lowest bin
+        return (np.where(rng.random((rows, cols)) < 0.8, 50, rng.integers(51, 3000, (rows, cols))).astype(np.uint16),
+                np.where(rng.random((rows, cols)) < 0.5, 70, rng.integers(71, 2500, (rows, cols))).astype(np.uint16))
+    if kind == "constant":       # one level per band: max == min, the rescale's scale is 1.0 (autoscale.rs:356)
+        return np.full((rows, cols), 777, np.uint16), np.full((rows, cols), 12, np.uint16)
+    if kind == "gradient":       # few values whose mix changes across the scene: the tiles' lowest levels differ
+        w = np.linspace(0.0, 1.0, cols)[None, :]
+        pick = (rng.random((rows, cols)) < w)
+        return (np.where(pick, rng.choice(few1[:3], size=(rows, cols)), rng.choice(few1[4:], size=(rows, cols))).astype(np.uint16),
+                np.where(pick, rng.choice(few2[3:], size=(rows, cols)), rng.choice(few2[:3], size=(rows, cols))).astype(np.uint16))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("shape", [(264, 520), (1000, 777), (700, 2100)])
+@pytest.mark.parametrize("kind", ["few_values", "one_band", "two_values", "high_plateau", "constant", "gradient"])
+def test_fused_rgb_pass_predicts_the_rescale_of_a_band_without_level_0(kind, shape, monkeypatch):
+    """A band without level 0 (a crop with no invalid pixel) has no identity proof.  Its lowest sampled level becomes a prediction:
+    the rescale (min_pred, 255) of autoscale.rs:348-364 is folded into the tables, the floor is predicted on the rescaled levels and
+    the fused pass counts the level bytes below min_pred beside the floor counts (spec_ok = 2).  Accepted or refuted, the raster is
+    the oracle's; accepted, the counts are the oracle's final levels'."""
+    rows, cols = shape
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
+    b1, b2 = _no_level0_scene(kind, rows, cols, np.random.default_rng(23))
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        rgb, names = run_rgb_only(c, b1, b2)
+        rep = c.spec_report()
+        assert "clahe_rgb_fused" in names
+        assert np.array_equal(rgb, rrgb), (kind, rep, int((rgb != rrgb).sum()))
+        if kind == "constant":  # one level per band, and it is not 255 (the clipped bin's share of the redistributed excess): level 255 is
+            assert rep["spec_ok"] == 0 and rep["verdict"] == 1, rep  # what the proof of the rescale's upper end needs -- the exact kernels run
+            return
+        assert rep["spec_ok"] == 2 and max(rep["min_pred"]) > 0, rep
+        if kind == "one_band":
+            assert rep["min_pred"][0] == 0, rep
+        if rep["verdict"] == 0:
+            assert rep["n_below_min"] == 0
+            f = rep["floor_pred"]
+            lv = np.concatenate([r1.ravel(), r2.ravel()])  # the oracle's FINAL levels
+            assert rep["n_lt"][0] == int((lv < f).sum()) and (f == 37 or rep["n_lt"][1] == int((lv <= f).sum())), rep
+            assert f == 37 or rep["n_lt"][0] < rep["target"] <= rep["n_lt"][1]
+        accepted = rep["verdict"] == 0
+        # a lowest level that the raster undercuts, and a floor that is off by one: both must be refuted, and the exact kernels' raster stands
+        for force in ("lowmin", "mispredict"):
+            c.set_attr("SPEC_FORCE", force)
+            rgb, _ = run_rgb_only(c, b1, b2)
+            rep2 = c.spec_report()
+            assert np.array_equal(rgb, rrgb), (kind, force, rep2)
+            if force == "lowmin":
+                assert rep2["spec_ok"] == 2 and rep2["verdict"] == 1 and rep2["n_below_min"] > 0, rep2
+            if force == "mispredict" and accepted:
+                assert rep2["verdict"] == 1, rep2
+        c.set_attr("SPEC_FORCE", None)
+        c.set_attr("NO_SPEC_RESCALE", 1)  # the round-4 behaviour: no proof, no speculation
+        rgb, _ = run_rgb_only(c, b1, b2)
+        rep3 = c.spec_report()
+        assert np.array_equal(rgb, rrgb) and rep3["spec_ok"] == 0 and rep3["verdict"] == 1, rep3
+        c.set_attr("NO_SPEC_RESCALE", None)
+        rgb, _ = run_rgb_only(c, b1, b2)  # and back: nothing of the refuted scenes leaks
+        assert np.array_equal(rgb, rrgb) and c.spec_report()["verdict"] == rep["verdict"]
+    assert accepted or kind in ("gradient",), rep  # the simple cases are all accepted: the route is worth something
+
+
 def test_fused_rgb_route_equals_the_other_routes_at_36mp(monkeypatch):
     rows, cols = 6000, 6016
     pitch = cols
@@ -262,6 +337,43 @@ def test_fused_rgb_route_equals_the_other_routes_at_36mp(monkeypatch):
                 assert c.spec_report()["verdict"] == 0  # the product's default at this size: accepted
             for k in env:
                 monkeypatch.delenv(k)
+            out.append(rgb)
+        assert int(out[0].max().item()) > 0
+        for o in out[1:]:
+            assert torch.equal(out[0], o)
+
+
+def test_predicted_rescale_equals_the_exact_routes_at_36mp():
+    """The scene of the test above with its DNs coarsened to a dozen values and no invalid pixel left: no band holds level 0, the fused
+    pass runs its rescaled form (spec_ok = 2).  Its raster against the exact kernels' (the same context with the prediction switched
+    off, and without the fused pass at all), at a size where every work item shape of the pass occurs."""
+    rows, cols = 6000, 6016
+    pitch = cols
+    q = synth.q_tables()
+    with S.Context(0, timing=True) as c:
+        band = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+        for b in range(2):
+            c.dev_synth_scene_u16(synth.SEED_SCENE_A + 9, b, q, rows, cols, 0, rows, band[b].data_ptr(), pitch)
+            t = band[b].to(torch.int32) & 0xFFFF
+            band[b].copy_((((t >> 8) << 8) + 77 + 40 * b).clamp_(max=32767).to(torch.int16))
+        torch.cuda.synchronize()
+        out = []
+        for attr in (None, "NO_SPEC_RESCALE", "NO_FUSED_RGB"):
+            if attr:
+                c.set_attr(attr, 1)
+            rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+            c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
+            rep = c.spec_report()
+            if attr is None:
+                assert rep["spec_ok"] == 2 and rep["verdict"] == 0 and rep["n_below_min"] == 0 and max(rep["min_pred"]) > 0, rep
+            else:
+                assert rep["spec_ok"] == 0 and rep["verdict"] == 1, (attr, rep)
+                # the exact kernels' level histogram holds EVERY band-pixel (no level 0 here: bin 0 = pixels - others must come out 0,
+                # or the rescale is taken for the identity -- round 5: the pass's last LDS adds were not waited for before the flush)
+                cr = c.chain_report()
+                assert [int(cr["level_hist"][b][1:].sum()) for b in range(2)] == [rows * cols] * 2, cr["level_hist"][:, :4]
+                assert cr["identity"] == [0, 0] and cr["floor_with_cushion"] == 3 and list(cr["rescale"][0][:4]) == [0, 0, 0, 1], cr
+                c.set_attr(attr, None)
             out.append(rgb)
         assert int(out[0].max().item()) > 0
         for o in out[1:]:
