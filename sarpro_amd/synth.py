@@ -62,7 +62,7 @@ BENCH_SCENES = (
     ("F-flat", 5, class_map(3), {"sigma": (160.0, 60.0)}, "one class everywhere (single-Rayleigh scene: IQR < 5 dB)"),
     ("G-no-bright", 6, class_map(1) | blocks(7) | NO_BRIGHT, {"sigma": (120.0, 80.0), "scales": (0.3, 1.0, 2.5, 5.0)}, "large blocks, no bright targets"),
     ("H-quantised-VH", 7, 0, {"sigma": (180.0, 2.5)}, "VH amplitudes of a few DN: heavily quantised band, a dozen occupied CLAHE bins"),
-    ("I-no-VH", 8, NO_BAND2, {}, "VH band without a valid sample (a missing polarisation): no level 255 in the band, nothing proven -> exact route"),
+    ("I-no-VH", 8, NO_BAND2, {}, "VH band without a valid sample (a missing polarisation): level 0 everywhere, its u8 rescale is the identity by max == min (autoscale.rs:356)"),
 )
 
 
