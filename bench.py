@@ -1013,6 +1013,72 @@ def secondary_records(torch, dev, rows, cols):
             group.close()
     except Exception as e:
         out["stripe_rank_model"] = {"error": f"{type(e).__name__}: {e}"}
+    # (3c) the same for the RESIZED product (config 2 / 5's flow over row stripes: each rank's PCIe link carries 1/8 of the scene, the
+    # product is 2048^2): eight ranks through sarpro_hip_stripe_run_resized_u16, the assembled raster compared with the one-piece flow's,
+    # then rank 3 alone with its all-reduces (level chain x 2 bands, geometry, halo, floor histogram) replayed.
+    try:
+        import threading
+        nr, target = 8, 2048
+        r0s, nrs = sarpro_amd.host_stripe_plan(rows, nr)
+        fc, fr = sarpro_amd.resize_output_dims(cols, rows, target, True)
+        one = torch.zeros((fr * fc * 3,), dtype=torch.uint8, device=dev)
+        with sarpro_amd.Context(dev.index) as c1:
+            c1.dev_dualpol_synrgb_resized(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, target, True, one.data_ptr())
+        group = sarpro_amd.LocalGroup(nr)
+        cr = [sarpro_amd.Context(dev.index, timing=(k == 3)) for k in range(nr)]
+        try:
+            for k, c_ in enumerate(cr):
+                c_.comm_init_local(group, k)
+            want = [sarpro_amd.host_stripe_resized_rows(rows, cols, int(r0s[k]), int(nrs[k]), target, True) for k in range(nr)]
+            sl = [torch.zeros((max(w[1], 1) * fc * 3,), dtype=torch.uint8, device=dev) for w in want]
+            errs, res = [], [None] * nr
+
+            def rank_call(k, c_=None):
+                try:
+                    r0, nrw = int(r0s[k]), int(nrs[k])
+                    res[k] = (c_ or cr[k]).stripe_run_resized_u16(band[0].data_ptr() + r0 * pitch * 2, band[1].data_ptr() + r0 * pitch * 2, rows, cols, r0, nrw, pitch,
+                                                                  St.Clahe, Mode.Default, target, True, sl[k].data_ptr())
+                except Exception as e:
+                    errs.append(f"rank {k}: {e}")
+
+            def all_ranks():
+                ths = [threading.Thread(target=rank_call, args=(k,)) for k in range(nr)]
+                [x.start() for x in ths]
+                [x.join() for x in ths]
+            torch.cuda.synchronize()
+            all_ranks()
+            cr[3].set_attr("COMM_RECORD", 1)
+            all_ranks()
+            if errs:
+                raise RuntimeError("; ".join(errs))
+            got = torch.cat([t[: res[k][1] * fc * 3] for k, t in enumerate(sl)])
+            equal = bool(torch.equal(got, one))
+            cr[3].reset_attr("COMM_RECORD")
+            for c_ in cr:
+                c_.comm_destroy()
+            cs = cr[3]
+            cs.set_attr("COMM_REPLAY", 1)
+            ms = timed(lambda: rank_call(3, cs), n=10, warm=3)
+            if errs:
+                raise RuntimeError("; ".join(errs))
+            kt = {}
+            for k, v in cs.last_kernel_times():
+                if not k.startswith("host:"):
+                    kt[k] = round(kt.get(k, 0.0) + v, 4)
+            out["stripe_resized_rank_model"] = {"what": f"one rank of 8, alone on the GPU: rows [{int(r0s[3])}, {int(r0s[3]) + int(nrs[3])}) of the {rows}x{cols} scene through "
+                                                        f"sarpro_hip_stripe_run_resized_u16 (CLAHE u8 x 2 -> Lanczos3 to {target}^2 -> pad -> suppressed synRGB), its all-reduces answered from the sums "
+                                                        "recorded in a real 8-rank run (COMM_RECORD / COMM_REPLAY); the rank returns its rows of the product",
+                                                "assembled_raster_of_the_8_rank_run_equals_the_one_piece_flow": equal,
+                                                "rows_of_the_product_per_rank": [w[1] for w in want], "ms_per_call_with_timing_events": round(ms, 4), "kernels_ms": kt,
+                                                }
+            del sl, got
+        finally:
+            for c_ in cr:
+                c_.close()
+            group.close()
+        del one
+    except Exception as e:
+        out["stripe_resized_rank_model"] = {"error": f"{type(e).__name__}: {e}"}
     # (4) several scenes in flight on the one GPU: one context (own stream, own workspaces) and one host thread per scene, as the batch
     # driver runs when a device is listed more than once -- the short dependent kernels of one scene's chain run beside another
     # scene's sweeps.  Beside the headline, which keeps ONE context and stream.

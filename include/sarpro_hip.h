@@ -461,6 +461,21 @@ int sarpro_hip_stripe_run_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, cons
                               size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode,
                               uint8_t *d_rgb, size_t rgb_pitch_px, sarpro_hip_stats *stats_out);
 
+/* Row stripes of one scene -> the RESIZED, padded product (save.rs:317-367: per-band u8 autoscale at native resolution -> Lanczos3
+ * resize -> pad -> synRGB; SURVEY.md 8e's halo item).  Each rank holds rows [row0, row0 + rows_local) of both DN rasters -- 1 / N of
+ * the scene crossed its PCIe link -- and produces a contiguous range of the FINAL raster's rows: output row j of the vertical pass
+ * belongs to the rank holding the centre row of j's window, the rows its window needs from the neighbours travel in ONE small
+ * all-reduce (sarpro_amd/csrc/resize_path.cpp); the rank owning the first / last resized row also owns the padding above / below.
+ * d_rgb_slice receives out_rows x final_cols x 3 bytes, compact; the caller places them at row *out_row0 of the product.  Size the
+ * slice with sarpro_hip_stripe_resized_rows (pure host arithmetic, the same answer on every rank).  The stripes must tile the scene in
+ * rank order; every rank of the communicator makes the call (a rank may hold an empty stripe).  The assembled raster is that of
+ * sarpro_hip_dualpol_synrgb_resized_u16_dev on the one-piece scene, bit for bit. */
+int sarpro_hip_stripe_resized_rows(size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t target_size, int pad,
+                                   size_t *out_row0, size_t *out_rows, size_t *final_cols, size_t *final_rows);
+int sarpro_hip_stripe_run_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total, size_t cols,
+                                      size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode, size_t target_size, int pad,
+                                      uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta);
+
 /* Self-test: the division the u16 pol-op kernels use (the Newton core of the IEEE division without its rescaling frame) against
  * the compiler's IEEE division over ALL 2^32 pairs of u16 values, ratio and normalised difference.  *mismatches_out must be 0. */
 int sarpro_hip_selftest_polop_division(sarpro_hip_ctx *ctx, uint64_t *mismatches_out);

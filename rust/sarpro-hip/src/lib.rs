@@ -497,6 +497,17 @@ impl RasterCore {
             mode as c_int, d_rgb, rgb_pitch_px, st.as_mut_ptr()))?;
         Ok(st)
     }
+    /// this rank's stripe of a dual-pol u16 scene -> its rows of the RESIZED, padded RGB product (save.rs:317-367 over row stripes: the
+    /// rows the vertical Lanczos windows need from the neighbouring ranks travel in one small all-reduce).  `d_rgb_slice` receives
+    /// `out_rows * final_cols * 3` bytes (size it with [`stripe_resized_rows`]); returns (out_row0, out_rows, meta).
+    pub unsafe fn stripe_run_resized_u16(&self, d_band1: *const u16, d_band2: *const u16, rows_total: usize, cols: usize, row0: usize,
+        rows_local: usize, in_pitch: usize, strategy: AutoscaleStrategy, mode: SyntheticRgbMode, target_size: Option<usize>, pad: bool,
+        d_rgb_slice: *mut u8) -> Result<(usize, usize, ResizeMeta)> {
+        let (mut r0, mut n, mut m) = (0usize, 0usize, zeroed_meta());
+        self.chk(sys::sarpro_hip_stripe_run_resized_u16(self.ctx, d_band1, d_band2, rows_total, cols, row0, rows_local, in_pitch, strategy as c_int,
+            mode as c_int, target_size.unwrap_or(0), pad as c_int, d_rgb_slice, &mut r0, &mut n, &mut m))?;
+        Ok((r0, n, m))
+    }
     /// this rank's stripe of an f32 band -> its stripe of the level raster
     pub unsafe fn stripe_run_f32(&self, d_in: *const f32, rows_total: usize, cols: usize, row0: usize, rows_local: usize, in_pitch: usize,
         strategy: AutoscaleStrategy, bit_depth: BitDepth, d_out: *mut c_void, out_pitch: usize) -> Result<HistogramStats> {
@@ -691,6 +702,15 @@ pub fn resize_image_data(u8_data: &[u8], u16_data: Option<&[u16]>, original_cols
 }
 
 /// save.rs:71-81 / 141-151: the geotransform of the resized, padded product
+/// Which rows of the resized, padded product the holder of input rows [row0, row0 + rows_local) produces:
+/// (out_row0, out_rows, final_cols, final_rows) -- pure host arithmetic, the same answer on every rank.
+pub fn stripe_resized_rows(rows_total: usize, cols: usize, row0: usize, rows_local: usize, target_size: Option<usize>, pad: bool)
+    -> Option<(usize, usize, usize, usize)> {
+    let (mut a, mut b, mut c, mut d) = (0usize, 0usize, 0usize, 0usize);
+    let rc = unsafe { sys::sarpro_hip_stripe_resized_rows(rows_total, cols, row0, rows_local, target_size.unwrap_or(0), pad as c_int, &mut a, &mut b, &mut c, &mut d) };
+    if rc == 0 { Some((a, b, c, d)) } else { None }
+}
+
 pub fn update_geotransform(gt: &mut [f64; 6], cols: usize, rows: usize, meta: &ResizeMeta) {
     unsafe { sys::sarpro_hip_host_update_geotransform(gt.as_mut_ptr(), cols, rows, meta) }
 }

@@ -454,6 +454,17 @@ class Context:
                                                 int(strategy), int(mode), _vp(d_rgb), rgb_pitch_px, st))
         return [st[0], st[1]]
 
+    def stripe_run_resized_u16(self, d_b1: int, d_b2: int, rows_total: int, cols: int, row0: int, rows_local: int, in_pitch: int,
+                               strategy, mode, target_size: int, pad: bool, d_rgb_slice: int):
+        """One row stripe of a scene -> this rank's rows of the resized, padded RGB product (sarpro_hip_stripe_run_resized_u16).
+        Returns (out_row0, out_rows, ResizeMeta); d_rgb_slice receives out_rows x final_cols x 3 bytes (host_stripe_resized_rows sizes it)."""
+        from ._lib import ResizeMeta
+        m = ResizeMeta()
+        r0, nr = C.c_size_t(), C.c_size_t()
+        self._chk(lib.sarpro_hip_stripe_run_resized_u16(self._h, _vp(d_b1), _vp(d_b2), rows_total, cols, row0, rows_local, in_pitch, int(strategy),
+                                                        int(mode), int(target_size or 0), int(bool(pad)), _vp(d_rgb_slice), C.byref(r0), C.byref(nr), C.byref(m)))
+        return int(r0.value), int(nr.value), m
+
     def stripe_begin_f32(self, d_in: int, rows_total: int, cols: int, row0: int, rows_local: int, in_pitch: int, strategy, bit_depth,
                          d_out: int, out_pitch: int) -> "StripeF32":
         h = C.c_void_p()
@@ -748,6 +759,16 @@ def host_stripe_plan(rows: int, nranks: int):
     if rc:
         raise SarproHipError(rc, "host_stripe_plan")
     return [int(x) for x in r0], [int(x) for x in nr]
+
+
+def host_stripe_resized_rows(rows_total: int, cols: int, row0: int, rows_local: int, target_size: int, pad: bool):
+    """Which rows of the resized, padded product the holder of input rows [row0, row0 + rows_local) produces:
+    (out_row0, out_rows, final_cols, final_rows) (sarpro_hip_stripe_resized_rows)."""
+    v = [C.c_size_t() for _ in range(4)]
+    rc = lib.sarpro_hip_stripe_resized_rows(rows_total, cols, row0, rows_local, int(target_size or 0), int(bool(pad)), *[C.byref(x) for x in v])
+    if rc:
+        raise SarproHipError(rc, "stripe_resized_rows")
+    return tuple(int(x.value) for x in v)
 
 
 def host_f32_valid_threshold() -> float:

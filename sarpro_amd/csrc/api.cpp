@@ -1708,6 +1708,16 @@ int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t c
     void *outs[kMaxBands] = {d_out, nullptr};
     return job_run_all(J, outs, out_pitch, nullptr, 0, nullptr);
 }
+int band_u8_stripe_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t in_pitch,
+                       int strategy, int tamed, uint8_t *d_out, size_t out_pitch) {
+    U16Job J;
+    J.ctx = ctx; J.nbands = 1; J.d_in[0] = d_in;
+    J.rows_total = rows_total; J.row0 = row0; J.rows_local = rows_local; J.cols = cols; J.in_pitch = in_pitch;
+    J.strategy = tamed ? SARPRO_STRATEGY_TAMED : strategy; J.bit_depth = SARPRO_BITDEPTH_U8; J.tamed_force = tamed;
+    J.reduce = true;
+    void *outs[kMaxBands] = {d_out, nullptr};
+    return job_run_all(J, outs, out_pitch, nullptr, 0, nullptr);
+}
 } // namespace sarpro
 
 extern "C" int sarpro_hip_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2,
@@ -1752,6 +1762,15 @@ extern "C" int sarpro_hip_synrgb_u8_dev(sarpro_hip_ctx *ctx, int mode, int strat
     if ((!d_b1 || !d_b2 || !d_rgb) && n) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null array");
     timing_reset(ctx);
     if (n == 0) return SARPRO_HIP_OK;
+    return sarpro::synrgb_flat_dev(ctx, mode, strategy, d_b1, d_b2, n, n, false, d_rgb);
+}
+
+// The composition of n pixels that are a PART of a product of n_total pixels (`reduce`: the other parts are other ranks' -- the
+// suppressed variant's combined histogram is summed over the ranks before the floor is taken, synthetic_rgb.rs:92-113; every rank calls,
+// also one with n = 0).  n == n_total, reduce false: the whole product (sarpro_hip_synrgb_u8_dev).
+int sarpro::synrgb_flat_dev(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *d_b1, const uint8_t *d_b2, size_t n, size_t n_total,
+                            bool reduce, uint8_t *d_rgb) {
+    (void)mode; // synthetic_rgb.rs:72-79: the mode is ignored
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // view the flat arrays as rows of 4096 px (+ one short row) so the 2-D kernels apply
     const size_t W = 4096;
@@ -1767,10 +1786,11 @@ extern "C" int sarpro_hip_synrgb_u8_dev(sarpro_hip_ctx *ctx, int mode, int strat
             if (full_rows) HIPCHK(ctx, launch_hist256_u8(p, W, (uint32_t)full_rows, (uint32_t)W, ctx->level_hist.as<unsigned long long>(), ctx->stream));
             if (tail) HIPCHK(ctx, launch_hist256_u8(p + full_rows * W, W, 1, (uint32_t)tail, ctx->level_hist.as<unsigned long long>(), ctx->stream));
         }
+        if (reduce) RETCHK(comm_allreduce_sum_u64_async(ctx, ctx->level_hist.as<uint64_t>(), 256));
         uint64_t h[256];
         HIPCHK(ctx, hipMemcpyAsync(h, ctx->level_hist.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        fwc = synrgb_floor_from_hist(h, n);
+        fwc = synrgb_floor_from_hist(h, n_total);
         synrgb_luts_suppressed(fwc, luts.data());
     } else {
         synrgb_luts_default(luts.data());

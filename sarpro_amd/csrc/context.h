@@ -225,6 +225,7 @@ struct sarpro_hip_ctx {
     sarpro::DevBuf f32zone;                      // f32 zone route: samples kept by the min / max pass (a few per cent of the scene)
     uint32_t resize_key[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}}; // (in, out, elem, precision, window, block span) of the cached coefficient tables
     sarpro::DevBuf resize_tmp, resize_coef[2], resized[2]; // resize path: intermediate image, coefficient tables, resized bands
+    sarpro::DevBuf resize_halo, resize_geom;               // striped resize: the boundary zones of the intermediate rasters, the ranks' stripe geometry
     sarpro::DevBuf chain_consts;                 // device-resident chain: dB table | suppressed lut_r/g per floor | blue pairs
     sarpro::DevBuf chain_scratch;               // statistics step: per-slice partials | 4096 bins per band
     sarpro::DevBuf chain_state;                  // ChainBandState[2] | resc[2][256] | identity[2] | floor

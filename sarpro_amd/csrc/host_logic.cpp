@@ -842,6 +842,22 @@ namespace sarpro {
 static double sinc_pi(double x) { if (x == 0.0) return 1.0; x *= 3.14159265358979323846; return std::sin(x) / x; }
 static double lanczos3(double x) { return (x >= -3.0 && x < 3.0) ? sinc_pi(x) * sinc_pi(x / 3.0) : 0.0; }
 
+// the windows of build_resize_coeffs without their weights (the same expressions): which input indices output ox reads
+void resize_bounds(uint32_t in_size, uint32_t out_size, uint32_t *window, std::vector<uint32_t> *start, std::vector<uint32_t> *size) {
+    const double scale = (double)in_size / (double)out_size;
+    const double radius = 3.0 * (scale > 1.0 ? scale : 1.0);
+    *window = (uint32_t)std::ceil(radius) * 2 + 1;
+    start->assign(out_size, 0);
+    size->assign(out_size, 0);
+    for (uint32_t ox = 0; ox < out_size; ++ox) {
+        const double in_center = ((double)ox + 0.5) * scale;
+        const uint32_t x_min = as_u32(std::fmax(std::floor(in_center - radius), 0.0));
+        const uint32_t x_max = as_u32(std::fmin(std::ceil(in_center + radius), (double)in_size));
+        (*start)[ox] = x_min;
+        (*size)[ox] = x_max - x_min;
+    }
+}
+
 void build_resize_coeffs(uint32_t in_size, uint32_t out_size, int elem_size, ResizeCoeffs *c) {
     c->in_size = in_size; c->out_size = out_size;
     const double scale = (double)in_size / (double)out_size;

@@ -129,5 +129,6 @@ struct ResizeCoeffs {
     std::vector<int32_t> k;            // [window][out_size] (tap-major so lanes over outputs coalesce)
 };
 void build_resize_coeffs(uint32_t in_size, uint32_t out_size, int elem_size /*1: i16 range, 2: i32 range*/, ResizeCoeffs *out);
+void resize_bounds(uint32_t in_size, uint32_t out_size, uint32_t *window, std::vector<uint32_t> *start, std::vector<uint32_t> *size); // build_resize_coeffs' windows alone
 void resize_dimensions(size_t original_cols, size_t original_rows, size_t target_size, size_t *new_cols, size_t *new_rows); // resize.rs:6-30
 } // namespace sarpro

@@ -41,6 +41,13 @@ int stream_upload_band(sarpro_hip_ctx *ctx, sarpro_hip_row_reader reader, void *
                        uint16_t *d_dst, size_t pitch, size_t chunk_rows);
 int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t cols, size_t in_pitch, int strategy, int tamed,
                 uint8_t *d_out, size_t out_pitch);
+// the same for a ROW STRIPE of the band (rows [row0, row0 + rows_local) of rows_total; the context holds a communicator): every global
+// quantity is all-reduced, the stripe's levels are those of the one-piece raster.  A rank with an empty stripe joins the reductions.
+int band_u8_stripe_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t in_pitch,
+                       int strategy, int tamed, uint8_t *d_out, size_t out_pitch);
+// composition of a part (n of n_total pixels; `reduce`: the parts are the ranks') of a flat dual-pol u8 product (api.cpp)
+int synrgb_flat_dev(sarpro_hip_ctx *ctx, int mode, int strategy, const uint8_t *d_b1, const uint8_t *d_b2, size_t n, size_t n_total, bool reduce,
+                    uint8_t *d_rgb);
 // the same band up to its DN -> final u8 TABLE (percentile strategies on the device chain: the table is the whole autoscale), for
 // a consumer that applies it itself (the horizontal resize pass).  out->lut == nullptr: this band / strategy has no such table
 // (CLAHE, host route): take band_u8_dev.  The table and the state it points to live in the context until its next chain.

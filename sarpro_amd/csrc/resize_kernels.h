@@ -18,6 +18,10 @@ struct ResizePassArgs {
     uint32_t block_span;          // horizontal pass: max over groups of kResizeHBlock consecutive outputs of start[last] - start[first]
     uint32_t k_small;             // every coefficient < 32640: k = 256 hi + lo with both halves signed bytes (else the horizontal pass's BIG form)
     uint32_t generic;             // context attribute RESIZE_GENERIC: the tap-by-tap kernels (cross-check twin of the register-resident forms)
+    // vertical pass over a WINDOW of the axis (a row stripe's share, stripe_resized.cpp): output rows [oy0, oy0 + oy_n) (oy_n = 0: all);
+    // source row y is at src + (y - src_row0) * src_pitch, output row oy at dst + (oy - dst_row0) * dst_pitch
+    uint32_t oy0, oy_n;
+    int32_t src_row0, dst_row0;
 };
 constexpr uint32_t kResizeHBlock = 256;
 constexpr uint32_t kResizeHMaxChunks = 16; // 8-byte chunks of taps a thread of the register-resident horizontal pass can hold (windows up to 114 taps)

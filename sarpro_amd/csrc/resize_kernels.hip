@@ -250,10 +250,10 @@ __global__ __launch_bounds__(kResizeHBlock, SARPRO_RESIZE_H_MINWAVES) void k_res
 // contiguous bytes of an intermediate row), the tap's coefficient is block-uniform (scalar).  Exact i32 sums, as the generic
 // kernel's.
 __global__ __launch_bounds__(256) void k_resize_v_u8_x8(ResizePassArgs a) {
-    const uint32_t oy = blockIdx.y;
+    const uint32_t oy = a.oy0 + blockIdx.y;
     const uint32_t x = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (x >= a.width) return;
-    const uint8_t *__restrict__ src = reinterpret_cast<const uint8_t *>(a.src);
+    const uint8_t *__restrict__ src = reinterpret_cast<const uint8_t *>(a.src) - (ptrdiff_t)a.src_row0 * (ptrdiff_t)a.src_pitch;
     const uint32_t y0 = a.start[oy], n = a.size[oy];
     const int32_t initial = a.precision > 0 ? (int32_t)1 << (a.precision - 1) : 0;
     int32_t ss[8];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_resize_v_u8_x8(ResizePassArgs a) {
             ss[4 + j] += (int32_t)((w1 >> (8 * j)) & 0xFFu) * k;
         }
     }
-    uint8_t *d = reinterpret_cast<uint8_t *>(a.dst) + (size_t)oy * a.dst_pitch + x;
+    uint8_t *d = reinterpret_cast<uint8_t *>(a.dst) + ((ptrdiff_t)oy - (ptrdiff_t)a.dst_row0) * (ptrdiff_t)a.dst_pitch + x;
     uint32_t o0 = 0, o1 = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -289,17 +289,17 @@ __global__ __launch_bounds__(256) void k_resize_v_u8_x8(ResizePassArgs a) {
 // Vertical pass: thread per output pixel; lanes run along x, so every tap is a coalesced row read.
 template <typename T, typename Acc>
 __global__ __launch_bounds__(kBlock) void k_resize_v(ResizePassArgs a) {
-    const uint32_t oy = blockIdx.y;
+    const uint32_t oy = a.oy0 + blockIdx.y;
     const uint32_t x = blockIdx.x * kBlock + threadIdx.x;
     if (x >= a.width) return;
-    const T *__restrict__ src = reinterpret_cast<const T *>(a.src);
+    const T *__restrict__ src = reinterpret_cast<const T *>(a.src) - (ptrdiff_t)a.src_row0 * (ptrdiff_t)a.src_pitch;
     const uint32_t y0 = a.start[oy], n = a.size[oy];
     Acc ss = a.precision > 0 ? (Acc)1 << (a.precision - 1) : 0;
     for (uint32_t t = 0; t < n; ++t)
         ss += (Acc)src[(size_t)(y0 + t) * a.src_pitch + x] * (Acc)a.k[(size_t)t * a.out_size + oy];
     Acc o = ss >> a.precision;
     o = o < 0 ? 0 : (o > (Acc)a.max_val ? (Acc)a.max_val : o);
-    reinterpret_cast<T *>(a.dst)[(size_t)oy * a.dst_pitch + x] = (T)o;
+    reinterpret_cast<T *>(a.dst)[((ptrdiff_t)oy - (ptrdiff_t)a.dst_row0) * (ptrdiff_t)a.dst_pitch + x] = (T)o;
 }
 
 } // namespace
@@ -372,10 +372,11 @@ hipError_t launch_resize_h(const ResizePassArgs &a, uint32_t rows, int elem_size
 }
 
 hipError_t launch_resize_v(const ResizePassArgs &a, int elem_size, hipStream_t s) {
-    if (!a.width || !a.out_size) return hipSuccess;
-    dim3 grid((a.width + kBlock - 1) / kBlock, a.out_size);
+    const uint32_t ny = a.oy_n ? a.oy_n : a.out_size - a.oy0; // (a window of the output rows: a row stripe's share)
+    if (!a.width || !a.out_size || !ny) return hipSuccess;
+    dim3 grid((a.width + kBlock - 1) / kBlock, ny);
     if (elem_size == 1 && !a.generic) {
-        hipLaunchKernelGGL(k_resize_v_u8_x8, dim3((a.width + kBlock * 8 - 1) / (kBlock * 8), a.out_size), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(k_resize_v_u8_x8, dim3((a.width + kBlock * 8 - 1) / (kBlock * 8), ny), dim3(kBlock), 0, s, a);
         return hipGetLastError();
     }
     if (elem_size == 1) hipLaunchKernelGGL((k_resize_v<uint8_t, int32_t>), grid, dim3(kBlock), 0, s, a);

@@ -306,3 +306,222 @@ static int dualpol_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const bands
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SARPRO_HIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Row stripes of ONE scene -> the resized, padded product ("the Lanczos resize needs a +-3 * scale-row halo per
+// stripe").  save.rs:317-367 with the scene's rows spread over the ranks of a communicator: each rank holds rows [row0, row0 +
+// rows_local) of both DN rasters (1/N of the scene crossed ITS PCIe link) and produces a contiguous range of the FINAL raster's rows.
+//   1. per band the stripe's u8 levels (band_u8_stripe_dev: the statistics, CLAHE bins and level histogram are all-reduced integers,
+//      so the levels are the one-piece raster's);
+//   2. the horizontal pass over the stripe's rows (rows are independent);
+//   3. the halo: output row j of the vertical pass belongs to the rank that holds the CENTRE row of j's window; its window reaches
+//      at most `window` rows into the neighbours.  Every rank writes the rows it holds within `window` of each stripe boundary into that
+//      boundary's zone of one exchange buffer (zero elsewhere), ONE all-reduce(sum) assembles all zones on all ranks -- each byte has
+//      exactly one non-zero contributor, so the sum is a gather and the only collective the library has carries it (integer, exact).
+//      (N - 1) zones x 2 window rows x 2 bands x the resized width: 1.8 MB for 400 MP -> 2048^2 on 8 ranks, against 41 MB per band for
+//      the whole intermediate raster.  The stripe geometry of all ranks travels the same way first (2 words per rank);
+//   4. the vertical pass for the rank's output rows, over its own intermediate rows + the two halos;
+//   5. padding + composition of the rank's rows of the final raster: the suppressed variant's floor is taken from the combined
+//      histogram of the WHOLE padded product (synthetic_rgb.rs:92-113), summed over the ranks (256 words).
+// The rank's rows are returned compact (out_rows x final_cols x 3 bytes) with their position; the caller places them (each rank's D2H
+// into one host raster, or a gather).  Bit for bit the raster of sarpro_hip_dualpol_synrgb_resized_u16_dev on the one-piece scene.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct StripeResizeGeom {
+    bool do_resize = false;
+    size_t nc = 0, nr = 0, fc = 0, fr = 0, pad_left = 0, pad_top = 0;
+    size_t j0 = 0, j1 = 0, f0 = 0, f1 = 0; // the rank's rows of the resized raster / of the final raster
+    uint32_t window = 0;                   // taps of the vertical pass (0: no resize)
+};
+
+// which rows of the product does the holder of input rows [row0, row0 + rows_local) produce?  (pure host arithmetic: every rank, and the
+// caller sizing its slice buffer, derive the same answer)
+void stripe_resize_geom(size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t target_size, int pad, StripeResizeGeom *g) {
+    g->nc = cols; g->nr = rows_total;
+    g->do_resize = target_size && std::max(cols, rows_total) != target_size && cols && rows_total; // resize.rs:110-145
+    if (g->do_resize) resize_dimensions(cols, rows_total, target_size, &g->nc, &g->nr);
+    g->fc = g->nc; g->fr = g->nr;
+    if (pad) { g->fc = g->fr = std::max(g->nc, g->nr); g->pad_left = (g->fc - g->nc) / 2; g->pad_top = (g->fr - g->nr) / 2; } // padding.rs:12-14
+    const size_t row1 = row0 + rows_local;
+    if (g->do_resize && g->nr && g->nc) {
+        std::vector<uint32_t> start, size; // (the windows without their weights: 2048 x 60 Lanczos evaluations per call otherwise)
+        resize_bounds((uint32_t)rows_total, (uint32_t)g->nr, &g->window, &start, &size);
+        auto centre = [&](size_t j) { return (size_t)start[j] + size[j] / 2; };
+        size_t j = 0;
+        while (j < g->nr && centre(j) < row0) ++j;
+        g->j0 = j;
+        while (j < g->nr && centre(j) < row1) ++j;
+        g->j1 = j;
+    } else {
+        g->j0 = std::min(row0, g->nr); g->j1 = std::min(row1, g->nr);
+    }
+    const bool any = g->j1 > g->j0;
+    g->f0 = any && g->j0 == 0 ? 0 : g->pad_top + g->j0;             // the holder of the first / last resized row also holds the padding above / below
+    g->f1 = any && g->j1 == g->nr ? g->fr : g->pad_top + g->j1;
+    if (!any) g->f1 = g->f0;
+}
+
+} // namespace
+
+extern "C" int sarpro_hip_stripe_resized_rows(size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t target_size, int pad,
+                                              size_t *out_row0, size_t *out_rows, size_t *final_cols, size_t *final_rows) {
+    if (row0 + rows_local > rows_total) return SARPRO_HIP_ERR_INVALID_ARG;
+    StripeResizeGeom g;
+    stripe_resize_geom(rows_total, cols, row0, rows_local, target_size, pad, &g);
+    if (out_row0) *out_row0 = g.f0;
+    if (out_rows) *out_rows = g.f1 - g.f0;
+    if (final_cols) *final_cols = g.fc;
+    if (final_rows) *final_rows = g.fr;
+    return SARPRO_HIP_OK;
+}
+
+static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const d_bands[2], size_t rows_total, size_t cols, size_t row0, size_t rows_local,
+                                   size_t in_pitch, int strategy, int mode, size_t target_size, int pad, uint8_t *d_rgb_slice, size_t *out_row0,
+                                   size_t *out_rows, sarpro_hip_resize_meta *meta) {
+    if (!ctx->comm && !ctx->local_group && !ctx->attrs.on(A_COMM_REPLAY)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no communicator on this context (sarpro_hip_comm_init / _init_local)");
+    if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
+    if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
+    if (row0 + rows_local > rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "stripe outside the scene");
+    if (rows_local * cols && (!d_bands[0] || !d_bands[1] || in_pitch < cols)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster / pitch < cols");
+    comm_replay_rewind(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TimingHold hold(ctx);
+    StripeResizeGeom g;
+    stripe_resize_geom(rows_total, cols, row0, rows_local, target_size, pad, &g);
+    if (g.do_resize && (!g.nc || !g.nr)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "target size collapses a dimension to zero");
+    sarpro_hip_resize_meta m{};
+    m.final_cols = g.fc; m.final_rows = g.fr; m.pad_left = g.pad_left; m.pad_top = g.pad_top;
+    m.scale_x = g.do_resize ? (double)g.nc / (double)cols : 1.0; m.scale_y = g.do_resize ? (double)g.nr / (double)rows_total : 1.0; // resize.rs:168-169
+    if (meta) *meta = m;
+    if (out_row0) *out_row0 = g.f0;
+    if (out_rows) *out_rows = g.f1 - g.f0;
+    const int nranks = std::max(ctx->comm_nranks, 1), rank = ctx->comm_rank;
+    const size_t K = g.window, row1 = row0 + rows_local;
+    const size_t lvl_pitch = round_up(std::max<size_t>(cols, 1), 64), tmp_pitch = round_up(std::max<size_t>(g.nc, 1), 64);
+    const size_t tmp_rows = rows_local + 2 * K, tmp_bytes = std::max<size_t>(tmp_rows, 1) * tmp_pitch; // per band: [K halo rows][the stripe's rows][K halo rows]
+
+    // ---- the ranks' stripes (every rank needs every boundary to lay the exchange buffer out)
+    HIPCHK(ctx, ctx->resize_geom.reserve(sizeof(uint64_t) * 2 * (size_t)nranks));
+    HIPCHK(ctx, hipMemsetAsync(ctx->resize_geom.p, 0, sizeof(uint64_t) * 2 * (size_t)nranks, ctx->stream));
+    const uint64_t mine[2] = {(uint64_t)row0 + 1u, (uint64_t)rows_local}; // (+ 1: a rank that never wrote its entry shows as 0)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->resize_geom.as<uint64_t>() + 2 * (size_t)rank, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    {
+        KernelTimer t(ctx, "allreduce_stripe_geometry");
+        RETCHK(comm_allreduce_sum_u64_async(ctx, ctx->resize_geom.as<uint64_t>(), 2 * (size_t)nranks));
+    }
+    std::vector<uint64_t> geom(2 * (size_t)nranks);
+    HIPCHK(ctx, hipMemcpyAsync(geom.data(), ctx->resize_geom.p, sizeof(uint64_t) * geom.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        size_t next = 0;
+        for (int r = 0; r < nranks; ++r) { // (every rank sees the same table: the same answer everywhere, nobody is left in a collective)
+            if (geom[2 * (size_t)r] != next + 1) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "row stripes must tile the scene in rank order");
+            next += geom[2 * (size_t)r + 1];
+        }
+        if (next != rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "row stripes must tile the scene in rank order");
+    }
+
+    // ---- 1 + 2: levels of the stripe, horizontal pass into the middle of the band's intermediate raster
+    HIPCHK(ctx, ctx->resize_tmp.reserve(2 * tmp_bytes));
+    HIPCHK(ctx, ctx->stage_out[0].reserve(std::max<size_t>(rows_local, 1) * lvl_pitch));
+    ResizePassArgs ah{}, av{};
+    ah.generic = av.generic = ctx->attrs.on(A_RESIZE_GENERIC) ? 1u : 0u;
+    if (g.do_resize) {
+        RETCHK(get_coeffs(ctx, 0, (uint32_t)cols, (uint32_t)g.nc, 1, &ah));
+        RETCHK(get_coeffs(ctx, 1, (uint32_t)rows_total, (uint32_t)g.nr, 1, &av));
+        if (av.window != g.window) return fail(ctx, SARPRO_HIP_ERR_HIP, "striped resize: the halo was sized for another window than the vertical pass's");
+    }
+    for (int b = 0; b < 2; ++b) {
+        uint8_t *tmp = ctx->resize_tmp.as<uint8_t>() + (size_t)b * tmp_bytes, *mid = tmp + K * tmp_pitch;
+        const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0; // save.rs:324-351
+        uint8_t *lvl = g.do_resize ? ctx->stage_out[0].as<uint8_t>() : mid;        // (no resize: the levels ARE the intermediate raster)
+        RETCHK(band_u8_stripe_dev(ctx, d_bands[b], rows_total, cols, row0, rows_local, in_pitch, strategy, tamed, lvl, g.do_resize ? lvl_pitch : tmp_pitch));
+        if (g.do_resize && rows_local) {
+            ah.src = lvl; ah.src_pitch = lvl_pitch; ah.dst = mid; ah.dst_pitch = tmp_pitch; ah.max_val = 255u;
+            KernelTimer t(ctx, "resize_h");
+            HIPCHK(ctx, launch_resize_h(ah, (uint32_t)rows_local, 1, ctx->stream));
+        }
+    }
+
+    // ---- 3: the halo rows, through the boundary zones
+    if (g.do_resize && nranks > 1) {
+        const size_t zone_bytes = 2 * K * tmp_pitch, nz = (size_t)nranks - 1, xbytes = 2 * nz * zone_bytes; // [band][zone][2 K rows][tmp_pitch]
+        HIPCHK(ctx, ctx->resize_halo.reserve(xbytes));
+        uint8_t *x = ctx->resize_halo.as<uint8_t>();
+        HIPCHK(ctx, hipMemsetAsync(x, 0, xbytes, ctx->stream));
+        for (size_t z = 0; z < nz; ++z) { // boundary between rank z and z + 1, at row B: the zone is rows [B - K, B + K)
+            const long long B = (long long)geom[2 * (z + 1)] - 1, lo = std::max<long long>(B - (long long)K, (long long)row0), hi = std::min<long long>(B + (long long)K, (long long)row1);
+            if (hi <= lo) continue; // none of this rank's rows lie in the zone
+            for (int b = 0; b < 2; ++b) {
+                const uint8_t *mid = ctx->resize_tmp.as<uint8_t>() + (size_t)b * tmp_bytes + K * tmp_pitch;
+                HIPCHK(ctx, hipMemcpyAsync(x + ((size_t)b * nz + z) * zone_bytes + (size_t)(lo - (B - (long long)K)) * tmp_pitch, mid + (size_t)(lo - (long long)row0) * tmp_pitch,
+                                           (size_t)(hi - lo) * tmp_pitch, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        {
+            KernelTimer t(ctx, "allreduce_resize_halo");
+            RETCHK(comm_allreduce_sum_u64_async(ctx, reinterpret_cast<uint64_t *>(x), xbytes / 8));
+        }
+        if (g.j1 > g.j0) // rows [row0 - K, row0) from the zone at this rank's upper boundary, rows [row1, row1 + K) from the one at its lower boundary
+            for (int b = 0; b < 2; ++b) {
+                uint8_t *tmp = ctx->resize_tmp.as<uint8_t>() + (size_t)b * tmp_bytes;
+                if (rank > 0) HIPCHK(ctx, hipMemcpyAsync(tmp, x + ((size_t)b * nz + (size_t)rank - 1) * zone_bytes, K * tmp_pitch, hipMemcpyDeviceToDevice, ctx->stream));
+                if (rank + 1 < nranks)
+                    HIPCHK(ctx, hipMemcpyAsync(tmp + (K + rows_local) * tmp_pitch, x + ((size_t)b * nz + (size_t)rank) * zone_bytes + K * tmp_pitch, K * tmp_pitch, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+    }
+
+    // ---- 4: the rank's rows of the resized bands, inside its rows of the padded bands
+    const size_t srows = g.f1 - g.f0, opitch = round_up(std::max<size_t>(g.fc, 1), 64);
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(ctx, ctx->resized[b].reserve(std::max<size_t>(srows, 1) * opitch));
+        if (srows) HIPCHK(ctx, hipMemsetAsync(ctx->resized[b].p, 0, srows * opitch, ctx->stream));
+        if (g.j1 <= g.j0) continue;
+        const uint8_t *tmp = ctx->resize_tmp.as<uint8_t>() + (size_t)b * tmp_bytes;
+        uint8_t *dst = ctx->resized[b].as<uint8_t>() + g.pad_left; // row (pad_top + j - f0) of the slice holds resized row j
+        if (g.do_resize) {
+            av.src = tmp; av.src_pitch = tmp_pitch; av.src_row0 = (int32_t)((long long)row0 - (long long)K);
+            av.dst = dst; av.dst_pitch = opitch; av.dst_row0 = (int32_t)((long long)g.f0 - (long long)g.pad_top);
+            av.width = (uint32_t)g.nc; av.max_val = 255u; av.oy0 = (uint32_t)g.j0; av.oy_n = (uint32_t)(g.j1 - g.j0);
+            KernelTimer t(ctx, "resize_v");
+            HIPCHK(ctx, launch_resize_v(av, 1, ctx->stream));
+        } else {
+            HIPCHK(ctx, hipMemcpy2DAsync(dst + (g.pad_top + g.j0 - g.f0) * opitch, opitch, tmp + (K + (g.j0 - row0)) * tmp_pitch, tmp_pitch, g.nc, g.j1 - g.j0,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+
+    // ---- 5: composition of the rank's rows; the suppressed floor from the whole padded product's histogram
+    const uint8_t *cb[2] = {ctx->resized[0].as<uint8_t>(), ctx->resized[1].as<uint8_t>()};
+    if (opitch != g.fc && srows) {
+        HIPCHK(ctx, ctx->stage_out[1].reserve(g.fc * srows));
+        HIPCHK(ctx, ctx->stage_out[2].reserve(g.fc * srows));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[1].p, g.fc, ctx->resized[0].p, opitch, g.fc, srows, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_out[2].p, g.fc, ctx->resized[1].p, opitch, g.fc, srows, hipMemcpyDeviceToDevice, ctx->stream));
+        cb[0] = ctx->stage_out[1].as<uint8_t>(); cb[1] = ctx->stage_out[2].as<uint8_t>();
+    }
+    const size_t n_local = g.fc * srows;
+    if (n_local && !d_rgb_slice) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null RGB slice");
+    if (!g.fc || !g.fr) return SARPRO_HIP_OK;
+    uint8_t *rgb = d_rgb_slice;
+    if (n_local && (reinterpret_cast<uintptr_t>(d_rgb_slice) & 15) != 0) { // (the vector composition wants 16-byte alignment: through a library raster then)
+        HIPCHK(ctx, ctx->stage_out[0].reserve(std::max(n_local * 3, std::max<size_t>(rows_local, 1) * lvl_pitch)));
+        rgb = ctx->stage_out[0].as<uint8_t>();
+    }
+    RETCHK(synrgb_flat_dev(ctx, mode, strategy, cb[0], cb[1], n_local, g.fc * g.fr, true, rgb));
+    if (rgb != d_rgb_slice && n_local) HIPCHK(ctx, hipMemcpyAsync(d_rgb_slice, rgb, n_local * 3, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SARPRO_HIP_OK;
+}
+
+extern "C" int sarpro_hip_stripe_run_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total, size_t cols,
+                                                 size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode, size_t target_size, int pad,
+                                                 uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const uint16_t *const bands[2] = {d_band1, d_band2};
+    const int rc = stripe_run_resized_impl(ctx, bands, rows_total, cols, row0, rows_local, in_pitch, strategy, mode, target_size, pad, d_rgb_slice, out_row0,
+                                           out_rows, meta);
+    if (rc != SARPRO_HIP_OK) comm_abort_local_group(ctx); // an in-process group: the peers of a rank that failed must not wait for it (comm.cpp)
+    return rc;
+}
