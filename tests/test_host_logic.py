@@ -104,6 +104,51 @@ def test_stripe_plan_covers_rows_once():
     assert S.host_stripe_plan(20000, 8)[1] == [2500] * 8  # = CLAHE tile rows of the 400 MP scene
 
 
+def test_striped_resize_geometry_tiles_the_product_and_bounds_the_halo():
+    """sarpro_hip_stripe_resized_rows (the arithmetic every rank of sarpro_hip_stripe_run_resized_u16 runs on its own): the ranks' row
+    ranges tile the final raster once, in rank order; the holder of the first / last resized row holds the padding above / below; an
+    output row belongs to the holder of its window's centre row, so its window reaches at most one window length into a neighbour --
+    the halo the exchange carries.  Windows re-derived here from the published formula (fast_image_resize's bounds: centre (j + 0.5) *
+    scale, radius 3 * max(scale, 1))."""
+    import math
+    for rows, cols, target, pad in [(20000, 20000, 2048, True), (5000, 5056, 1024, True), (384, 520, 128, True), (384, 520, 100, False),
+                                    (1100, 300, 90, False), (300, 1100, 256, True), (384, 520, None, True), (264, 264, 264, True)]:
+        fc, fr = S.resize_output_dims(cols, rows, target, pad)
+        resized = bool(target) and max(rows, cols) != target
+        nr_out = fr if not pad else None
+        for plan in ([(0, rows)], list(zip(*S.host_stripe_plan(rows, 2))), list(zip(*S.host_stripe_plan(rows, 8))),
+                     [(0, 5), (5, 0), (5, rows - 105), (rows - 100, 100)], [(0, rows // 2), (rows // 2, 3), (rows // 2 + 3, 2), (rows // 2 + 5, rows - rows // 2 - 5)]):
+            got = [S.host_stripe_resized_rows(rows, cols, r0, n, target, pad) for r0, n in plan]
+            assert all((g[2], g[3]) == (fc, fr) for g in got)
+            pos = 0
+            for (o0, on, _, _) in got:  # contiguous, in rank order; empty ranges allowed
+                if on:
+                    assert o0 == pos, (rows, cols, target, pad, plan, got)
+                    pos += on
+            assert pos == fr, (rows, cols, target, pad, plan, got)
+            if not resized:
+                continue
+            # the resized rows: nr = the product's rows minus the padding
+            long_side, short = max(rows, cols), min(rows, cols)
+            nr = target if rows >= cols else int(math.floor(short * (target / long_side) + 0.5))
+            if target > long_side:
+                nr = rows
+            pad_top = (fr - nr) // 2 if pad else 0
+            scale = rows / nr
+            radius = 3.0 * max(scale, 1.0)
+            window = math.ceil(radius) * 2 + 1
+            for (r0, n), (o0, on, _, _) in zip(plan, got):
+                for f in range(o0, o0 + on):
+                    j = f - pad_top
+                    if j < 0 or j >= nr:
+                        continue  # a padding row
+                    c = (j + 0.5) * scale
+                    lo, hi = max(math.floor(c - radius), 0), min(math.ceil(c + radius), rows)
+                    centre = lo + (hi - lo) // 2
+                    assert r0 <= centre < r0 + n, (rows, target, plan, j, centre)
+                    assert lo >= r0 - window and hi <= r0 + n + window
+
+
 def test_parse_cpulist_of_the_batch_workers_numa_binding():
     """sysfs cpulist syntax -> CPU numbers (csrc/batch.cpp binds each batch worker to its GPU's NUMA node with it)."""
     import ctypes as C
