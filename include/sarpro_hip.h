@@ -475,6 +475,12 @@ int sarpro_hip_stripe_resized_rows(size_t rows_total, size_t cols, size_t row0, 
 int sarpro_hip_stripe_run_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *d_band1, const uint16_t *d_band2, size_t rows_total, size_t cols,
                                       size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode, size_t target_size, int pad,
                                       uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta);
+/* the same for f32 bands (the reference's default, resampled-on-read flow; flags: SARPRO_HIP_DUALPOL_*): the levels come from the
+ * striped f32 chain (process_scalar_data_pipeline at U8).  Under Tamed only with SARPRO_HIP_DUALPOL_PLAIN_PIPELINE (api/mod.rs:404-437):
+ * the band-specific re-autoscale of save.rs:324-351 has no striped form (SARPRO_HIP_ERR_INVALID_ARG). */
+int sarpro_hip_stripe_run_resized_f32(sarpro_hip_ctx *ctx, const float *d_band1, const float *d_band2, size_t rows_total, size_t cols, size_t row0,
+                                      size_t rows_local, size_t in_pitch, int strategy, int mode, unsigned flags, size_t target_size, int pad,
+                                      uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta);
 
 /* Self-test: the division the u16 pol-op kernels use (the Newton core of the IEEE division without its rescaling frame) against
  * the compiler's IEEE division over ALL 2^32 pairs of u16 values, ratio and normalised difference.  *mismatches_out must be 0. */

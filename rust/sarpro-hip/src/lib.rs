@@ -508,6 +508,16 @@ impl RasterCore {
             mode as c_int, target_size.unwrap_or(0), pad as c_int, d_rgb_slice, &mut r0, &mut n, &mut m))?;
         Ok((r0, n, m))
     }
+    /// [`stripe_run_resized_u16`] for f32 bands (the reference's resampled-on-read flow); Tamed needs `plain_pipeline`
+    pub unsafe fn stripe_run_resized_f32(&self, d_band1: *const f32, d_band2: *const f32, rows_total: usize, cols: usize, row0: usize,
+        rows_local: usize, in_pitch: usize, strategy: AutoscaleStrategy, mode: SyntheticRgbMode, plain_pipeline: bool, target_size: Option<usize>,
+        pad: bool, d_rgb_slice: *mut u8) -> Result<(usize, usize, ResizeMeta)> {
+        let (mut r0, mut n, mut m) = (0usize, 0usize, zeroed_meta());
+        self.chk(sys::sarpro_hip_stripe_run_resized_f32(self.ctx, d_band1, d_band2, rows_total, cols, row0, rows_local, in_pitch, strategy as c_int,
+            mode as c_int, if plain_pipeline { sys::SARPRO_HIP_DUALPOL_PLAIN_PIPELINE } else { 0 }, target_size.unwrap_or(0), pad as c_int, d_rgb_slice,
+            &mut r0, &mut n, &mut m))?;
+        Ok((r0, n, m))
+    }
     /// this rank's stripe of an f32 band -> its stripe of the level raster
     pub unsafe fn stripe_run_f32(&self, d_in: *const f32, rows_total: usize, cols: usize, row0: usize, rows_local: usize, in_pitch: usize,
         strategy: AutoscaleStrategy, bit_depth: BitDepth, d_out: *mut c_void, out_pitch: usize) -> Result<HistogramStats> {

@@ -82,7 +82,7 @@ SYMBOLS = [
     "sarpro_hip_last_kernel_times",
     "sarpro_hip_ctx_time_only", "sarpro_hip_ctx_spec_report", "sarpro_hip_ctx_chain_report",
     "sarpro_hip_stripe_begin_u16", "sarpro_hip_stripe_phase1", "sarpro_hip_stripe_phase2",
-    "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end", "sarpro_hip_stripe_run_u16", "sarpro_hip_stripe_resized_rows", "sarpro_hip_stripe_run_resized_u16",
+    "sarpro_hip_stripe_phase3", "sarpro_hip_stripe_phase4", "sarpro_hip_stripe_end", "sarpro_hip_stripe_run_u16", "sarpro_hip_stripe_resized_rows", "sarpro_hip_stripe_run_resized_u16", "sarpro_hip_stripe_run_resized_f32",
     "sarpro_hip_dualpol_synrgb_stream_u16", "sarpro_hip_dualpol_synrgb_resized_stream_u16", "sarpro_hip_tiff_open", "sarpro_hip_tiff_read_rows_u16", "sarpro_hip_tiff_close",
     "sarpro_hip_tiff_pair_reader", "sarpro_hip_tiff_create", "sarpro_hip_tiff_write_rows", "sarpro_hip_tiff_row_sink",
     "sarpro_hip_tiff_finish", "sarpro_hip_tiff_last_error", "sarpro_hip_host_update_geotransform",
@@ -254,6 +254,7 @@ _proto("sarpro_hip_batch_dualpol_synrgb_u16_dev", _i, _vp, C.POINTER(ResidentSce
 _proto("sarpro_hip_stripe_run_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
 _proto("sarpro_hip_stripe_resized_rows", _i, _sz, _sz, _sz, _sz, _sz, _i, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz))
 _proto("sarpro_hip_stripe_run_resized_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _sz, _i, _vp, C.POINTER(_sz), C.POINTER(_sz), _M)
+_proto("sarpro_hip_stripe_run_resized_f32", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, C.c_uint, _sz, _i, _vp, C.POINTER(_sz), C.POINTER(_sz), _M)
 _proto("sarpro_hip_dualpol_synrgb_stream_u16", _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _vp, _vp, _S)
 _proto("sarpro_hip_tiff_open", _i, C.c_char_p, C.POINTER(_vp), C.POINTER(TiffInfo))
 _proto("sarpro_hip_tiff_read_rows_u16", _i, _vp, _i, _sz, _sz, _vp, _sz)

@@ -465,6 +465,17 @@ class Context:
                                                         int(mode), int(target_size or 0), int(bool(pad)), _vp(d_rgb_slice), C.byref(r0), C.byref(nr), C.byref(m)))
         return int(r0.value), int(nr.value), m
 
+    def stripe_run_resized_f32(self, d_b1: int, d_b2: int, rows_total: int, cols: int, row0: int, rows_local: int, in_pitch: int,
+                               strategy, mode, target_size: int, pad: bool, d_rgb_slice: int, plain_pipeline: bool = True):
+        """stripe_run_resized_u16 for f32 bands (sarpro_hip_stripe_run_resized_f32); Tamed needs plain_pipeline."""
+        from ._lib import ResizeMeta
+        m = ResizeMeta()
+        r0, nr = C.c_size_t(), C.c_size_t()
+        self._chk(lib.sarpro_hip_stripe_run_resized_f32(self._h, _vp(d_b1), _vp(d_b2), rows_total, cols, row0, rows_local, in_pitch, int(strategy),
+                                                        int(mode), 1 if plain_pipeline else 0, int(target_size or 0), int(bool(pad)), _vp(d_rgb_slice),
+                                                        C.byref(r0), C.byref(nr), C.byref(m)))
+        return int(r0.value), int(nr.value), m
+
     def stripe_begin_f32(self, d_in: int, rows_total: int, cols: int, row0: int, rows_local: int, in_pitch: int, strategy, bit_depth,
                          d_out: int, out_pitch: int) -> "StripeF32":
         h = C.c_void_p()

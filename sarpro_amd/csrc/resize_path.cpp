@@ -376,13 +376,17 @@ extern "C" int sarpro_hip_stripe_resized_rows(size_t rows_total, size_t cols, si
     return SARPRO_HIP_OK;
 }
 
-static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const d_bands[2], size_t rows_total, size_t cols, size_t row0, size_t rows_local,
-                                   size_t in_pitch, int strategy, int mode, size_t target_size, int pad, uint8_t *d_rgb_slice, size_t *out_row0,
+// f32 bands (elem_f32; flags: SARPRO_HIP_DUALPOL_*): the levels come from the striped f32 chain (sarpro_hip_stripe_run_f32 =
+// process_scalar_data_pipeline at U8 over stripes), which has no band-specific Tamed re-autoscale: Tamed needs the PLAIN_PIPELINE flag.
+static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const void *const d_bands[2], bool elem_f32, unsigned flags, size_t rows_total, size_t cols, size_t row0,
+                                   size_t rows_local, size_t in_pitch, int strategy, int mode, size_t target_size, int pad, uint8_t *d_rgb_slice, size_t *out_row0,
                                    size_t *out_rows, sarpro_hip_resize_meta *meta) {
     if (!ctx->comm && !ctx->local_group && !ctx->attrs.on(A_COMM_REPLAY)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "no communicator on this context (sarpro_hip_comm_init / _init_local)");
     if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
     if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
     if (row0 + rows_local > rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "stripe outside the scene");
+    if (elem_f32 && strategy == SARPRO_STRATEGY_TAMED && !(flags & SARPRO_HIP_DUALPOL_PLAIN_PIPELINE))
+        return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "striped f32 bands under Tamed: only with SARPRO_HIP_DUALPOL_PLAIN_PIPELINE (the band-specific re-autoscale has no striped form)");
     if (rows_local * cols && (!d_bands[0] || !d_bands[1] || in_pitch < cols)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster / pitch < cols");
     comm_replay_rewind(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -436,7 +440,13 @@ static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const uint16_t *const d_
         uint8_t *tmp = ctx->resize_tmp.as<uint8_t>() + (size_t)b * tmp_bytes, *mid = tmp + K * tmp_pitch;
         const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0; // save.rs:324-351
         uint8_t *lvl = g.do_resize ? ctx->stage_out[0].as<uint8_t>() : mid;        // (no resize: the levels ARE the intermediate raster)
-        RETCHK(band_u8_stripe_dev(ctx, d_bands[b], rows_total, cols, row0, rows_local, in_pitch, strategy, tamed, lvl, g.do_resize ? lvl_pitch : tmp_pitch));
+        if (elem_f32) {
+            RETCHK(sarpro_hip_stripe_run_f32(ctx, reinterpret_cast<const float *>(d_bands[b]), rows_total, cols, row0, rows_local, in_pitch, strategy, SARPRO_BITDEPTH_U8, lvl,
+                                             g.do_resize ? lvl_pitch : tmp_pitch, nullptr));
+        } else {
+            RETCHK(band_u8_stripe_dev(ctx, reinterpret_cast<const uint16_t *>(d_bands[b]), rows_total, cols, row0, rows_local, in_pitch, strategy, tamed, lvl,
+                                      g.do_resize ? lvl_pitch : tmp_pitch));
+        }
         if (g.do_resize && rows_local) {
             ah.src = lvl; ah.src_pitch = lvl_pitch; ah.dst = mid; ah.dst_pitch = tmp_pitch; ah.max_val = 255u;
             KernelTimer t(ctx, "resize_h");
@@ -519,9 +529,20 @@ extern "C" int sarpro_hip_stripe_run_resized_u16(sarpro_hip_ctx *ctx, const uint
                                                  size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode, size_t target_size, int pad,
                                                  uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta) {
     if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
-    const uint16_t *const bands[2] = {d_band1, d_band2};
-    const int rc = stripe_run_resized_impl(ctx, bands, rows_total, cols, row0, rows_local, in_pitch, strategy, mode, target_size, pad, d_rgb_slice, out_row0,
-                                           out_rows, meta);
+    const void *const bands[2] = {d_band1, d_band2};
+    const int rc = stripe_run_resized_impl(ctx, bands, false, 0u, rows_total, cols, row0, rows_local, in_pitch, strategy, mode, target_size, pad, d_rgb_slice,
+                                           out_row0, out_rows, meta);
     if (rc != SARPRO_HIP_OK) comm_abort_local_group(ctx); // an in-process group: the peers of a rank that failed must not wait for it (comm.cpp)
+    return rc;
+}
+
+extern "C" int sarpro_hip_stripe_run_resized_f32(sarpro_hip_ctx *ctx, const float *d_band1, const float *d_band2, size_t rows_total, size_t cols, size_t row0,
+                                                 size_t rows_local, size_t in_pitch, int strategy, int mode, unsigned flags, size_t target_size, int pad,
+                                                 uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    const void *const bands[2] = {d_band1, d_band2};
+    const int rc = stripe_run_resized_impl(ctx, bands, true, flags, rows_total, cols, row0, rows_local, in_pitch, strategy, mode, target_size, pad, d_rgb_slice,
+                                           out_row0, out_rows, meta);
+    if (rc != SARPRO_HIP_OK) comm_abort_local_group(ctx);
     return rc;
 }

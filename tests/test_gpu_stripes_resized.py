@@ -139,3 +139,36 @@ def test_striped_resized_over_the_rccl_communicator_with_one_rank(strategy):
         names = [x for x, _ in c.last_kernel_times()]
     assert (r0, n) == (0, 128) and "allreduce_stripe_geometry" in names and "allreduce_resize_halo" not in names
     assert np.array_equal(rgb.cpu().numpy().reshape(fr, fc, 3), ref)
+
+
+@pytest.mark.parametrize("strategy", [St.Clahe, St.Standard, St.Tamed])
+@pytest.mark.parametrize("ranks", [3, "ragged+empty"])
+def test_striped_resized_product_of_f32_bands(strategy, ranks):
+    """sarpro_hip_stripe_run_resized_f32: the reference's default flow hands the raster core non-integer f32 bands (resampled on read,
+    api/mod.rs:404-437: both through process_scalar_data_pipeline, resize -> pad -> synRGB); the levels come from the striped f32 chain."""
+    import f32data
+    rows, cols, target, pad = 384, 520, 128, True
+    b = [f32data.resampled_scene(rows, cols, k) for k in (0, 1)]
+    u8 = [oracle.resize_image_data_with_meta(oracle.pipeline(x, 0, int(strategy))[1], target, pad)[0] for x in b]
+    ref = oracle.synrgb(0, int(strategy), u8[0], u8[1])
+    splits = SPLITS.get(ranks) or list(zip(*S.host_stripe_plan(rows, ranks)))
+    pitch = 576
+    d = [[to_dev(x[r0:r0 + nr], pitch, torch.float32) for x in b] for r0, nr in splits]
+    want = [S.host_stripe_resized_rows(rows, cols, r0, nr, target, pad) for r0, nr in splits]
+    fc, fr = want[0][2], want[0][3]
+    sl = [torch.zeros((max(w[1], 1) * fc * 3,), dtype=torch.uint8, device="cuda") for w in want]
+    out, _ = run_ranks(splits, lambda c, k, r0, nr: c.stripe_run_resized_f32(d[k][0].data_ptr(), d[k][1].data_ptr(), rows, cols, r0, nr, pitch, strategy, Mode.Default,
+                                                                           target, pad, sl[k].data_ptr()))
+    got = np.concatenate([t.cpu().numpy()[: on * fc * 3].reshape(on, fc, 3) for (o0, on, _), t in zip(out, sl)], axis=0)
+    assert got.shape == ref.shape and np.array_equal(got, ref), (strategy, ranks, int((got != ref).any(axis=2).sum()))
+    if strategy == St.Tamed:  # without the plain-pipeline flag the band-specific re-autoscale would be needed: refused, on every rank alike
+        errs = []
+
+        def body(c, k, r0, nr):
+            try:
+                c.stripe_run_resized_f32(d[k][0].data_ptr(), d[k][1].data_ptr(), rows, cols, r0, nr, pitch, strategy, Mode.Default, target, pad, sl[k].data_ptr(),
+                                         plain_pipeline=False)
+            except S.SarproHipError as e:
+                errs.append(str(e))
+        run_ranks(splits, body)
+        assert len(errs) == len(splits) and all("PLAIN_PIPELINE" in e for e in errs), errs
