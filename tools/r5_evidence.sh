@@ -29,6 +29,7 @@ python3 tools/time_resize_flow.py > $O/time_resize_flow.txt 2>&1
 python3 tools/time_configs.py > $O/time_configs.txt 2>&1
 timeout 600 python3 tools/soak_spec_vs_exact.py 6 > $O/soak_spec_vs_exact.txt 2>&1
 timeout 900 python3 tools/soak_routes.py 2 > $O/soak_routes.txt 2>&1
+timeout 600 python3 tools/soak_random_rasters.py 90 30 1 > $O/soak_random_rasters.txt 2>&1
 python3 -m pytest tests -q -m gpu > $O/gpu_suite.txt 2>&1
 for d in bench_stats bench_one_stream_stats config2_stats config3_stats; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
 rm -rf $O/pmc_traffic/*/pmc_* $O/pmc_rgb_fused $O/pmc_dn_hist_pieces $O/pmc_resize_h $O/pmc_f32/*/ $O/bench_stats $O/bench_one_stream_stats $O/config2_stats $O/config3_stats 2>/dev/null
