@@ -1478,7 +1478,10 @@ static_assert(kRgbPoolEntries / 4 + 2 <= kRgbBlock, "one pass of the workgroup e
 // final values reach F and F + 1: the rescale is strictly increasing from min_pred on), and a fourth count -- level bytes below
 // min_pred -- must be zero.  Eight more v_sad_u8 per lane and row pair than the identity form, which is why it is its own body.
 template <bool GENERAL>
-__device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a, unsigned char *lds) {
+__device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
+    // (declared HERE, not handed in by the kernel: as a pointer argument the compiler treated it as a flat address -- 104 bytes of scratch
+    // and 25 spilled registers in the identity form against 76 and 18, and 8 % more bytes fetched by the pass, profiles/r5/pmc_traffic.txt)
+    extern __shared__ __align__(16) unsigned char lds[];
     constexpr int VEC = 8;
     ChainSpecState *sp = a.spec;
     const uint32_t win_hi[2] = {a.dev_state[0].win_hi, a.dev_state[1].win_hi};
@@ -1979,24 +1982,24 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a, unsi
 // Two kernels, two launches (the second returns at once on all but the rare scene): with both bodies in ONE kernel the identity form ran
 // 2 % slower (0.697-0.707 ms against 0.681-0.693 on the same box, the register allocator spills for the union of the two), the extra
 // launch costs nothing measurable (host time of the chain 1.179-1.190 ms against 1.186-1.195).  -DSARPRO_RGB_ONE_KERNEL = the merged form.
+// (The rescaled body as a noinline function called from the one kernel: 0.86-0.89 ms against 0.715 -- the call ABI costs the hot loop far
+// more than the spills.)  Inside a resident batch the second launch's empty workgroups still wait for whole compute units (160 KiB of LDS
+// each): its bracket reads 15 us on average there, on the lane's own stream, behind which only the gated fallbacks follow.
 #ifndef SARPRO_RGB_ONE_KERNEL
 __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    if (a.spec->spec_ok == kSpecIdentity) clahe_rgb_fused_body<false>(a, lds);
+    if (a.spec->spec_ok == kSpecIdentity) clahe_rgb_fused_body<false>(a);
 }
 #ifndef SARPRO_RGB_LITE
 __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused_rescaled(ClaheRgbArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    if (a.spec->spec_ok == kSpecRescaled) clahe_rgb_fused_body<true>(a, lds);
+    if (a.spec->spec_ok == kSpecRescaled) clahe_rgb_fused_body<true>(a);
 }
 #endif
 #else
 __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t how = a.spec->spec_ok;
-    if (how == kSpecIdentity) clahe_rgb_fused_body<false>(a, lds);
+    if (how == kSpecIdentity) clahe_rgb_fused_body<false>(a);
 #ifndef SARPRO_RGB_LITE // (the LITE form's water test reads the levels themselves: identity only)
-    else if (how == kSpecRescaled) clahe_rgb_fused_body<true>(a, lds);
+    else if (how == kSpecRescaled) clahe_rgb_fused_body<true>(a);
 #endif
 }
 #endif

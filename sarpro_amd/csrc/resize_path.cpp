@@ -427,6 +427,24 @@ static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const void *const d_band
     }
 
     // ---- 1 + 2: levels of the stripe, horizontal pass into the middle of the band's intermediate raster
+    // (u16: which chain a stripe takes -- and with it the sequence of collectives -- follows from the layout of its rasters; a stripe that is
+    // not in the aligned form is staged through a library raster, an empty one adopts the library's pitch: every rank takes the same route,
+    // as sarpro_hip_stripe_run_u16 does)
+    const void *band_ptr[2] = {d_bands[0], d_bands[1]};
+    if (!elem_f32) {
+        const bool empty = rows_local == 0 || cols == 0;
+        const bool aligned = !empty && in_pitch % 16 == 0 && (reinterpret_cast<uintptr_t>(d_bands[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_bands[1]) & 15) == 0;
+        if (empty) in_pitch = lvl_pitch;
+        else if (!aligned) {
+            for (int b = 0; b < 2; ++b) {
+                HIPCHK(ctx, ctx->stage_in[b].reserve(rows_local * lvl_pitch * sizeof(uint16_t)));
+                HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage_in[b].p, lvl_pitch * sizeof(uint16_t), d_bands[b], in_pitch * sizeof(uint16_t), cols * sizeof(uint16_t), rows_local,
+                                             hipMemcpyDeviceToDevice, ctx->stream));
+                band_ptr[b] = ctx->stage_in[b].p;
+            }
+            in_pitch = lvl_pitch;
+        }
+    }
     HIPCHK(ctx, ctx->resize_tmp.reserve(2 * tmp_bytes));
     HIPCHK(ctx, ctx->stage_out[0].reserve(std::max<size_t>(rows_local, 1) * lvl_pitch));
     ResizePassArgs ah{}, av{};
@@ -441,10 +459,10 @@ static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const void *const d_band
         const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0; // save.rs:324-351
         uint8_t *lvl = g.do_resize ? ctx->stage_out[0].as<uint8_t>() : mid;        // (no resize: the levels ARE the intermediate raster)
         if (elem_f32) {
-            RETCHK(sarpro_hip_stripe_run_f32(ctx, reinterpret_cast<const float *>(d_bands[b]), rows_total, cols, row0, rows_local, in_pitch, strategy, SARPRO_BITDEPTH_U8, lvl,
+            RETCHK(sarpro_hip_stripe_run_f32(ctx, reinterpret_cast<const float *>(band_ptr[b]), rows_total, cols, row0, rows_local, in_pitch, strategy, SARPRO_BITDEPTH_U8, lvl,
                                              g.do_resize ? lvl_pitch : tmp_pitch, nullptr));
         } else {
-            RETCHK(band_u8_stripe_dev(ctx, reinterpret_cast<const uint16_t *>(d_bands[b]), rows_total, cols, row0, rows_local, in_pitch, strategy, tamed, lvl,
+            RETCHK(band_u8_stripe_dev(ctx, reinterpret_cast<const uint16_t *>(band_ptr[b]), rows_total, cols, row0, rows_local, in_pitch, strategy, tamed, lvl,
                                       g.do_resize ? lvl_pitch : tmp_pitch));
         }
         if (g.do_resize && rows_local) {

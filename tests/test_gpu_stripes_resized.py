@@ -172,3 +172,29 @@ def test_striped_resized_product_of_f32_bands(strategy, ranks):
                 errs.append(str(e))
         run_ranks(splits, body)
         assert len(errs) == len(splits) and all("PLAIN_PIPELINE" in e for e in errs), errs
+
+
+def test_ranks_with_different_raster_layouts_produce_the_same_product():
+    """One rank's stripe at an odd pitch, one at an unaligned base, one in the aligned form: the unaligned ones are staged, so all three
+    take the same chain and meet in the same collectives (a rank alone on another route would leave its peers waiting)."""
+    rows, cols, target = 384, 520, 128
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    ref = oracle_product(b, St.Clahe, target, True)
+    splits = list(zip(*S.host_stripe_plan(rows, 3)))
+    pitches = [cols + 7, 576, 576]
+    d, ptrs = [], []
+    for k, (r0, nr) in enumerate(splits):
+        row = []
+        for x in b:
+            t = torch.zeros((nr * pitches[k] + 8,), dtype=torch.int16, device="cuda")
+            off = 3 if k == 1 else 0  # rank 1: base pointer 6 bytes off a 16-byte boundary
+            t[off:off + nr * pitches[k]].view(nr, pitches[k])[:, :cols] = torch.from_numpy(np.ascontiguousarray(x[r0:r0 + nr].view(np.int16))).cuda()
+            row.append((t, t.data_ptr() + 2 * off))
+        d.append(row)
+    want = [S.host_stripe_resized_rows(rows, cols, r0, nr, target, True) for r0, nr in splits]
+    fc, fr = want[0][2], want[0][3]
+    sl = [torch.zeros((max(w[1], 1) * fc * 3,), dtype=torch.uint8, device="cuda") for w in want]
+    out, _ = run_ranks(splits, lambda c, k, r0, nr: c.stripe_run_resized_u16(d[k][0][1], d[k][1][1], rows, cols, r0, nr, pitches[k], St.Clahe, Mode.Default, target, True,
+                                                                           sl[k].data_ptr()))
+    got = np.concatenate([t.cpu().numpy()[: on * fc * 3].reshape(on, fc, 3) for (o0, on, _), t in zip(out, sl)], axis=0)
+    assert np.array_equal(got, ref)

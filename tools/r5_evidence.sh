@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace -d $O/pipe_trace -o pipe --output-format csv -- python3
 python3 $R/tools/trace_overlap.py $O/pipe_trace 6 > $O/pipe_trace_overlap.txt 2>&1
 # 3. HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes); SQ counters of the fused pass, of the piece histogram, of the resize passes, of the f32 kernels
 bash $R/tools/pmc_traffic.sh $O/pmc_traffic > $O/pmc_traffic.txt 2>&1
-PMC_KERNEL=k_clahe_rgb_fused bash $R/tools/pmc_apply.sh $O/pmc_rgb_fused > $O/pmc_rgb_fused.txt 2>&1
+PMC_KERNEL='k_clahe_rgb_fused(' bash $R/tools/pmc_apply.sh $O/pmc_rgb_fused > $O/pmc_rgb_fused.txt 2>&1
 PMC_KERNEL=k_dn_hist_pieces bash $R/tools/pmc_apply.sh $O/pmc_dn_hist_pieces > $O/pmc_dn_hist_pieces.txt 2>&1
 PMC_KERNEL=k_resize_h PROFILE_SCRIPT=$R/tools/profile_resize.py bash $R/tools/pmc_apply.sh $O/pmc_resize_h > $O/pmc_resize_h.txt 2>&1
 bash $R/tools/pmc_f32.sh $O/pmc_f32 > $O/pmc_f32.txt 2>&1
