@@ -288,6 +288,8 @@ namespace sarpro {
 // so with the vector width alone (8) nearly every segment straddled a line at both ends: +13 % of HBM traffic on the apply
 // pass by the PMC counters (profiles/r2_traffic.json).  The leading lanes of a cell's first strip are masked instead.
 constexpr size_t kRgbItemRows = 256, kSampleItemRows = 1024, kU16ItemRows = 1024;
+constexpr size_t kRgbTailRows = 1024, kRgbTailItemRows = 96; // fused CLAHE -> RGB pass: the stripe's last rows in small items (see get_plan)
+constexpr size_t kRgbItemRowsLarge = 512, kRgbTailRowsLarge = 2500, kRgbTailItemRowsLarge = 128;
 static size_t strip_align(const StripePlan &P, int vecw) { // (STRIP_ALIGN: planner tuning, read when the plan is built)
     if (vecw != 8 && vecw != 4) return (size_t)vecw;
     return std::max<size_t>(vecw, P.strip_align_px / vecw * vecw);
@@ -528,9 +530,20 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
                 add_rects(P->u16_rects, nullptr, *P, r0, r1, c0, c1, ids, urows, vecw, cell_flags);
             }
             if (vecw == 8) { // the fused CLAHE -> RGB pass (whole scenes and row stripes): 16 waves walk an item, so items are taller
-                size_t frows = kRgbItemRows;
+                // the pass hands its items out by a counter, in sweep order: the last rows of the stripe are cut into small items, so that
+                // the workgroups that finish their last large item early find something left to do (a tail of at most one small item).
+                // Large scenes (six 512-row items per workgroup or more) take the taller items: fewer prologues.  Scene A at 400 MP,
+                // configurations interleaved on one box (tools/time_rgb_items.py, profiles/r5/rgb_items.txt): static stride 0.632 ms;
+                // counter, 256-row items, no tail 0.607; + 1024 tail rows in 96-row items 0.601; 512 / 2500 / 128 0.597; 640 / 2500 / 128 0.614.
+                const bool large = ((rows_local + 511) / 512) * ((cols + 511) / 512) >= (size_t)6 * (size_t)std::max(ctx->cu_count, 1);
+                size_t frows = large ? kRgbItemRowsLarge : kRgbItemRows;
                 if (at.is_set(A_RGB_ITEM_ROWS)) frows = (size_t)std::max<long long>(16, at.val(A_RGB_ITEM_ROWS, 0));
-                add_rects(P->rgb_rects, nullptr, *P, r0, r1, c0, c1, ids, frows, vecw, cell_flags);
+                size_t tail_rows = std::min<size_t>(large ? kRgbTailRowsLarge : kRgbTailRows, rows_local / 8), tail_item = large ? kRgbTailItemRowsLarge : kRgbTailItemRows;
+                if (at.is_set(A_RGB_TAIL_ROWS)) tail_rows = (size_t)std::max<long long>(0, at.val(A_RGB_TAIL_ROWS, 0));
+                if (at.is_set(A_RGB_TAIL_ITEM_ROWS)) tail_item = (size_t)std::max<long long>(16, at.val(A_RGB_TAIL_ITEM_ROWS, 0));
+                const size_t stripe_end = row0 + rows_local, tail_start = stripe_end > tail_rows ? stripe_end - tail_rows : 0;
+                if (r0 < tail_start) add_rects(P->rgb_rects, nullptr, *P, r0, std::min(r1, tail_start), c0, c1, ids, frows, vecw, cell_flags);
+                if (r1 > tail_start) add_rects(P->rgb_rects, nullptr, *P, std::max(r0, tail_start), r1, c0, c1, ids, std::min(frows, tail_item), vecw, cell_flags);
                 size_t srows = kSampleItemRows;
                 if (at.is_set(A_SAMPLE_ITEM_ROWS)) srows = (size_t)std::max<long long>(16, at.val(A_SAMPLE_ITEM_ROWS, 0));
                 add_rects(P->sample_rects, nullptr, *P, r0, r1, c0, c1, ids, srows, vecw, cell_flags);

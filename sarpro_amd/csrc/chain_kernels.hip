@@ -662,6 +662,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
             sp->est_lt[0] = lt0; sp->est_lt[1] = lt1;
             sp->force = a.force;
             sp->pool_overflow = 0u;
+            sp->next_item = 0u;
             if (a.floor_out) *a.floor_out = s_fwc; // stands iff the verdict accepts; k_chain_finish rewrites it otherwise
         }
     }

@@ -176,7 +176,7 @@ struct BandWorker {
     X(STRIP_ALIGN) X(PIECE_ALIGN) X(CHUNK_ROWS) X(RGB_ITEM_ROWS) X(SAMPLE_ITEM_ROWS) \
     X(NO_MAILBOX) X(NO_STEP_ESTIMATE) X(F32_ZONES) X(F32_ZONES_DEBUG) X(F32_DIRECT) X(F32_DIRECT_QCAP) X(F32_LEVEL_GENERAL) \
     X(F32_LEVEL_TABLE) X(F32_LEVEL_QCAP) X(F32_HOST_CDFS) X(F32_NO_VEC8) X(NO_BAND_TWIN) X(RESIZE_GENERIC) X(NO_RESIZE_LUT) \
-    X(NO_U16_CF) X(U16_ITEM_ROWS) X(PIPE_LANES) X(PIPE_ORDER) X(RGB_GRID) X(PIECE_GRID) X(COMM_RECORD) X(COMM_REPLAY) X(NO_SPEC_RESCALE)
+    X(NO_U16_CF) X(U16_ITEM_ROWS) X(PIPE_LANES) X(PIPE_ORDER) X(RGB_GRID) X(PIECE_GRID) X(COMM_RECORD) X(COMM_REPLAY) X(NO_SPEC_RESCALE) X(RGB_TAIL_ROWS) X(RGB_TAIL_ITEM_ROWS)
 namespace sarpro {
 enum Attr : int {
 #define X(n) A_##n,

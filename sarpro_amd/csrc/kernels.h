@@ -106,6 +106,7 @@ struct ChainSpecState {
     double est_lt[2];              // the sample's estimate of n_lt (diagnostics)
     uint32_t force;                // test switches (kSpecForce*)
     uint32_t pool_overflow;        // the fused CLAHE -> RGB pass stepped aside: the bands' DN windows do not fit its LDS pool
+    uint32_t next_item;            // the fused pass's work list: the next item to hand out (cleared by k_chain_predict; ends at items + workgroups)
 };
 constexpr uint32_t kSpecIdentity = 1u, kSpecRescaled = 2u;
 constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it

@@ -722,6 +722,9 @@ __device__ __forceinline__ float spec_delta(int pad0) { // the f32 blend's margi
     return !(pad0 & 1) ? kSpecDeltaInner : (pad0 & 6) == 2 ? kSpecDeltaEdgeY : (pad0 & 6) == 4 ? kSpecDeltaEdgeX : kSpecDeltaEdge;
 #endif
 }
+#ifdef SARPRO_RGB_WG_TIMES // instrumented build (tools/rgb_wg_times.py): when each persistent workgroup of the fused CLAHE -> RGB pass started and ended (100 MHz clock)
+__device__ unsigned long long g_rgb_wg_times[1024][2];
+#endif
 #ifdef SARPRO_SPEC_MEASURE // instrumented build (tools/spec_margin.py): the largest |y32 - y| the speculative blend produced, per margin class
 __device__ uint32_t g_spec_max_err[4]; // float bits, one per margin of spec_delta: [0] interior cells, [1] dy < 0 only, [2] dx < 0 only, [3] the corner (both)
 __device__ __forceinline__ int spec_class(int pad0) { return !(pad0 & 1) ? 0 : (pad0 & 6) == 2 ? 1 : (pad0 & 6) == 4 ? 2 : 3; }
@@ -1484,6 +1487,9 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     extern __shared__ __align__(16) unsigned char lds[];
     constexpr int VEC = 8;
     ChainSpecState *sp = a.spec;
+#ifdef SARPRO_RGB_WG_TIMES
+    if (threadIdx.x == 0) g_rgb_wg_times[blockIdx.x & 1023][0] = wall_clock64();
+#endif
     const uint32_t win_hi[2] = {a.dev_state[0].win_hi, a.dev_state[1].win_hi};
     const uint64_t nwin = (uint64_t)win_hi[0] + win_hi[1] + 2u;
     const bool wide = nwin > kRgbPoolEntries; // the windows do not fit the DN-indexed pool: bin-indexed entries behind a DN -> bin byte table
@@ -1527,11 +1533,31 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     const RowWeight *__restrict__ row_w = a.row_w + a.row_off;
     const uint32_t stage_w = RgbLds::stage + (uint32_t)wave * 1536u;
 
+    // Items are handed out by a device counter (ChainSpecState::next_item, cleared by k_chain_predict), in the list's order (sweep order:
+    // the planner puts small items last).  With the static stride `item = blockIdx.x + k * gridDim.x` the workgroups ended up to 18 % apart
+    // (13 items of different sizes each; the mean workgroup was done 7 % before the last: tools/rgb_wg_times.py).  The counter's round trip
+    // is hidden behind the prologue: thread 0 asks for the NEXT item when this one starts and puts the answer into LDS after the
+    // prologue's last barrier, so the value lives in a register through the prologue only -- not through the rows.
+    // -DSARPRO_RGB_STATIC_ITEMS: the stride.
+    uint32_t *const s_next = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 8;
+#ifndef SARPRO_RGB_STATIC_ITEMS
+    if (threadIdx.x == 0) s_next[0] = atomicAdd(&sp->next_item, 1u);
+#endif
+#ifdef SARPRO_RGB_STATIC_ITEMS
     for (int item = blockIdx.x; item < a.nrects; item += gridDim.x) {
-        const Rect rc = a.rects[item];
+#else
+    for (;;) {
+#endif
         uint32_t *const s_bsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 4; // WIDE: per band the first saturated bin (256: none)
         if (wide && threadIdx.x < 2) s_bsat[threadIdx.x] = 256u; // (only the prologue reads it: no wave of the previous item does)
         __syncthreads(); // the previous item's rows are done (its tables may go; the compose tables have landed)
+#ifndef SARPRO_RGB_STATIC_ITEMS
+        const int item = (int)to_sgpr_u32(s_next[0]);
+        if (item >= a.nrects) break;
+        uint32_t next_item = 0u;
+        if (threadIdx.x == 0) next_item = atomicAdd(&sp->next_item, 1u); // (every workgroup overshoots the list once: the counter ends at nrects + grid)
+#endif
+        const Rect rc = a.rects[item];
 #ifdef SARPRO_ABL_RGB_PROLOGUE2 // timing ablation: every item builds its tables twice (the difference to the default build = what the prologues cost)
         for (int rep = 0; rep < 2; ++rep)
 #endif
@@ -1611,6 +1637,9 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
         }
         __syncthreads();
         }
+#ifndef SARPRO_RGB_STATIC_ITEMS
+        if (threadIdx.x == 0) s_next[0] = next_item; // (every thread read the slot before the prologue's barriers; the next read is behind the barrier that ends this item)
+#endif
 
         // The rows of the item, compiled twice and chosen per item by a wave-uniform branch: items of extrapolating cells (EDGE) and
         // the others.
@@ -1939,6 +1968,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
         }
     }
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
+#ifdef SARPRO_RGB_WG_TIMES
+    __syncthreads();
+    if (threadIdx.x == 0) g_rgb_wg_times[blockIdx.x & 1023][1] = wall_clock64();
+#endif
     uint32_t lt0, lt1, below = 0u;
     if (GENERAL) {
         lt0 = 0u; lt1 = 0u;
@@ -2470,6 +2503,11 @@ hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q, 
 
 } // namespace sarpro
 
+#ifdef SARPRO_RGB_WG_TIMES
+extern "C" int sarpro_hip_debug_rgb_wg_times(unsigned long long *out /* [1024][2] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sarpro::g_rgb_wg_times), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef SARPRO_SPEC_MEASURE
 // instrumented build only: reads and clears the largest speculation errors seen so far, per margin class (interior, dy < 0, dx < 0, corner)
 extern "C" int sarpro_hip_debug_spec_max_err(float out[4]) {

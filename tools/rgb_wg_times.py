@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""When each persistent workgroup of the fused CLAHE -> RGB pass starts and ends (instrumented build: tools/build_variant.sh wgtimes
+"-DSARPRO_RGB_WG_TIMES"; SARPRO_HIP_LIB=lib_wgtimes.so): the tail of the pass = the time between the mean and the last workgroup's end."""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import sarpro_amd as S
+from sarpro_amd import AutoscaleStrategy as St, SyntheticRgbMode as Mode, synth
+from sarpro_amd._lib import lib
+rows = cols = int(os.environ.get("SIDE", "20000")); pitch = (cols + 63) // 64 * 64
+q = synth.q_tables()
+with S.Context(0, timing=True) as c:
+    for k, v in [x.split("=") for x in os.environ.get("ATTRS", "").split(",") if x]:
+        c.set_attr(k, int(v))
+    d = [torch.empty((rows, pitch), dtype=torch.int16, device="cuda") for _ in range(2)]
+    for k in range(2):
+        c.dev_synth_scene_u16(synth.SEED_SCENE_A, k, q, rows, cols, 0, rows, d[k].data_ptr(), pitch)
+    rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+    for it in range(4):
+        c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
+        t = np.zeros((1024, 2), np.uint64)
+        assert lib.sarpro_hip_debug_rgb_wg_times(t.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0
+        kt = dict(c.last_kernel_times())
+        t = t[:256].astype(np.int64)
+        t0 = t[:, 0].min()
+        st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0  # us
+        busy = en - st
+        print(json.dumps({"kernel_ms": round(kt.get("clahe_rgb_fused", 0), 4), "last_end_us": round(float(en.max()), 1), "mean_end_us": round(float(en.mean()), 1),
+                          "first_end_us": round(float(en.min()), 1), "p10_end_us": round(float(np.percentile(en, 10)), 1), "p90_end_us": round(float(np.percentile(en, 90)), 1),
+                          "latest_start_us": round(float(st.max()), 1), "mean_busy_us": round(float(busy.mean()), 1), "max_busy_us": round(float(busy.max()), 1)}), flush=True)
