@@ -68,8 +68,14 @@ __device__ __forceinline__ int p_lane() { return (int)(threadIdx.x & 63); }
 // the tile's global histogram -- ; bin 0 is not published (it is what is left of the tile, restored by the consumer).  The LDS
 // histograms are published when the tile changes.
 // ------------------------------------------------------------------------------------
+#ifdef SARPRO_PIECE_WG_TIMES // instrumented build (tools/rgb_wg_times.py): when each persistent workgroup of the histogram pass started and ended (100 MHz clock)
+__device__ unsigned long long g_piece_wg_times[1024][2];
+#endif
 __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
+#ifdef SARPRO_PIECE_WG_TIMES
+    if (threadIdx.x == 0) g_piece_wg_times[blockIdx.x & 1023][0] = wall_clock64();
+#endif
     uint32_t *h = reinterpret_cast<uint32_t *>(lds); // band b: [b * (W + 64), + W) bins, then 64 dummy words
     const uint32_t W = a.lds_bins, S = W + 64u;
     const int first = a.wg_first[blockIdx.x], last = a.wg_first[blockIdx.x + 1];
@@ -242,9 +248,18 @@ __global__ __launch_bounds__(kPBlock) void k_dn_hist_pieces(DnHistPiecesArgs a) 
     }
     __syncthreads();
     publish();
+#ifdef SARPRO_PIECE_WG_TIMES
+    __syncthreads();
+    if (threadIdx.x == 0) g_piece_wg_times[blockIdx.x & 1023][1] = wall_clock64();
+#endif
 }
 
 } // namespace
+#ifdef SARPRO_PIECE_WG_TIMES
+extern "C" int sarpro_hip_debug_piece_wg_times(unsigned long long *out /* [1024][2] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sarpro::g_piece_wg_times), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_dn_hist_pieces(const DnHistPiecesArgs &a, int grid, hipStream_t s) {
     if (grid <= 0 || grid > kPieceMaxGrid) return hipErrorInvalidValue;

@@ -20,12 +20,14 @@ with S.Context(0, timing=True) as c:
     for it in range(4):
         c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
         t = np.zeros((1024, 2), np.uint64)
-        assert lib.sarpro_hip_debug_rgb_wg_times(t.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0
+        which = os.environ.get("KERNEL", "clahe_rgb_fused")  # or dn_hist_u16 (the piece histogram: build with -DSARPRO_PIECE_WG_TIMES, file piece_kernels.hip)
+        fn = lib.sarpro_hip_debug_rgb_wg_times if which == "clahe_rgb_fused" else lib.sarpro_hip_debug_piece_wg_times
+        assert fn(t.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0
         kt = dict(c.last_kernel_times())
         t = t[:256].astype(np.int64)
         t0 = t[:, 0].min()
         st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0  # us
         busy = en - st
-        print(json.dumps({"kernel_ms": round(kt.get("clahe_rgb_fused", 0), 4), "last_end_us": round(float(en.max()), 1), "mean_end_us": round(float(en.mean()), 1),
+        print(json.dumps({"kernel_ms": round(kt.get(which, 0), 4), "last_end_us": round(float(en.max()), 1), "mean_end_us": round(float(en.mean()), 1),
                           "first_end_us": round(float(en.min()), 1), "p10_end_us": round(float(np.percentile(en, 10)), 1), "p90_end_us": round(float(np.percentile(en, 90)), 1),
                           "latest_start_us": round(float(st.max()), 1), "mean_busy_us": round(float(busy.mean()), 1), "max_busy_us": round(float(busy.max()), 1)}), flush=True)
