@@ -723,7 +723,7 @@ __device__ __forceinline__ float spec_delta(int pad0) { // the f32 blend's margi
 #endif
 }
 #ifdef SARPRO_RGB_WG_TIMES // instrumented build (tools/rgb_wg_times.py): when each persistent workgroup of the fused CLAHE -> RGB pass started and ended (100 MHz clock)
-__device__ unsigned long long g_rgb_wg_times[1024][2];
+__device__ unsigned long long g_rgb_wg_times[1024][8]; // start, end, then thread 0's sums: wait at the item barrier, prologue, rows, items
 #endif
 #ifdef SARPRO_SPEC_MEASURE // instrumented build (tools/spec_margin.py): the largest |y32 - y| the speculative blend produced, per margin class
 __device__ uint32_t g_spec_max_err[4]; // float bits, one per margin of spec_delta: [0] interior cells, [1] dy < 0 only, [2] dx < 0 only, [3] the corner (both)
@@ -1489,6 +1489,7 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     ChainSpecState *sp = a.spec;
 #ifdef SARPRO_RGB_WG_TIMES
     if (threadIdx.x == 0) g_rgb_wg_times[blockIdx.x & 1023][0] = wall_clock64();
+    unsigned long long wg_t_wait = 0ull, wg_t_pro = 0ull, wg_t_rows = 0ull, wg_items = 0ull, wg_ta = 0ull, wg_tb = 0ull, wg_tc = 0ull;
 #endif
     const uint32_t win_hi[2] = {a.dev_state[0].win_hi, a.dev_state[1].win_hi};
     const uint64_t nwin = (uint64_t)win_hi[0] + win_hi[1] + 2u;
@@ -1550,7 +1551,16 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
 #endif
         uint32_t *const s_bsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 4; // WIDE: per band the first saturated bin (256: none)
         if (wide && threadIdx.x < 2) s_bsat[threadIdx.x] = 256u; // (only the prologue reads it: no wave of the previous item does)
+#ifdef SARPRO_RGB_WG_TIMES
+        if (threadIdx.x == 0) { wg_ta = wall_clock64(); if (wg_items) wg_t_rows += wg_ta - wg_tc; }
+#endif
         __syncthreads(); // the previous item's rows are done (its tables may go; the compose tables have landed)
+#ifdef SARPRO_RGB_WG_TIMES
+        if (threadIdx.x == 0) { wg_tb = wall_clock64(); wg_t_wait += wg_tb - wg_ta; }
+#endif
+#ifndef SARPRO_RGB_STATIC_ROWS
+        if (threadIdx.x == 0) s_next[1] = 2u * kRgbWaves; // the item's row counter (see the row loop): rows 0 .. 2 * 16 - 1 are assigned by wave number
+#endif
 #ifndef SARPRO_RGB_STATIC_ITEMS
         const int item = (int)to_sgpr_u32(s_next[0]);
         if (item >= a.nrects) break;
@@ -1637,6 +1647,9 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
         }
         __syncthreads();
         }
+#ifdef SARPRO_RGB_WG_TIMES
+        if (threadIdx.x == 0) { wg_tc = wall_clock64(); wg_t_pro += wg_tc - wg_tb; ++wg_items; }
+#endif
 #ifndef SARPRO_RGB_STATIC_ITEMS
         if (threadIdx.x == 0) s_next[0] = next_item; // (every thread read the slot before the prologue's barriers; the next read is behind the barrier that ends this item)
 #endif
@@ -1810,6 +1823,14 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             const int lcol = min(col, (int)a.in_pitch - VEC); // a lane past the row's pitch loads (and ignores) the row's last vector
             const uint16_t *p0 = a.in[0] + lcol, *p1 = a.in[1] + lcol;
             int r = __builtin_amdgcn_readfirstlane(rc.r0 + wave);
+#ifndef SARPRO_RGB_STATIC_ROWS
+            // The waves of a workgroup do not advance together (the oldest wave of a SIMD wins every arbitration): with rows r0 + wave + 16 k
+            // the first wave stood at the item's closing barrier 18 us of every 70 (tools/rgb_wg_times.py), and while the waves trickle in the
+            // compute unit runs ever emptier.  Rows are handed out by an LDS counter instead: a wave's first two rows by its number, then the
+            // row after next with every row it starts -- the answer travels behind the row's own LDS gathers.
+            int kn = wave + step; // the NEXT row of this wave, relative to r0 (>= the item's rows: none)
+            const int nrows = rc.r1 - rc.r0;
+#endif
             if (r < rc.r1) {
                 uint4 c0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)r * a.in_pitch), c1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)r * a.in_pitch);
                 double dyv = row_w[r].d;
@@ -1824,8 +1845,15 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                     __builtin_amdgcn_raw_buffer_store_b128(z, rgb_rsrc, 0xFFFFFFF0u, 0, 2); // (another offset: two identical stores would be merged)
                 }
 #endif
+#ifdef SARPRO_RGB_STATIC_ROWS
                 for (; r < rc.r1; r += step) {
                     const int rn = min(r + step, rc.r1 - 1); // the next row of both bands is always in flight
+#else
+                for (;;) {
+                    const int rn = rc.r0 + min(kn, nrows - 1); // the next row of both bands is always in flight
+                    uint32_t grab = 0u;
+                    if (lane == 0) grab = atomicAdd(&s_next[1], 1u);
+#endif
                     const uint4 n0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)rn * a.in_pitch), n1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)rn * a.in_pitch);
                     const double dyn = row_w[rn].d;
                     const uint32_t srn = (EDGE && a.sat_ok) ? (uint32_t)a.sat_row[rn] : 7u;
@@ -1955,6 +1983,11 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                             }
                     }
                     c0 = n0; c1 = n1; dyv = dyn; srv = srn;
+#ifndef SARPRO_RGB_STATIC_ROWS
+                    if (kn >= nrows) break;
+                    r = rc.r0 + kn;
+                    kn = (int)to_sgpr_u32(grab);
+#endif
                 }
             }
         }
@@ -1970,7 +2003,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
 #ifdef SARPRO_RGB_WG_TIMES
     __syncthreads();
-    if (threadIdx.x == 0) g_rgb_wg_times[blockIdx.x & 1023][1] = wall_clock64();
+    if (threadIdx.x == 0) {
+        unsigned long long *o = g_rgb_wg_times[blockIdx.x & 1023];
+        o[1] = wall_clock64(); o[2] = wg_t_wait; o[3] = wg_t_pro; o[4] = wg_t_rows; o[5] = wg_items;
+    }
 #endif
     uint32_t lt0, lt1, below = 0u;
     if (GENERAL) {
@@ -2505,7 +2541,7 @@ hipError_t launch_synth_scene_u16(uint64_t seed, int band, const uint16_t *d_q, 
 
 #ifdef SARPRO_RGB_WG_TIMES
 extern "C" int sarpro_hip_debug_rgb_wg_times(unsigned long long *out /* [1024][2] */) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sarpro::g_rgb_wg_times), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sarpro::g_rgb_wg_times), sizeof(unsigned long long) * 8192) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef SARPRO_SPEC_MEASURE

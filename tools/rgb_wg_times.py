@@ -19,12 +19,16 @@ with S.Context(0, timing=True) as c:
     rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
     for it in range(4):
         c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
-        t = np.zeros((1024, 2), np.uint64)
         which = os.environ.get("KERNEL", "clahe_rgb_fused")  # or dn_hist_u16 (the piece histogram: build with -DSARPRO_PIECE_WG_TIMES, file piece_kernels.hip)
         fn = lib.sarpro_hip_debug_rgb_wg_times if which == "clahe_rgb_fused" else lib.sarpro_hip_debug_piece_wg_times
+        t = np.zeros((1024, 8 if which == "clahe_rgb_fused" else 2), np.uint64)
         assert fn(t.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0
         kt = dict(c.last_kernel_times())
         t = t[:256].astype(np.int64)
+        if which == "clahe_rgb_fused":  # thread 0's view of its workgroup: time at the item barrier, in the prologues, in the rows (100 MHz ticks -> us)
+            print(json.dumps({"items_per_wg_mean": round(float(t[:, 5].mean()), 2), "wait_us_mean": round(float(t[:, 2].mean()) / 100, 1), "prologue_us_mean": round(float(t[:, 3].mean()) / 100, 1),
+                              "rows_us_mean": round(float(t[:, 4].mean()) / 100, 1), "prologue_us_per_item": round(float(t[:, 3].sum()) / max(float(t[:, 5].sum()), 1) / 100, 2),
+                              "wait_us_per_item": round(float(t[:, 2].sum()) / max(float(t[:, 5].sum()), 1) / 100, 2)}), flush=True)
         t0 = t[:, 0].min()
         st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0  # us
         busy = en - st
