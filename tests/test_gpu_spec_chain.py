@@ -317,6 +317,28 @@ def test_fused_rgb_pass_predicts_the_rescale_of_a_band_without_level_0(kind, sha
     assert accepted or kind in ("gradient",), rep  # the simple cases are all accepted: the route is worth something
 
 
+@pytest.mark.parametrize("item_rows,tail_rows,tail_item_rows", [(16, 0, 16), (48, 100, 16), (512, 2500, 128), (4096, 64, 24), (96, 100000, 32)])
+def test_fused_rgb_pass_item_geometry_does_not_change_the_raster(item_rows, tail_rows, tail_item_rows, monkeypatch):
+    """The pass's work list: items of RGB_ITEM_ROWS rows, the last RGB_TAIL_ROWS rows of the scene in items of RGB_TAIL_ITEM_ROWS rows, handed
+    out by a device counter; inside an item the rows are handed out by an LDS counter.  Whatever the cut -- one row per wave, a tail
+    longer than the scene, one item per cell -- the raster is the oracle's and the verification counts are the whole scene's."""
+    rows, cols = 1000, 1300
+    monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
+    monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
+    b1, b2 = synth.scene_u16(rows, cols, 0, seed=synth.SEED_SCENE_A + 2), synth.scene_u16(rows, cols, 1, seed=synth.SEED_SCENE_A + 2)
+    rrgb, r1, r2 = ref(b1, b2)
+    with S.Context(0, timing=True) as c:
+        c.set_attr("RGB_ITEM_ROWS", item_rows); c.set_attr("RGB_TAIL_ROWS", tail_rows); c.set_attr("RGB_TAIL_ITEM_ROWS", tail_item_rows)
+        for _ in range(2):  # (twice: the counter is cleared per scene)
+            rgb, names = run_rgb_only(c, b1, b2)
+            rep = c.spec_report()
+            assert "clahe_rgb_fused" in names and np.array_equal(rgb, rrgb), rep
+            if rep["verdict"] == 0:
+                f = rep["floor_pred"]
+                lv = np.concatenate([r1.ravel(), r2.ravel()])
+                assert rep["n_lt"][0] == int((lv < f).sum()) and (f == 37 or rep["n_lt"][1] == int((lv <= f).sum())), rep
+
+
 def test_fused_rgb_route_equals_the_other_routes_at_36mp(monkeypatch):
     rows, cols = 6000, 6016
     pitch = cols
