@@ -1442,8 +1442,11 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
 #endif
 constexpr uint32_t kRgbB2Stride = SARPRO_RGB_B2_STRIDE;
 static_assert(kRgbB2Stride == 256 || kRgbB2Stride == 260, "blue table rows: 256 (as in global memory) or 260 bytes");
-#ifndef SARPRO_RGB_BLOCK // (occupancy experiment: -DSARPRO_RGB_BLOCK=512 -DSARPRO_RGB_POOL=2040)
+#ifndef SARPRO_RGB_BLOCK // (experiments: -DSARPRO_RGB_BLOCK=512 = eight waves with up to 256 registers each -- 161 used, nothing spilled, and 0.65 ms against 0.60:
+                         // the gathers want sixteen waves to hide behind; with -DSARPRO_RGB_POOL=2040 two such workgroups fit a compute unit)
 #define SARPRO_RGB_BLOCK 1024
+#endif
+#ifndef SARPRO_RGB_POOL
 #define SARPRO_RGB_POOL (SARPRO_RGB_B2_STRIDE == 256 ? 3072 : 3008)
 #endif
 constexpr int kRgbBlock = SARPRO_RGB_BLOCK, kRgbWaves = kRgbBlock / kWave;
@@ -1474,7 +1477,6 @@ constexpr uint32_t kWideBytes = kWideEnt - RgbLds::binof;         // capacity: w
 static_assert(kWideEnt % 16 == 0, "alignment");
 static_assert(RgbLds::total <= 160 * 1024, "fused pass: LDS budget");
 static_assert(RgbLds::stage % 16 == 0 && RgbLds::pool % 16 == 0 && RgbLds::cdf64 % 16 == 0, "alignment");
-static_assert(kRgbPoolEntries / 4 + 2 <= kRgbBlock, "one pass of the workgroup expands the whole pool");
 
 // GENERAL (ChainSpecState::spec_ok == kSpecRescaled): a band's lowest level is a prediction too.  The compose tables hold that band's
 // u8 rescale folded in (k_chain_predict), the floor counts compare each band's level bytes with ITS thresholds (the lowest levels whose
@@ -1610,14 +1612,20 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
         // to L2, issued with the CDF loads above (a byte per thread and pass made three dependent round trips per item)
         uint32_t *const s_dnsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 2; // per band: the first DN of a saturated bin (0xFFFF: none)
         if (threadIdx.x < 2) s_dnsat[threadIdx.x] = 0xFFFFu;
-        uint32_t q4 = 0u, qdn = 0u;
-        int qb = -1;
+        constexpr int kPoolPasses = (int)((kRgbPoolEntries / 4 + 2 + kRgbBlock - 1) / kRgbBlock); // (1 with 1024 threads)
+        uint32_t q4s[kPoolPasses], qdns[kPoolPasses];
+        int qbs[kPoolPasses];
         {
-            const uint32_t n0q = (win_hi[0] >> 2) + 1u, n1q = (win_hi[1] >> 2) + 1u; // n0q + n1q <= kRgbPoolEntries / 4 + 2 <= kRgbBlock
-            if (!wide && threadIdx.x < n0q + n1q) {
-                qb = threadIdx.x >= n0q ? 1 : 0;
-                qdn = (threadIdx.x - (qb ? n0q : 0u)) * 4u;
-                q4 = *reinterpret_cast<const uint32_t *>(a.binlut[qb] + qdn);
+            const uint32_t n0q = (win_hi[0] >> 2) + 1u, n1q = (win_hi[1] >> 2) + 1u; // n0q + n1q <= kRgbPoolEntries / 4 + 2
+#pragma unroll
+            for (int ps = 0; ps < kPoolPasses; ++ps) {
+                const uint32_t t = threadIdx.x + (uint32_t)ps * kRgbBlock;
+                q4s[ps] = 0u; qdns[ps] = 0u; qbs[ps] = -1;
+                if (!wide && t < n0q + n1q) {
+                    qbs[ps] = t >= n0q ? 1 : 0;
+                    qdns[ps] = (t - (qbs[ps] ? n0q : 0u)) * 4u;
+                    q4s[ps] = *reinterpret_cast<const uint32_t *>(a.binlut[qbs[ps]] + qdns[ps]);
+                }
             }
         }
         __syncthreads();
@@ -1633,17 +1641,23 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                 }
                 s_dnsat[b] = (bs < 256u && lo <= win_hi[b]) ? lo : 0xFFFFu;
             }
-        } else if (qb >= 0) {
+        } else {
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                const uint32_t dn = qdn + k;
-                if (dn <= win_hi[qb]) {
-                    const uint32_t bin = dn ? (q4 >> (8 * k)) & 0xFFu : 256u;
-                    const uint32_t i = kb[qb] + dn;
-                    *reinterpret_cast<float4 *>(lds + RgbLds::pool + i * 16) = *reinterpret_cast<const float4 *>(lds + RgbLds::stage + (qb * 257 + bin) * 16);
-                    lds[RgbLds::binof + i] = (uint8_t)bin; // (DN = 0 never reaches the exact path: its biased entry is never "near")
-                    if ((rc.pad[0] & 1) && reinterpret_cast<const float *>(lds + RgbLds::stage + (qb * 257 + bin) * 16)[0] > 1.0005f)
-                        atomicMin(&s_dnsat[qb], dn); // (bins and CDFs are monotone: every DN from here on is saturated too)
+            for (int ps = 0; ps < kPoolPasses; ++ps) {
+                const int qb = qbs[ps];
+                const uint32_t qdn = qdns[ps], q4 = q4s[ps];
+                if (qb < 0) continue;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t dn = qdn + k;
+                    if (dn <= win_hi[qb]) {
+                        const uint32_t bin = dn ? (q4 >> (8 * k)) & 0xFFu : 256u;
+                        const uint32_t i = kb[qb] + dn;
+                        *reinterpret_cast<float4 *>(lds + RgbLds::pool + i * 16) = *reinterpret_cast<const float4 *>(lds + RgbLds::stage + (qb * 257 + bin) * 16);
+                        lds[RgbLds::binof + i] = (uint8_t)bin; // (DN = 0 never reaches the exact path: its biased entry is never "near")
+                        if ((rc.pad[0] & 1) && reinterpret_cast<const float *>(lds + RgbLds::stage + (qb * 257 + bin) * 16)[0] > 1.0005f)
+                            atomicMin(&s_dnsat[qb], dn); // (bins and CDFs are monotone: every DN from here on is saturated too)
+                    }
                 }
             }
         }
