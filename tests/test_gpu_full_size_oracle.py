@@ -82,6 +82,43 @@ def test_headline_400mp_clahe_synrgb_equals_oracle_every_pixel(scene, headline_r
     _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, "apply + compose route RGB")
 
 
+def test_400mp_crop_without_level_0_takes_the_predicted_rescale_and_equals_oracle_every_pixel(scene):
+    """A 400 MP raster without an invalid pixel whose bands hold no level 0 (scene A's DNs coarsened to steps of 256 and lifted off
+    zero): no identity proof exists, the fused pass predicts each band's lowest level, folds the u8 rescale (autoscale.rs:348-364) into
+    its tables and verifies both predictions while it composes (round 5, spec_ok = 2).  Its raster and the gated exact kernels' (the
+    prediction switched off: the route round 5 found a lost-LDS-add bug in, at 36 MP and up) against the oracle, every pixel."""
+    c, band, host = scene
+    b = []
+    for k in (0, 1):
+        t = band[k].to(torch.int32) & 0xFFFF
+        b.append((((t >> 8) << 8) + 77 + 40 * k).clamp_(max=32767).to(torch.int16))
+        del t
+    hb = [x[:, :COLS].contiguous().cpu().numpy().view(np.uint16).astype(np.float32) for x in b]
+    rc, ref, r1, r2 = oracle.dualpol_synrgb(hb[0], hb[1], int(St.Clahe))
+    assert rc == 0 and int(r1.min()) == 0 and int(r1.max()) == 255  # (the FINAL bands span 0..255: the rescale did its work)
+    del hb
+    rgb = torch.zeros((ROWS, PITCH * 3), dtype=torch.uint8, device="cuda")
+    c.dev_dualpol_synrgb_u16(b[0].data_ptr(), b[1].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Mode.Default, rgb.data_ptr(), PITCH, want_stats=False)
+    rep = c.spec_report()
+    assert rep["spec_ok"] == 2 and rep["verdict"] == 0 and rep["n_below_min"] == 0 and min(rep["min_pred"]) > 0, rep
+    lv = np.concatenate([r1.ravel(), r2.ravel()])
+    f = rep["floor_pred"]
+    assert rep["n_lt"][0] == int((lv < f).sum()) and (f == 37 or rep["n_lt"][1] == int((lv <= f).sum())), rep
+    del lv
+    _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, "fused route with the predicted rescale")
+    rgb.zero_()
+    c.set_attr("NO_SPEC_RESCALE", 1)
+    try:
+        c.dev_dualpol_synrgb_u16(b[0].data_ptr(), b[1].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Mode.Default, rgb.data_ptr(), PITCH, want_stats=False)
+        rep = c.spec_report()
+        assert rep["spec_ok"] == 0 and rep["verdict"] == 1, rep
+        cr = c.chain_report()
+        assert [int(cr["level_hist"][k][1:].sum()) for k in range(2)] == [ROWS * COLS] * 2  # every band-pixel counted: bin 0 = pixels - others = 0
+    finally:
+        c.set_attr("NO_SPEC_RESCALE", None)
+    _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, "gated exact kernels")
+
+
 def test_config1_400mp_robust_u8_and_resized_synrgb_equal_oracle_every_pixel(scene):
     """configs[1]: Robust autoscale of both 400 MP bands -> u8 (every pixel == oracle.pipeline), the native-resolution default
     synRGB of those rasters (every pixel), and the config's flow -- Lanczos3 to 2048^2 + pad + synRGB -- from the ORACLE's rasters."""
