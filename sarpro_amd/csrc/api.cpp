@@ -1284,7 +1284,11 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
     const bool fused_wanted = !d_out[0] && !d_out[1] && !ctx->attrs.on(A_NO_FUSED_RGB) && J.in_pitch % 8 == 0;
     bool sampled = J.synrgb && J.nbands == 2 && J.u8_out() && !exact_only && !ctx->attrs.on(A_FULL_LEVEL_HIST) &&
                    !ctx->attrs.on(A_NO_SAMPLED_HIST) && rgb_pitch_px % 16 == 0 && (J.reduce ? fused_wanted : (d_rgb && rgb_pitch_ok && whole));
-    uint32_t sample_stride = 17; // sampled rows cost the apply pass ~0.4 % each ninth: 9 -> 17 -> 33 measured 0.540 / 0.535 / 0.529 ms; the estimate's sigma grows with sqrt(stride)
+    // every 17th row; every 33rd on scenes of 12000 rows and more (606 sampled rows at 20000).  The sample pass is 5 % of the fused pass's work
+    // and, in a resident batch, runs beside another lane's histogram sweep: nine-scene cycle on three lanes 0.967 -> 0.949 ms per scene with
+    // 33, 0.944 with 65 (all nine accepted either way); the estimate's error on these scenes is a bias of the row phase against the scene's
+    // structure (1-2.5 % of a level's population at 9, 17, 33 and 65 alike: profiles/r3/spec_accuracy.txt), its random part grows with sqrt(stride)
+    uint32_t sample_stride = J.rows_total >= 12000 ? 33 : 17;
     if (sampled) {
         size_t min_px = kSampledHistMinPx;
         if (ctx->attrs.is_set(A_SAMPLED_HIST_MIN_PX)) min_px = (size_t)std::max<long long>(0, ctx->attrs.val(A_SAMPLED_HIST_MIN_PX, 0));
