@@ -198,3 +198,38 @@ def test_ranks_with_different_raster_layouts_produce_the_same_product():
                                                                            sl[k].data_ptr()))
     got = np.concatenate([t.cpu().numpy()[: on * fc * 3].reshape(on, fc, 3) for (o0, on, _), t in zip(out, sl)], axis=0)
     assert np.array_equal(got, ref)
+
+
+def test_striped_resized_argument_errors_and_geometry_of_one_rank():
+    """One rank holding the whole scene: the entry point is the one-piece flow plus two trivial all-reduces; bad arguments are refused
+    before any collective (a stripe outside the scene, a missing communicator, a target that collapses a dimension)."""
+    rows, cols, pitch = 384, 520, 576
+    b = [synth.scene_u16(rows, cols, k) for k in (0, 1)]
+    d = [to_dev(x, pitch, torch.int16) for x in b]
+    rgb = torch.zeros((128 * 128 * 3,), dtype=torch.uint8, device="cuda")
+    with S.Context(0) as c:
+        with pytest.raises(S.SarproHipError, match="communicator"):
+            c.stripe_run_resized_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, 0, rows, pitch, St.Clahe, Mode.Default, 128, True, rgb.data_ptr())
+    group = S.LocalGroup(1)
+    try:
+        with S.Context(0) as c:
+            c.comm_init_local(group, 0)
+            with pytest.raises(S.SarproHipError, match="outside the scene"):
+                c.stripe_run_resized_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, 10, rows, pitch, St.Clahe, Mode.Default, 128, True, rgb.data_ptr())
+            with pytest.raises(S.SarproHipError):
+                c.stripe_run_resized_u16(0, 0, rows, cols, 0, rows, pitch, St.Clahe, Mode.Default, 128, True, rgb.data_ptr())
+    finally:
+        group.close()
+    # (a group is aborted by a failing rank: a fresh one for the good call)
+    group = S.LocalGroup(1)
+    try:
+        with S.Context(0) as c:
+            c.comm_init_local(group, 0)
+            o0, on, m = c.stripe_run_resized_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, 0, rows, pitch, St.Clahe, Mode.Default, 128, True, rgb.data_ptr())
+            assert (o0, on, m.final_cols, m.final_rows) == (0, 128, 128, 128)
+            assert np.array_equal(rgb.cpu().numpy().reshape(128, 128, 3), oracle_product(b, St.Clahe, 128, True))
+    finally:
+        group.close()
+    assert S.host_stripe_resized_rows(rows, cols, 0, rows, 128, True) == (0, 128, 128, 128)
+    with pytest.raises(S.SarproHipError):
+        S.host_stripe_resized_rows(rows, cols, 300, 200, 128, True)
