@@ -1,7 +1,7 @@
 // piece_kernels.hip -- per-tile DN histograms of a whole dual-pol scene on gfx950, walked as cost-balanced "pieces" by
 // persistent 1024-thread workgroups (the first pass of the CLAHE chain: autoscale.rs:259-268 needs the per-tile counts,
 // autoscale.rs:35-160 their sum).  Round 2's one-sweep CLAHE -> RGB pass lived on the same traversal; it measured slower
-// than apply + compose (DESIGN.md section 6b keeps the numbers) and was removed in round 3.
+// than apply + compose (NOTEBOOK.md section 6b keeps the numbers) and was removed in round 3.
 #include "piece_kernels.h"
 
 namespace sarpro {

@@ -1,5 +1,5 @@
 """PCIe-inclusive rate of the host entry point (host u16 bands in, RGB out), pinned vs pageable buffers.
-Never the bench `value` (that is HBM-resident); reported in DESIGN.md section 6."""
+Never the bench `value` (that is HBM-resident); reported in NOTEBOOK.md section 6 (and the state table of DESIGN.md)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
