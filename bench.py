@@ -240,6 +240,7 @@ def main():
         dtimes = [ms for i, ms in enumerate(dtimes) if rts[i] in ("accepted", "refuted")]
 
     subset_dom_ms: list[float] = []  # the dominant kernel's event times of the LAST timed_subset run (one stream: nothing beside the kernel)
+    subset_dom_scene: list[int] = []  # ... and the scene of each
 
     def timed_subset(idx):  # the same enqueue pattern over a subset of the scenes (beside `value`, after the timed region)
         idx = idx or [0]  # (every rank takes part in the barriers, whatever its scenes did)
@@ -253,18 +254,22 @@ def main():
             runs.append((time.perf_counter() - t) / args.steps * 1e3)
             kt = [ms for name, ms in ctx.last_kernel_times() if name == dom_warm]  # (drained: nothing of these steps reaches the per-kernel table below)
             if len(kt) == args.steps:
-                subset_dom_ms[:] = [ms for i, ms in enumerate(kt) if outcomes[idx[i % len(idx)]] in ("accepted", "refuted", "n/a")]
+                keep = [i for i in range(len(kt)) if outcomes[idx[i % len(idx)]] in ("accepted", "refuted", "n/a")]
+                subset_dom_ms[:] = [kt[i] for i in keep]
+                subset_dom_scene[:] = [idx[i % len(idx)] for i in keep]
         return sorted(runs)[1]
     ms_accepted = timed_subset([i for i in range(K) if outcomes[i] in ("accepted", "n/a")]) if K > 1 else None
     ms_scene_a = timed_subset([0]) if (K > 1 or pipelined) else None
     ms_one_stream = timed_subset(list(range(K))) if pipelined else None  # the whole cycle, one call per scene on one stream (the headline loop of rounds 3-4)
-    dtimes_region = None
-    if pipelined and subset_dom_ms:
-        # Under the lanes a kernel's event pair brackets more than the kernel: its workgroups are dispatched as the other lane's
-        # sweep releases compute units, and both share HBM while they overlap.  The roofline figure of the dominant kernel is
-        # therefore taken from the one-stream cycle just measured (same scenes, same process, nothing beside the kernel); the
-        # event times inside the timed region are reported next to it (`roofline.in_timed_region`).
-        dtimes_region, dtimes = dtimes, list(subset_dom_ms)
+    # Under the lanes a kernel's event pair brackets more than the kernel when another lane's sweep shares the chip (round 5's free
+    # run: its workgroups are dispatched as the other sweep releases compute units).  `roofline.frac` / `achieved` / `ms_per_launch`
+    # are the figures of the TIMED REGION, whatever they bracket; the same kernel on the one-stream cycle measured right after it
+    # (same scenes, same process, nothing beside the kernel) is reported beside them as `frac_one_stream` / `ms_per_launch_one_stream`,
+    # and the slowest scene of that cycle as `frac_worst_scene`.
+    one_stream_ms = list(subset_dom_ms) if (pipelined and subset_dom_ms) else None
+    per_scene_ms = {}
+    for sc_i, ms in zip(subset_dom_scene, subset_dom_ms):
+        per_scene_ms.setdefault(sc_i, []).append(ms)
     ctx.time_only(None)
     ktimes: dict[str, list[float]] = {}
     for _ in range(EXTRA_STEPS):  # (scene A: the per-kernel breakdown of the route that is taken when the speculation holds)
@@ -299,32 +304,43 @@ def main():
             # alg_bpp covers both bands; a kernel launched once per band (the staggered two-stream chain) moves half per launch
             bytes_launch = alg_bpp.get(dom, 0.0) * local_px / max(launches[dom], 1.0)
             achieved = bytes_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
+            tr = pmc_traffic_gb(dom, rows_local * cols / max(launches[dom], 1.0))
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic_gb(dom, rows_local * cols / max(launches[dom], 1.0)),
+                        # scalars only at this level (a reader that flattens the record keeps them); the dicts follow under *_detail
+                        "traffic": tr.get("value") if isinstance(tr, dict) else None,
+                        "traffic_unit": "GB per launch (HBM bytes by the PMC counters: FETCH_SIZE x 2 + WRITE_SIZE, KiB)",
+                        "algorithmic_gb": round(bytes_launch / 1e9, 3),
+                        "traffic_ratio": round(tr["value"] / (bytes_launch / 1e9), 3) if isinstance(tr, dict) and tr.get("value") and bytes_launch else None,
+                        "traffic_detail": tr,
                         "launches_per_step": launches[dom],
                         "ms_per_launch": round(per_launch[dom], 4),
-                        "timed_in": ("the nine-scene cycle on ONE stream right after the timed region (events on this kernel only); inside the timed region the lanes overlap "
-                                     "this kernel with the next scene's histogram sweep, see in_timed_region") if dtimes_region is not None
-                                    else "timed region (events on this kernel only)" if (dom == dom_warm and dtimes) else "extra steps",
+                        "frac_in_timed_region": round(achieved / HBM_PEAK_GBS, 4) if (dom == dom_warm and dtimes) else None,
+                        "timed_in": "timed region (HIP events on this kernel only, on the stream it is launched on)" if (dom == dom_warm and dtimes) else "extra steps",
                         "kernels_ms_per_step": {k: round(total_ms[k], 4) for k in sorted(total_ms)},
                         "kernels_ms_per_step_from": f"{EXTRA_STEPS} fully instrumented steps after the timed region"}
-        if roofline and dtimes_region:
-            m = float(np.mean(dtimes_region))
-            roofline["in_timed_region"] = {"ms_per_launch": round(m, 4), "launches": len(dtimes_region),
-                                           "achieved": round(alg_bpp.get(dom, 0.0) * rows_local * cols / (m * 1e-3) / 1e9, 1) if m > 0 else None,
-                                           "frac": round(alg_bpp.get(dom, 0.0) * rows_local * cols / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if m > 0 else None,
-                                           "note": "event pairs on the lanes' streams while another lane's sweep shares the chip: a launch's bracket includes the time its workgroups wait for compute units"}
+            if one_stream_ms:
+                m1 = float(np.mean(one_stream_ms))
+                roofline["ms_per_launch_one_stream"] = round(m1, 4)
+                roofline["frac_one_stream"] = round(alg_bpp.get(dom, 0.0) * local_px / (m1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if m1 > 0 else None
+            if per_scene_ms:
+                worst_i = max(per_scene_ms, key=lambda i: float(np.mean(per_scene_ms[i])))
+                mw = float(np.mean(per_scene_ms[worst_i]))
+                roofline["frac_worst_scene"] = round(alg_bpp.get(dom, 0.0) * local_px / (mw * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mw > 0 else None
+                roofline["worst_scene"] = scene_defs[worst_i][0]
+                roofline["ms_per_launch_by_scene"] = {scene_defs[i][0]: round(float(np.mean(v)), 4) for i, v in sorted(per_scene_ms.items())}
         out = {
             "metric": "Mpix/s calibrate+CLAHE+synRGB, 400MP dual-pol scene; % HBM roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if (args.mode == "stripe" and world > 1) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"dual-pol u16 {rows}x{cols} scene resident in HBM -> dB + {strategy.name} autoscale u8 x2 "
-                                   f"-> synRGB ({'suppressed' if strategy.name in ('Clahe', 'Tamed') else 'default'} variant) interleaved u8, native resolution (save.rs:317-367); "
-                                   + (f"the steps cycle over {K} resident scenes that differ in distribution ({', '.join(d[0] for d in scene_defs)}), scene A = the scene of rounds 1-3 first"
-                                      if K > 1 else "one scene (A) in every step"),
+            "config": {"workload": f"{rows}x{cols} dual-pol u16 in HBM -> dB+{strategy.name} u8 x2 -> synRGB u8, native res (save.rs:317-367)",
+                       "workload_detail": f"dual-pol u16 {rows}x{cols} scene resident in HBM -> dB + {strategy.name} autoscale u8 x2 "
+                                          f"-> synRGB ({'suppressed' if strategy.name in ('Clahe', 'Tamed') else 'default'} variant) interleaved u8, native resolution (save.rs:317-367); "
+                                          + (f"the steps cycle over {K} resident scenes that differ in distribution ({', '.join(d[0] for d in scene_defs)}), scene A = the scene of rounds 1-3 first"
+                                             if K > 1 else "one scene (A) in every step"),
+                       "scenes_in_cycle": K,
                        "mode": args.mode if world > 1 else "single", "rows": rows, "cols": cols,
                        "scenes_per_step": scenes_per_step,
                        "scenes": [{"name": d[0], "what": d[4], "route": outcomes[i], "ms_one_synchronous_call": round(scene_sync_ms[i], 3)} for i, d in enumerate(scene_defs)],
@@ -378,7 +394,10 @@ def main():
         if traffic_proc is not None and out.get("roofline"):
             live = traffic_collect(traffic_proc, out["roofline"]["kernel"])
             if live and "value" in live:
-                out["roofline"]["traffic"] = live
+                out["roofline"]["traffic"] = live["value"]
+                out["roofline"]["traffic_detail"] = live
+                if out["roofline"].get("algorithmic_gb"):
+                    out["roofline"]["traffic_ratio"] = round(live["value"] / out["roofline"]["algorithmic_gb"], 3)
             elif live:
                 out["roofline"]["traffic_live_error"] = live.get("error")
         if sec_child is not None:

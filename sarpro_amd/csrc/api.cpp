@@ -64,17 +64,17 @@ static hipEvent_t next_event(sarpro_hip_ctx *ctx) {
     return ctx->event_pool[ctx->events_used++];
 }
 
-KernelTimer::KernelTimer(sarpro_hip_ctx *c, const char *name) : ctx(c) {
+KernelTimer::KernelTimer(sarpro_hip_ctx *c, const char *name, hipStream_t on) : ctx(c), stream(on ? on : c->stream) {
     if (!ctx->timing) return;
     if (!ctx->time_only.empty() && ctx->time_only != name) return;
     KernelTime t{name, next_event(ctx), next_event(ctx)};
     if (!t.start || !t.stop) return;
-    (void)hipEventRecord(t.start, ctx->stream);
+    (void)hipEventRecord(t.start, stream);
     ctx->times.push_back(t);
     active = true;
 }
 KernelTimer::~KernelTimer() {
-    if (active) (void)hipEventRecord(ctx->times.back().stop, ctx->stream);
+    if (active) (void)hipEventRecord(ctx->times.back().stop, stream);
 }
 
 size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
@@ -290,6 +290,7 @@ namespace sarpro {
 constexpr size_t kRgbItemRows = 256, kSampleItemRows = 1024, kU16ItemRows = 1024;
 constexpr size_t kRgbTailRows = 1024, kRgbTailItemRows = 96; // fused CLAHE -> RGB pass: the stripe's last rows in small items (see get_plan)
 constexpr size_t kRgbItemRowsLarge = 512, kRgbTailRowsLarge = 2500, kRgbTailItemRowsLarge = 128;
+constexpr long long kRgbGroup = 1; // fused pass: items per hand-out unit (see get_plan)
 static size_t strip_align(const StripePlan &P, int vecw) { // (STRIP_ALIGN: planner tuning, read when the plan is built)
     if (vecw != 8 && vecw != 4) return (size_t)vecw;
     return std::max<size_t>(vecw, P.strip_align_px / vecw * vecw);
@@ -576,6 +577,22 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_rgb_rects, P->rgb_rects.data(), P->rgb_rects.size() * sizeof(Rect));
+    {   // the fused pass's hand-out units: runs of up to RGB_GROUP items that share cell, rows and flags (in sweep order they are
+        // neighbouring column strips): the first builds the cell's tables, the others reuse them (kernels.hip 6a)
+        const size_t gmax = (size_t)std::min<long long>(16, std::max<long long>(1, at.val(A_RGB_GROUP, kRgbGroup)));
+        P->rgb_groups.clear();
+        for (size_t i = 0; i < P->rgb_rects.size(); ++i) {
+            const Rect &x = P->rgb_rects[i];
+            bool joins = false;
+            if (!P->rgb_groups.empty() && i - (size_t)P->rgb_groups.back() < gmax) {
+                const Rect &y = P->rgb_rects[i - 1];
+                joins = x.r0 == y.r0 && x.r1 == y.r1 && x.pad[0] == y.pad[0] && x.id[0] == y.id[0] && x.id[1] == y.id[1] && x.id[2] == y.id[2] && x.id[3] == y.id[3];
+            }
+            if (!joins) P->rgb_groups.push_back((int32_t)i);
+        }
+        P->rgb_groups.push_back((int32_t)P->rgb_rects.size());
+        if (!rc) rc = upload_vec(ctx, P->d_rgb_groups, P->rgb_groups.data(), P->rgb_groups.size() * sizeof(int32_t));
+    }
     if (!rc && !P->rgb_rects.empty()) { // the fused pass's saturation tables (host_logic.h); the column table padded so that every lane's 8-byte load is in range
         std::vector<uint8_t> cc, rb;
         P->sat_ok = clahe_saturated_levels(g, &cc, &rb);
@@ -719,8 +736,11 @@ static int job_phase1(U16Job &J, bool begin = true, int first = 0, int last = -1
         for (int b = 0; b < 2; ++b) { pa.in[b] = a.in[b]; pa.tile_hist[b] = a.tile_hist[b]; }
         pa.pitch = a.pitch; pa.items = J.plan->d_piece_items.as<PieceItem>(); pa.wg_first = J.plan->d_piece_first.as<int32_t>();
         pa.lds_bins = kPieceLdsBins;
-        KernelTimer t(ctx, "dn_hist_u16");
-        HIPCHK(ctx, launch_dn_hist_pieces(pa, J.plan->piece_grid, ctx->stream));
+        {
+            KernelTimer t(ctx, "dn_hist_u16");
+            HIPCHK(ctx, launch_dn_hist_pieces(pa, J.plan->piece_grid, ctx->stream));
+        }
+        if (ctx->pipe_record_after_hist) { HIPCHK(ctx, hipEventRecord(ctx->pipe_record_after_hist, ctx->stream)); ctx->pipe_record_after_hist = nullptr; }
     } else if (J.vec && !tiled && first == 0 && last == nall && nall > 0 && !ctx->attrs.on(A_NO_LINEAR_HIST)) {
         KernelTimer t(ctx, "dn_hist_u16"); // whole untiled pass in one go: the in-order sweep
         HIPCHK(ctx, launch_dn_hist_u16_linear(a, (uint32_t)J.rows_local, (uint32_t)J.cols, J.nbands, ctx->stream));
@@ -1157,6 +1177,71 @@ static uint32_t spec_force_flags(const sarpro_hip_ctx *ctx) { // SPEC_FORCE = mi
 
 static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_state);
 
+struct FusedTail {
+    sarpro_hip_ctx *ctx; U16Job *J; ClaheRgbArgs fa; ClaheApplyArgs a; ChainSpecState *d_spec; ChainBandState *d_state;
+    unsigned long long *exact_hist; StripePlan *plan; uint8_t *d_levels[2]; size_t lvl_pitch; uint32_t rows, cols;
+    unsigned long long total_px; uint8_t *d_rgb; size_t rgb_pitch_px;
+};
+// The fused pass and what is gated on its verdict (job_run_fused_rgb's second half).  T.J is null when the call is deferred (never a row stripe).
+static int fused_rgb_tail(const FusedTail &T) {
+    sarpro_hip_ctx *ctx = T.ctx;
+    uint8_t *consts = ctx->chain_consts.as<uint8_t>(), *state = ctx->chain_state.as<uint8_t>();
+    ChainSpecState *d_spec = T.d_spec;
+    ClaheApplyArgs a = T.a;
+    const bool reduce = T.J && T.J->reduce;
+    {
+        // resident batch (pipeline.cpp): this scene's pass behind the previous scene's pass (another lane's stream), its own completion
+        // published for the next one -- the passes own whole compute units (160 KiB of LDS each), two of them at once only split the chip
+        if (ctx->pipe_wait_before_fused) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_wait_before_fused, 0));
+        if (ctx->pipe_record_before_fused) { HIPCHK(ctx, hipEventRecord(ctx->pipe_record_before_fused, ctx->stream)); ctx->pipe_record_before_fused = nullptr; }
+        int grid = std::max(ctx->cu_count, 1);
+        if (ctx->attrs.is_set(A_RGB_GRID)) grid = (int)std::min<long long>(1024, std::max<long long>(1, ctx->attrs.val(A_RGB_GRID, grid)));
+        {
+            KernelTimer t(ctx, "clahe_rgb_fused");
+            HIPCHK(ctx, launch_clahe_rgb_fused(T.fa, grid, ctx->stream));
+        }
+        if (ctx->pipe_record_after_fused) {
+            HIPCHK(ctx, hipEventRecord(ctx->pipe_record_after_fused, ctx->stream));
+            ctx->pipe_record_after_fused = nullptr; // recorded (the batch records it itself behind a chain that never got here)
+        }
+    }
+    if (reduce) { // the verification counts of all stripes, then the verdict every rank shares
+        static_assert(offsetof(ChainSpecState, n_below_min) == offsetof(ChainSpecState, n_lt) + 16, "the verification counts are one buffer");
+        RETCHK(chain_reduce(*T.J, &d_spec->n_lt[0], 3, "allreduce_spec_counts"));
+        HIPCHK(ctx, launch_spec_verdict(d_spec, T.d_state, ctx->stream));
+    }
+    {   // gated on the verdict: levels of every pixel with the full histogram -> exact tables -> composition
+        KernelTimer t(ctx, "spec_fallback_apply");
+        a.hist_mode = 0u; a.gate = d_spec;
+        a.rects = T.plan->d_apply_rects.as<Rect>();
+        for (int b = 0; b < 2; ++b) a.level_hist[b] = T.exact_hist + (size_t)b * 256;
+        HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)T.plan->apply_rects.size(), 2, ctx->stream));
+    }
+    if (reduce) RETCHK(chain_reduce(*T.J, T.exact_hist, (size_t)256 * kMaxBands, "allreduce_level_hist")); // (all zero when the fused RGB stood: the gated recount did not run)
+    {
+        ChainFinishArgs f{};
+        f.level_hist = T.exact_hist; f.gate = d_spec;
+        f.total_px = T.total_px; f.nbands = 2;
+        f.resc_out = state + kStateOffResc; f.identity_out = state + kStateOffIdent;
+        f.tables = ctx->tables.as<uint8_t>();
+        f.supp_rg = consts + kChainOffSupp; f.blue_pair_supp = consts + kChainOffBlue;
+        f.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        f.suppressed = 1;
+        KernelTimer t(ctx, "chain_finish");
+        HIPCHK(ctx, launch_chain_finish(f, ctx->stream));
+    }
+    {
+        ComposeArgs c{};
+        c.b1 = T.d_levels[0]; c.b2 = T.d_levels[1]; c.in_pitch = T.lvl_pitch;
+        c.rgb = T.d_rgb; c.rgb_pitch_px = T.rgb_pitch_px; c.rows = T.rows; c.cols = T.cols;
+        c.tables = ctx->tables.as<uint8_t>();
+        c.spec = d_spec; c.speculative = 0;
+        KernelTimer t(ctx, "spec_fallback_compose");
+        HIPCHK(ctx, launch_compose_u8(c, 16, ctx->stream));
+    }
+    return SARPRO_HIP_OK;
+}
+
 // The fused CLAHE -> RGB route of job_run_chain, from the CDFs on (everything before it is shared with the other routes).
 static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, size_t rgb_pitch_px, uint32_t sample_stride,
                              sarpro_hip_stats *stats_out) {
@@ -1206,56 +1291,20 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         KernelTimer t(ctx, "chain_predict");
         HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
     }
-    {
-        // resident batch (pipeline.cpp): this scene's pass behind the previous scene's pass (another lane's stream), its own completion
-        // published for the next one -- the passes own whole compute units (160 KiB of LDS each), two of them at once only split the chip
-        if (ctx->pipe_wait_before_fused) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_wait_before_fused, 0));
-        if (ctx->pipe_record_before_fused) { HIPCHK(ctx, hipEventRecord(ctx->pipe_record_before_fused, ctx->stream)); ctx->pipe_record_before_fused = nullptr; }
-        int grid = std::max(ctx->cu_count, 1);
-        if (ctx->attrs.is_set(A_RGB_GRID)) grid = (int)std::min<long long>(1024, std::max<long long>(1, ctx->attrs.val(A_RGB_GRID, grid)));
-        {
-            KernelTimer t(ctx, "clahe_rgb_fused");
-            HIPCHK(ctx, launch_clahe_rgb_fused(fa, grid, ctx->stream));
-        }
-        if (ctx->pipe_record_after_fused) {
-            HIPCHK(ctx, hipEventRecord(ctx->pipe_record_after_fused, ctx->stream));
-            ctx->pipe_record_after_fused = nullptr; // recorded (the batch records it itself behind a chain that never got here)
-        }
+    // everything from the fused pass on: at once, or -- resident batch with PIPE_ORDER = 3 -- when the batch driver says so (the next
+    // scene's histogram sweep is enqueued on another lane FIRST, so that this pass can wait for it: an event must be recorded
+    // before a stream can be made to wait for it)
+    FusedTail T{};
+    T.ctx = ctx; T.J = &J; T.fa = fa; T.a = a; T.d_spec = d_spec; T.d_state = d_state; T.exact_hist = exact_hist;
+    T.plan = J.plan; T.d_levels[0] = J.d_levels[0]; T.d_levels[1] = J.d_levels[1]; T.lvl_pitch = J.lvl_pitch;
+    T.rows = rows; T.cols = cols; T.total_px = (unsigned long long)J.rows_total * J.cols; T.d_rgb = d_rgb; T.rgb_pitch_px = rgb_pitch_px;
+    if (ctx->pipe_defer && !J.reduce && ctx->async_dev && J.allow_async && !stats_out) {
+        T.J = nullptr; // (the job object is the caller's: gone when the tail runs)
+        ctx->pipe_deferred = [T]() { return fused_rgb_tail(T); };
+        ctx->async_pending = ctx->timing; // what chain_tail does on a stream-ordered context
+        return SARPRO_HIP_OK;
     }
-    if (J.reduce) { // the verification counts of all stripes, then the verdict every rank shares
-        static_assert(offsetof(ChainSpecState, n_below_min) == offsetof(ChainSpecState, n_lt) + 16, "the verification counts are one buffer");
-        RETCHK(chain_reduce(J, &d_spec->n_lt[0], 3, "allreduce_spec_counts"));
-        HIPCHK(ctx, launch_spec_verdict(d_spec, d_state, ctx->stream));
-    }
-    {   // gated on the verdict: levels of every pixel with the full histogram -> exact tables -> composition
-        KernelTimer t(ctx, "spec_fallback_apply");
-        a.hist_mode = 0u; a.gate = d_spec;
-        a.rects = J.plan->d_apply_rects.as<Rect>();
-        for (int b = 0; b < 2; ++b) a.level_hist[b] = exact_hist + (size_t)b * 256;
-        HIPCHK(ctx, launch_clahe_apply_u8_spec(a, (int)J.plan->apply_rects.size(), 2, ctx->stream));
-    }
-    RETCHK(chain_reduce(J, exact_hist, (size_t)256 * kMaxBands, "allreduce_level_hist")); // (all zero when the fused RGB stood: the gated recount did not run)
-    {
-        ChainFinishArgs f{};
-        f.level_hist = exact_hist; f.gate = d_spec;
-        f.total_px = (unsigned long long)J.rows_total * J.cols; f.nbands = 2;
-        f.resc_out = state + kStateOffResc; f.identity_out = state + kStateOffIdent;
-        f.tables = ctx->tables.as<uint8_t>();
-        f.supp_rg = consts + kChainOffSupp; f.blue_pair_supp = consts + kChainOffBlue;
-        f.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
-        f.suppressed = 1;
-        KernelTimer t(ctx, "chain_finish");
-        HIPCHK(ctx, launch_chain_finish(f, ctx->stream));
-    }
-    {
-        ComposeArgs c{};
-        c.b1 = J.d_levels[0]; c.b2 = J.d_levels[1]; c.in_pitch = J.lvl_pitch;
-        c.rgb = d_rgb; c.rgb_pitch_px = rgb_pitch_px; c.rows = rows; c.cols = cols;
-        c.tables = ctx->tables.as<uint8_t>();
-        c.spec = d_spec; c.speculative = 0;
-        KernelTimer t(ctx, "spec_fallback_compose");
-        HIPCHK(ctx, launch_compose_u8(c, 16, ctx->stream));
-    }
+    RETCHK(fused_rgb_tail(T));
     return chain_tail(J, stats_out, d_state);
 }
 
@@ -1351,6 +1400,7 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         }
         fa.in_pitch = J.in_pitch; fa.rgb = d_rgb; fa.rgb_pitch_px = rgb_pitch_px;
         fa.rects = J.plan->d_rgb_rects.as<Rect>(); fa.nrects = (int)J.plan->rgb_rects.size();
+        fa.groups = J.plan->d_rgb_groups.as<int32_t>(); fa.ngroups = (int)J.plan->rgb_groups.size() - 1;
         fa.row_w = J.plan->d_row_w.as<RowWeight>(); fa.col_w = J.plan->d_col_w.as<RowWeight>(); fa.row_off = (int32_t)J.row0;
         fa.dev_state = d_state; fa.spec = d_spec; fa.tables = ctx->tables.as<uint8_t>();
         fa.blue_by_level = ctx->blue_factors_ok ? reinterpret_cast<const float *>(ctx->tables.as<uint8_t>() + kTablesOffPQ) : nullptr;

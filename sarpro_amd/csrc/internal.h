@@ -8,7 +8,8 @@ namespace sarpro {
 struct KernelTimer {
     sarpro_hip_ctx *ctx;
     bool active = false;
-    KernelTimer(sarpro_hip_ctx *c, const char *name);
+    hipStream_t stream; // the stream the kernel is launched on (default: the context's)
+    KernelTimer(sarpro_hip_ctx *c, const char *name, hipStream_t on = nullptr);
     ~KernelTimer();
 };
 // Wall-clock time of a host segment (reported with the kernel times, names start with "host:").

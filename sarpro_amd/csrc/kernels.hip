@@ -569,11 +569,7 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const bool on = k + i < nrows_w; // wave-uniform
-#ifdef SARPRO_ABL_CF_NOLOAD // timing ablation: no row is read (every sample invalid)
-                    dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, 0xFFFFFFFFu, 0u, 0);
-#else
                     dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, on ? voff_ld : 0xFFFFFFFFu, on ? (uint32_t)(wave + kCfWaves * (k + i)) * in_row_bytes : 0u, 0);
-#endif
                 }
             };
             v4u cur[NR], nxt[NR];
@@ -638,11 +634,7 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
                     const uint32_t soff = on ? (uint32_t)(wave + kCfWaves * (k + i)) * out_row_bytes : 0u;
                     // (gfx950: the data registers of a 128-bit buffer store with an SGPR offset must not be written in the next issue
                     // slots -- see the fused CLAHE -> RGB pass)
-#ifdef SARPRO_ABL_CF_NOSTORE // timing ablation: nothing is written
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, 0xFFFFFFFFu, soff, 2);
-#else
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, on ? voff_st : 0xFFFFFFFFu, soff, 2 /* nt */);
-#endif
                     asm volatile("s_nop 1" : : "v"(pk) : "memory");
                     if (on && lane_on && !full) { // a lane that straddles the item's edge: sample by sample
                         uint16_t *o16 = out + (size_t)(rc.r0 + wave + kCfWaves * (k + i)) * a.out_pitch + col;
@@ -701,26 +693,16 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
 // ------------------------------------------------------------------------------------
 //     Round 4: the margins went from 1.8x to 1.17x what the bound requires (6.2e-4 / 1.6e-4 against 5.3e-4 / 1.37e-4; the largest
 //     error ever measured is 0.13 / 0.28 of them; bias = fl(-0.5 - delta) and fl(2 delta) add < 1e-7): a third fewer samples on the
-//     exact path, whose block sits in the row loop of every wave-row that holds one.  -DSARPRO_SPEC_DELTA_R3 restores 2^-10 / 2^-12.
+//     exact path, whose block sits in the row loop of every wave-row that holds one.
 //     Cells that extrapolate along ONE axis only (every cell of the first half tile row or column but the corner) get their own
 //     margins.  dy in [-0.5, 0), x interior: |top|, |bottom| <= 1 with |dtop| <= 4u as in interior cells; 255 (1.5 (4u + 2u) +
 //     0.5 (4u + 2u)) for the two products, u |inner| <= 383u and u |y| <= 510u for the two fma roundings: 3953u = 2.36e-4, and yb's own
 //     rounding 510u: delta > 2.66e-4.  dx in [-0.5, 0), y interior: |top| <= 2, |dtop| <= 5u: 255 (5u + 2 * 2u) + 511u + 510u = 3316u =
 //     1.98e-4, + 510u: delta > 2.28e-4.  (Rect::pad[0] bit 1: dy < 0, bit 2: dx < 0.)
 constexpr float kSpecDeltaEdgeY = 3.0e-4f, kSpecDeltaEdgeX = 2.6e-4f;
-#ifdef SARPRO_SPEC_DELTA_R3
-constexpr float kSpecDeltaEdge = 1.0f / 1024.0f, kSpecDeltaInner = 1.0f / 4096.0f;
-#elif defined(SARPRO_ABL_SPEC_DELTA_SMALL) // timing experiment only (the bound does not cover it)
-constexpr float kSpecDeltaEdge = 7.0e-5f, kSpecDeltaInner = 6.4e-5f;
-#else
 constexpr float kSpecDeltaEdge = 6.2e-4f, kSpecDeltaInner = 1.6e-4f;
-#endif
 __device__ __forceinline__ float spec_delta(int pad0) { // the f32 blend's margin for a work item of this kind of cell
-#ifdef SARPRO_SPEC_DELTA_R3
-    return (pad0 & 1) ? kSpecDeltaEdge : kSpecDeltaInner;
-#else
     return !(pad0 & 1) ? kSpecDeltaInner : (pad0 & 6) == 2 ? kSpecDeltaEdgeY : (pad0 & 6) == 4 ? kSpecDeltaEdgeX : kSpecDeltaEdge;
-#endif
 }
 #ifdef SARPRO_RGB_WG_TIMES // instrumented build (tools/rgb_wg_times.py): when each persistent workgroup of the fused CLAHE -> RGB pass started and ended (100 MHz clock)
 __device__ unsigned long long g_rgb_wg_times[1024][8]; // start, end, then thread 0's sums: wait at the item barrier, prologue, rows, items
@@ -785,25 +767,11 @@ __device__ __forceinline__ double to_sgpr(double x) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-#ifndef SARPRO_LUT_GLOBAL_N
-#define SARPRO_LUT_GLOBAL_N 0
-#endif
-#if SARPRO_LUT_GLOBAL_N > 0
-__device__ uint16_t g_offlut_dev[2 * 65536]; // experiment: DN -> LDS byte offset of the CDF entry, in global memory
-__global__ void k_build_offlut(const uint8_t *b0, const uint8_t *b1) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2 * 65536) { const uint32_t d = i & 65535; const uint8_t *b = (i >> 16) ? b1 : b0; g_offlut_dev[i] = (uint16_t)(SpecLds::cdf32 + cdf32_offset(d ? (uint32_t)b[d] : 256u)); }
-}
-#endif
 // HIST: 0 = every level of every pixel counted, 1 = partial (levels < kPartialHistLevels one by one, the rest in bulk), 2 = the
 // partial form on SAMPLED rows only (row % sample_stride == sample_phase): the histogram is then an estimate that the chain
 // uses to PREDICT the synRGB floor, which the compose pass verifies exactly (chain_kernels.hip, k_chain_predict); together
 // with the levels the sampled rows count their valid (DN != 0) pixels, the stratum the estimate is scaled by.
-#ifdef SARPRO_NT_LOAD
-#define SPEC_LOAD(p) U16Vec<VEC>::load_stream(p)
-#else
 #define SPEC_LOAD(p) U16Vec<VEC>::load(p)
-#endif
 template <bool LUT_LDS, int HIST>
 __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const Rect &rc, int band, unsigned char *lds,
                                                 uint32_t win_hi) {
@@ -811,11 +779,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
     const uint16_t *__restrict__ in = a.in[band];
     const uint8_t *__restrict__ glut = a.binlut[band];
     const RowWeight *__restrict__ row_w = a.row_w + a.row_off;
-#ifdef SARPRO_ABL_NO_HIST // timing ablation: no level histogram at all (the chain's raster is garbage)
-    const bool count_levels = false;
-#else
     const bool count_levels = a.level_hist[band] != nullptr;
-#endif
     const int col = rc.cstart + lane_id() * VEC;
     const bool full = col >= rc.c0 && col + VEC <= rc.c1;
     // edge lanes: samples outside the item are computed like the others (whatever DN the row holds there), then their
@@ -869,18 +833,8 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 uint32_t a0, a1;
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(1u), "v"(cw));
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(1u), "v"(cw));
-#if defined(SARPRO_ABL_NOLOOKUP) // timing ablation (garbage raster): no DN -> offset lookup, the gather address straight from the DN bits
-                off[2 * k] = SpecLds::cdf32 + ((a0 << 3) & 0xFF0u);
-                off[2 * k + 1] = SpecLds::cdf32 + ((a1 << 3) & 0xFF0u);
-#elif SARPRO_LUT_GLOBAL_N > 0 // experiment: the first N of a lane's 8 offset lookups through the vector L1 instead of LDS
-                off[2 * k] = (2 * k < SARPRO_LUT_GLOBAL_N) ? (uint32_t)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(g_offlut_dev + band * 65536) + a0)
-                                                          : (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a0);
-                off[2 * k + 1] = (2 * k + 1 < SARPRO_LUT_GLOBAL_N) ? (uint32_t)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(g_offlut_dev + band * 65536) + a1)
-                                                                  : (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a1);
-#else
                 off[2 * k] = (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a0);
                 off[2 * k + 1] = (uint32_t)LDS_AT(uint16_t, SpecLds::lut + a1);
-#endif
             }
         } else {
 #pragma unroll
@@ -889,10 +843,6 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
                 off[j] = SpecLds::cdf32 + cdf32_offset(i ? (uint32_t)glut[i] : 256u);
             }
         }
-#ifdef SARPRO_ABL_NOCONFLICT // timing ablation (garbage raster): every lane of a 16-lane group gathers from its own 16-B slot class
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) off[j] = SpecLds::cdf32 + (((off[j] - SpecLds::cdf32) & 0xF00u) | (((uint32_t)lane_id() & 15u) << 4));
-#endif
         constexpr int kAhead = 2; // CDF gathers issued ahead of their use (3 in flight; measured: 1 -> 2 -1.4 %, 4 no better)
         v4f cq[VEC];
 #pragma unroll
@@ -924,11 +874,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
 #endif
         }
         const uint32_t d0 = pk[0] ^ pb[0], d1 = pk[1] ^ pb[1];
-#ifdef SARPRO_ABL_NOEXACT // timing ablation (garbage raster): no exact path
-        if (false) {
-#else
         if (d0 | d1) { // rare: some pixel of this lane lies within the margin of an integer -> exact path
-#endif
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 if (((j < 4 ? d0 : d1) >> (8 * (j & 3))) & 0xFFu) { // reference op order (autoscale.rs:327-329, 602)
@@ -995,11 +941,7 @@ __device__ __forceinline__ void clahe_spec_rows(const ClaheApplyArgs &a, const R
         // Every lane issues the 8-byte store, edge lanes into the scratch line: a store inside a divergent branch sits
         // behind an `execz` skip, the waitcnt pass then sees a path through the row without a store and makes the next
         // row wait for vmcnt(0) -- i.e. for this row's store to be acknowledged -- before it may use its prefetched data.
-#ifdef SARPRO_NT_STORE
-        { typedef uint32_t v2u __attribute__((ext_vector_type(2))); v2u t; t.x = pk[0]; t.y = pk[1]; __builtin_nontemporal_store(t, reinterpret_cast<v2u *>(full ? o8 : dump)); }
-#else
         *reinterpret_cast<uint2 *>(full ? o8 : dump) = make_uint2(pk[0], pk[1]);
-#endif
         if (!full) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
@@ -1312,15 +1254,8 @@ __global__ __launch_bounds__(kComposeBlock) void k_compose_u8(ComposeArgs a) {
             const uint4 q1 = n1, q2 = n2;
             {
                 const size_t on = chunk_off(min(ch + nwaves, chunks - 1));
-#ifdef SARPRO_NT_LEVELS
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v4u t1 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(a.b1 + on));
-                const v4u t2 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(a.b2 + on));
-                n1 = make_uint4(t1.x, t1.y, t1.z, t1.w); n2 = make_uint4(t2.x, t2.y, t2.z, t2.w);
-#else
                 n1 = *reinterpret_cast<const uint4 *>(a.b1 + on);
                 n2 = *reinterpret_cast<const uint4 *>(a.b2 + on);
-#endif
             }
             if (fullv) {
                 const uint32_t w1[4] = {q1.x, q1.y, q1.z, q1.w}, w2[4] = {q2.x, q2.y, q2.z, q2.w};
@@ -1451,17 +1386,11 @@ static_assert(kRgbB2Stride == 256 || kRgbB2Stride == 260, "blue table rows: 256 
 #endif
 constexpr int kRgbBlock = SARPRO_RGB_BLOCK, kRgbWaves = kRgbBlock / kWave;
 constexpr uint32_t kRgbPoolEntries = SARPRO_RGB_POOL;
-// SARPRO_RGB_LITE (round 5 experiment): no blue table in LDS.  The suppressed variant's blue is rne(Pv[level1] * Qv[level2]) -- two
-// 256-entry f32 tables by LEVEL that k_chain_predict derives from the host's verified factors (host_logic: synrgb_blue_factors_supp) --
-// and 0 for water (both levels <= floor + cushion): 2.5 KB of tables instead of 67, so that the pass leaves LDS for other workgroups
-// on its compute unit.
-#ifdef SARPRO_RGB_LITE
-constexpr uint32_t kRgbTableBytes = 512 + 2048;                             // R2[256] | G2[256] | Pv[256] f32 | Qv[256] f32
-#else
+// (Round 5's "LITE" form -- no blue table in LDS, blue = rne(Pv[level1] * Qv[level2]) from two 256-entry f32 tables, so that a histogram
+// workgroup fits beside the pass on a compute unit -- ran 8-10 % slower alone and 1.43 ms per pair co-resident: removed, NOTEBOOK.md 6e item 1.)
 constexpr uint32_t kRgbTableBytes = 512 + 256 * kRgbB2Stride;
-#endif
 struct RgbLds {
-    static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[256][kRgbB2Stride]  (LITE: | Pv | Qv)
+    static constexpr uint32_t tables = 0;                                   // R2[256] | G2[256] | B2[256][kRgbB2Stride]  
     static constexpr uint32_t stage = kRgbTableBytes;                       // [16][1536] RGB of a wave-row | tmp32 [2][257] float4 while staging
     static constexpr uint32_t cdf64 = stage + kRgbWaves * 1536;             // [2][257][4] double
     static constexpr uint32_t colw = cdf64 + 2 * 257 * 32;                  // [512] double
@@ -1509,18 +1438,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     {   // compose tables, once per workgroup: R2 | G2 as they are, the blue table's 256-byte rows at their LDS stride
         const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables);
         for (int i = threadIdx.x; i < 512 / 4; i += kRgbBlock) LDS_AT(uint32_t, RgbLds::tables + 4 * i) = src[i];
-#ifdef SARPRO_RGB_LITE
-        const uint32_t *pq = reinterpret_cast<const uint32_t *>(a.blue_by_level);
-        for (int i = threadIdx.x; i < 512; i += kRgbBlock) LDS_AT(uint32_t, RgbLds::tables + 512 + 4 * i) = pq[i];
-#else
         for (int i = threadIdx.x; i < 65536 / 4; i += kRgbBlock)
             LDS_AT(uint32_t, RgbLds::tables + 512 + (uint32_t)(i >> 6) * kRgbB2Stride + (uint32_t)(i & 63) * 4u) = src[128 + i];
-#endif
     }
     const uint32_t fpred = (uint32_t)sp->floor_pred;
-#ifdef SARPRO_RGB_LITE
-    const uint32_t fwc_lite = fpred + 3u < 40u ? fpred + 3u : 40u; // floor_with_cushion of the prediction (k_chain_predict's s_fwc)
-#endif
     const uint32_t t4[3] = {(fpred ? fpred - 1u : 0u) * 0x01010101u, fpred * 0x01010101u, (fpred + 1u) * 0x01010101u};
     uint32_t sad[3] = {0u, 0u, 0u}, n_all = 0u, n_kept = 0u; // this lane's |x - T| sums, level bytes seen (8 per band-row), kept ones
     // GENERAL: per band |x - T| sums at T0 - 1, T0, T0 + 1 (T0 = thr[b][0]; thr[b][1] is T0 or T0 + 1) and at min_pred - 1, min_pred
@@ -1541,16 +1462,14 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     // (13 items of different sizes each; the mean workgroup was done 7 % before the last: tools/rgb_wg_times.py).  The counter's round trip
     // is hidden behind the prologue: thread 0 asks for the NEXT item when this one starts and puts the answer into LDS after the
     // prologue's last barrier, so the value lives in a register through the prologue only -- not through the rows.
-    // -DSARPRO_RGB_STATIC_ITEMS: the stride.
     uint32_t *const s_next = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 8;
-#ifndef SARPRO_RGB_STATIC_ITEMS
+    // What the counter hands out is a GROUP of items (a.groups: first item of each group, the planner's list): neighbouring column strips of
+    // one interpolation cell over the same rows.  The group's first item builds the cell's tables; the others find them in LDS and only
+    // fetch their own columns' weights -- the table prologue costs 4.5-6 us per item (6-7 % of the pass, tools/rgb_wg_times.py) and the
+    // tables depend on the cell alone.  A group is walked left to right, so the sweep order of the scene stays what it was.
+    const int ngroups = a.groups ? a.ngroups : a.nrects;
     if (threadIdx.x == 0) s_next[0] = atomicAdd(&sp->next_item, 1u);
-#endif
-#ifdef SARPRO_RGB_STATIC_ITEMS
-    for (int item = blockIdx.x; item < a.nrects; item += gridDim.x) {
-#else
     for (;;) {
-#endif
         uint32_t *const s_bsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 4; // WIDE: per band the first saturated bin (256: none)
         if (wide && threadIdx.x < 2) s_bsat[threadIdx.x] = 256u; // (only the prologue reads it: no wave of the previous item does)
 #ifdef SARPRO_RGB_WG_TIMES
@@ -1560,25 +1479,33 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
 #ifdef SARPRO_RGB_WG_TIMES
         if (threadIdx.x == 0) { wg_tb = wall_clock64(); wg_t_wait += wg_tb - wg_ta; }
 #endif
-#ifndef SARPRO_RGB_STATIC_ROWS
+        const int group = (int)to_sgpr_u32(s_next[0]);
+        if (group >= ngroups) break;
+        uint32_t next_group = 0u;
+        if (threadIdx.x == 0) next_group = atomicAdd(&sp->next_item, 1u); // (every workgroup overshoots the list once: the counter ends at groups + grid)
+        const int item0 = a.groups ? a.groups[group] : group, item1 = a.groups ? a.groups[group + 1] : group + 1;
+        for (int item = item0; item < item1; ++item) {
+        const bool first_of_group = item == item0;
+        if (!first_of_group) {
+#ifdef SARPRO_RGB_WG_TIMES
+            if (threadIdx.x == 0) { wg_ta = wall_clock64(); wg_t_rows += wg_ta - wg_tc; }
+#endif
+            __syncthreads(); // the previous item's rows are done (its column weights may go)
+#ifdef SARPRO_RGB_WG_TIMES
+            if (threadIdx.x == 0) { wg_tb = wall_clock64(); wg_t_wait += wg_tb - wg_ta; }
+#endif
+        }
         if (threadIdx.x == 0) s_next[1] = 2u * kRgbWaves; // the item's row counter (see the row loop): rows 0 .. 2 * 16 - 1 are assigned by wave number
-#endif
-#ifndef SARPRO_RGB_STATIC_ITEMS
-        const int item = (int)to_sgpr_u32(s_next[0]);
-        if (item >= a.nrects) break;
-        uint32_t next_item = 0u;
-        if (threadIdx.x == 0) next_item = atomicAdd(&sp->next_item, 1u); // (every workgroup overshoots the list once: the counter ends at nrects + grid)
-#endif
         const Rect rc = a.rects[item];
         // (Requesting the wave's first row of both bands HERE, before the tables are built, so that its round trip does not open the rows:
         // measured 0.620 ms against 0.600 -- ten more registers live through the prologue, 34 spilled instead of 21.)
-#ifdef SARPRO_ABL_RGB_PROLOGUE2 // timing ablation: every item builds its tables twice (the difference to the default build = what the prologues cost)
-        for (int rep = 0; rep < 2; ++rep)
-#endif
-        {
-#ifdef SARPRO_ABL_RGB_PROLOGUE2
-        __syncthreads();
-#endif
+        if (!first_of_group) { // the cell's tables stand: this strip's column weights, one round trip and one barrier
+            for (int i = threadIdx.x; i < 512; i += kRgbBlock) {
+                const int c2 = rc.cstart + i;
+                *reinterpret_cast<double *>(lds + RgbLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
+            }
+            __syncthreads();
+        } else {
         // ---- this item's tables: bin-indexed (f64 for the exact path, biased f32 for staging), then expanded by DN
         for (int t = threadIdx.x; t < 2 * 257; t += kRgbBlock) {
             const int b = t / 257, bin = t - b * 257;
@@ -1589,12 +1516,8 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             }
             *reinterpret_cast<double4 *>(lds + RgbLds::cdf64 + (b * 257 + bin) * 32) = make_double4(c[0], c[1], c[2], c[3]);
             // the f32 entry: as kernel 4b stages it (saturated interior bins -> 1.001, all-zero bins and the invalid entry -> 0.5 / 255)
-#ifdef SARPRO_ABL_RGB_EDGESAT // timing ablation (wrong levels where a saturated bin of an extrapolating cell rounds to 254)
-            const bool saturated = bin < 256 && c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0;
-#else
             // (extrapolating cells: only with the saturation tables -- the entry then yields 255 and the row loop takes the 254s from them)
             const bool saturated = bin < 256 && c[0] == 1.0 && c[1] == 1.0 && c[2] == 1.0 && c[3] == 1.0 && (!(rc.pad[0] & 1) || a.sat_ok);
-#endif
             const bool zero = c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0 && c[3] == 0.0;
             const float kz = 0.5f / 255.0f;
             const float c00 = (float)c[0], c01 = (float)c[1], c10 = (float)c[2], c11 = (float)c[3];
@@ -1662,12 +1585,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             }
         }
         __syncthreads();
+        if (threadIdx.x == 0) s_next[0] = next_group; // (every thread read the slot before the prologue's barriers; the next read is behind the barrier that ends this group)
         }
 #ifdef SARPRO_RGB_WG_TIMES
         if (threadIdx.x == 0) { wg_tc = wall_clock64(); wg_t_pro += wg_tc - wg_tb; ++wg_items; }
-#endif
-#ifndef SARPRO_RGB_STATIC_ITEMS
-        if (threadIdx.x == 0) s_next[0] = next_item; // (every thread read the slot before the prologue's barriers; the next read is behind the barrier that ends this item)
 #endif
 
         // The rows of the item, compiled twice and chosen per item by a wave-uniform branch: items of extrapolating cells (EDGE) and
@@ -1716,7 +1637,6 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             const bool kept = col + j >= rc.c0 && col + j < rc.c1;
             if (kept && !(chunk_safe((3 * pr) / 16) && chunk_safe((3 * pr + 2) / 16))) bytewise |= 1u << j;
         }
-#ifndef SARPRO_RGB_OLDSTORE
         // The two chunk stores of a row go through a buffer descriptor over the item's rows: a lane whose chunk is not stored passes
         // an out-of-range offset and the hardware drops its write.  EVERY path through a row therefore holds the same two store
         // instructions, and the wait for the prefetched row at the loop top is vmcnt(2) instead of vmcnt(0) -- with the stores inside
@@ -1726,7 +1646,6 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
         const uint32_t row_bytes = (uint32_t)a.rgb_pitch_px * 3u;
         const __amdgpu_buffer_rsrc_t rgb_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rgb + item_off, 0, (int)((uint32_t)(rc.r1 - rc.r0) * row_bytes), 0x00020000);
         const uint32_t voff1 = safe1 ? (uint32_t)lane * 16u : 0xFFFFFFFFu, voff2 = safe2 ? 1024u + (uint32_t)lane * 16u : 0xFFFFFFFFu;
-#endif
         float dxf[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) dxf[j] = (float)*reinterpret_cast<const double *>(lds + RgbLds::colw + (lane * VEC + j) * 8);
@@ -1761,16 +1680,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                     off[2 * k] = a0; off[2 * k + 1] = a1;
                     continue;
                 }
-#ifdef SARPRO_RGB_OLDADDR
-                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(4u), "v"(cw));
-                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(4u), "v"(cw));
-                off[2 * k] = pbase + a0; off[2 * k + 1] = pbase + a1; // LDS address of the entry: pool + (first entry + clamped DN) x 16
-#else
                 // one instruction per sample: (16-bit half of the clamped pair) x 16 + the band's base in the pool
                 asm("v_mad_u32_u16 %0, %1, 16, %2" : "=v"(a0) : "v"(cw), "s"(pbase));
                 asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(cw), "s"(pbase));
                 off[2 * k] = a0; off[2 * k + 1] = a1;
-#endif
             }
             if (WIDE) { // bin -> entry address, all eight byte reads in flight before the first is used
                 uint32_t bq[VEC];
@@ -1800,11 +1713,7 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                 pb[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(yb, j & 3, pb[j >> 2]);
             }
             const uint32_t d0 = pk[0] ^ pb[0], d1 = pk[1] ^ pb[1];
-#ifdef SARPRO_ABL_RGB_NOEXACT
-            if (false) {
-#else
             if (d0 | d1) { // rare: the exact f64 sequence of autoscale.rs:327-329, 602
-#endif
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     if (((j < 4 ? d0 : d1) >> (8 * (j & 3))) & 0xFFu) {
@@ -1839,19 +1748,16 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             const int lcol = min(col, (int)a.in_pitch - VEC); // a lane past the row's pitch loads (and ignores) the row's last vector
             const uint16_t *p0 = a.in[0] + lcol, *p1 = a.in[1] + lcol;
             int r = __builtin_amdgcn_readfirstlane(rc.r0 + wave);
-#ifndef SARPRO_RGB_STATIC_ROWS
             // The waves of a workgroup do not advance together (the oldest wave of a SIMD wins every arbitration): with rows r0 + wave + 16 k
             // the first wave stood at the item's closing barrier 18 us of every 70 (tools/rgb_wg_times.py), and while the waves trickle in the
             // compute unit runs ever emptier.  Rows are handed out by an LDS counter instead: a wave's first two rows by its number, then the
             // row after next with every row it starts -- the answer travels behind the row's own LDS gathers.
             int kn = wave + step; // the NEXT row of this wave, relative to r0 (>= the item's rows: none)
             const int nrows = rc.r1 - rc.r0;
-#endif
             if (r < rc.r1) {
                 uint4 c0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)r * a.in_pitch), c1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)r * a.in_pitch);
                 double dyv = row_w[r].d;
                 uint32_t srv = (EDGE && a.sat_ok) ? (uint32_t)a.sat_row[r] : 7u;
-#ifndef SARPRO_RGB_OLDSTORE
                 // (two stores behind the first row's loads, as every later row has them behind its own: the loop is entered in its
                 // steady state and its top waits with vmcnt(2))
                 {
@@ -1860,16 +1766,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                     __builtin_amdgcn_raw_buffer_store_b128(z, rgb_rsrc, 0xFFFFFFFFu, 0, 2); // (out of range in every lane: nothing is written)
                     __builtin_amdgcn_raw_buffer_store_b128(z, rgb_rsrc, 0xFFFFFFF0u, 0, 2); // (another offset: two identical stores would be merged)
                 }
-#endif
-#ifdef SARPRO_RGB_STATIC_ROWS
-                for (; r < rc.r1; r += step) {
-                    const int rn = min(r + step, rc.r1 - 1); // the next row of both bands is always in flight
-#else
                 for (;;) {
                     const int rn = rc.r0 + min(kn, nrows - 1); // the next row of both bands is always in flight
                     uint32_t grab = 0u;
                     if (lane == 0) grab = atomicAdd(&s_next[1], 1u);
-#endif
                     const uint4 n0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)rn * a.in_pitch), n1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)rn * a.in_pitch);
                     const double dyn = row_w[rn].d;
                     const uint32_t srn = (EDGE && a.sat_ok) ? (uint32_t)a.sat_row[rn] : 7u;
@@ -1903,39 +1803,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         uint32_t px[4][3];
-#ifdef SARPRO_RGB_OLDCOMPOSE
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t v1 = (l1[g] >> (8 * j)) & 0xFFu, v2 = (l2[g] >> (8 * j)) & 0xFFu;
-#ifdef SARPRO_ABL_RGB_NOLOOKUP // timing ablation (garbage raster)
-                            px[j][0] = v1; px[j][1] = v2; px[j][2] = v1 ^ v2;
-#else
-                            px[j][0] = lds[RgbLds::tables + v1]; px[j][1] = lds[RgbLds::tables + 256 + v2]; px[j][2] = lds[RgbLds::tables + 512 + v1 * kRgbB2Stride + v2];
-#endif
-                        }
-                        o[3 * g + 0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
-                        o[3 * g + 1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
-                        o[3 * g + 2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
-#else
                         // Table addresses straight from the packed level bytes: one bit-field extract per R2 / G2 index, ONE v_perm_b32 per
                         // B2 index ((level1 << 8) | level2 from the two packed registers), the table bases in the instructions' offset
                         // fields; the 12 bytes are packed by v_lshl_or pairs (left to the compiler the same lines cost twice the VALU
                         // instructions: byte masks after zero-extending loads, multiply-adds for the pair index, three-step packing).
-#ifdef SARPRO_RGB_LITE
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t v1 = j == 0 ? (l1[g] & 0xFFu) : j == 3 ? (l1[g] >> 24) : __builtin_amdgcn_ubfe(l1[g], 8 * j, 8);
-                            const uint32_t v2 = j == 0 ? (l2[g] & 0xFFu) : j == 3 ? (l2[g] >> 24) : __builtin_amdgcn_ubfe(l2[g], 8 * j, 8);
-                            px[j][0] = LDS_AT(uint8_t, RgbLds::tables + v1);
-                            px[j][1] = LDS_AT(uint8_t, RgbLds::tables + 256 + v2);
-                            const float pv = LDS_AT(float, RgbLds::tables + 512 + 4u * v1), qv = LDS_AT(float, RgbLds::tables + 1536 + 4u * v2);
-                            const uint32_t blue = __builtin_amdgcn_cvt_pk_u8_f32(pv * qv, 0, 0u); // round to nearest even, as the host's check of the factors
-                            px[j][2] = max(v1, v2) <= fwc_lite ? 0u : blue;                       // water: both levels at or below floor + cushion (synthetic_rgb.rs:158-164)
-                        }
-                        o[3 * g + 0] = pack4(px[0][0], px[0][1], px[0][2], px[1][0]);
-                        o[3 * g + 1] = pack4(px[1][1], px[1][2], px[2][0], px[2][1]);
-                        o[3 * g + 2] = pack4(px[2][2], px[3][0], px[3][1], px[3][2]);
-#else
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const uint32_t v1 = j == 0 ? (l1[g] & 0xFFu) : j == 3 ? (l1[g] >> 24) : __builtin_amdgcn_ubfe(l1[g], 8 * j, 8);
@@ -1943,31 +1814,19 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                             uint32_t pair; // byte offset of B2[level1][level2]
                             if (kRgbB2Stride == 256) pair = __builtin_amdgcn_perm(l1[g], l2[g], to_sgpr_u32(0x0c0c0400u + 0x0101u * (uint32_t)j)); // (0, 0, level1, level2)
                             else asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair) : "v"(v1), "s"(kRgbB2Stride), "v"(v2));
-#ifdef SARPRO_ABL_RGB_NOLOOKUP // timing ablation (garbage raster)
-                            px[j][0] = v1; px[j][1] = v2; px[j][2] = pair & 0xFFu;
-#else
                             px[j][0] = LDS_AT(uint8_t, RgbLds::tables + v1);
                             px[j][1] = LDS_AT(uint8_t, RgbLds::tables + 256 + v2);
                             px[j][2] = LDS_AT(uint8_t, RgbLds::tables + 512 + pair);
-#endif
                         }
                         o[3 * g + 0] = pack4(px[0][0], px[0][1], px[0][2], px[1][0]);
                         o[3 * g + 1] = pack4(px[1][1], px[1][2], px[2][0], px[2][1]);
                         o[3 * g + 2] = pack4(px[2][2], px[3][0], px[3][1], px[3][2]);
-#endif
-#endif
                     }
                     uint8_t *rowp = a.rgb + ((size_t)r * a.rgb_pitch_px + (size_t)rc.cstart) * 3;
                     // (same wave writes and reads its stage: program order inside a wave, no barrier)
                     *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24) = make_uint2(o[0], o[1]);
                     *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24 + 8) = make_uint2(o[2], o[3]);
                     *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24 + 16) = make_uint2(o[4], o[5]);
-#ifdef SARPRO_ABL_RGB_NOSTORE
-                    if (safe1 && o[0] == 0x12345678u) store_stream16(reinterpret_cast<uint4 *>(rowp) + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + lane * 16));
-#elif defined(SARPRO_RGB_OLDSTORE)
-                    if (safe1) store_stream16(reinterpret_cast<uint4 *>(rowp) + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + lane * 16));
-                    if (safe2) store_stream16(reinterpret_cast<uint4 *>(rowp) + 64 + lane, *reinterpret_cast<const uint4 *>(lds + stage_w + 1024 + lane * 16));
-#else
                     {
                         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
                         const uint32_t soff = (uint32_t)(r - rc.r0) * row_bytes;
@@ -1986,7 +1845,6 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                         __builtin_amdgcn_raw_buffer_store_b128(d2, rgb_rsrc, voff2, soff, 2);
                         asm volatile("s_nop 1" : : "v"(d2) : "memory");
                     }
-#endif
                     if (bytewise) {
                         uint8_t *po = rowp + (size_t)lane * 24;
 #pragma unroll
@@ -1999,11 +1857,9 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                             }
                     }
                     c0 = n0; c1 = n1; dyv = dyn; srv = srn;
-#ifndef SARPRO_RGB_STATIC_ROWS
                     if (kn >= nrows) break;
                     r = rc.r0 + kn;
                     kn = (int)to_sgpr_u32(grab);
-#endif
                 }
             }
         }
@@ -2015,6 +1871,7 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             if (rc.pad[0] & 1) item_rows(std::true_type{}, std::true_type{});
             else item_rows(std::false_type{}, std::true_type{});
         }
+        } // the group's items
     }
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
 #ifdef SARPRO_RGB_WG_TIMES
@@ -2066,28 +1923,16 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
 }
 // Two kernels, two launches (the second returns at once on all but the rare scene): with both bodies in ONE kernel the identity form ran
 // 2 % slower (0.697-0.707 ms against 0.681-0.693 on the same box, the register allocator spills for the union of the two), the extra
-// launch costs nothing measurable (host time of the chain 1.179-1.190 ms against 1.186-1.195).  -DSARPRO_RGB_ONE_KERNEL = the merged form.
+// launch costs nothing measurable (host time of the chain 1.179-1.190 ms against 1.186-1.195).
 // (The rescaled body as a noinline function called from the one kernel: 0.86-0.89 ms against 0.715 -- the call ABI costs the hot loop far
 // more than the spills.)  Inside a resident batch the second launch's empty workgroups still wait for whole compute units (160 KiB of LDS
 // each): its bracket reads 15 us on average there, on the lane's own stream, behind which only the gated fallbacks follow.
-#ifndef SARPRO_RGB_ONE_KERNEL
 __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
     if (a.spec->spec_ok == kSpecIdentity) clahe_rgb_fused_body<false>(a);
 }
-#ifndef SARPRO_RGB_LITE
 __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused_rescaled(ClaheRgbArgs a) {
     if (a.spec->spec_ok == kSpecRescaled) clahe_rgb_fused_body<true>(a);
 }
-#endif
-#else
-__global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
-    const uint32_t how = a.spec->spec_ok;
-    if (how == kSpecIdentity) clahe_rgb_fused_body<false>(a);
-#ifndef SARPRO_RGB_LITE // (the LITE form's water test reads the levels themselves: identity only)
-    else if (how == kSpecRescaled) clahe_rgb_fused_body<true>(a);
-#endif
-}
-#endif
 // Row stripes: every rank's pass has added its counts, the ranks have summed them; the same verdict on every rank.
 __global__ void k_spec_verdict(ChainSpecState *sp, const ChainBandState *state) {
     // (the windows are the same on every rank; `pool_overflow` is raised by block 0 of the pass, which a rank with an empty stripe
@@ -2376,9 +2221,6 @@ hipError_t launch_clahe_apply_u8_spec(ClaheApplyArgs a, int nrects, int nbands, 
 #define SARPRO_LDS_PAD 0
 #endif
     const size_t lds = SpecLds::lut + (((size_t)a.lut_cap) * 2 + 15 & ~(size_t)15) + SARPRO_LDS_PAD;
-#if SARPRO_LUT_GLOBAL_N > 0
-    hipLaunchKernelGGL(k_build_offlut, dim3(512), dim3(256), 0, s, a.binlut[0], a.binlut[nbands > 1 ? 1 : 0]);
-#endif
     if (a.hist_mode == 3) hipLaunchKernelGGL(k_clahe_apply_u8_spec<3>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     else if (a.hist_mode == 2) hipLaunchKernelGGL(k_clahe_apply_u8_spec<2>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
     else if (a.hist_mode == 1) hipLaunchKernelGGL(k_clahe_apply_u8_spec<1>, dim3(nrects, nbands), dim3(kBlock), lds, s, a);
@@ -2451,9 +2293,6 @@ hipError_t opt_in_dynamic_lds(const void *kernel) {
 }
 
 bool clahe_rgb_fused_supported(const ClaheRgbArgs &a) { // (nrects == 0: a rank whose stripe is empty -- nothing to launch, nothing to align)
-#ifdef SARPRO_RGB_LITE
-    if (!a.blue_by_level) return false;
-#endif
     return a.nrects >= 0 && a.spec && a.dev_state && a.in_pitch % 8 == 0 && a.rgb_pitch_px % 16 == 0 &&
            (a.nrects == 0 || ((reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 &&
                               (reinterpret_cast<uintptr_t>(a.rgb) & 15) == 0));
@@ -2466,11 +2305,9 @@ hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s
     if (!clahe_rgb_fused_supported(a) || grid <= 0) return hipErrorInvalidValue;
     if (a.nrects == 0) return hipSuccess;
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused))) return e;
-    hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
-#if !defined(SARPRO_RGB_ONE_KERNEL) && !defined(SARPRO_RGB_LITE) // (the LITE form's water test reads the levels themselves: identity only)
+    hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.groups ? a.ngroups : a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused_rescaled))) return e;
-    hipLaunchKernelGGL(k_clahe_rgb_fused_rescaled, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
-#endif
+    hipLaunchKernelGGL(k_clahe_rgb_fused_rescaled, dim3(std::min(grid, a.groups ? a.ngroups : a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
     return hipGetLastError();
 }
 

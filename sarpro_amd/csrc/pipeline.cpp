@@ -41,7 +41,7 @@ static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
     return code;
 }
 
-constexpr int kPipeDefaultLanes = 3, kPipeMaxLanes = 8;
+constexpr int kPipeDefaultLanes = 3, kPipeMaxLanes = 8, kPipeDefaultOrder = 3;
 
 static int ensure_lanes(sarpro_hip_ctx *ctx, int lanes) {
     while ((int)ctx->lanes.size() < lanes) {
@@ -57,6 +57,9 @@ static int ensure_lanes(sarpro_hip_ctx *ctx, int lanes) {
         l->pipe_record_after_fused = nullptr;
         l->pipe_wait_before_hist = nullptr;
         l->pipe_record_before_fused = nullptr;
+        l->pipe_record_after_hist = nullptr;
+        l->pipe_defer = false;
+        l->pipe_deferred = nullptr;
     }
     return SARPRO_HIP_OK;
 }
@@ -80,10 +83,17 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
     lanes = (int)std::min<size_t>((size_t)lanes, nscenes);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (int rc = ensure_lanes(ctx, lanes)) return rc;
-    const long long order = ctx->attrs.val(A_PIPE_ORDER, 0);
-    const bool chain_f = order != 0 && lanes > 1;
+    // PIPE_ORDER: 3 (default) = the two sweeps of all lanes in ONE order, H(i + 1), F(i), H(i + 2), F(i + 1), ... -- F(i) waits for the NEXT
+    // scene's histogram sweep, H(i + 2) for F(i): a sweep owns whole compute units, two of them at once only take turns at the chip's
+    // compute units and at HBM (and a late workgroup of H's static pieces ends late); the short kernels S(i + 1) between a scene's sweeps
+    // run beside H(i + 2), which leaves them registers and LDS.  An event has to be recorded before a stream can wait for it, so the
+    // chain of scene i stops in front of its fused pass (pipe_defer) and its rest is enqueued after scene i + 1's sweep.
+    // 0 = free run (round 5), 1 = the fused passes chained, 2 = H(i + 1) paired with F(i) (the co-residency experiment).
+    const long long order = ctx->attrs.val(A_PIPE_ORDER, kPipeDefaultOrder);
+    const bool serial = order == 3 && lanes > 1;
+    const bool chain_f = (order == 1 || order == 2) && lanes > 1;
     const bool pair_fh = order == 2 && lanes > 1; // scene i + 1's histogram pass starts when scene i's fused pass starts (and the fused passes follow each other)
-    while (chain_f && ctx->pipe_events.size() < (pair_fh ? 2 : 1) * nscenes) {
+    while ((chain_f || serial) && ctx->pipe_events.size() < ((pair_fh || serial) ? 2 : 1) * nscenes) {
         hipEvent_t e;
         HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->pipe_events.push_back(e);
@@ -96,6 +106,35 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
     ctx->lane_times.clear();
 
     int first_error = SARPRO_HIP_OK;
+    auto scene_failed = [&](size_t i, int rc, sarpro_hip_ctx *l) {
+        if (scenes[i].status != SARPRO_HIP_OK) return; // (counted already)
+        scenes[i].status = rc;
+        ctx->err = std::string("resident batch: scene ") + std::to_string(i) + ": " + l->err;
+        ++report->errors;
+        if (first_error == SARPRO_HIP_OK) first_error = rc;
+    };
+    auto copy_route = [&](size_t i, sarpro_hip_ctx *l) {
+        // the scene's verdict, copied out in stream order (the next scene of this lane overwrites the state)
+        if (scenes[i].status == SARPRO_HIP_OK && strategy == SARPRO_STRATEGY_CLAHE && l->spec_state.p && l->spec_ran &&
+            hipMemcpyAsync(&routes[i], l->spec_state.p, sizeof(ChainSpecState), hipMemcpyDeviceToHost, l->stream) == hipSuccess) has_route[i] = 1;
+    };
+    // serial order: the rest of scene i's chain (its fused pass waits for scene i + 1's sweep when there is one)
+    auto finish_scene = [&](size_t i, bool has_next) {
+        sarpro_hip_ctx *l = ctx->lanes[i % (size_t)lanes];
+        hipEvent_t e_f = ctx->pipe_events[i];
+        if (l->pipe_deferred) {
+            l->pipe_wait_before_fused = has_next ? ctx->pipe_events[nscenes + i + 1] : nullptr;
+            l->pipe_record_after_fused = e_f;
+            const int rc = l->pipe_deferred();
+            l->pipe_deferred = nullptr;
+            l->pipe_wait_before_fused = nullptr;
+            if (rc != SARPRO_HIP_OK) scene_failed(i, rc, l);
+            if (l->pipe_record_after_fused) { (void)hipEventRecord(e_f, l->stream); l->pipe_record_after_fused = nullptr; }
+        } else {
+            (void)hipEventRecord(e_f, l->stream); // a scene whose chain never reached the fused pass (another route, an error) still releases its successors
+        }
+        copy_route(i, l);
+    };
     size_t enq = 0;
     for (; enq < nscenes; ++enq) {
         sarpro_hip_resident_scene &sc = scenes[enq];
@@ -108,8 +147,14 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
             l->pipe_wait_before_hist = enq >= 2 ? ctx->pipe_events[nscenes + enq - 1] : nullptr; // (scene 1 starts at once: it has scene 0's whole chain to hide behind)
             l->pipe_record_before_fused = ctx->pipe_events[nscenes + enq];
         }
-        int rc = sarpro_hip_dualpol_synrgb_u16_dev(l, sc.d_band1, sc.d_band2, rows, cols, in_pitch, strategy, mode, sc.d_rgb, rgb_pitch_px,
-                                                   nullptr, nullptr, 0, nullptr);
+        if (serial) {
+            l->pipe_defer = true;
+            l->pipe_deferred = nullptr;
+            l->pipe_wait_before_hist = enq >= 2 ? ctx->pipe_events[enq - 2] : nullptr; // H(i) behind F(i - 2)
+            l->pipe_record_after_hist = ctx->pipe_events[nscenes + enq];
+        }
+        const int rc = sarpro_hip_dualpol_synrgb_u16_dev(l, sc.d_band1, sc.d_band2, rows, cols, in_pitch, strategy, mode, sc.d_rgb, rgb_pitch_px,
+                                                         nullptr, nullptr, 0, nullptr);
         if (chain_f) {
             // a scene whose chain never reached the fused pass (another route, an error) still releases its successor
             if (l->pipe_record_after_fused) (void)hipEventRecord(l->pipe_record_after_fused, l->stream);
@@ -119,18 +164,21 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
             l->pipe_wait_before_hist = nullptr;
             l->pipe_record_before_fused = nullptr;
         }
-        if (rc == SARPRO_HIP_OK && strategy == SARPRO_STRATEGY_CLAHE && l->spec_state.p && l->spec_ran) {
-            // the scene's verdict, copied out in stream order (the next scene of this lane overwrites the state)
-            if (hipMemcpyAsync(&routes[enq], l->spec_state.p, sizeof(ChainSpecState), hipMemcpyDeviceToHost, l->stream) == hipSuccess) has_route[enq] = 1;
+        if (serial) {
+            if (l->pipe_record_after_hist) (void)hipEventRecord(l->pipe_record_after_hist, l->stream); // (a chain without the piece sweep: recorded where it stands)
+            l->pipe_record_after_hist = nullptr;
+            l->pipe_wait_before_hist = nullptr;
+            l->pipe_defer = false;
         }
-        sc.status = rc;
-        if (rc != SARPRO_HIP_OK) {
-            ctx->err = std::string("resident batch: scene ") + std::to_string(enq) + ": " + l->err;
-            ++report->errors;
-            if (first_error == SARPRO_HIP_OK) first_error = rc;
-            if (!continue_on_error) { ++enq; break; } // api/mod.rs:518-526
+        if (rc != SARPRO_HIP_OK) scene_failed(enq, rc, l);
+        if (serial) {
+            if (enq) finish_scene(enq - 1, true);
+        } else {
+            copy_route(enq, l);
         }
+        if (report->errors && !continue_on_error) { ++enq; break; } // api/mod.rs:518-526
     }
+    if (serial && enq) finish_scene(enq - 1, false);
     int sync_rc = SARPRO_HIP_OK;
     for (int k = 0; k < lanes; ++k) {
         sarpro_hip_ctx *l = ctx->lanes[(size_t)k];

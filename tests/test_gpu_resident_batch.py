@@ -42,7 +42,7 @@ def rgb_of(t, rows, cols, pitch):
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 3])
-@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("order", [0, 1, 3])
 def test_resident_batch_matches_oracle_scene_by_scene(lanes, order, monkeypatch):
     rows, cols = 1000, 1300
     pitch = (cols + 63) // 64 * 64

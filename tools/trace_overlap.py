@@ -21,7 +21,7 @@ queues = sorted({e[2] for e in batch})
 print(f"# {os.path.basename(f)}: {len(batch)} kernels of the last batch on {len(queues)} queues (lanes); times in us from the batch's first kernel")
 sweeps = [e for e in batch if e[3] in ("k_dn_hist_pieces", "k_clahe_rgb_fused")]
 for e in batch:
-    if e[1] - e[0] < 15000 and e[3] not in ("k_chain_predict",):
+    if e[1] - e[0] < int(os.environ.get("MIN_US", "15")) * 1000 and e[3] not in ("k_chain_predict",):
         continue  # (only kernels of 15 us and more, and the prediction: the rest are listed in the count below)
     ov = 0
     if e in sweeps:
