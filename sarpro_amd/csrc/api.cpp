@@ -290,7 +290,6 @@ namespace sarpro {
 constexpr size_t kRgbItemRows = 256, kSampleItemRows = 1024, kU16ItemRows = 1024;
 constexpr size_t kRgbTailRows = 1024, kRgbTailItemRows = 96; // fused CLAHE -> RGB pass: the stripe's last rows in small items (see get_plan)
 constexpr size_t kRgbItemRowsLarge = 512, kRgbTailRowsLarge = 2500, kRgbTailItemRowsLarge = 128;
-constexpr long long kRgbGroup = 1; // fused pass: items per hand-out unit (see get_plan)
 static size_t strip_align(const StripePlan &P, int vecw) { // (STRIP_ALIGN: planner tuning, read when the plan is built)
     if (vecw != 8 && vecw != 4) return (size_t)vecw;
     return std::max<size_t>(vecw, P.strip_align_px / vecw * vecw);
@@ -577,22 +576,6 @@ int get_plan(sarpro_hip_ctx *ctx, size_t rows_total, size_t cols, size_t row0, s
     if (!rc) rc = upload_vec(ctx, P->d_hist_rects_flat, P->hist_rects_flat.data(), P->hist_rects_flat.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_apply_rects, P->apply_rects.data(), P->apply_rects.size() * sizeof(Rect));
     if (!rc) rc = upload_vec(ctx, P->d_rgb_rects, P->rgb_rects.data(), P->rgb_rects.size() * sizeof(Rect));
-    {   // the fused pass's hand-out units: runs of up to RGB_GROUP items that share cell, rows and flags (in sweep order they are
-        // neighbouring column strips): the first builds the cell's tables, the others reuse them (kernels.hip 6a)
-        const size_t gmax = (size_t)std::min<long long>(16, std::max<long long>(1, at.val(A_RGB_GROUP, kRgbGroup)));
-        P->rgb_groups.clear();
-        for (size_t i = 0; i < P->rgb_rects.size(); ++i) {
-            const Rect &x = P->rgb_rects[i];
-            bool joins = false;
-            if (!P->rgb_groups.empty() && i - (size_t)P->rgb_groups.back() < gmax) {
-                const Rect &y = P->rgb_rects[i - 1];
-                joins = x.r0 == y.r0 && x.r1 == y.r1 && x.pad[0] == y.pad[0] && x.id[0] == y.id[0] && x.id[1] == y.id[1] && x.id[2] == y.id[2] && x.id[3] == y.id[3];
-            }
-            if (!joins) P->rgb_groups.push_back((int32_t)i);
-        }
-        P->rgb_groups.push_back((int32_t)P->rgb_rects.size());
-        if (!rc) rc = upload_vec(ctx, P->d_rgb_groups, P->rgb_groups.data(), P->rgb_groups.size() * sizeof(int32_t));
-    }
     if (!rc && !P->rgb_rects.empty()) { // the fused pass's saturation tables (host_logic.h); the column table padded so that every lane's 8-byte load is in range
         std::vector<uint8_t> cc, rb;
         P->sat_ok = clahe_saturated_levels(g, &cc, &rb);
@@ -1400,7 +1383,6 @@ static int job_run_chain(U16Job &J, void *const d_out[kMaxBands], size_t out_pit
         }
         fa.in_pitch = J.in_pitch; fa.rgb = d_rgb; fa.rgb_pitch_px = rgb_pitch_px;
         fa.rects = J.plan->d_rgb_rects.as<Rect>(); fa.nrects = (int)J.plan->rgb_rects.size();
-        fa.groups = J.plan->d_rgb_groups.as<int32_t>(); fa.ngroups = (int)J.plan->rgb_groups.size() - 1;
         fa.row_w = J.plan->d_row_w.as<RowWeight>(); fa.col_w = J.plan->d_col_w.as<RowWeight>(); fa.row_off = (int32_t)J.row0;
         fa.dev_state = d_state; fa.spec = d_spec; fa.tables = ctx->tables.as<uint8_t>();
         fa.blue_by_level = ctx->blue_factors_ok ? reinterpret_cast<const float *>(ctx->tables.as<uint8_t>() + kTablesOffPQ) : nullptr;

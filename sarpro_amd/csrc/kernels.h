@@ -121,8 +121,6 @@ struct ClaheRgbArgs {
     size_t rgb_pitch_px;                // % 16 == 0
     const Rect *rects;                  // interpolation-cell items (512 columns x rows), line-aligned strips
     int nrects;
-    const int32_t *groups;              // [ngroups + 1] first item of each group (neighbouring strips of one cell over the same rows: the tables are
-    int ngroups;                        // built once per group); null: every item is its own group
     const double *cdfs[kMaxBands];      // [64][256]
     const uint8_t *binlut[kMaxBands];   // DN -> CLAHE bin, constant from win_hi on
     const RowWeight *row_w, *col_w;     // row_w indexed by GLOBAL row

@@ -1463,11 +1463,6 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     // is hidden behind the prologue: thread 0 asks for the NEXT item when this one starts and puts the answer into LDS after the
     // prologue's last barrier, so the value lives in a register through the prologue only -- not through the rows.
     uint32_t *const s_next = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 8;
-    // What the counter hands out is a GROUP of items (a.groups: first item of each group, the planner's list): neighbouring column strips of
-    // one interpolation cell over the same rows.  The group's first item builds the cell's tables; the others find them in LDS and only
-    // fetch their own columns' weights -- the table prologue costs 4.5-6 us per item (6-7 % of the pass, tools/rgb_wg_times.py) and the
-    // tables depend on the cell alone.  A group is walked left to right, so the sweep order of the scene stays what it was.
-    const int ngroups = a.groups ? a.ngroups : a.nrects;
     if (threadIdx.x == 0) s_next[0] = atomicAdd(&sp->next_item, 1u);
     for (;;) {
         uint32_t *const s_bsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 4; // WIDE: per band the first saturated bin (256: none)
@@ -1479,33 +1474,15 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
 #ifdef SARPRO_RGB_WG_TIMES
         if (threadIdx.x == 0) { wg_tb = wall_clock64(); wg_t_wait += wg_tb - wg_ta; }
 #endif
-        const int group = (int)to_sgpr_u32(s_next[0]);
-        if (group >= ngroups) break;
-        uint32_t next_group = 0u;
-        if (threadIdx.x == 0) next_group = atomicAdd(&sp->next_item, 1u); // (every workgroup overshoots the list once: the counter ends at groups + grid)
-        const int item0 = a.groups ? a.groups[group] : group, item1 = a.groups ? a.groups[group + 1] : group + 1;
-        for (int item = item0; item < item1; ++item) {
-        const bool first_of_group = item == item0;
-        if (!first_of_group) {
-#ifdef SARPRO_RGB_WG_TIMES
-            if (threadIdx.x == 0) { wg_ta = wall_clock64(); wg_t_rows += wg_ta - wg_tc; }
-#endif
-            __syncthreads(); // the previous item's rows are done (its column weights may go)
-#ifdef SARPRO_RGB_WG_TIMES
-            if (threadIdx.x == 0) { wg_tb = wall_clock64(); wg_t_wait += wg_tb - wg_ta; }
-#endif
-        }
         if (threadIdx.x == 0) s_next[1] = 2u * kRgbWaves; // the item's row counter (see the row loop): rows 0 .. 2 * 16 - 1 are assigned by wave number
+        const int item = (int)to_sgpr_u32(s_next[0]);
+        if (item >= a.nrects) break;
+        uint32_t next_item = 0u;
+        if (threadIdx.x == 0) next_item = atomicAdd(&sp->next_item, 1u); // (every workgroup overshoots the list once: the counter ends at nrects + grid)
         const Rect rc = a.rects[item];
         // (Requesting the wave's first row of both bands HERE, before the tables are built, so that its round trip does not open the rows:
         // measured 0.620 ms against 0.600 -- ten more registers live through the prologue, 34 spilled instead of 21.)
-        if (!first_of_group) { // the cell's tables stand: this strip's column weights, one round trip and one barrier
-            for (int i = threadIdx.x; i < 512; i += kRgbBlock) {
-                const int c2 = rc.cstart + i;
-                *reinterpret_cast<double *>(lds + RgbLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
-            }
-            __syncthreads();
-        } else {
+        {
         // ---- this item's tables: bin-indexed (f64 for the exact path, biased f32 for staging), then expanded by DN
         for (int t = threadIdx.x; t < 2 * 257; t += kRgbBlock) {
             const int b = t / 257, bin = t - b * 257;
@@ -1585,7 +1562,7 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_next[0] = next_group; // (every thread read the slot before the prologue's barriers; the next read is behind the barrier that ends this group)
+        if (threadIdx.x == 0) s_next[0] = next_item; // (every thread read the slot before the prologue's barriers; the next read is behind the barrier that ends this item)
         }
 #ifdef SARPRO_RGB_WG_TIMES
         if (threadIdx.x == 0) { wg_tc = wall_clock64(); wg_t_pro += wg_tc - wg_tb; ++wg_items; }
@@ -1871,7 +1848,6 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             if (rc.pad[0] & 1) item_rows(std::true_type{}, std::true_type{});
             else item_rows(std::false_type{}, std::true_type{});
         }
-        } // the group's items
     }
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
 #ifdef SARPRO_RGB_WG_TIMES
@@ -2305,9 +2281,9 @@ hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s
     if (!clahe_rgb_fused_supported(a) || grid <= 0) return hipErrorInvalidValue;
     if (a.nrects == 0) return hipSuccess;
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused))) return e;
-    hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.groups ? a.ngroups : a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
+    hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused_rescaled))) return e;
-    hipLaunchKernelGGL(k_clahe_rgb_fused_rescaled, dim3(std::min(grid, a.groups ? a.ngroups : a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
+    hipLaunchKernelGGL(k_clahe_rgb_fused_rescaled, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
     return hipGetLastError();
 }
 

@@ -41,7 +41,7 @@ static int fail(sarpro_hip_ctx *ctx, int code, const char *msg) {
     return code;
 }
 
-constexpr int kPipeDefaultLanes = 3, kPipeMaxLanes = 8, kPipeDefaultOrder = 3;
+constexpr int kPipeDefaultLanes = 3, kPipeMaxLanes = 8, kPipeDefaultOrder = 0;
 
 static int ensure_lanes(sarpro_hip_ctx *ctx, int lanes) {
     while ((int)ctx->lanes.size() < lanes) {
@@ -83,12 +83,17 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
     lanes = (int)std::min<size_t>((size_t)lanes, nscenes);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (int rc = ensure_lanes(ctx, lanes)) return rc;
-    // PIPE_ORDER: 3 (default) = the two sweeps of all lanes in ONE order, H(i + 1), F(i), H(i + 2), F(i + 1), ... -- F(i) waits for the NEXT
-    // scene's histogram sweep, H(i + 2) for F(i): a sweep owns whole compute units, two of them at once only take turns at the chip's
-    // compute units and at HBM (and a late workgroup of H's static pieces ends late); the short kernels S(i + 1) between a scene's sweeps
-    // run beside H(i + 2), which leaves them registers and LDS.  An event has to be recorded before a stream can wait for it, so the
-    // chain of scene i stops in front of its fused pass (pipe_defer) and its rest is enqueued after scene i + 1's sweep.
-    // 0 = free run (round 5), 1 = the fused passes chained, 2 = H(i + 1) paired with F(i) (the co-residency experiment).
+    // PIPE_ORDER: 0 (default) = free run: every lane enqueues its chain, the hardware interleaves.
+    // 3 = the two sweeps of all lanes in ONE order, H(i + 1), F(i), H(i + 2), F(i + 1), ... -- F(i) waits for the NEXT scene's histogram
+    // sweep, H(i + 2) for F(i), so the fused pass has the chip to itself and its event bracket is its own time (an event has to be recorded
+    // before a stream can wait for it: the chain of scene i stops in front of its fused pass -- pipe_defer -- and its rest is enqueued after
+    // scene i + 1's sweep).  Round 6, nine-scene cycle (profiles/r6/pipe_sweep*.txt, trace_ord3.txt): 0.936-0.948 ms per scene against
+    // 0.913-0.954 for the free run -- the sweeps never overlap, but two event hand-overs per scene (15-19 us each) stand in the critical
+    // path and the short kernels S(i + 1) slow the sweep they run beside (H 330-347 us instead of 297); with bench.py's event pair around
+    // the fused pass 0.991 against 0.961.  CU-time is the conserved quantity: H + S + F = 297 + ~45 + 575 us of a full chip per scene,
+    // and the free run already packs it to within 1-3 %.  (One stream for both sweeps of all lanes, the lanes' own streams joining before
+    // and after, measured 0.97: the statistics chain starved behind the fused pass.)
+    // 1 = the fused passes chained, 2 = H(i + 1) paired with F(i) (round 5's co-residency experiment).
     const long long order = ctx->attrs.val(A_PIPE_ORDER, kPipeDefaultOrder);
     const bool serial = order == 3 && lanes > 1;
     const bool chain_f = (order == 1 || order == 2) && lanes > 1;

@@ -18,13 +18,13 @@ with S.Context(0, timing=True) as c:
     rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     acc = {}
-    N = 8
+    N = int(os.environ.get('N', '8'))
     for it in range(N + 2):
         c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
         if it >= 2:
             for n, ms in c.last_kernel_times():
                 acc.setdefault(n, []).append(ms)
-    print(json.dumps({n: round(sorted(v)[len(v) // 2], 4) for n, v in acc.items()}))
+    print(json.dumps({n: round(sorted(v)[len(v) // 2], 4) for n, v in acc.items()} | ({'fused_min': round(min(acc['clahe_rgb_fused']), 4), 'fused_mean': round(sum(acc['clahe_rgb_fused']) / len(acc['clahe_rgb_fused']), 4)} if 'clahe_rgb_fused' in acc else {})))
 ''' % ROOT
 for spec in sys.argv[1:]:
     lib, _, envs = spec.partition(":")
