@@ -280,6 +280,7 @@ int sarpro_hip_batch_dualpol_synrgb_resized_f32(const int *devices, int ndevices
 #define SARPRO_HIP_ROUTE_REFUTED 1      /* the predicted floor / rescale range was refuted in the pass: exact kernels produced the raster */
 #define SARPRO_HIP_ROUTE_UNPROVEN 2     /* the speculation never started */
 #define SARPRO_HIP_ROUTE_POOL_OVERFLOW 3 /* DN windows beyond the fused pass's LDS pool: exact kernels */
+#define SARPRO_HIP_ROUTE_RETRIED 4      /* the first floor was refuted, a second fused pass with the floor its counts point to stood */
 typedef struct {
     const uint16_t *d_band1, *d_band2; /* device, rows x in_pitch */
     uint8_t *d_rgb;                    /* device, rows x rgb_pitch_px x 3 */
@@ -351,7 +352,8 @@ const char *sarpro_hip_attr_name(int index);
  * context's stream.  spec_ok: 1 = the proof held and the speculative composition ran; 2 = a band holds no level 0 (a crop
  * without invalid pixels), its lowest level min_pred is a PREDICTION too, the rescale (min_pred, 255) is folded into the tables and
  * the fused pass counts the level bytes below min_pred (n_below_min: any refutes); 0 = no speculation.  verdict 0: the speculative
- * RGB stood, 1: refuted (or never ran) and the exact recount + composition ran; the raster is the reference's either way. */
+ * RGB stood, 1: refuted (or never ran) and the exact recount + composition ran; the raster is the reference's either way.
+ * A refuted FLOOR gets one second fused pass first (retried = 1): the pass's counts say on which side of the prediction the floor lies. */
 typedef struct {
     uint32_t spec_ok, verdict;
     int32_t floor_pred;       /* predicted floor before the +3 cushion; 37 stands for "37 or more" (the cushion caps at 40) */
@@ -362,6 +364,8 @@ typedef struct {
     uint64_t sample_valid[2]; /* per band: valid pixels on the sampled rows, each work item weighted by rows / sampled rows, 4096 = 1.0 */
     uint64_t n_below_min;     /* spec_ok 2: band-pixels whose level lies below their band's min_pred (exact; 0 or refuted) */
     uint32_t min_pred[2];     /* spec_ok 2: predicted lowest level per band (0: proven) */
+    uint32_t retried;         /* 1: the first floor was refuted and a second fused pass ran with the floor the counts pointed to (floor_pred is that floor, verdict its verdict) */
+    int32_t floor_first;      /* the floor the first pass tried */
 } sarpro_hip_spec_report;
 int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_report *out);
 

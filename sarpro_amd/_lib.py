@@ -176,7 +176,7 @@ _proto("sarpro_hip_ctx_time_only", _i, _vp, C.c_char_p)
 class SpecReport(C.Structure):
     _fields_ = [("spec_ok", C.c_uint32), ("verdict", C.c_uint32), ("floor_pred", C.c_int32), ("pool_overflow", C.c_uint32),
                 ("n_lt", C.c_uint64 * 2), ("target", C.c_uint64), ("est_lt", C.c_double * 2), ("sample_valid", C.c_uint64 * 2),
-                ("n_below_min", C.c_uint64), ("min_pred", C.c_uint32 * 2)]
+                ("n_below_min", C.c_uint64), ("min_pred", C.c_uint32 * 2), ("retried", C.c_uint32), ("floor_first", C.c_int32)]
 
 
 _proto("sarpro_hip_ctx_spec_report", _i, _vp, C.POINTER(SpecReport))

@@ -101,8 +101,8 @@ class Context:
         self._chk(lib.sarpro_hip_ctx_spec_report(self._h, C.byref(r)))
         return {"spec_ok": int(r.spec_ok), "verdict": int(r.verdict), "floor_pred": int(r.floor_pred), "n_lt": [int(x) for x in r.n_lt],
                 "target": int(r.target), "est_lt": [float(x) for x in r.est_lt], "sample_valid": [int(x) for x in r.sample_valid], "pool_overflow": int(r.pool_overflow),
-                "n_below_min": int(r.n_below_min), "min_pred": [int(x) for x in r.min_pred],
-                "outcome": ("unproven" if not r.spec_ok else "pool_overflow" if r.pool_overflow else "refuted" if r.verdict else "accepted")}
+                "n_below_min": int(r.n_below_min), "min_pred": [int(x) for x in r.min_pred], "retried": int(r.retried), "floor_first": int(r.floor_first),
+                "outcome": ("unproven" if not r.spec_ok else "pool_overflow" if r.pool_overflow else "refuted" if r.verdict else "retried" if r.retried else "accepted")}
 
     def chain_report(self) -> dict:
         """What stood between the CLAHE levels and the composition in the last u16 chain (sarpro_hip_ctx_chain_report): the u8 rescale
@@ -118,11 +118,11 @@ class Context:
     def set_attr(self, name: str, value=1):
         """sarpro_hip_ctx_set_attr: `name` as in DESIGN.md's list of cross-check switches ("NO_SPEC", "SAMPLE_STRIDE", ...; the
         SARPRO_HIP_ prefix is optional).  value None resets the attribute to "unset"; the two word-valued attributes also take their
-        words (SPEC_FORCE: "mispredict", "nospec", "lowmin", comma-joined; F32_ZONES: "tiny")."""
+        words (SPEC_FORCE: "mispredict", "nospec", "lowmin", "noretry", "mispredict2", comma-joined; F32_ZONES: "tiny")."""
         if value is None:
             return self.reset_attr(name)
         if isinstance(value, str):
-            words = {"mispredict": 1, "nospec": 2, "lowmin": 4, "tiny": 2}
+            words = {"tiny": 2} if name.upper().endswith("F32_ZONES") else {"mispredict": 1, "nospec": 2, "lowmin": 4, "noretry": 8, "mispredict2": 16}
             try:
                 value = sum(words[w] for w in value.split(",")) if all(w in words for w in value.split(",")) else int(value)
             except ValueError:
@@ -404,7 +404,7 @@ class Context:
                                                         _vp(d_u8_1), _vp(d_u8_2), u8_pitch, st))
         return [st[0], st[1]] if want_stats else None
 
-    ROUTES = {-1: "n/a", 0: "accepted", 1: "refuted", 2: "unproven", 3: "pool_overflow"}
+    ROUTES = {-1: "n/a", 0: "accepted", 1: "refuted", 2: "unproven", 3: "pool_overflow", 4: "retried"}
 
     def dev_batch_dualpol_synrgb_u16(self, scenes, rows: int, cols: int, in_pitch: int, strategy, mode, rgb_pitch_px: int,
                                      lanes: int = 0, continue_on_error: bool = True, check: bool = True):

@@ -115,8 +115,13 @@ int attr_index(const char *name) {
 // used to be the switch); the two word-valued ones: SPEC_FORCE = "mispredict" (1), "nospec" (2), "lowmin" (4) in any combination, F32_ZONES = "tiny" (2).
 static long long attr_parse(int a, const char *e) {
     if (a == A_SPEC_FORCE && !(e[0] >= '0' && e[0] <= '9'))
-        return (strstr(e, "mispredict") ? (long long)kSpecForceMispredict : 0) | (strstr(e, "nospec") ? (long long)kSpecForceNoSpec : 0) |
-               (strstr(e, "lowmin") ? (long long)kSpecForceMinMispredict : 0);
+    {
+        long long v = (strstr(e, "mispredict2") ? (long long)kSpecForceMispredict2 : 0) | (strstr(e, "nospec") ? (long long)kSpecForceNoSpec : 0) |
+                      (strstr(e, "lowmin") ? (long long)kSpecForceMinMispredict : 0) | (strstr(e, "noretry") ? (long long)kSpecForceNoRetry : 0);
+        for (const char *q = strstr(e, "mispredict"); q; q = strstr(q + 10, "mispredict"))
+            if (q[10] != '2') v |= (long long)kSpecForceMispredict; // ("mispredict" on its own: one level off)
+        return v;
+    }
     if (a == A_F32_ZONES && !strcmp(e, "tiny")) return 2;
     char *end = nullptr;
     const long long v = strtoll(e, &end, 10);
@@ -246,6 +251,7 @@ extern "C" int sarpro_hip_ctx_spec_report(sarpro_hip_ctx *ctx, sarpro_hip_spec_r
     out->sample_valid[0] = st.sample_valid[0]; out->sample_valid[1] = st.sample_valid[1];
     out->pool_overflow = st.pool_overflow;
     out->n_below_min = st.n_below_min; out->min_pred[0] = st.min_pred[0]; out->min_pred[1] = st.min_pred[1];
+    out->retried = st.retried; out->floor_first = st.floor_first;
     return SARPRO_HIP_OK;
 }
 
@@ -1155,7 +1161,7 @@ static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_
 // the sampled histogram saves.  SARPRO_HIP_SAMPLED_HIST_MIN_PX overrides (the tests run the speculative chain on small rasters).
 constexpr size_t kSampledHistMinPx = 32u << 20;
 static uint32_t spec_force_flags(const sarpro_hip_ctx *ctx) { // SPEC_FORCE = mispredict (1) | nospec (2) | predicted lowest level + 1 (4): every rare branch of the speculative chain is testable
-    return (uint32_t)ctx->attrs.val(A_SPEC_FORCE, 0) & (kSpecForceMispredict | kSpecForceNoSpec | kSpecForceMinMispredict);
+    return (uint32_t)ctx->attrs.val(A_SPEC_FORCE, 0) & (kSpecForceMispredict | kSpecForceNoSpec | kSpecForceMinMispredict | kSpecForceNoRetry | kSpecForceMispredict2);
 }
 
 static int chain_tail(U16Job &J, sarpro_hip_stats *stats_out, ChainBandState *d_state);
@@ -1192,6 +1198,30 @@ static int fused_rgb_tail(const FusedTail &T) {
         static_assert(offsetof(ChainSpecState, n_below_min) == offsetof(ChainSpecState, n_lt) + 16, "the verification counts are one buffer");
         RETCHK(chain_reduce(*T.J, &d_spec->n_lt[0], 3, "allreduce_spec_counts"));
         HIPCHK(ctx, launch_spec_verdict(d_spec, T.d_state, ctx->stream));
+    }
+    {   // a refuted floor gets one second pass with the floor the first pass's counts point to (both launches return at once otherwise)
+        ChainRepredictArgs ra{};
+        ra.spec = d_spec; ra.resc_in = state + kStateOffResc; ra.floor_out = reinterpret_cast<int *>(state + kStateOffFloor);
+        ra.tables = ctx->tables.as<uint8_t>(); ra.supp_rg = consts + kChainOffSupp; ra.blue_pair_supp = consts + kChainOffBlue;
+        ra.blue_pq = ctx->blue_factors_ok ? reinterpret_cast<const float *>(consts + kChainOffBluePQ) : nullptr;
+        ra.blue_by_level = reinterpret_cast<float *>(ctx->tables.as<uint8_t>() + kTablesOffPQ);
+        ra.stripes = reduce ? 1u : 0u;
+        {
+            KernelTimer t(ctx, "chain_repredict");
+            HIPCHK(ctx, launch_chain_repredict(ra, ctx->stream));
+        }
+        ClaheRgbArgs fr = T.fa;
+        fr.retry = 1u;
+        int grid = std::max(ctx->cu_count, 1);
+        if (ctx->attrs.is_set(A_RGB_GRID)) grid = (int)std::min<long long>(1024, std::max<long long>(1, ctx->attrs.val(A_RGB_GRID, grid)));
+        {
+            KernelTimer t(ctx, "clahe_rgb_fused_retry");
+            HIPCHK(ctx, launch_clahe_rgb_fused_retry(fr, grid, ctx->stream));
+        }
+        if (reduce) {
+            RETCHK(chain_reduce(*T.J, &d_spec->n_lt[0], 3, "allreduce_spec_counts_retry"));
+            HIPCHK(ctx, launch_spec_verdict(d_spec, T.d_state, ctx->stream, 1));
+        }
     }
     {   // gated on the verdict: levels of every pixel with the full histogram -> exact tables -> composition
         KernelTimer t(ctx, "spec_fallback_apply");

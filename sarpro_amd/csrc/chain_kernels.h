@@ -93,6 +93,18 @@ struct ChainPredictArgs {
     float *blue_by_level;                  // out: Pv[256] | Qv[256] with Pv[v] = P[R2[v]], Qv[v] = Q[G2[v]] (the fused pass's LITE form reads these instead of B2)
 };
 hipError_t launch_chain_predict(const ChainPredictArgs &a, hipStream_t s);
+struct ChainRepredictArgs {
+    ChainSpecState *spec;
+    const uint8_t *resc_in;                // [2][256] the bands' u8 rescale tables as k_chain_predict left them (identity, or the predicted rescale)
+    int *floor_out;
+    uint8_t *tables;                       // compose tables R2|G2|B2
+    const uint8_t *supp_rg;                // [41][512]
+    const uint8_t *blue_pair_supp;         // [256][256]
+    const float *blue_pq;
+    float *blue_by_level;
+    uint32_t stripes;                      // 1: a row stripe (the counts are all-reduced behind the retry kernel whether it ran or not)
+};
+hipError_t launch_chain_repredict(const ChainRepredictArgs &a, hipStream_t s); // behind the fused pass's verdict, before launch_clahe_rgb_fused_retry
 hipError_t launch_level_hist_if_flagged(const LevelRecountArgs &a, int nbands, hipStream_t s);
 // dst = map[src] unless skip_flag && *skip_flag (device byte) is non-zero and src == dst
 hipError_t launch_chain_remap(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, uint32_t rows,

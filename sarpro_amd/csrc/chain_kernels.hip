@@ -647,6 +647,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
         bool ok = s_ok[0] && s_ok[1];
         if (a.force & kSpecForceNoSpec) ok = false;
         if (a.force & kSpecForceMispredict) f = f < kSpecFloorCap ? f + 1 : kSpecFloorCap - 1;
+        if (a.force & kSpecForceMispredict2) f = f + 2 <= kSpecFloorCap ? f + 2 : (f >= 2 ? f - 2 : f); // (two levels off: the second pass's floor is refuted too)
         for (int i = 0; i <= f && i < 64; ++i) { if (i < f) lt0 += fin[0][i] + fin[1][i]; lt1 += fin[0][i] + fin[1][i]; }
         s_fwc = f + 3 < 40 ? f + 3 : 40;
         s_f = f;
@@ -663,6 +664,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
             sp->force = a.force;
             sp->pool_overflow = 0u;
             sp->next_item = 0u;
+            sp->retry_floor = -1; sp->retry_armed = 0u; sp->retried = 0u; sp->floor_first = f;
             if (a.floor_out) *a.floor_out = s_fwc; // stands iff the verdict accepts; k_chain_finish rewrites it otherwise
         }
     }
@@ -699,6 +701,66 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
     for (int i = blockIdx.x * kStatsBlock + t; i < 65536; i += gridDim.x * kStatsBlock) {
         const int r1 = resc[0][i >> 8], r2 = resc[1][i & 255];
         B2[i] = (r1 <= fwc && r2 <= fwc) ? 0 : a.blue_pair_supp[((size_t)lut_r[r1] << 8) | lut_g[r2]];
+    }
+}
+
+// The second chance of a refuted floor (round 6): the fused pass's own counts say on which side of the prediction the floor lies
+// (ChainSpecState::retry_floor, written with the verdict); this kernel rebuilds what k_chain_predict built for the first floor --
+// the compose tables, the rescaled form's thresholds -- for that floor, clears the pass's counters and arms the retry kernel.  It
+// returns at once on every scene whose first pass stood (and after a refuted lowest level, a pool overflow, SPEC_FORCE = noretry):
+// the exact kernels behind it are gated on the verdict as before.
+__global__ __launch_bounds__(kStatsBlock) void k_chain_repredict(ChainRepredictArgs a) {
+    ChainSpecState *sp = a.spec;
+    // (nothing this kernel writes is read by this test: every block decides the same)
+    if (!sp->spec_ok || sp->verdict == 0u || sp->pool_overflow || sp->retry_floor < 0 || (sp->force & kSpecForceNoRetry)) {
+        // row stripes: the retry's all-reduce of the counts is enqueued on every scene; without a second pass it must sum zeros
+        // (the counts are the ranks' sums already), and k_spec_verdict puts them back
+        if (a.stripes && blockIdx.x == 0 && threadIdx.x == 0) {
+            sp->saved_counts[0] = sp->n_lt[0]; sp->saved_counts[1] = sp->n_lt[1]; sp->saved_counts[2] = sp->n_below_min;
+            sp->n_lt[0] = 0ull; sp->n_lt[1] = 0ull; sp->n_below_min = 0ull;
+        }
+        return;
+    }
+    __shared__ uint8_t resc[2][256];
+    const int t = threadIdx.x, wb = t >> 6, ln = t & 63;
+    if (t < 512) resc[t >> 8][t & 255] = a.resc_in[t];
+    __syncthreads();
+    const int f = sp->retry_floor, fwc = f + 3 < 40 ? f + 3 : 40;
+    if (blockIdx.x == 0 && wb < 2) { // per band the lowest level (from min_pred on) whose final value reaches F, F + 1 (as k_chain_predict)
+        const unsigned mn = sp->min_pred[wb];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            unsigned thr = 256u;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const unsigned x = ln * 4 + k;
+                if (x >= mn && (int)resc[wb][x] >= f + q) thr = x;
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) thr = min(thr, (unsigned)__shfl_xor((int)thr, m, 64));
+            if (ln == 0) sp->thr[wb][q] = thr;
+        }
+    }
+    const uint8_t *lut_r = a.supp_rg + (size_t)fwc * 512, *lut_g = lut_r + 256;
+    uint8_t *R2 = a.tables, *G2 = a.tables + 256, *B2 = a.tables + 512;
+    if (blockIdx.x == 0 && t < 256) {
+        const int r1 = resc[0][t], r2 = resc[1][t];
+        const uint8_t r = r1 <= fwc ? 0 : lut_r[r1], g = r2 <= fwc ? 0 : lut_g[r2];
+        R2[t] = r;
+        G2[t] = g;
+        if (a.blue_pq && a.blue_by_level) { a.blue_by_level[t] = a.blue_pq[r]; a.blue_by_level[256 + t] = a.blue_pq[256 + g]; }
+    }
+    for (int i = blockIdx.x * kStatsBlock + t; i < 65536; i += gridDim.x * kStatsBlock) {
+        const int r1 = resc[0][i >> 8], r2 = resc[1][i & 255];
+        B2[i] = (r1 <= fwc && r2 <= fwc) ? 0 : a.blue_pair_supp[((size_t)lut_r[r1] << 8) | lut_g[r2]];
+    }
+    if (blockIdx.x == 0 && t == 0) {
+        sp->floor_pred = f;
+        sp->done = 0u;
+        sp->n_lt[0] = 0ull; sp->n_lt[1] = 0ull; sp->n_below_min = 0ull;
+        sp->next_item = 0u;
+        sp->retry_armed = 1u;
+        if (a.floor_out) *a.floor_out = fwc; // stands iff the second verdict accepts; k_chain_finish rewrites it otherwise
     }
 }
 
@@ -805,6 +867,10 @@ hipError_t launch_chain_cdfs(const unsigned long long *tile_bins, double *cdfs, 
 }
 hipError_t launch_chain_finish(const ChainFinishArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_finish, dim3((a.nbands == 2 && a.tables) || a.levels_mode ? 64 : 1), dim3(kStatsBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_chain_repredict(const ChainRepredictArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_repredict, dim3(64), dim3(kStatsBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_chain_predict(const ChainPredictArgs &a, hipStream_t s) {

@@ -107,11 +107,20 @@ struct ChainSpecState {
     uint32_t force;                // test switches (kSpecForce*)
     uint32_t pool_overflow;        // the fused CLAHE -> RGB pass stepped aside: the bands' DN windows do not fit its LDS pool
     uint32_t next_item;            // the fused pass's work list: the next item to hand out (cleared by k_chain_predict; ends at items + workgroups)
+    // A refuted floor gets ONE second fused pass before the exact kernels (round 6): the pass's own counts say on which side of the
+    // prediction the floor lies (n_lt[0] >= target: below it; target > n_lt[1]: above it), the sample's error is rarely more than one level.
+    int32_t retry_floor;           // written with the verdict: the floor to try next (-1: none -- accepted, a lowest level undercut, no room on that side)
+    uint32_t retry_armed;          // k_chain_repredict: tables, thresholds and counters are set up for the second pass (the retry kernel runs iff 1)
+    uint32_t retried;              // the second pass ran: `verdict` is its verdict, floor_pred the floor it tried
+    int32_t floor_first;           // the floor the first pass tried (diagnostics)
+    unsigned long long saved_counts[3]; // row stripes without a second pass: the summed counts, set aside while the second all-reduce sums zeros
 };
 constexpr uint32_t kSpecIdentity = 1u, kSpecRescaled = 2u;
 constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it
 constexpr uint32_t kSpecForceNoSpec = 2u;     // "level 0 or 255 missing": no speculative composition at all
 constexpr uint32_t kSpecForceMinMispredict = 4u; // a predicted lowest level + 1: the verification must refute it
+constexpr uint32_t kSpecForceNoRetry = 8u;        // no second fused pass: a refuted floor goes straight to the exact kernels (round 5's behaviour)
+constexpr uint32_t kSpecForceMispredict2 = 16u;   // predicted floor + 2 (- 2 at the cap): the second pass's floor is wrong too
 
 // The fused CLAHE -> RGB pass (kernels.hip 6a): both DN rasters in, interleaved RGB out.
 struct ClaheRgbArgs {
@@ -136,10 +145,12 @@ struct ClaheRgbArgs {
     uint32_t no_verdict;                // a row stripe: the counts are summed over the ranks first, launch_spec_verdict takes the verdict
     uint32_t sat_cols;                  // entries of sat_col
     uint32_t sat_ok;                    // 0: tables absent (the geometry produced more than three classes): such pixels take the exact path
+    uint32_t retry;                     // 1: the second pass of a refuted floor (launch_clahe_rgb_fused_retry): runs iff ChainSpecState::retry_armed
 };
 bool clahe_rgb_fused_supported(const ClaheRgbArgs &a);
 hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid /* persistent workgroups: one per CU */, hipStream_t s);
-hipError_t launch_spec_verdict(struct ChainSpecState *spec, const struct ChainBandState *state, hipStream_t s); // the fused pass's verdict from counts that were all-reduced
+hipError_t launch_clahe_rgb_fused_retry(const ClaheRgbArgs &a, int grid, hipStream_t s); // behind launch_chain_repredict: one kernel, both forms, returns at once unless armed
+hipError_t launch_spec_verdict(struct ChainSpecState *spec, const struct ChainBandState *state, hipStream_t s, int second = 0); // the fused pass's verdict from counts that were all-reduced (second: behind the retry's all-reduce)
 
 constexpr size_t kSpecDumpBytes = 256 * 1024;
 hipError_t launch_dn_hist_u16(const DnHistArgs &a, int nrects, int nbands, bool vec, hipStream_t s);

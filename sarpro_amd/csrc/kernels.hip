@@ -1411,6 +1411,12 @@ static_assert(RgbLds::stage % 16 == 0 && RgbLds::pool % 16 == 0 && RgbLds::cdf64
 // u8 rescale folded in (k_chain_predict), the floor counts compare each band's level bytes with ITS thresholds (the lowest levels whose
 // final values reach F and F + 1: the rescale is strictly increasing from min_pred on), and a fourth count -- level bytes below
 // min_pred -- must be zero.  Eight more v_sad_u8 per lane and row pair than the identity form, which is why it is its own body.
+// A refuted floor F: which floor the counts point to (c0 = band-pixels with final level < F).  c0 >= target: the floor lies below F;
+// otherwise (the pass refuted it, so target > c1) above.  -1: no room on that side.
+__device__ __forceinline__ int spec_retry_floor(int f, unsigned long long c0, unsigned long long target) {
+    if (c0 >= target) return f > 0 ? f - 1 : -1;
+    return f < kSpecFloorCap ? f + 1 : -1;
+}
 template <bool GENERAL>
 __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     // (declared HERE, not handed in by the kernel: as a pointer argument the compiler treated it as a flat address -- 104 bytes of scratch
@@ -1894,6 +1900,8 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             const unsigned long long under = GENERAL ? atomicAdd(&sp->n_below_min, 0ull) : 0ull;
             const bool ok = (sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1)) && under == 0ull;
             sp->verdict = ok ? 0u : 1u;
+            sp->retry_floor = ok || under != 0ull ? -1 : spec_retry_floor(sp->floor_pred, c0, target);
+            if (a.retry) sp->retried = 1u;
         }
     }
 }
@@ -1909,16 +1917,30 @@ __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused(ClaheRgbArgs a) {
 __global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused_rescaled(ClaheRgbArgs a) {
     if (a.spec->spec_ok == kSpecRescaled) clahe_rgb_fused_body<true>(a);
 }
+// The second pass of a refuted floor (k_chain_repredict has set it up): both forms in ONE kernel -- it runs on a scene in fifty, its launch
+// is on every scene's chain (2 % of the pass against a launch).
+__global__ __launch_bounds__(kRgbBlock) void k_clahe_rgb_fused_retry(ClaheRgbArgs a) {
+    if (a.spec->retry_armed != 1u) return;
+    if (a.spec->spec_ok == kSpecIdentity) clahe_rgb_fused_body<false>(a);
+    else if (a.spec->spec_ok == kSpecRescaled) clahe_rgb_fused_body<true>(a);
+}
 // Row stripes: every rank's pass has added its counts, the ranks have summed them; the same verdict on every rank.
-__global__ void k_spec_verdict(ChainSpecState *sp, const ChainBandState *state) {
+__global__ void k_spec_verdict(ChainSpecState *sp, const ChainBandState *state, int second) {
+    if (second && !sp->retry_armed) { // no second pass ran: the all-reduce behind it summed zeros (k_chain_repredict set the counts aside); the first verdict stands
+        sp->n_lt[0] = sp->saved_counts[0]; sp->n_lt[1] = sp->saved_counts[1]; sp->n_below_min = sp->saved_counts[2];
+        return;
+    }
     // (the windows are the same on every rank; `pool_overflow` is raised by block 0 of the pass, which a rank with an empty stripe
     // never launches: every rank derives it here, so that verdict, floor and report agree across the ranks)
     const uint64_t nwin = (uint64_t)state[0].win_hi + state[1].win_hi + 2u;
     if (sp->spec_ok && nwin > kRgbPoolEntries && nwin > kWideBytes) sp->pool_overflow = 1u;
     if (!sp->spec_ok || sp->pool_overflow) return; // the passes did not run: "refuted" stands
     const unsigned long long c0 = sp->n_lt[0], c1 = sp->n_lt[1], target = sp->target;
-    const bool ok = (sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1)) && (sp->spec_ok != kSpecRescaled || sp->n_below_min == 0ull);
+    const bool undercut = sp->spec_ok == kSpecRescaled && sp->n_below_min != 0ull;
+    const bool ok = (sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1)) && !undercut;
     sp->verdict = ok ? 0u : 1u;
+    sp->retry_floor = ok || undercut ? -1 : spec_retry_floor(sp->floor_pred, c0, target);
+    if (sp->retry_armed) sp->retried = 1u; // (this is the second pass's verdict)
 }
 
 // ------------------------------------------------------------------------------------
@@ -2273,8 +2295,8 @@ bool clahe_rgb_fused_supported(const ClaheRgbArgs &a) { // (nrects == 0: a rank 
            (a.nrects == 0 || ((reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 &&
                               (reinterpret_cast<uintptr_t>(a.rgb) & 15) == 0));
 }
-hipError_t launch_spec_verdict(ChainSpecState *spec, const ChainBandState *state, hipStream_t s) {
-    hipLaunchKernelGGL(k_spec_verdict, dim3(1), dim3(1), 0, s, spec, state);
+hipError_t launch_spec_verdict(ChainSpecState *spec, const ChainBandState *state, hipStream_t s, int second) {
+    hipLaunchKernelGGL(k_spec_verdict, dim3(1), dim3(1), 0, s, spec, state, second);
     return hipGetLastError();
 }
 hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s) {
@@ -2284,6 +2306,13 @@ hipError_t launch_clahe_rgb_fused(const ClaheRgbArgs &a, int grid, hipStream_t s
     hipLaunchKernelGGL(k_clahe_rgb_fused, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
     if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused_rescaled))) return e;
     hipLaunchKernelGGL(k_clahe_rgb_fused_rescaled, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_clahe_rgb_fused_retry(const ClaheRgbArgs &a, int grid, hipStream_t s) {
+    if (!clahe_rgb_fused_supported(a) || grid <= 0 || !a.retry) return hipErrorInvalidValue;
+    if (a.nrects == 0) return hipSuccess;
+    if (hipError_t e = opt_in_dynamic_lds(reinterpret_cast<const void *>(k_clahe_rgb_fused_retry))) return e;
+    hipLaunchKernelGGL(k_clahe_rgb_fused_retry, dim3(std::min(grid, a.nrects)), dim3(kRgbBlock), RgbLds::total, s, a);
     return hipGetLastError();
 }
 

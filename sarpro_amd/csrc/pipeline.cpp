@@ -67,7 +67,7 @@ static int ensure_lanes(sarpro_hip_ctx *ctx, int lanes) {
 static int route_of(const ChainSpecState &st) {
     if (!st.spec_ok) return SARPRO_HIP_ROUTE_UNPROVEN;
     if (st.pool_overflow) return SARPRO_HIP_ROUTE_POOL_OVERFLOW;
-    return st.verdict == 0 ? SARPRO_HIP_ROUTE_ACCEPTED : SARPRO_HIP_ROUTE_REFUTED;
+    return st.verdict != 0 ? SARPRO_HIP_ROUTE_REFUTED : st.retried ? SARPRO_HIP_ROUTE_RETRIED : SARPRO_HIP_ROUTE_ACCEPTED;
 }
 
 extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarpro_hip_resident_scene *scenes, size_t nscenes, size_t rows,

@@ -71,6 +71,16 @@ def test_headline_400mp_clahe_synrgb_equals_oracle_every_pixel(scene, headline_r
     rep = c.spec_report()
     assert rep["spec_ok"] == 1 and rep["verdict"] == 0, rep  # the prediction stood: the raster below is the fused pass's own
     _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, "fused route RGB")
+    # a floor predicted one level off: refuted, the second fused pass with the floor the counts point to stands (round 6); two off: the exact kernels
+    for force, want in (("mispredict", "retried"), ("mispredict2", "refuted")):
+        rgb.zero_()
+        c.set_attr("SPEC_FORCE", force)
+        c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Mode.Default, rgb.data_ptr(), PITCH,
+                                 want_stats=False)
+        c.set_attr("SPEC_FORCE", None)
+        rep2 = c.spec_report()
+        assert rep2["outcome"] == want and rep2["retried"] == 1 and rep2["floor_first"] == rep["floor_pred"] + (1 if force == "mispredict" else 2), rep2
+        _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, f"fused route RGB, SPEC_FORCE = {force} ({want})")
     rgb.zero_()
     u8 = [torch.zeros((ROWS, PITCH), dtype=torch.uint8, device="cuda") for _ in range(2)]
     c.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), ROWS, COLS, PITCH, St.Clahe, Mode.Default, rgb.data_ptr(), PITCH,
@@ -223,7 +233,7 @@ def _run_stripes(band, rgb, n, attrs=None):
     return list(zip(r0s, nrs)), names, reps
 
 
-@pytest.mark.parametrize("ranks,force", [(8, None), (8, "mispredict"), (4, None), (2, None)])
+@pytest.mark.parametrize("ranks,force", [(8, None), (8, "mispredict"), (8, "mispredict2"), (4, None), (2, None)])
 def test_config3_400mp_scene_as_row_stripes_equals_oracle_every_pixel(scene, headline_ref, ranks, force):
     """configs[3] at its stated size: ONE 400 MP scene as 8 (4, 2) row stripes of 2500 (5000, 10000) rows, each rank's single-call
     chain with its integer all-reduces (in-process communicator: the ranks are contexts of this GPU), the fused CLAHE -> RGB route on
@@ -236,9 +246,10 @@ def test_config3_400mp_scene_as_row_stripes_equals_oracle_every_pixel(scene, hea
     assert [int(nr) for _, nr in splits] == [ROWS // ranks] * ranks
     for nm in names:
         assert "clahe_rgb_fused" in nm and "allreduce_sample_hist" in nm and "allreduce_spec_counts" in nm, nm
-    key = [(r["spec_ok"], r["verdict"], r["floor_pred"], tuple(r["n_lt"]), r["target"]) for r in reps]
+    key = [(r["spec_ok"], r["verdict"], r["floor_pred"], tuple(r["n_lt"]), r["target"], r["retried"]) for r in reps]
     assert all(k == key[0] for k in key), key  # every rank proved, predicted and decided the same
-    assert key[0][0] == 1 and key[0][1] == (1 if force else 0), key[0]
+    # one level off: the second fused pass stands on every rank; two off: refuted twice, the exact kernels
+    assert key[0][0] == 1 and key[0][1] == (1 if force == "mispredict2" else 0) and key[0][5] == (1 if force else 0), key[0]
     _same(rgb.view(ROWS, PITCH, 3)[:, :COLS], ref, f"{ranks} row stripes{' (forced refutation)' if force else ''}")
 
 

@@ -110,7 +110,7 @@ def test_stripe_run_f32_and_polop_with_n_ranks_in_one_process(strategy, bd):
     assert np.array_equal(got, ref), (strategy, bd, "polop")
 
 
-@pytest.mark.parametrize("force", [None, "mispredict", "nospec", "few_values", "few_values+lowmin"])
+@pytest.mark.parametrize("force", [None, "mispredict", "mispredict,noretry", "mispredict2", "nospec", "few_values", "few_values+lowmin"])
 @pytest.mark.parametrize("ranks", [2, 8, "ragged+empty"])
 def test_row_stripes_take_the_fused_clahe_rgb_route(ranks, force):
     """A striped CLAHE scene above the speculative route's size threshold (lowered to zero here) runs the fused CLAHE -> RGB pass on
@@ -144,15 +144,18 @@ def test_row_stripes_take_the_fused_clahe_rgb_route(ranks, force):
         assert "allreduce_sample_hist" in nm and "allreduce_spec_counts" in nm and "allreduce_level_hist" in nm, nm
         assert ("clahe_rgb_fused" in nm) and "clahe_apply_u8_spec" not in nm, nm  # (the gated recount is timed as spec_fallback_apply)
     # every rank holds the same state: same proof, same prediction, same (summed) counts, same verdict
-    key = [(r["spec_ok"], r["verdict"], r["floor_pred"], tuple(r["n_lt"]), r["target"], r["n_below_min"], tuple(r["min_pred"])) for r in reports]
+    key = [(r["spec_ok"], r["verdict"], r["floor_pred"], tuple(r["n_lt"]), r["target"], r["n_below_min"], tuple(r["min_pred"]), r["retried"], r["floor_first"]) for r in reports]
     assert all(k == key[0] for k in key), key
     if few:
         assert key[0][0] == 2 and key[0][6][0] == 0 and key[0][6][1] > 0, key[0]
         assert (key[0][1] == 1 and key[0][5] > 0) if force == "lowmin" else key[0][5] == 0, key[0]
     if force == "nospec":
         assert key[0][0] == 0 and key[0][1] == 1
-    elif force == "mispredict":
-        assert key[0][1] == 1
+    elif force == "mispredict":  # one off: the ranks' summed counts point back, every rank runs the second pass, the second verdict accepts
+        assert key[0][1] == 0 and key[0][7] == 1 and key[0][2] == key[0][8] - 1, key[0]
+        assert all("allreduce_spec_counts_retry" in nm and "clahe_rgb_fused_retry" in nm for nm in names)
+    elif force in ("mispredict,noretry", "mispredict2"):
+        assert key[0][1] == 1 and key[0][7] == (1 if force == "mispredict2" else 0), key[0]
     if key[0][0] and force is None and key[0][1] == 0:
         u = [oracle.pipeline(x.astype(np.float32), 0, int(St.Clahe))[1] for x in b]
         lv = np.concatenate([u[0].ravel(), u[1].ravel()])

@@ -67,13 +67,15 @@ def test_resident_batch_matches_oracle_scene_by_scene(lanes, order, monkeypatch)
     assert routes[[d[0] for d in defs].index("I-no-VH")] == "accepted", routes
 
 
-def test_resident_batch_forced_refutation_in_the_middle(monkeypatch):
+@pytest.mark.parametrize("force,route", [("mispredict", "retried"), ("mispredict,noretry", "refuted"), ("mispredict2", "refuted")])
+def test_resident_batch_forced_refutation_in_the_middle(force, route, monkeypatch):
     """Refuted scenes (SPEC_FORCE = mispredict shifts every predicted floor by one: a prediction that was right is refuted, one that was
-    off by one the other way becomes right) run their exact kernels beside the other lane's chains."""
+    off by one the other way becomes right) run a second fused pass -- or, noretry / two levels off, their exact kernels -- beside the
+    other lane's chains."""
     rows, cols = 700, 1100
     pitch = (cols + 63) // 64 * 64
     monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
-    monkeypatch.setenv("SARPRO_HIP_SPEC_FORCE", "mispredict")
+    monkeypatch.setenv("SARPRO_HIP_SPEC_FORCE", force)
     monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
     defs = synth.BENCH_SCENES[:4]
     host, dev = make_scenes(rows, cols, pitch, defs)
@@ -81,7 +83,7 @@ def test_resident_batch_forced_refutation_in_the_middle(monkeypatch):
     with S.Context(0) as c:
         batch = [(d[0].data_ptr(), d[1].data_ptr(), o.data_ptr()) for d, o in zip(dev, outs)]
         rep, st, routes = c.dev_batch_dualpol_synrgb_u16(batch, rows, cols, pitch, St.Clahe, Mode.Default, pitch, lanes=2)
-    assert rep["processed"] == len(defs) and "refuted" in routes and "n/a" not in routes, routes
+    assert rep["processed"] == len(defs) and route in routes and "n/a" not in routes, routes
     for i in range(len(defs)):
         assert np.array_equal(rgb_of(outs[i], rows, cols, pitch), oracle_rgb(host[i], St.Clahe))
 
@@ -150,8 +152,12 @@ def test_resident_batch_36mp_four_scenes_every_pixel(monkeypatch):
         for o in outs:
             o.zero_()
         torch.cuda.synchronize()
-        monkeypatch.setenv("SARPRO_HIP_SPEC_FORCE", "mispredict")
-        rep, st, forced = c.dev_batch_dualpol_synrgb_u16(batch, rows, cols, pitch, St.Clahe, Mode.Default, pitch, lanes=3)
-        assert rep["processed"] == 4 and "refuted" in forced, forced
-        for i, d in enumerate(defs):
-            assert np.array_equal(rgb_of(outs[i], rows, cols, pitch), refs[i]), (d[0], forced[i])
+        for force, route in (("mispredict", "retried"), ("mispredict2", "refuted")):
+            monkeypatch.setenv("SARPRO_HIP_SPEC_FORCE", force)
+            rep, st, forced = c.dev_batch_dualpol_synrgb_u16(batch, rows, cols, pitch, St.Clahe, Mode.Default, pitch, lanes=3)
+            assert rep["processed"] == 4 and route in forced, forced
+            for i, d in enumerate(defs):
+                assert np.array_equal(rgb_of(outs[i], rows, cols, pitch), refs[i]), (d[0], forced[i])
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()

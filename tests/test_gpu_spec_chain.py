@@ -182,10 +182,11 @@ def test_fused_rgb_pass_matches_oracle(shape, seed, monkeypatch):
         assert rep["n_lt"][0] == int((lv < f).sum()) and (f == 37 or rep["n_lt"][1] == int((lv <= f).sum()))
 
 
-@pytest.mark.parametrize("force", ["", "mispredict", "nospec"])
+@pytest.mark.parametrize("force", ["", "mispredict", "mispredict,noretry", "mispredict2", "nospec"])
 def test_fused_rgb_pass_fallbacks(force, monkeypatch):
     """Refuted floor / no identity proof: the gated apply -> finish -> compose kernels produce the raster; accepted: they do nothing.
-    Three scenes in a row on one context: the state of one must not leak into the next."""
+    A floor that is off by one gets ONE second fused pass with the floor the first pass's counts point to (round 6: `retried`); off by
+    two, or with SPEC_FORCE = noretry, the exact kernels.  Three scenes in a row on one context: the state of one must not leak into the next."""
     rows, cols = 900, 1300
     monkeypatch.setenv("SARPRO_HIP_SAMPLED_HIST_MIN_PX", "0")
     monkeypatch.setenv("SARPRO_HIP_SAMPLE_STRIDE", "5")
@@ -199,11 +200,19 @@ def test_fused_rgb_pass_fallbacks(force, monkeypatch):
         rgb, names = run_rgb_only(c, b1, b2)
         rep = c.spec_report()
         assert np.array_equal(rgb, rrgb), rep
+        assert "chain_repredict" in names and "clahe_rgb_fused_retry" in names, names  # (enqueued on every scene; they return at once unless armed)
+        if force == "mispredict":  # the prediction of this scene is right: + 1 is refuted, the counts point back to it
+            assert rep["verdict"] == 0 and rep["retried"] == 1 and rep["outcome"] == "retried" and rep["floor_pred"] == rep["floor_first"] - 1, rep
+        elif force == "mispredict2":  # two off: the second pass tries + 1 and is refuted too
+            assert rep["verdict"] == 1 and rep["retried"] == 1 and rep["outcome"] == "refuted", rep
+        elif force:
+            assert rep["verdict"] == 1 and rep["retried"] == 0, rep
+        else:
+            assert rep["verdict"] == 0 and rep["retried"] == 0 and rep["outcome"] == "accepted", rep
         if force:
-            assert rep["verdict"] == 1, rep
             monkeypatch.delenv("SARPRO_HIP_SPEC_FORCE")
         rgb, _ = run_rgb_only(c, b1, b2)
-        assert np.array_equal(rgb, rrgb)
+        assert np.array_equal(rgb, rrgb) and c.spec_report()["outcome"] == "accepted"
 
 
 def test_fused_rgb_pass_steps_aside_for_windows_beyond_its_lds_pool(monkeypatch):
@@ -297,15 +306,19 @@ def test_fused_rgb_pass_predicts_the_rescale_of_a_band_without_level_0(kind, sha
             assert f == 37 or rep["n_lt"][0] < rep["target"] <= rep["n_lt"][1]
         accepted = rep["verdict"] == 0
         # a lowest level that the raster undercuts, and a floor that is off by one: both must be refuted, and the exact kernels' raster stands
-        for force in ("lowmin", "mispredict"):
+        for force in ("lowmin", "mispredict,noretry", "mispredict", "mispredict2"):
             c.set_attr("SPEC_FORCE", force)
             rgb, _ = run_rgb_only(c, b1, b2)
             rep2 = c.spec_report()
             assert np.array_equal(rgb, rrgb), (kind, force, rep2)
-            if force == "lowmin":
-                assert rep2["spec_ok"] == 2 and rep2["verdict"] == 1 and rep2["n_below_min"] > 0, rep2
-            if force == "mispredict" and accepted:
-                assert rep2["verdict"] == 1, rep2
+            if force == "lowmin":  # (an undercut lowest level: no second pass, the true one is not known)
+                assert rep2["spec_ok"] == 2 and rep2["verdict"] == 1 and rep2["n_below_min"] > 0 and rep2["retried"] == 0, rep2
+            if force == "mispredict,noretry" and accepted:
+                assert rep2["verdict"] == 1 and rep2["retried"] == 0, rep2
+            if force == "mispredict" and accepted and rep["floor_pred"] < 36:  # the rescaled form's second pass: its thresholds are rebuilt for the new floor
+                assert rep2["verdict"] == 0 and rep2["retried"] == 1 and rep2["floor_pred"] == rep["floor_pred"], rep2
+            if force == "mispredict2" and accepted and rep["floor_pred"] < 35:
+                assert rep2["verdict"] == 1 and rep2["retried"] == 1, rep2
         c.set_attr("SPEC_FORCE", None)
         c.set_attr("NO_SPEC_RESCALE", 1)  # the round-4 behaviour: no proof, no speculation
         rgb, _ = run_rgb_only(c, b1, b2)
