@@ -237,7 +237,7 @@ def main():
     # such launches moved no bytes and are left out of the roofline average (one launch of the dominant kernel per step)
     if K > 1 and len(dtimes) == args.steps and dom_warm == "clahe_rgb_fused":
         rts = routes_timed if routes_timed is not None else [outcomes[i % K] for i in range(args.steps)]
-        dtimes = [ms for i, ms in enumerate(dtimes) if rts[i] in ("accepted", "refuted")]
+        dtimes = [ms for i, ms in enumerate(dtimes) if rts[i] in ("accepted", "retried", "refuted")]
 
     subset_dom_ms: list[float] = []  # the dominant kernel's event times of the LAST timed_subset run (one stream: nothing beside the kernel)
     subset_dom_scene: list[int] = []  # ... and the scene of each
@@ -254,12 +254,30 @@ def main():
             runs.append((time.perf_counter() - t) / args.steps * 1e3)
             kt = [ms for name, ms in ctx.last_kernel_times() if name == dom_warm]  # (drained: nothing of these steps reaches the per-kernel table below)
             if len(kt) == args.steps:
-                keep = [i for i in range(len(kt)) if outcomes[idx[i % len(idx)]] in ("accepted", "refuted", "n/a")]
+                keep = [i for i in range(len(kt)) if outcomes[idx[i % len(idx)]] in ("accepted", "retried", "refuted", "n/a")]
                 subset_dom_ms[:] = [kt[i] for i in keep]
                 subset_dom_scene[:] = [idx[i % len(idx)] for i in keep]
         return sorted(runs)[1]
     ms_accepted = timed_subset([i for i in range(K) if outcomes[i] in ("accepted", "n/a")]) if K > 1 else None
     ms_scene_a = timed_subset([0]) if (K > 1 or pipelined) else None
+    # What the speculative route costs when it does NOT hold, on scene A, one stream, beside ms_per_step_scene_a: the floor predicted one
+    # level off (SPEC_FORCE = mispredict: refuted, the second fused pass with the floor the counts point to stands -- `retried`), two
+    # levels off (mispredict2: both passes refuted, the exact apply -> finish -> compose kernels), no proof at all (nospec: `unproven`,
+    # the exact kernels alone).  None of the nine scenes of the cycle takes these routes by itself; on 200 GRD-like rasters of 36-52 MP
+    # (profiles/r6/soak_grd_like.txt) 189 were accepted, 6 retried, 5 refuted (a lowest level the sample missed), none unproven.
+    ms_forced = {}
+    if strategy == AutoscaleStrategy.Clahe and not striped:
+        for label, force in (("retried", "mispredict"), ("refuted", "mispredict2"), ("unproven", "nospec")):
+            try:
+                ctx.set_attr("SPEC_FORCE", force)
+                step(0); ctx.synchronize()
+                got = ctx.spec_report()["outcome"]
+                ms_forced[label] = round(timed_subset([0]), 3) if got == label else None
+            except Exception:
+                ms_forced[label] = None
+            finally:
+                ctx.set_attr("SPEC_FORCE", None)
+        step(0); ctx.synchronize(); ctx.last_kernel_times()
     ms_one_stream = timed_subset(list(range(K))) if pipelined else None  # the whole cycle, one call per scene on one stream (the headline loop of rounds 3-4)
     # Under the lanes a kernel's event pair brackets more than the kernel when another lane's sweep shares the chip (round 5's free
     # run: its workgroups are dispatched as the other sweep releases compute units).  `roofline.frac` / `achieved` / `ms_per_launch`
@@ -356,7 +374,15 @@ def main():
             # unproven = level 0 or 255 not proven in both bands, pool_overflow = DN windows beyond the pass's LDS pool: in those
             # three the exact apply -> finish -> compose kernels produced the raster (inside `value`)
             per_step = routes_timed if routes_timed is not None else [outcomes[i % K] for i in range(args.steps)]  # pipelined: what the batch reported per scene
-            out["spec"] = {k: per_step.count(k) for k in ("accepted", "refuted", "unproven", "pool_overflow")}
+            out["spec"] = {k: per_step.count(k) for k in ("accepted", "retried", "refuted", "unproven", "pool_overflow")}
+            for label, v in ms_forced.items():
+                out[f"ms_per_step_{label}"] = v
+            if ms_forced.get("retried") and ms_scene_a:
+                out["retried_over_accepted"] = round(ms_forced["retried"] / ms_scene_a, 3)
+            if ms_forced.get("refuted") and ms_scene_a:
+                out["refuted_over_accepted"] = round(ms_forced["refuted"] / ms_scene_a, 3)
+            out["ms_per_step_forced_note"] = ("scene A on one stream with SPEC_FORCE = mispredict (retried: a second fused pass), mispredict2 (refuted twice: exact kernels), "
+                                              "nospec (unproven: exact kernels only); compare with ms_per_step_scene_a")
             out["ms_per_step_accepted_scenes"] = round(ms_accepted, 3) if ms_accepted is not None else out["ms_per_step"]
             out["ms_per_step_scene_a"] = round(ms_scene_a, 3) if ms_scene_a is not None else out["ms_per_step"]
             if ms_one_stream is not None:
