@@ -480,8 +480,9 @@ int sarpro_hip_stripe_run_resized_u16(sarpro_hip_ctx *ctx, const uint16_t *d_ban
                                       size_t row0, size_t rows_local, size_t in_pitch, int strategy, int mode, size_t target_size, int pad,
                                       uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta);
 /* the same for f32 bands (the reference's default, resampled-on-read flow; flags: SARPRO_HIP_DUALPOL_*): the levels come from the
- * striped f32 chain (process_scalar_data_pipeline at U8).  Under Tamed only with SARPRO_HIP_DUALPOL_PLAIN_PIPELINE (api/mod.rs:404-437):
- * the band-specific re-autoscale of save.rs:324-351 has no striped form (SARPRO_HIP_ERR_INVALID_ARG). */
+ * striped f32 chain (process_scalar_data_pipeline at U8); under Tamed without SARPRO_HIP_DUALPOL_PLAIN_PIPELINE from the band-specific
+ * re-autoscale of save.rs:324-351 (autoscale_db_image_tamed_synrgb_u8 over stripes: the same collectives, the Tamed windows from the
+ * same all-reduced bins), with the flag as api/mod.rs:404-437 has it (both bands through the pipeline's Tamed arm). */
 int sarpro_hip_stripe_run_resized_f32(sarpro_hip_ctx *ctx, const float *d_band1, const float *d_band2, size_t rows_total, size_t cols, size_t row0,
                                       size_t rows_local, size_t in_pitch, int strategy, int mode, unsigned flags, size_t target_size, int pad,
                                       uint8_t *d_rgb_slice, size_t *out_row0, size_t *out_rows, sarpro_hip_resize_meta *meta);

@@ -1126,6 +1126,25 @@ extern "C" int sarpro_hip_stripe_run_f32(sarpro_hip_ctx *ctx, const float *d_in,
     return rc;
 }
 
+namespace sarpro {
+// One f32 band's row stripe through autoscale_db_image_tamed_synrgb_u8 (autoscale.rs:710-742; tamed = 1 co-pol, 2 cross-pol): the
+// band-specific re-autoscale of save.rs:324-351 over stripes.  The same collectives as sarpro_hip_stripe_run_f32 at U8 -- the
+// Tamed windows (p02 / p05 .. p99) come from the same all-reduced 4096 bins, the level histogram joins its all-reduce although
+// a9 has no u8 rescale (every rank takes the same sequence).
+int stripe_run_f32_tamed(sarpro_hip_ctx *ctx, const float *d_in, size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int tamed,
+                         uint8_t *d_out, size_t out_pitch) {
+    sarpro_hip_stripe_f32 *s = nullptr;
+    int rc = stripe_f32_begin(ctx, d_in, -1, nullptr, nullptr, 0, rows_total, cols, row0, rows_local, in_pitch, SARPRO_STRATEGY_TAMED, SARPRO_BITDEPTH_U8, d_out, out_pitch, &s);
+    if (rc == SARPRO_HIP_OK) {
+        s->B.tamed = tamed;
+        rc = stripe_f32_run(s, nullptr);
+        sarpro_hip_stripe_f32_end(s);
+    }
+    if (rc != SARPRO_HIP_OK) comm_abort_local_group(ctx);
+    return rc;
+}
+} // namespace sarpro
+
 extern "C" int sarpro_hip_stripe_run_polop(sarpro_hip_ctx *ctx, int op, const void *d_a, const void *d_b, int elem_u16, size_t rows_total,
                                            size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int strategy, int bit_depth,
                                            void *d_out, size_t out_pitch, sarpro_hip_stats *stats_out) {

@@ -44,6 +44,8 @@ int band_u8_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows, size_t c
                 uint8_t *d_out, size_t out_pitch);
 // the same for a ROW STRIPE of the band (rows [row0, row0 + rows_local) of rows_total; the context holds a communicator): every global
 // quantity is all-reduced, the stripe's levels are those of the one-piece raster.  A rank with an empty stripe joins the reductions.
+int stripe_run_f32_tamed(sarpro_hip_ctx *ctx, const float *d_in, size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t in_pitch, int tamed,
+                         uint8_t *d_out, size_t out_pitch); // f32_path.cpp: a9 over row stripes
 int band_u8_stripe_dev(sarpro_hip_ctx *ctx, const uint16_t *d_in, size_t rows_total, size_t cols, size_t row0, size_t rows_local, size_t in_pitch,
                        int strategy, int tamed, uint8_t *d_out, size_t out_pitch);
 // composition of a part (n of n_total pixels; `reduce`: the parts are the ranks') of a flat dual-pol u8 product (api.cpp)

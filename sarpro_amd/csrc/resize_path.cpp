@@ -377,7 +377,8 @@ extern "C" int sarpro_hip_stripe_resized_rows(size_t rows_total, size_t cols, si
 }
 
 // f32 bands (elem_f32; flags: SARPRO_HIP_DUALPOL_*): the levels come from the striped f32 chain (sarpro_hip_stripe_run_f32 =
-// process_scalar_data_pipeline at U8 over stripes), which has no band-specific Tamed re-autoscale: Tamed needs the PLAIN_PIPELINE flag.
+// process_scalar_data_pipeline at U8 over stripes); under Tamed without the PLAIN_PIPELINE flag from its band-specific form
+// (stripe_run_f32_tamed = autoscale_db_image_tamed_synrgb_u8 over stripes: save.rs:324-351).
 static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const void *const d_bands[2], bool elem_f32, unsigned flags, size_t rows_total, size_t cols, size_t row0,
                                    size_t rows_local, size_t in_pitch, int strategy, int mode, size_t target_size, int pad, uint8_t *d_rgb_slice, size_t *out_row0,
                                    size_t *out_rows, sarpro_hip_resize_meta *meta) {
@@ -385,8 +386,6 @@ static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const void *const d_band
     if (strategy < 0 || strategy > SARPRO_STRATEGY_DEFAULT) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad strategy");
     if (mode < 0 || mode > SARPRO_SYNRGB_ENHANCED) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "bad synrgb mode");
     if (row0 + rows_local > rows_total) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "stripe outside the scene");
-    if (elem_f32 && strategy == SARPRO_STRATEGY_TAMED && !(flags & SARPRO_HIP_DUALPOL_PLAIN_PIPELINE))
-        return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "striped f32 bands under Tamed: only with SARPRO_HIP_DUALPOL_PLAIN_PIPELINE (the band-specific re-autoscale has no striped form)");
     if (rows_local * cols && (!d_bands[0] || !d_bands[1] || in_pitch < cols)) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "null raster / pitch < cols");
     comm_replay_rewind(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -458,7 +457,9 @@ static int stripe_run_resized_impl(sarpro_hip_ctx *ctx, const void *const d_band
         uint8_t *tmp = ctx->resize_tmp.as<uint8_t>() + (size_t)b * tmp_bytes, *mid = tmp + K * tmp_pitch;
         const int tamed = strategy == SARPRO_STRATEGY_TAMED ? (b == 0 ? 1 : 2) : 0; // save.rs:324-351
         uint8_t *lvl = g.do_resize ? ctx->stage_out[0].as<uint8_t>() : mid;        // (no resize: the levels ARE the intermediate raster)
-        if (elem_f32) {
+        if (elem_f32 && tamed && !(flags & SARPRO_HIP_DUALPOL_PLAIN_PIPELINE)) {
+            RETCHK(stripe_run_f32_tamed(ctx, reinterpret_cast<const float *>(band_ptr[b]), rows_total, cols, row0, rows_local, in_pitch, tamed, lvl, g.do_resize ? lvl_pitch : tmp_pitch));
+        } else if (elem_f32) {
             RETCHK(sarpro_hip_stripe_run_f32(ctx, reinterpret_cast<const float *>(band_ptr[b]), rows_total, cols, row0, rows_local, in_pitch, strategy, SARPRO_BITDEPTH_U8, lvl,
                                              g.do_resize ? lvl_pitch : tmp_pitch, nullptr));
         } else {

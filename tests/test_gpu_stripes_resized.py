@@ -161,17 +161,30 @@ def test_striped_resized_product_of_f32_bands(strategy, ranks):
                                                                            target, pad, sl[k].data_ptr()))
     got = np.concatenate([t.cpu().numpy()[: on * fc * 3].reshape(on, fc, 3) for (o0, on, _), t in zip(out, sl)], axis=0)
     assert got.shape == ref.shape and np.array_equal(got, ref), (strategy, ranks, int((got != ref).any(axis=2).sum()))
-    if strategy == St.Tamed:  # without the plain-pipeline flag the band-specific re-autoscale would be needed: refused, on every rank alike
-        errs = []
 
-        def body(c, k, r0, nr):
-            try:
-                c.stripe_run_resized_f32(d[k][0].data_ptr(), d[k][1].data_ptr(), rows, cols, r0, nr, pitch, strategy, Mode.Default, target, pad, sl[k].data_ptr(),
-                                         plain_pipeline=False)
-            except S.SarproHipError as e:
-                errs.append(str(e))
-        run_ranks(splits, body)
-        assert len(errs) == len(splits) and all("PLAIN_PIPELINE" in e for e in errs), errs
+
+@pytest.mark.parametrize("ranks", [2, 3, 8, "ragged+empty"])
+def test_striped_resized_product_of_f32_bands_under_tamed_takes_the_band_specific_autoscale(ranks):
+    """save.rs:317-367 for Tamed: each band's u8 raster comes from autoscale_db_image_tamed_synrgb_u8 (autoscale.rs:710-742: co-pol
+    min(p02, p05) .. p99, cross-pol p05 .. p99, no u8 rescale), not from the pipeline's Tamed arm -- the reference's own headline flow
+    (README.md:8,63).  Round 6: the striped f32 form (refused until now) -- the windows come from the same all-reduced 4096 bins."""
+    import f32data
+    rows, cols, target, pad = 384, 520, 128, True
+    b = [f32data.resampled_scene(rows, cols, k) for k in (0, 1)]
+    u8 = [oracle.resize_image_data_with_meta(oracle.tamed_synrgb_u8(x, k == 0), target, pad)[0] for k, x in enumerate(b)]
+    ref = oracle.synrgb(0, int(St.Tamed), u8[0], u8[1])
+    plain = oracle.synrgb(0, int(St.Tamed), *[oracle.resize_image_data_with_meta(oracle.pipeline(x, 0, int(St.Tamed))[1], target, pad)[0] for x in b])
+    assert not np.array_equal(ref, plain)  # (the two flows differ on this scene: the test can tell them apart)
+    splits = SPLITS.get(ranks) or list(zip(*S.host_stripe_plan(rows, ranks)))
+    pitch = 576
+    d = [[to_dev(x[r0:r0 + nr], pitch, torch.float32) for x in b] for r0, nr in splits]
+    want = [S.host_stripe_resized_rows(rows, cols, r0, nr, target, pad) for r0, nr in splits]
+    fc, fr = want[0][2], want[0][3]
+    sl = [torch.zeros((max(w[1], 1) * fc * 3,), dtype=torch.uint8, device="cuda") for w in want]
+    out, _ = run_ranks(splits, lambda c, k, r0, nr: c.stripe_run_resized_f32(d[k][0].data_ptr(), d[k][1].data_ptr(), rows, cols, r0, nr, pitch, St.Tamed, Mode.Default,
+                                                                           target, pad, sl[k].data_ptr(), plain_pipeline=False))
+    got = np.concatenate([t.cpu().numpy()[: on * fc * 3].reshape(on, fc, 3) for (o0, on, _), t in zip(out, sl)], axis=0)
+    assert got.shape == ref.shape and np.array_equal(got, ref), (ranks, int((got != ref).any(axis=2).sum()))
 
 
 def test_ranks_with_different_raster_layouts_produce_the_same_product():
