@@ -264,7 +264,7 @@ def main():
     # level off (SPEC_FORCE = mispredict: refuted, the second fused pass with the floor the counts point to stands -- `retried`), two
     # levels off (mispredict2: both passes refuted, the exact apply -> finish -> compose kernels), no proof at all (nospec: `unproven`,
     # the exact kernels alone).  None of the nine scenes of the cycle takes these routes by itself; on 200 GRD-like rasters of 36-52 MP
-    # (profiles/r6/soak_grd_like.txt) 189 were accepted, 6 retried, 5 refuted (a lowest level the sample missed), none unproven.
+    # (profiles/r6/soak_grd_like.txt) 189 were accepted, 11 took the second pass (6 floors one level off, 5 lowest levels the sample missed), none went to the exact kernels.
     ms_forced = {}
     if strategy == AutoscaleStrategy.Clahe and not striped:
         for label, force in (("retried", "mispredict"), ("refuted", "mispredict2"), ("unproven", "nospec")):

@@ -1170,6 +1170,7 @@ struct FusedTail {
     sarpro_hip_ctx *ctx; U16Job *J; ClaheRgbArgs fa; ClaheApplyArgs a; ChainSpecState *d_spec; ChainBandState *d_state;
     unsigned long long *exact_hist; StripePlan *plan; uint8_t *d_levels[2]; size_t lvl_pitch; uint32_t rows, cols;
     unsigned long long total_px; uint8_t *d_rgb; size_t rgb_pitch_px;
+    ChainPredictArgs pa; // (the prediction's arguments: its second launch, behind an undercut lowest level, takes the same)
 };
 // The fused pass and what is gated on its verdict (job_run_fused_rgb's second half).  T.J is null when the call is deferred (never a row stripe).
 static int fused_rgb_tail(const FusedTail &T) {
@@ -1209,6 +1210,11 @@ static int fused_rgb_tail(const FusedTail &T) {
         {
             KernelTimer t(ctx, "chain_repredict");
             HIPCHK(ctx, launch_chain_repredict(ra, ctx->stream));
+            if (!reduce) { // an undercut lowest level whose true value the pass recorded: the prediction again, on that level (one device)
+                ChainPredictArgs p2 = T.pa;
+                p2.second = 1u;
+                HIPCHK(ctx, launch_chain_predict(p2, ctx->stream));
+            }
         }
         ClaheRgbArgs fr = T.fa;
         fr.retry = 1u;
@@ -1289,6 +1295,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
     // row stripes: the sample of the SCENE (every replica of the sampled histogram, the valid counts beside them)
     RETCHK(chain_reduce(J, sample_hist, (size_t)256 * kMaxBands * kSampleReplicas, "allreduce_sample_hist"));
     RETCHK(chain_reduce(J, d_spec->sample_valid_rep, (size_t)kSampleReplicas * 2, "allreduce_sample_valid"));
+    ChainPredictArgs pa_first{};
     {
         ChainPredictArgs pa{};
         pa.sample_hist = sample_hist; pa.exact_hist = exact_hist; pa.spec = d_spec; pa.state = d_state;
@@ -1301,6 +1308,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
         pa.allow_rescaled = ctx->attrs.on(A_NO_SPEC_RESCALE) ? 0u : 1u; // the fused pass verifies a predicted lowest level
         pa.blue_pq = ctx->blue_factors_ok ? reinterpret_cast<const float *>(consts + kChainOffBluePQ) : nullptr;
         pa.blue_by_level = reinterpret_cast<float *>(ctx->tables.as<uint8_t>() + kTablesOffPQ);
+        pa_first = pa;
         KernelTimer t(ctx, "chain_predict");
         HIPCHK(ctx, launch_chain_predict(pa, ctx->stream));
     }
@@ -1311,6 +1319,7 @@ static int job_run_fused_rgb(U16Job &J, const ClaheRgbArgs &fa, uint8_t *d_rgb, 
     T.ctx = ctx; T.J = &J; T.fa = fa; T.a = a; T.d_spec = d_spec; T.d_state = d_state; T.exact_hist = exact_hist;
     T.plan = J.plan; T.d_levels[0] = J.d_levels[0]; T.d_levels[1] = J.d_levels[1]; T.lvl_pitch = J.lvl_pitch;
     T.rows = rows; T.cols = cols; T.total_px = (unsigned long long)J.rows_total * J.cols; T.d_rgb = d_rgb; T.rgb_pitch_px = rgb_pitch_px;
+    T.pa = pa_first;
     if (ctx->pipe_defer && !J.reduce && ctx->async_dev && J.allow_async && !stats_out) {
         T.J = nullptr; // (the job object is the caller's: gone when the tail runs)
         ctx->pipe_deferred = [T]() { return fused_rgb_tail(T); };

@@ -91,6 +91,8 @@ struct ChainPredictArgs {
     uint32_t allow_rescaled;               // the consumer verifies a predicted lowest level (the fused CLAHE -> RGB pass does)
     const float *blue_pq;                  // P[256] | Q[256] (host-built, verified) or null
     float *blue_by_level;                  // out: Pv[256] | Qv[256] with Pv[v] = P[R2[v]], Qv[v] = Q[G2[v]] (the fused pass's LITE form reads these instead of B2)
+    uint32_t second;                       // 1: the launch behind a refuted fused pass: runs iff ChainSpecState::retry_min (an undercut lowest level whose true value the
+                                           // pass recorded), with that level instead of the sample's, and arms the retry kernel
 };
 hipError_t launch_chain_predict(const ChainPredictArgs &a, hipStream_t s);
 struct ChainRepredictArgs {

@@ -567,6 +567,10 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_finish(ChainFinishArgs a)
 // min_pred -- any such byte refutes (spec_ok = kSpecRescaled; kernels.hip, clahe_rgb_fused_body<true>).  Level 255 stays a proof.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs a) {
+    // The second launch (behind a fused pass): only after an undercut lowest level whose true value the pass recorded, on a chain that
+    // has not had its second pass yet (nothing this kernel writes is read by this test -- `retried` is the retry kernel's).
+    if (a.second && !(a.spec->spec_ok == kSpecRescaled && a.spec->verdict == 1u && !a.spec->pool_overflow && a.spec->retry_min == 1u &&
+                      !a.spec->retried && !(a.spec->force & kSpecForceNoRetry))) return;
     __shared__ double est[2][256], fin[2][256]; // per band: estimated pixels per level, per FINAL level (after the predicted rescale)
     __shared__ uint8_t resc[2][256];
     __shared__ int s_ok[2], s_fwc, s_f;
@@ -605,6 +609,11 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
         for (int m = 32; m > 0; m >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, m, 64));
         if (has0 || empty_band || mn == 256u) mn = 0u;
         if ((a.force & kSpecForceMinMispredict) && mn && mn < 255u) mn += 1u; // (a level the raster undercuts: the verification must refute it)
+        bool min_is_exact = false;
+        if (a.second) { // the level the first pass found below the prediction IS the band's lowest (it looked at every pixel)
+            const unsigned tm = a.spec->true_min[wb]; // (recorded by the pass; cleared by the FIRST launch only: no block of this one writes it)
+            if (tm < mn) { mn = tm; min_is_exact = true; }
+        }
         const double scale = consistent ? (double)valid / (double)sv : 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
         }
         if (ln == 0) {
             s_mn[wb] = mn;
-            s_ok[wb] = (empty_band || (consistent && has255 && (mn == 0u ? has0 : a.allow_rescaled != 0u))) ? 1 : 0;
+            s_ok[wb] = (empty_band || (consistent && has255 && (mn == 0u ? (has0 || min_is_exact) : a.allow_rescaled != 0u))) ? 1 : 0;
         }
     }
     __syncthreads();
@@ -664,7 +673,9 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
             sp->force = a.force;
             sp->pool_overflow = 0u;
             sp->next_item = 0u;
-            sp->retry_floor = -1; sp->retry_armed = 0u; sp->retried = 0u; sp->floor_first = f;
+            sp->retry_floor = -1; sp->retry_armed = a.second ? 1u : 0u;
+            if (!a.second) { sp->retried = 0u; sp->floor_first = f; sp->retry_min = 0u; }
+            if (!a.second) { sp->true_min[0] = 256u; sp->true_min[1] = 256u; }
             if (a.floor_out) *a.floor_out = s_fwc; // stands iff the verdict accepts; k_chain_finish rewrites it otherwise
         }
     }

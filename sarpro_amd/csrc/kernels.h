@@ -114,6 +114,10 @@ struct ChainSpecState {
     uint32_t retried;              // the second pass ran: `verdict` is its verdict, floor_pred the floor it tried
     int32_t floor_first;           // the floor the first pass tried (diagnostics)
     unsigned long long saved_counts[3]; // row stripes without a second pass: the summed counts, set aside while the second all-reduce sums zeros
+    // A lowest level the sample missed (n_below_min != 0): the pass that finds such bytes records the lowest of them per band, and the
+    // second pass runs with the TRUE lowest level (k_chain_predict again, its estimate rebuilt on the new rescale); one device only.
+    uint32_t true_min[2];          // lowest level byte below min_pred the fused pass met, per band (256: none)
+    uint32_t retry_min;            // written with the verdict: 1 = undercut, the true lowest levels are known: k_chain_predict's second launch takes them
 };
 constexpr uint32_t kSpecIdentity = 1u, kSpecRescaled = 2u;
 constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it

@@ -1452,6 +1452,14 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     uint32_t sad[3] = {0u, 0u, 0u}, n_all = 0u, n_kept = 0u; // this lane's |x - T| sums, level bytes seen (8 per band-row), kept ones
     // GENERAL: per band |x - T| sums at T0 - 1, T0, T0 + 1 (T0 = thr[b][0]; thr[b][1] is T0 or T0 + 1) and at min_pred - 1, min_pred
     uint32_t tg[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}}, sadg[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}};
+    uint32_t min_track = 0u; // GENERAL, one device: bit b = band b's lowest level is a prediction in 1 .. 127 (the byte test below needs min <= 127)
+    if (GENERAL) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (!a.no_verdict && sp->min_pred[b] >= 1u && sp->min_pred[b] <= 127u) min_track |= 1u << b;
+        }
+        min_track = to_sgpr_u32(min_track);
+    }
     if (GENERAL) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -1775,6 +1783,28 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                             sadg[0][k] = __builtin_amdgcn_sad_u8(l1[1], tg[0][k], __builtin_amdgcn_sad_u8(l1[0], tg[0][k], sadg[0][k]));
                             sadg[1][k] = __builtin_amdgcn_sad_u8(l2[1], tg[1][k], __builtin_amdgcn_sad_u8(l2[0], tg[1][k], sadg[1][k]));
                         }
+                        // A kept byte below its band's predicted lowest level refutes the prediction; which level it is decides what the second
+                        // pass tries (ChainSpecState::true_min).  Per dword: bit 7 of byte i of ((x & 0x7f..) | 0x80..) - min x 0x01.. is set iff
+                        // the byte's low seven bits reach min (no borrow crosses a byte: every byte starts at 0x80 or more and min <= 127), so
+                        // a byte is below iff that bit AND its own bit 7 are clear; bytes outside the item (masked to 0) are taken out by `keep`.
+                        // Rare by construction (the sample held every level but the rarest): the branch is taken on a handful of rows per scene.
+                        if (min_track) {
+                            const uint32_t lv[2][2] = {{l1[0], l1[1]}, {l2[0], l2[1]}};
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                uint32_t below[2];
+#pragma unroll
+                                for (int g = 0; g < 2; ++g)
+                                    below[g] = ~(((lv[b][g] & 0x7F7F7F7Fu) | 0x80808080u) - tg[b][4]) & ~lv[b][g] & keep[g] & 0x80808080u;
+                                if (((min_track >> b) & 1u) && (below[0] | below[1])) {
+                                    uint32_t lowest = 256u;
+#pragma unroll
+                                    for (int j = 0; j < VEC; ++j)
+                                        if ((below[j >> 2] >> (8 * (j & 3))) & 0x80u) lowest = min(lowest, (lv[b][j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                                    atomicMin(&sp->true_min[b], lowest);
+                                }
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
@@ -1901,6 +1931,14 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             const bool ok = (sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1)) && under == 0ull;
             sp->verdict = ok ? 0u : 1u;
             sp->retry_floor = ok || under != 0ull ? -1 : spec_retry_floor(sp->floor_pred, c0, target);
+            // an undercut lowest level: the second pass can run iff every undercut band's true lowest level was recorded (a band whose
+            // prediction lies above 127 is not tracked) -- the bytes below were counted over BOTH bands, so both records are looked at
+            bool min_known = false;
+            if (GENERAL && under != 0ull) {
+                const uint32_t t0 = atomicMin(&sp->true_min[0], 256u), t1 = atomicMin(&sp->true_min[1], 256u);
+                min_known = (t0 < sp->min_pred[0] || t1 < sp->min_pred[1]) && (sp->min_pred[0] <= 127u) && (sp->min_pred[1] <= 127u);
+            }
+            sp->retry_min = min_known ? 1u : 0u;
             if (a.retry) sp->retried = 1u;
         }
     }

@@ -306,13 +306,15 @@ def test_fused_rgb_pass_predicts_the_rescale_of_a_band_without_level_0(kind, sha
             assert f == 37 or rep["n_lt"][0] < rep["target"] <= rep["n_lt"][1]
         accepted = rep["verdict"] == 0
         # a lowest level that the raster undercuts, and a floor that is off by one: both must be refuted, and the exact kernels' raster stands
-        for force in ("lowmin", "mispredict,noretry", "mispredict", "mispredict2"):
+        for force in ("lowmin,noretry", "lowmin", "mispredict,noretry", "mispredict", "mispredict2"):
             c.set_attr("SPEC_FORCE", force)
             rgb, _ = run_rgb_only(c, b1, b2)
             rep2 = c.spec_report()
             assert np.array_equal(rgb, rrgb), (kind, force, rep2)
-            if force == "lowmin":  # (an undercut lowest level: no second pass, the true one is not known)
+            if force == "lowmin,noretry":  # an undercut lowest level, the exact kernels (round 5's behaviour)
                 assert rep2["spec_ok"] == 2 and rep2["verdict"] == 1 and rep2["n_below_min"] > 0 and rep2["retried"] == 0, rep2
+            if force == "lowmin" and accepted:  # round 6: the pass records the lowest byte it met below the prediction, the second pass runs on it
+                assert rep2["verdict"] == 0 and rep2["retried"] == 1 and rep2["n_below_min"] == 0 and rep2["min_pred"] == rep["min_pred"], (rep2, rep)
             if force == "mispredict,noretry" and accepted:
                 assert rep2["verdict"] == 1 and rep2["retried"] == 0, rep2
             if force == "mispredict" and accepted and rep["floor_pred"] < 36:  # the rescaled form's second pass: its thresholds are rebuilt for the new floor
