@@ -840,6 +840,41 @@ def secondary_records(torch, dev, rows, cols):
         del fb, rgb1
     except Exception as e:
         out["config1_dualpol_f32"] = {"error": f"{type(e).__name__}: {e}"}
+    # The same flow as a BATCH (api/mod.rs:474-536 loops over a directory's scenes): 64 scenes of 2048 x 2048 and of 1024 x 1024 f32 bands
+    # -> CLAHE (plain pipeline, api/mod.rs:404-437) -> resize + pad to the same side -> synRGB, resident: one call per scene on one
+    # context against sarpro_hip_batch_dualpol_synrgb_resized_f32_dev (the context's lanes, a host thread each: the f32 chain's host turns
+    # overlap), and host to host through the batch driver (pageable numpy bands in, RGB out: PCIe and the staging copies bound it).
+    try:
+        rec = {"what": "64 dual-pol f32 scenes -> CLAHE -> resize + pad -> synRGB (the reference's default flow, api/mod.rs:404-437, 474-536)", "unit": "scenes per second"}
+        for side in (2048, 1024):
+            n, distinct = 64, 4
+            fb = [[torch.rand((side, side), dtype=torch.float32, device=dev) * 900.0 + 1.0 for _ in range(2)] for _ in range(distinct)]
+            outs = [torch.empty((side * side * 3,), dtype=torch.uint8, device=dev) for _ in range(n)]
+            batch = [(fb[i % distinct][0].data_ptr(), fb[i % distinct][1].data_ptr(), outs[i].data_ptr()) for i in range(n)]
+            c3 = sarpro_amd.Context(dev.index)
+            try:
+                def single():
+                    for b1, b2, o in batch:
+                        c3.dev_dualpol_synrgb_resized_f32(b1, b2, side, side, side, St.Clahe, side, True, o, plain_pipeline=True)
+                t1 = timed(single, n=3, warm=1)
+                r = {"resident_one_call_per_scene": round(n / t1 * 1e3, 1)}
+                for lanes in (1, 4, 8):
+                    tl = timed(lambda: c3.dev_batch_dualpol_synrgb_resized_f32(batch, side, side, side, St.Clahe, side, True, plain_pipeline=True, lanes=lanes), n=3, warm=1)
+                    r[f"resident_batch_{lanes}_lanes"] = round(n / tl * 1e3, 1)
+                r["resident_batch_over_one_call_per_scene"] = round(r["resident_batch_8_lanes"] / r["resident_one_call_per_scene"], 2)
+            finally:
+                c3.close()
+            hs = [(fb[i % distinct][0].cpu().numpy(), fb[i % distinct][1].cpu().numpy()) for i in range(distinct)]
+            hs = [hs[i % distinct] for i in range(n)]
+            for w in (1, 2):
+                t0 = time.perf_counter()
+                sarpro_amd.batch_dualpol_synrgb_resized_f32([dev.index], hs, St.Clahe, side, True, plain_pipeline=True, workers_per_device=w)
+                r[f"host_to_host_{w}_workers"] = round(n / (time.perf_counter() - t0), 1)
+            rec[f"{side}x{side}"] = r
+            del fb, outs, hs
+        out["small_scene_batch_f32"] = rec
+    except Exception as e:
+        out["small_scene_batch_f32"] = {"error": f"{type(e).__name__}: {e}"}
     ctx = sarpro_amd.Context(dev.index, timing=True)  # per-kernel tables (an event pair costs the stream ~10 us per kernel)
     cp = sarpro_amd.Context(dev.index)                # the ms figures: what a caller sees
     band = [torch.empty((rows, pitch), dtype=torch.int16, device=dev) for _ in range(2)]

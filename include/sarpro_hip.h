@@ -291,6 +291,21 @@ int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarpro_hip_resi
                                             size_t cols, size_t in_pitch, int strategy, int mode, size_t rgb_pitch_px, int lanes,
                                             int continue_on_error, sarpro_hip_batch_report *report);
 
+/* The resident batch for f32 bands -- the reference's default flow (api/mod.rs:374-449: bands resampled on read, a few megapixels) looped
+ * over the scenes of a directory (api/mod.rs:474-536), for bands that are already in device memory: per scene
+ * sarpro_hip_dualpol_synrgb_resized_f32_dev (flags: SARPRO_HIP_DUALPOL_*; d_rgb: final_rows * final_cols * 3 bytes, compact), on one of
+ * `lanes` internal lanes of the context (0 = the default), each driven by a host thread of its own for the duration of the call: at this
+ * size the chain is bound by its host turns, which now overlap.  The rasters are the single call's, bit for bit.  BatchReport semantics
+ * as the other batch entry points; the call returns when every raster is complete. */
+typedef struct {
+    const float *d_band1, *d_band2;    /* device, rows x in_pitch */
+    uint8_t *d_rgb;                    /* device, final_rows x final_cols x 3 */
+    int status;                        /* out */
+} sarpro_hip_resident_scene_f32;
+int sarpro_hip_batch_dualpol_synrgb_resized_f32_dev(sarpro_hip_ctx *ctx, sarpro_hip_resident_scene_f32 *scenes, size_t nscenes, size_t rows, size_t cols,
+                                                    size_t in_pitch, int strategy, int mode, unsigned flags, size_t target_size, int pad, int lanes,
+                                                    int continue_on_error, sarpro_hip_batch_report *report);
+
 /* ================= device-pointer entry points ================= */
 /* Same operations on rasters already resident in HBM.  pitch = row stride in elements
  * (>= cols).  The vectorised kernels need base pointers aligned to 16 bytes and

@@ -60,6 +60,11 @@ class BatchSceneF32(C.Structure):
                 ("rgb_out", C.c_void_p), ("status_out", C.POINTER(C.c_int))]
 
 
+class ResidentSceneF32(C.Structure):
+    """sarpro_hip_resident_scene_f32: device pointers in, status out (sarpro_hip_batch_dualpol_synrgb_resized_f32_dev)."""
+    _fields_ = [("d_band1", C.c_void_p), ("d_band2", C.c_void_p), ("d_rgb", C.c_void_p), ("status", C.c_int)]
+
+
 class ResidentScene(C.Structure):
     """sarpro_hip_resident_scene: device pointers in, status / route out (sarpro_hip_batch_dualpol_synrgb_u16_dev)."""
     _fields_ = [("d_band1", C.c_void_p), ("d_band2", C.c_void_p), ("d_rgb", C.c_void_p), ("status", C.c_int), ("route", C.c_int)]
@@ -100,7 +105,7 @@ SYMBOLS = [
     "sarpro_hip_resize_output_dims", "sarpro_hip_resize_image_data", "sarpro_hip_resize_image_data_dev",
     "sarpro_hip_dualpol_synrgb_resized_u16", "sarpro_hip_dualpol_synrgb_resized_u16_dev", "sarpro_hip_dualpol_synrgb_f32_dev",
     "sarpro_hip_dualpol_synrgb_resized_f32", "sarpro_hip_dualpol_synrgb_resized_f32_dev", "sarpro_hip_batch_dualpol_synrgb_resized_f32", "sarpro_hip_process_band_resized_u16", "sarpro_hip_process_band_resized_f32",
-    "sarpro_hip_batch_dualpol_synrgb_resized_u16", "sarpro_hip_batch_dualpol_synrgb_u16_dev",
+    "sarpro_hip_batch_dualpol_synrgb_resized_u16", "sarpro_hip_batch_dualpol_synrgb_u16_dev", "sarpro_hip_batch_dualpol_synrgb_resized_f32_dev",
     "sarpro_hip_synth_scene_u16_dev", "sarpro_hip_synth_scene_u16_dev_ex",
     "sarpro_hip_local_group_create", "sarpro_hip_local_group_destroy", "sarpro_hip_comm_init_local", "sarpro_hip_host_clahe_saturated_levels", "sarpro_hip_ctx_set_attr", "sarpro_hip_ctx_reset_attr", "sarpro_hip_ctx_get_attr", "sarpro_hip_attr_name",
 ]
@@ -250,6 +255,7 @@ _proto("sarpro_hip_process_band_resized_u16", _i, _vp, _vp, _sz, _sz, _i, _i, _s
 _proto("sarpro_hip_process_band_resized_f32", _i, _vp, _vp, _sz, _sz, _i, _i, _sz, _i, _vp, _M)
 _proto("sarpro_hip_batch_dualpol_synrgb_resized_u16", _i, C.POINTER(_i), _i, _i, C.POINTER(BatchScene), _sz, _i, _i, _sz, _i, _i,
        C.POINTER(BatchReport))
+_proto("sarpro_hip_batch_dualpol_synrgb_resized_f32_dev", _i, _vp, C.POINTER(ResidentSceneF32), _sz, _sz, _sz, _sz, _i, _i, C.c_uint, _sz, _i, _i, _i, C.POINTER(BatchReport))
 _proto("sarpro_hip_batch_dualpol_synrgb_u16_dev", _i, _vp, C.POINTER(ResidentScene), _sz, _sz, _sz, _sz, _i, _i, _sz, _i, _i, C.POINTER(BatchReport))
 _proto("sarpro_hip_stripe_run_u16", _i, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _i, _vp, _sz, _S)
 _proto("sarpro_hip_stripe_resized_rows", _i, _sz, _sz, _sz, _sz, _sz, _i, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz))

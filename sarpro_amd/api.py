@@ -424,6 +424,23 @@ class Context:
         return ({"processed": int(rep.processed), "skipped": int(rep.skipped), "errors": int(rep.errors), "rc": int(rc)},
                 [int(arr[i].status) for i in range(n)], [self.ROUTES.get(int(arr[i].route), "n/a") for i in range(n)])
 
+    def dev_batch_dualpol_synrgb_resized_f32(self, scenes, rows: int, cols: int, in_pitch: int, strategy, target_size, pad: bool,
+                                             mode=SyntheticRgbMode.Default, plain_pipeline: bool = False, lanes: int = 0, continue_on_error: bool = True,
+                                             check: bool = True):
+        """sarpro_hip_batch_dualpol_synrgb_resized_f32_dev: `scenes` = [(d_band1, d_band2, d_rgb), ...] device pointers of one shape (f32 bands,
+        compact RGB out); the reference's default flow over the scenes of a directory, on `lanes` internal lanes with a host thread each.
+        Returns (report dict, per-scene statuses)."""
+        from ._lib import BatchReport, ResidentSceneF32
+        arr = (ResidentSceneF32 * max(len(scenes), 1))()
+        for i, (b1, b2, rgb) in enumerate(scenes):
+            arr[i].d_band1, arr[i].d_band2, arr[i].d_rgb = b1, b2, rgb
+        rep = BatchReport()
+        rc = lib.sarpro_hip_batch_dualpol_synrgb_resized_f32_dev(self._h, arr, len(scenes), rows, cols, in_pitch, int(strategy), int(mode),
+                                                                 1 if plain_pipeline else 0, target_size or 0, int(pad), int(lanes), 1 if continue_on_error else 0, C.byref(rep))
+        if check:
+            self._chk(rc)
+        return ({"processed": int(rep.processed), "skipped": int(rep.skipped), "errors": int(rep.errors), "rc": int(rc)}, [int(arr[i].status) for i in range(len(scenes))])
+
     def dev_polop_f32(self, op, d_a: int, d_b: int, n: int, d_out: int):
         self._chk(lib.sarpro_hip_polop_f32_dev(self._h, int(op), _vp(d_a), _vp(d_b), n, _vp(d_out)))
 

@@ -18,8 +18,10 @@
 // of compute units (RGB_GRID + PIECE_GRID = 256) so that they run side by side was measured too and lost -- 1.12 ms at 192 + 64,
 // 1.35 at 208 + 48, 1.54 at 224 + 32: H on a quarter of the chip cannot pull its 1.6 GB in the time F needs.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "chain_kernels.h"
@@ -213,5 +215,61 @@ extern "C" int sarpro_hip_batch_dualpol_synrgb_u16_dev(sarpro_hip_ctx *ctx, sarp
         }
     }
     if (report->errors && !continue_on_error) return first_error;
+    return SARPRO_HIP_OK;
+}
+
+
+// The resident batch for f32 bands (round 6): the reference's DEFAULT flow hands the raster core bands of a few megapixels, resampled
+// on read (api/mod.rs:374-449: ~4 MP), and loops over the scenes of a directory (api/mod.rs:474-536).  At that size the f32 chain is
+// bound by its host turns, not by its kernels: thresholds are found on the host between its sweeps (bisection against glibc, section 3
+// of DESIGN.md), three or four stream synchronisations per band, ~0.25 ms per 2048 x 2048 dual-pol scene of which the GPU works ~0.1.
+// With L lanes -- the parent's internal contexts (stream, workspaces, plans: kept between calls) -- each driven by a host thread of its
+// own for the duration of the call, the host turn of one scene runs while the other lanes' kernels do; scenes are dealt dynamically.
+// Every scene is sarpro_hip_dualpol_synrgb_resized_f32_dev on its lane: the rasters are that call's, bit for bit.
+extern "C" int sarpro_hip_batch_dualpol_synrgb_resized_f32_dev(sarpro_hip_ctx *ctx, sarpro_hip_resident_scene_f32 *scenes, size_t nscenes, size_t rows, size_t cols,
+                                                               size_t in_pitch, int strategy, int mode, unsigned flags, size_t target_size, int pad, int lanes,
+                                                               int continue_on_error, sarpro_hip_batch_report *report) {
+    if (!ctx) return SARPRO_HIP_ERR_INVALID_ARG;
+    if ((!scenes && nscenes) || !report) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "resident f32 batch: null scenes / report");
+    if (lanes < 0 || lanes > kPipeMaxLanes) return fail(ctx, SARPRO_HIP_ERR_INVALID_ARG, "resident f32 batch: lanes must be 0 (default) .. 8");
+    std::memset(report, 0, sizeof(*report));
+    for (size_t i = 0; i < nscenes; ++i) scenes[i].status = SARPRO_HIP_OK;
+    if (!nscenes) return SARPRO_HIP_OK;
+    if (lanes == 0) lanes = 8; // (64 scenes of 2048 x 2048, CLAHE: one call per scene 2490 scenes / s, 1 lane 2250, 2 lanes 3630, 4 lanes 4530, 8 lanes 5110: profiles/r6/batch_rate_f32.txt)
+    lanes = (int)std::min<size_t>((size_t)lanes, nscenes);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int rc = ensure_lanes(ctx, lanes)) return rc;
+    std::atomic<size_t> next{0}, processed{0}, errors{0};
+    std::atomic<bool> stop{false};
+    std::atomic<int> first_error{SARPRO_HIP_OK};
+    std::vector<std::string> lane_err((size_t)lanes);
+    auto worker = [&](int k) {
+        sarpro_hip_ctx *l = ctx->lanes[(size_t)k];
+        for (;;) {
+            if (stop.load()) break;
+            const size_t i = next.fetch_add(1);
+            if (i >= nscenes) break;
+            sarpro_hip_resident_scene_f32 &sc = scenes[i];
+            const int rc = sarpro_hip_dualpol_synrgb_resized_f32_dev(l, sc.d_band1, sc.d_band2, rows, cols, in_pitch, strategy, mode, flags, target_size, pad, sc.d_rgb, nullptr);
+            sc.status = rc;
+            if (rc == SARPRO_HIP_OK) {
+                processed.fetch_add(1);
+            } else {
+                errors.fetch_add(1);
+                int expected = SARPRO_HIP_OK;
+                if (first_error.compare_exchange_strong(expected, rc)) lane_err[(size_t)k] = std::string("resident f32 batch: scene ") + std::to_string(i) + ": " + l->err;
+                if (!continue_on_error) stop.store(true); // api/mod.rs:518-526
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < lanes; ++k) pool.emplace_back(worker, k);
+    worker(0); // (the calling thread drives lane 0)
+    for (auto &t : pool) t.join();
+    report->processed = processed.load();
+    report->errors = errors.load();
+    report->skipped = nscenes - report->processed - report->errors;
+    for (const std::string &e : lane_err) if (!e.empty()) ctx->err = e;
+    if (report->errors && !continue_on_error) return first_error.load();
     return SARPRO_HIP_OK;
 }

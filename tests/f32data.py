@@ -12,9 +12,9 @@ def ratio_scene(rows, cols):
         return np.where(np.abs(b) > np.float32(1e-10), a / b, np.float32(0)).astype(np.float32)
 
 
-def resampled_scene(rows, cols, band=0):
+def resampled_scene(rows, cols, band=0, seed=None):
     """Non-integer amplitudes, as a downsample-on-read produces (sentinel1.rs:1074-1108)."""
-    a = synth.scene_u16(rows * 2, cols * 2, band).astype(np.float32)
+    a = (synth.scene_u16(rows * 2, cols * 2, band) if seed is None else synth.scene_u16(rows * 2, cols * 2, band, seed=synth.SEED_SCENE_A + seed)).astype(np.float32)
     return (0.25 * (a[0::2, 0::2] + a[1::2, 0::2] + a[0::2, 1::2] + a[1::2, 1::2])).astype(np.float32)
 
 

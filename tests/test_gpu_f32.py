@@ -247,6 +247,45 @@ def test_batch_driver_with_f32_scenes():
         assert np.array_equal(o, ref), i
 
 
+@pytest.mark.parametrize("lanes", [1, 3, 4])
+@pytest.mark.parametrize("strategy,plain", [(St.Clahe, True), (St.Tamed, False), (St.Robust, True)])
+def test_resident_batch_of_f32_scenes_over_lanes(lanes, strategy, plain):
+    """sarpro_hip_batch_dualpol_synrgb_resized_f32_dev (round 6): the reference's default flow (api/mod.rs:404-437; without the flag
+    save.rs:317-367) over a directory's scenes (api/mod.rs:474-536) for bands resident in device memory, `lanes` lanes with a host thread
+    each -- the host turns of the f32 chain overlap.  Twelve different scenes, twice in a row on the same context (warm lanes): every
+    raster == the oracle's flow; a null band is counted and does not stop the others."""
+    import torch
+    from f32data import resampled_scene
+    rows, cols, pitch, target = 200, 264, 320, 96
+    host = [(resampled_scene(rows, cols, 0, seed=100 + i), resampled_scene(rows, cols, 1, seed=200 + i)) for i in range(12)]
+    refs = [_api_flow_oracle(a, b, strategy, target, True, plain=plain)[0] for a, b in host]
+    fc, fr = resize_output_dims(cols, rows, target, True)
+    dev = []
+    for a, b in host:
+        pair = []
+        for x in (a, b):
+            t = torch.zeros((rows, pitch), dtype=torch.float32, device="cuda")
+            t[:, :cols] = torch.from_numpy(x).cuda()
+            pair.append(t)
+        dev.append(pair)
+    outs = [torch.zeros((fr * fc * 3,), dtype=torch.uint8, device="cuda") for _ in host]
+    torch.cuda.synchronize()
+    with S.Context(0) as c:
+        batch = [(d[0].data_ptr(), d[1].data_ptr(), o.data_ptr()) for d, o in zip(dev, outs)]
+        for _ in range(2):
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            rep, st = c.dev_batch_dualpol_synrgb_resized_f32(batch, rows, cols, pitch, strategy, target, True, plain_pipeline=plain, lanes=lanes)
+            assert rep == {"processed": 12, "skipped": 0, "errors": 0, "rc": 0} and not any(st)
+            for i, o in enumerate(outs):
+                assert np.array_equal(o.cpu().numpy().reshape(fr, fc, 3), refs[i]), (i, strategy, lanes)
+        bad = list(batch)
+        bad[5] = (0, bad[5][1], bad[5][2])
+        rep, st = c.dev_batch_dualpol_synrgb_resized_f32(bad, rows, cols, pitch, strategy, target, True, plain_pipeline=plain, lanes=lanes, check=False)
+        assert rep["processed"] == 11 and rep["errors"] == 1 and rep["rc"] == 0 and st[5] != 0 and sum(1 for x in st if x) == 1
+
+
 # ---------------------------------------------------------------------------- small-scene direct route vs the threshold / zone routes
 @pytest.mark.parametrize("name,make", CASES)
 @pytest.mark.parametrize("strategy", list(St))  # (CLAHE takes the direct route for its statistics only)
