@@ -861,7 +861,7 @@ def secondary_records(torch, dev, rows, cols):
                 for lanes in (1, 4, 8):
                     tl = timed(lambda: c3.dev_batch_dualpol_synrgb_resized_f32(batch, side, side, side, St.Clahe, side, True, plain_pipeline=True, lanes=lanes), n=3, warm=1)
                     r[f"resident_batch_{lanes}_lanes"] = round(n / tl * 1e3, 1)
-                r["resident_batch_over_one_call_per_scene"] = round(r["resident_batch_8_lanes"] / r["resident_one_call_per_scene"], 2)
+                r["resident_batch_over_one_call_per_scene"] = round(max(r["resident_batch_4_lanes"], r["resident_batch_8_lanes"]) / r["resident_one_call_per_scene"], 2)  # (the better of 4 / 8 lanes)
             finally:
                 c3.close()
             hs = [(fb[i % distinct][0].cpu().numpy(), fb[i % distinct][1].cpu().numpy()) for i in range(distinct)]
