@@ -260,24 +260,6 @@ def main():
         return sorted(runs)[1]
     ms_accepted = timed_subset([i for i in range(K) if outcomes[i] in ("accepted", "n/a")]) if K > 1 else None
     ms_scene_a = timed_subset([0]) if (K > 1 or pipelined) else None
-    # What the speculative route costs when it does NOT hold, on scene A, one stream, beside ms_per_step_scene_a: the floor predicted one
-    # level off (SPEC_FORCE = mispredict: refuted, the second fused pass with the floor the counts point to stands -- `retried`), two
-    # levels off (mispredict2: both passes refuted, the exact apply -> finish -> compose kernels), no proof at all (nospec: `unproven`,
-    # the exact kernels alone).  None of the nine scenes of the cycle takes these routes by itself; on 200 GRD-like rasters of 36-52 MP
-    # (profiles/r6/soak_grd_like.txt) 189 were accepted, 11 took the second pass (6 floors one level off, 5 lowest levels the sample missed), none went to the exact kernels.
-    ms_forced = {}
-    if strategy == AutoscaleStrategy.Clahe and not striped:
-        for label, force in (("retried", "mispredict"), ("refuted", "mispredict2"), ("unproven", "nospec")):
-            try:
-                ctx.set_attr("SPEC_FORCE", force)
-                step(0); ctx.synchronize()
-                got = ctx.spec_report()["outcome"]
-                ms_forced[label] = round(timed_subset([0]), 3) if got == label else None
-            except Exception:
-                ms_forced[label] = None
-            finally:
-                ctx.set_attr("SPEC_FORCE", None)
-        step(0); ctx.synchronize(); ctx.last_kernel_times()
     ms_one_stream = timed_subset(list(range(K))) if pipelined else None  # the whole cycle, one call per scene on one stream (the headline loop of rounds 3-4)
     # Under the lanes a kernel's event pair brackets more than the kernel when another lane's sweep shares the chip (round 5's free
     # run: its workgroups are dispatched as the other sweep releases compute units).  `roofline.frac` / `achieved` / `ms_per_launch`
@@ -375,14 +357,6 @@ def main():
             # three the exact apply -> finish -> compose kernels produced the raster (inside `value`)
             per_step = routes_timed if routes_timed is not None else [outcomes[i % K] for i in range(args.steps)]  # pipelined: what the batch reported per scene
             out["spec"] = {k: per_step.count(k) for k in ("accepted", "retried", "refuted", "unproven", "pool_overflow")}
-            for label, v in ms_forced.items():
-                out[f"ms_per_step_{label}"] = v
-            if ms_forced.get("retried") and ms_scene_a:
-                out["retried_over_accepted"] = round(ms_forced["retried"] / ms_scene_a, 3)
-            if ms_forced.get("refuted") and ms_scene_a:
-                out["refuted_over_accepted"] = round(ms_forced["refuted"] / ms_scene_a, 3)
-            out["ms_per_step_forced_note"] = ("scene A on one stream with SPEC_FORCE = mispredict (retried: a second fused pass), mispredict2 (refuted twice: exact kernels), "
-                                              "nospec (unproven: exact kernels only); compare with ms_per_step_scene_a")
             out["ms_per_step_accepted_scenes"] = round(ms_accepted, 3) if ms_accepted is not None else out["ms_per_step"]
             out["ms_per_step_scene_a"] = round(ms_scene_a, 3) if ms_scene_a is not None else out["ms_per_step"]
             if ms_one_stream is not None:
@@ -428,6 +402,14 @@ def main():
                 out["roofline"]["traffic_live_error"] = live.get("error")
         if sec_child is not None:
             out["secondary"] = secondary_collect(sec_child)
+            fr = out["secondary"].get("forced_routes") if isinstance(out["secondary"], dict) else None
+            if isinstance(fr, dict) and "error" not in fr:  # scalars at the top level: what a refuted or unproven scene costs beside an accepted one
+                for label in ("retried", "refuted", "unproven"):
+                    out[f"ms_per_step_{label}"] = fr.get(label)
+                out["retried_over_accepted"] = fr.get("retried_over_accepted")
+                out["refuted_over_accepted"] = fr.get("refuted_over_accepted")
+                out["ms_per_step_forced_note"] = ("scene A on one stream with SPEC_FORCE = mispredict (retried: a second fused pass), mispredict2 (refuted twice: exact kernels), "
+                                                  "nospec (unproven: exact kernels only), measured by the secondary child; compare with secondary.forced_routes.accepted")
         print(json.dumps(out), flush=True)
         parity_failed = isinstance(out.get("cpu_baseline"), dict) and out["cpu_baseline"].get("gpu_equals_oracle_full_size") is False
     if world > 1:
@@ -886,6 +868,35 @@ def secondary_records(torch, dev, rows, cols):
         return {k: round(v, 4) for k, v in ctx.last_kernel_times() if not k.startswith("host:")}
 
     px = rows * cols
+    # (0) What the speculative route costs when it does NOT hold -- scene A, one call per scene enqueued on one stream, in THIS child process
+    # (the headline process launches the fused pass on accepted scenes only: its rocprofv3 kernel statistics stay those of the timed
+    # kernel): the floor predicted one level off (SPEC_FORCE = mispredict: refuted, the second fused pass with the floor the counts point
+    # to stands -- `retried`), two levels off (mispredict2: both passes refuted, the exact apply -> finish -> compose kernels), no proof
+    # at all (nospec: `unproven`, the exact kernels alone).  None of the nine scenes of the cycle takes these routes by itself; on 200
+    # GRD-like rasters of 36-52 MP (profiles/r6/soak_grd_like.txt) 189 were accepted, 11 took the second pass (6 floors one level off, 5
+    # lowest levels the sample missed), none went to the exact kernels.
+    try:
+        rec = {"what": "scene A, 400 MP, CLAHE + synRGB, one call per scene enqueued on one stream; SPEC_FORCE = mispredict / mispredict2 / nospec", "unit": "ms per scene"}
+        cf = sarpro_amd.Context(dev.index, async_dev=True)
+        rgbf = torch.empty((rows, pitch * 3), dtype=torch.uint8, device=dev)
+        try:
+            one = lambda: cf.dev_dualpol_synrgb_u16(band[0].data_ptr(), band[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgbf.data_ptr(), pitch, want_stats=False)
+            for label, force in (("accepted", None), ("retried", "mispredict"), ("refuted", "mispredict2"), ("unproven", "nospec")):
+                cf.set_attr("SPEC_FORCE", force)
+                one(); cf.synchronize()
+                got = cf.spec_report()["outcome"]
+                rec[label] = round(timed(one, n=20, warm=3), 3) if got == label else None
+            cf.set_attr("SPEC_FORCE", None)
+            if rec.get("accepted"):
+                for label in ("retried", "refuted", "unproven"):
+                    if rec.get(label):
+                        rec[f"{label}_over_accepted"] = round(rec[label] / rec["accepted"], 3)
+        finally:
+            cf.close()
+        del rgbf
+        out["forced_routes"] = rec
+    except Exception as e:
+        out["forced_routes"] = {"error": f"{type(e).__name__}: {e}"}
     # (1) end to end: pinned host u16 bands -> H2D -> chain -> D2H of the RGB raster, through the host entry point
     try:
         host = [torch.empty((rows, cols), dtype=torch.int16, pin_memory=True) for _ in range(2)]
