@@ -151,8 +151,9 @@ static int fused_rgb_tail(const FusedTail &T) {
         }
     }
     if (reduce) { // the verification counts of all stripes, then the verdict every rank shares
-        static_assert(offsetof(ChainSpecState, n_below_min) == offsetof(ChainSpecState, n_lt) + 16, "the verification counts are one buffer");
-        RETCHK(chain_reduce(*T.J, &d_spec->n_lt[0], 3, "allreduce_spec_counts"));
+        static_assert(offsetof(ChainSpecState, n_below_min) == offsetof(ChainSpecState, n_lt) + 16 && offsetof(ChainSpecState, below_hist) == offsetof(ChainSpecState, n_lt) + 24,
+                      "the verification counts are one buffer");
+        RETCHK(chain_reduce(*T.J, &d_spec->n_lt[0], kSpecCountWords, "allreduce_spec_counts"));
         HIPCHK(ctx, launch_spec_verdict(d_spec, T.d_state, ctx->stream));
     }
     {   // a refuted floor gets one second pass with the floor the first pass's counts point to (both launches return at once otherwise)
@@ -165,7 +166,7 @@ static int fused_rgb_tail(const FusedTail &T) {
         {
             KernelTimer t(ctx, "chain_repredict");
             HIPCHK(ctx, launch_chain_repredict(ra, ctx->stream));
-            if (!reduce) { // an undercut lowest level whose true value the pass recorded: the prediction again, on that level (one device)
+            {   // an undercut lowest level whose true value the pass recorded (row stripes: the ranks' summed presence counts): the prediction again, on that level
                 ChainPredictArgs p2 = T.pa;
                 p2.second = 1u;
                 HIPCHK(ctx, launch_chain_predict(p2, ctx->stream));
@@ -180,7 +181,7 @@ static int fused_rgb_tail(const FusedTail &T) {
             HIPCHK(ctx, launch_clahe_rgb_fused_retry(fr, grid, ctx->stream));
         }
         if (reduce) {
-            RETCHK(chain_reduce(*T.J, &d_spec->n_lt[0], 3, "allreduce_spec_counts_retry"));
+            RETCHK(chain_reduce(*T.J, &d_spec->n_lt[0], kSpecCountWords, "allreduce_spec_counts_retry"));
             HIPCHK(ctx, launch_spec_verdict(d_spec, T.d_state, ctx->stream, 1));
         }
     }

@@ -676,6 +676,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_predict(ChainPredictArgs 
             sp->retry_floor = -1; sp->retry_armed = a.second ? 1u : 0u;
             if (!a.second) { sp->retried = 0u; sp->floor_first = f; sp->retry_min = 0u; }
             if (!a.second) { sp->true_min[0] = 256u; sp->true_min[1] = 256u; }
+            for (int i = 0; i < 256; ++i) (&sp->below_hist[0][0])[i] = 0ull;
             if (a.floor_out) *a.floor_out = s_fwc; // stands iff the verdict accepts; k_chain_finish rewrites it otherwise
         }
     }
@@ -729,6 +730,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_repredict(ChainRepredictA
         if (a.stripes && blockIdx.x == 0 && threadIdx.x == 0) {
             sp->saved_counts[0] = sp->n_lt[0]; sp->saved_counts[1] = sp->n_lt[1]; sp->saved_counts[2] = sp->n_below_min;
             sp->n_lt[0] = 0ull; sp->n_lt[1] = 0ull; sp->n_below_min = 0ull;
+            for (int i = 0; i < 256; ++i) (&sp->below_hist[0][0])[i] = 0ull; // (read by the first verdict only; the second all-reduce sums the whole block)
         }
         return;
     }
@@ -769,6 +771,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_chain_repredict(ChainRepredictA
         sp->floor_pred = f;
         sp->done = 0u;
         sp->n_lt[0] = 0ull; sp->n_lt[1] = 0ull; sp->n_below_min = 0ull;
+        for (int i = 0; i < 256; ++i) (&sp->below_hist[0][0])[i] = 0ull;
         sp->next_item = 0u;
         sp->retry_armed = 1u;
         if (a.floor_out) *a.floor_out = fwc; // stands iff the second verdict accepts; k_chain_finish rewrites it otherwise

@@ -98,6 +98,8 @@ struct ChainSpecState {
     uint32_t done;                 // workgroups of the speculative compose pass that have added their counts
     unsigned long long n_lt[2];    // band-pixels with final level < F, < F + 1, counted by the speculative compose pass
     unsigned long long n_below_min; // kSpecRescaled: valid-raster band-pixels with level < min_pred of their band (0 or the prediction is refuted); follows n_lt (one all-reduce)
+    unsigned long long below_hist[2][128]; // kSpecRescaled: per band, how often level l was the LOWEST byte a lane met below min_pred in a row (the rare branch of the
+                                   // fused pass adds here; row stripes: summed with the counts -- a minimum does not travel through a sum, the presence of a level does)
     unsigned long long target;     // synthetic_rgb.rs:99-100
     uint32_t min_pred[2];          // kSpecRescaled: predicted lowest level of each band (the highest is 255: proven from the sample)
     uint32_t thr[2][2];            // kSpecRescaled: per band the lowest LEVEL whose final value is >= F, >= F + 1 (256: none)
@@ -120,6 +122,7 @@ struct ChainSpecState {
     uint32_t retry_min;            // written with the verdict: 1 = undercut, the true lowest levels are known: k_chain_predict's second launch takes them
 };
 constexpr uint32_t kSpecIdentity = 1u, kSpecRescaled = 2u;
+constexpr size_t kSpecCountWords = 3 + 2 * 128; // n_lt[2] | n_below_min | below_hist: what a row stripe all-reduces behind a fused pass
 constexpr uint32_t kSpecForceMispredict = 1u; // predicted floor + 1 (- 1 at the cap): the verification must refute it
 constexpr uint32_t kSpecForceNoSpec = 2u;     // "level 0 or 255 missing": no speculative composition at all
 constexpr uint32_t kSpecForceMinMispredict = 4u; // a predicted lowest level + 1: the verification must refute it

@@ -1452,11 +1452,11 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     uint32_t sad[3] = {0u, 0u, 0u}, n_all = 0u, n_kept = 0u; // this lane's |x - T| sums, level bytes seen (8 per band-row), kept ones
     // GENERAL: per band |x - T| sums at T0 - 1, T0, T0 + 1 (T0 = thr[b][0]; thr[b][1] is T0 or T0 + 1) and at min_pred - 1, min_pred
     uint32_t tg[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}}, sadg[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}};
-    uint32_t min_track = 0u; // GENERAL, one device: bit b = band b's lowest level is a prediction in 1 .. 127 (the byte test below needs min <= 127)
+    uint32_t min_track = 0u; // GENERAL: bit b = band b's lowest level is a prediction in 1 .. 127 (the byte test below needs min <= 127)
     if (GENERAL) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            if (!a.no_verdict && sp->min_pred[b] >= 1u && sp->min_pred[b] <= 127u) min_track |= 1u << b;
+            if (sp->min_pred[b] >= 1u && sp->min_pred[b] <= 127u) min_track |= 1u << b;
         }
         min_track = to_sgpr_u32(min_track);
     }
@@ -1802,6 +1802,7 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                                     for (int j = 0; j < VEC; ++j)
                                         if ((below[j >> 2] >> (8 * (j & 3))) & 0x80u) lowest = min(lowest, (lv[b][j >> 2] >> (8 * (j & 3))) & 0xFFu);
                                     atomicMin(&sp->true_min[b], lowest);
+                                    atomicAdd(&sp->below_hist[b][lowest & 127u], 1ull); // (row stripes: the ranks' sums say which levels occurred)
                                 }
                             }
                         }
@@ -1978,6 +1979,17 @@ __global__ void k_spec_verdict(ChainSpecState *sp, const ChainBandState *state, 
     const bool ok = (sp->floor_pred >= kSpecFloorCap ? c0 < target : (c0 < target && target <= c1)) && !undercut;
     sp->verdict = ok ? 0u : 1u;
     sp->retry_floor = ok || undercut ? -1 : spec_retry_floor(sp->floor_pred, c0, target);
+    if (undercut && !second) { // the true lowest levels from the ranks' summed presence counts; every rank reads the same sums
+        bool known = sp->min_pred[0] <= 127u && sp->min_pred[1] <= 127u, any = false;
+        for (int b = 0; b < 2; ++b) {
+            uint32_t tm = 256u;
+            for (uint32_t l = 0; l < sp->min_pred[b] && l < 128u; ++l)
+                if (sp->below_hist[b][l]) { tm = l; break; }
+            sp->true_min[b] = tm;
+            any = any || tm < sp->min_pred[b];
+        }
+        sp->retry_min = known && any ? 1u : 0u;
+    }
     if (sp->retry_armed) sp->retried = 1u; // (this is the second pass's verdict)
 }
 
