@@ -1437,7 +1437,7 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     }
     const uint32_t kb[2] = {0u, win_hi[0] + 1u}; // first pool entry (WIDE: first table byte) of each band
     const int lane = lane_id(), wave = wave_id();
-    if (wide) { // the DN -> bin bytes of both windows, once per workgroup (the item loop's first barrier publishes them)
+    {   // the DN -> bin bytes of both windows, once per workgroup (the item loop's first barrier publishes them)
         for (int b = 0; b < 2; ++b)
             for (uint32_t i = threadIdx.x; i <= win_hi[b]; i += kRgbBlock) lds[RgbLds::binof + kb[b] + i] = a.binlut[b][i];
     }
@@ -1522,26 +1522,8 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             const int c2 = rc.cstart + i;
             *reinterpret_cast<double *>(lds + RgbLds::colw + i * 8) = a.col_w[(c2 >= rc.c0 && c2 < rc.c1) ? c2 : rc.c0].d;
         }
-        // DN -> bin of both windows, FOUR DNs per thread and load: the whole pool in one pass of the workgroup, i.e. one round trip
-        // to L2, issued with the CDF loads above (a byte per thread and pass made three dependent round trips per item)
         uint32_t *const s_dnsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 2; // per band: the first DN of a saturated bin (0xFFFF: none)
         if (threadIdx.x < 2) s_dnsat[threadIdx.x] = 0xFFFFu;
-        constexpr int kPoolPasses = (int)((kRgbPoolEntries / 4 + 2 + kRgbBlock - 1) / kRgbBlock); // (1 with 1024 threads)
-        uint32_t q4s[kPoolPasses], qdns[kPoolPasses];
-        int qbs[kPoolPasses];
-        {
-            const uint32_t n0q = (win_hi[0] >> 2) + 1u, n1q = (win_hi[1] >> 2) + 1u; // n0q + n1q <= kRgbPoolEntries / 4 + 2
-#pragma unroll
-            for (int ps = 0; ps < kPoolPasses; ++ps) {
-                const uint32_t t = threadIdx.x + (uint32_t)ps * kRgbBlock;
-                q4s[ps] = 0u; qdns[ps] = 0u; qbs[ps] = -1;
-                if (!wide && t < n0q + n1q) {
-                    qbs[ps] = t >= n0q ? 1 : 0;
-                    qdns[ps] = (t - (qbs[ps] ? n0q : 0u)) * 4u;
-                    q4s[ps] = *reinterpret_cast<const uint32_t *>(a.binlut[qbs[ps]] + qdns[ps]);
-                }
-            }
-        }
         __syncthreads();
         if (wide) { // the item's bin-indexed entries to their place; the first DN of a saturated bin by bisection of the (monotone) byte table
             for (int t = threadIdx.x; t < 2 * 257; t += kRgbBlock)
@@ -1555,22 +1537,21 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                 }
                 s_dnsat[b] = (bs < 256u && lo <= win_hi[b]) ? lo : 0xFFFFu;
             }
-        } else {
+        } else { // the DN-indexed pool: consecutive threads take consecutive DNs (a wave's 16-byte writes fall side by side; the DN -> bin bytes
+                 // stay in LDS for the whole pass -- round 5 fetched them per item, four DNs per thread: 0.4 % of the pass, profiles/r6/ab_expansion.txt)
+            const uint32_t nwin32 = win_hi[0] + win_hi[1] + 2u;
+            for (uint32_t i = threadIdx.x; i < nwin32; i += kRgbBlock) {
+                const int qb = i >= kb[1] ? 1 : 0;
+                const uint32_t dn = i - kb[qb];
+                const uint32_t bin = dn ? (uint32_t)lds[RgbLds::binof + i] : 256u; // (DN = 0: the invalid entry; its byte in the table is never looked at)
+                const float4 e = *reinterpret_cast<const float4 *>(lds + RgbLds::stage + ((uint32_t)qb * 257u + bin) * 16u);
+                *reinterpret_cast<float4 *>(lds + RgbLds::pool + i * 16) = e;
+                if (rc.pad[0] & 1) { // (bins and CDFs are monotone: every DN from the first saturated one on is saturated too -- a wave's first speaks for it)
+                    const bool sat = e.x > 1.0005f;
 #pragma unroll
-            for (int ps = 0; ps < kPoolPasses; ++ps) {
-                const int qb = qbs[ps];
-                const uint32_t qdn = qdns[ps], q4 = q4s[ps];
-                if (qb < 0) continue;
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t dn = qdn + k;
-                    if (dn <= win_hi[qb]) {
-                        const uint32_t bin = dn ? (q4 >> (8 * k)) & 0xFFu : 256u;
-                        const uint32_t i = kb[qb] + dn;
-                        *reinterpret_cast<float4 *>(lds + RgbLds::pool + i * 16) = *reinterpret_cast<const float4 *>(lds + RgbLds::stage + (qb * 257 + bin) * 16);
-                        lds[RgbLds::binof + i] = (uint8_t)bin; // (DN = 0 never reaches the exact path: its biased entry is never "near")
-                        if ((rc.pad[0] & 1) && reinterpret_cast<const float *>(lds + RgbLds::stage + (qb * 257 + bin) * 16)[0] > 1.0005f)
-                            atomicMin(&s_dnsat[qb], dn); // (bins and CDFs are monotone: every DN from here on is saturated too)
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const unsigned long long m = __ballot(sat && qb == bb);
+                        if (m && lane == __builtin_ctzll(m)) atomicMin(&s_dnsat[bb], dn);
                     }
                 }
             }
