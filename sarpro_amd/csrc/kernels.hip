@@ -1602,16 +1602,25 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             return rc.cstart + plo >= rc.c0 && rc.cstart + phi < rc.c1;
         };
         const bool safe1 = chunk_safe(lane), safe2 = lane < 32 && chunk_safe(64 + lane);
-        uint32_t bytewise = 0u;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const int pr = lane * VEC + j;
-            const bool kept = col + j >= rc.c0 && col + j < rc.c1;
-            if (kept && !(chunk_safe((3 * pr) / 16) && chunk_safe((3 * pr + 2) / 16))) bytewise |= 1u << j;
+        // The kept bytes of the chunks that are NOT stored -- at most fifteen at the item's left edge (from its first pixel to the end of the
+        // last chunk that also holds a neighbour's bytes) and fifteen at its right edge -- leave as ONE byte store per row: lane l < 32 takes
+        // byte l of the left run, lane 32 + l byte l of the right run, out of the wave's staged row; every other lane passes an out-of-range
+        // offset.  (Round 3-5 wrote them from the lane that computed the pixel, inside a divergent branch: with stores on one path only, the
+        // wait for the prefetched row at the loop's bottom -- vmcnt(2), the smaller of the two paths' counts -- waited for the write
+        // acknowledgements of that row's own chunk stores in every row of the two strips in five that have such an edge: 5 % of the pass,
+        // profiles/r6/ab_edge_bytes.txt.)
+        uint32_t edge_voff = 0xFFFFFFFFu, edge_lds = stage_w;
+        {
+            const int L = rc.c0 - rc.cstart, R = min(rc.c1 - rc.cstart, 64 * VEC); // the item's pixels of the strip: [L, R)
+            int nleft = 0, start_r = 0, nright = 0;
+            if (L > 0) nleft = min(16 * ((3 * L - 1) / 16 + 1), 3 * R) - 3 * L;
+            if (R < 64 * VEC) { start_r = max(16 * ((3 * R) / 16), 3 * L + nleft); nright = max(3 * R - start_r, 0); }
+            const int eb = lane < 32 ? (lane < nleft ? 3 * L + lane : -1) : (lane - 32 < nright ? start_r + lane - 32 : -1);
+            if (eb >= 0) { edge_voff = (uint32_t)eb; edge_lds = stage_w + (uint32_t)eb; }
         }
         // The two chunk stores of a row go through a buffer descriptor over the item's rows: a lane whose chunk is not stored passes
         // an out-of-range offset and the hardware drops its write.  EVERY path through a row therefore holds the same two store
-        // instructions, and the wait for the prefetched row at the loop top is vmcnt(2) instead of vmcnt(0) -- with the stores inside
+        // (+ the edge bytes' one) instructions, and the wait for the prefetched row at the loop top is vmcnt(3) instead of vmcnt(0) -- with the stores inside
         // divergent branches the compiler must assume the row issued none, and vmcnt(0) also waits for the write acknowledgements
         // of the row just stored.  (Sending those lanes' chunks to a scratch line instead cost 13 %: a fifth of the pass's stores.)
         const size_t item_off = ((size_t)rc.r0 * a.rgb_pitch_px + (size_t)rc.cstart) * 3;
@@ -1730,13 +1739,14 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                 uint4 c0 = *reinterpret_cast<const uint4 *>(p0 + (size_t)r * a.in_pitch), c1 = *reinterpret_cast<const uint4 *>(p1 + (size_t)r * a.in_pitch);
                 double dyv = row_w[r].d;
                 uint32_t srv = (EDGE && a.sat_ok) ? (uint32_t)a.sat_row[r] : 7u;
-                // (two stores behind the first row's loads, as every later row has them behind its own: the loop is entered in its
-                // steady state and its top waits with vmcnt(2))
+                // (three stores behind the first row's loads, as every later row has them behind its own: the loop is entered in its
+                // steady state and its top waits with vmcnt(3))
                 {
                     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
                     const v4u z = {0u, 0u, 0u, 0u};
                     __builtin_amdgcn_raw_buffer_store_b128(z, rgb_rsrc, 0xFFFFFFFFu, 0, 2); // (out of range in every lane: nothing is written)
                     __builtin_amdgcn_raw_buffer_store_b128(z, rgb_rsrc, 0xFFFFFFF0u, 0, 2); // (another offset: two identical stores would be merged)
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, rgb_rsrc, 0xFFFFFFFFu, 0, 0);
                 }
                 for (;;) {
                     const int rn = rc.r0 + min(kn, nrows - 1); // the next row of both bands is always in flight
@@ -1817,7 +1827,6 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                         o[3 * g + 1] = pack4(px[1][1], px[1][2], px[2][0], px[2][1]);
                         o[3 * g + 2] = pack4(px[2][2], px[3][0], px[3][1], px[3][2]);
                     }
-                    uint8_t *rowp = a.rgb + ((size_t)r * a.rgb_pitch_px + (size_t)rc.cstart) * 3;
                     // (same wave writes and reads its stage: program order inside a wave, no barrier)
                     *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24) = make_uint2(o[0], o[1]);
                     *reinterpret_cast<uint2 *>(lds + stage_w + lane * 24 + 8) = make_uint2(o[2], o[3]);
@@ -1835,21 +1844,12 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
                         // chunk boundary came out wrong, at 36 MP and up).  Both chunks are read first, and an s_nop that names the
                         // data registers follows each store: they stay live, and two wait states pass, before anything may touch them.
                         const v4u d1 = LDS_AT(v4u, stage_w + lane * 16), d2 = LDS_AT(v4u, stage_w + 1024 + lane * 16);
+                        const uint32_t e8 = LDS_AT(uint8_t, edge_lds);
                         __builtin_amdgcn_raw_buffer_store_b128(d1, rgb_rsrc, voff1, soff, 2 /* nt */);
                         asm volatile("s_nop 1" : : "v"(d1) : "memory");
                         __builtin_amdgcn_raw_buffer_store_b128(d2, rgb_rsrc, voff2, soff, 2);
                         asm volatile("s_nop 1" : : "v"(d2) : "memory");
-                    }
-                    if (bytewise) {
-                        uint8_t *po = rowp + (size_t)lane * 24;
-#pragma unroll
-                        for (int j = 0; j < VEC; ++j)
-                            if ((bytewise >> j) & 1u) {
-                                const uint32_t b0 = 3 * j;
-                                po[b0] = (uint8_t)(o[b0 >> 2] >> (8 * (b0 & 3)));
-                                po[b0 + 1] = (uint8_t)(o[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3)));
-                                po[b0 + 2] = (uint8_t)(o[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3)));
-                            }
+                        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)e8, rgb_rsrc, edge_voff, soff, 0);
                     }
                     c0 = n0; c1 = n1; dyv = dyn; srv = srn;
                     if (kn >= nrows) break;
