@@ -562,6 +562,18 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)rc.r0 * a.out_pitch + rc.cstart, 0,
                                                                                 (int)((uint32_t)(rc.r1 - rc.r0) * out_row_bytes), 0x00020000);
         const uint32_t voff_ld = lane_on ? (uint32_t)lane * 16u : 0xFFFFFFFFu, voff_st = full ? (uint32_t)lane * 16u : 0xFFFFFFFFu;
+        // The samples of a lane that straddles the item's edge (at most one lane at each edge) leave as ONE 2-byte store per row that every
+        // lane issues: lanes 0-7 take the eight samples of the left straddling lane, lanes 8-15 those of the right one (v_readlane of its
+        // packed row), every other lane -- and every sample outside the item -- passes an out-of-range offset.  (Written from the
+        // straddling lane itself, inside a divergent branch, the stores were on one path only and the wait for the prefetched rows at the
+        // loop top covered the turn's own stores in every item with such a lane: the fused pass's edge bytes)
+        const int edge_l = (rc.c0 - rc.cstart) % VEC != 0 ? (rc.c0 - rc.cstart) / VEC : -1;                                       // (wave-uniform)
+        const int edge_r = ((rc.c1 - rc.cstart) % VEC != 0 && rc.c1 - rc.cstart < 64 * VEC) ? (rc.c1 - rc.cstart) / VEC : -1;
+        uint32_t voff_edge = 0xFFFFFFFFu;
+        {
+            const int src = lane < 8 ? edge_l : (lane < 16 && edge_r != edge_l) ? edge_r : -1, c = rc.cstart + src * VEC + (lane & 7);
+            if (src >= 0 && c >= rc.c0 && c < rc.c1) voff_edge = (uint32_t)(src * VEC + (lane & 7)) * 2u;
+        }
 
         auto item_rows = [&](auto edge_tag, auto lds_tag) {
             constexpr bool EDGE = decltype(edge_tag)::value, LUTLDS = decltype(lds_tag)::value;
@@ -575,13 +587,19 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
             v4u cur[NR], nxt[NR];
             load_rows(cur, 0);
             // NR dropped stores behind the first rows' loads: the loop is entered in its steady state (NR loads, then NR stores in
-            // flight), so the wait for a turn's rows at the loop top is vmcnt(NR) on both edges -- without them the entry edge asks
+            // flight -- two per row with the edge samples' one --), so the wait for a turn's rows at the loop top is vmcnt(2 NR) on both edges -- without them the entry edge asks
             // for vmcnt(NR - 1), which in every later turn also waits for the write acknowledgement of the turn's first store
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 v4u z; z.x = z.y = z.z = z.w = 0u;
                 __builtin_amdgcn_raw_buffer_store_b128(z, rs_out, 0xFFFFFFFFu - 16u * (uint32_t)i, 0u, 2);
+                __builtin_amdgcn_raw_buffer_store_b16((uint16_t)0, rs_out, 0xFFFFFFFFu - 2u * (uint32_t)i, 0u, 0);
             }
+            // (everything requested so far is waited for HERE: a first row that the allocator parks in scratch and reloads on the loop's doorstep
+            // is otherwise the newest operation in flight at the entry edge, and the wait at the loop top becomes vmcnt(0) for every turn)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) asm volatile("" : "+v"(cur[i])); // (the rows are USED here: a reload, and the wait for it, come before this line)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             for (int k = 0; k < nrows_w; k += NR) {
                 load_rows(nxt, k + NR);
 #pragma unroll
@@ -636,12 +654,23 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
                     // slots -- see the fused CLAHE -> RGB pass)
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, on ? voff_st : 0xFFFFFFFFu, soff, 2 /* nt */);
                     asm volatile("s_nop 1" : : "v"(pk) : "memory");
-                    if (on && lane_on && !full) { // a lane that straddles the item's edge: sample by sample
-                        uint16_t *o16 = out + (size_t)(rc.r0 + wave + kCfWaves * (k + i)) * a.out_pitch + col;
+                    uint32_t e16 = 0u;
+                    if (edge_l >= 0 || edge_r >= 0) { // (wave-uniform; nothing but register moves inside)
+                        const int el = max(edge_l, 0), er = max(edge_r, 0);
+                        uint32_t lid; // (the lane number made HERE: kept across the row loop, the shift below was spilled -- and a reload waits with vmcnt(0))
+                        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+                        const bool lid8 = lid < 8u;
+                        const uint32_t j = lid & 7u;
+                        uint32_t xs[4];
 #pragma unroll
-                        for (int j = 0; j < VEC; ++j)
-                            if (col + j >= rc.c0 && col + j < rc.c1) o16[j] = (uint16_t)lv[j];
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)pw[q], el), xr = (uint32_t)__builtin_amdgcn_readlane((int)pw[q], er);
+                            xs[q] = lid8 ? xl : xr;
+                        }
+                        const uint32_t w2 = (j & 4u) ? ((j & 2u) ? xs[3] : xs[2]) : ((j & 2u) ? xs[1] : xs[0]);
+                        e16 = (j & 1u) ? w2 >> 16 : w2 & 0xFFFFu;
                     }
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)e16, rs_out, on ? voff_edge : 0xFFFFFFFFu, soff, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < NR; ++i) cur[i] = nxt[i];
