@@ -1426,7 +1426,7 @@ struct RgbLds {
     static constexpr uint32_t binof = colw + 512 * 8;                       // [kRgbPoolEntries] u8: CLAHE bin of the entry's DN
     static constexpr uint32_t pool = binof + kRgbPoolEntries;               // [kRgbPoolEntries] float4
     static constexpr uint32_t misc = pool + kRgbPoolEntries * 16;           // scratch words of the epilogue
-    static constexpr uint32_t total = misc + 64;
+    static constexpr uint32_t total = misc + 128;                           // (words 16..27: the next item's Rect)
 };
 // WIDE form (DN windows that do not fit the pool): the region [binof, misc) holds the DN -> bin bytes of both windows (loaded once per
 // workgroup) and, at its end, the item's 2 x 257 bin-indexed 16-byte entries; a sample costs one more LDS byte read (its bin).
@@ -1506,7 +1506,20 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
     // is hidden behind the prologue: thread 0 asks for the NEXT item when this one starts and puts the answer into LDS after the
     // prologue's last barrier, so the value lives in a register through the prologue only -- not through the rows.
     uint32_t *const s_next = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 8;
-    if (threadIdx.x == 0) s_next[0] = atomicAdd(&sp->next_item, 1u);
+    // An item's Rect comes through LDS: twelve lanes of the first wave request the NEXT item's twelve words when this item's rows start and
+    // put them into LDS when the rows are done -- the round trip that opened every prologue (Rect, then the CDFs it names) runs beside the
+    // rows, for one register in the row loop.  (0.5-0.8 % of the pass, profiles/r6/ab_rect_prefetch.txt; with the 21 spilled registers the
+    // pass had until its edge bytes were rewritten, the request was caught by the vmcnt(0) of a reload in the item's set-up and bought nothing.)
+    uint32_t *const s_rect = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 16;
+    uint32_t rect_word = 0u;
+    {
+        uint32_t first = 0u;
+        if (threadIdx.x == 0) { first = atomicAdd(&sp->next_item, 1u); s_next[0] = first; }
+        if (wave == 0) {
+            const int it0 = (int)to_sgpr_u32(first);
+            if (lane < 12 && it0 < a.nrects) s_rect[lane] = reinterpret_cast<const uint32_t *>(a.rects + it0)[lane];
+        }
+    }
     for (;;) {
         uint32_t *const s_bsat = reinterpret_cast<uint32_t *>(lds + RgbLds::misc) + 4; // WIDE: per band the first saturated bin (256: none)
         if (wide && threadIdx.x < 2) s_bsat[threadIdx.x] = 256u; // (only the prologue reads it: no wave of the previous item does)
@@ -1522,7 +1535,12 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
         if (item >= a.nrects) break;
         uint32_t next_item = 0u;
         if (threadIdx.x == 0) next_item = atomicAdd(&sp->next_item, 1u); // (every workgroup overshoots the list once: the counter ends at nrects + grid)
-        const Rect rc = a.rects[item];
+        Rect rc;
+        rc.r0 = (int)to_sgpr_u32(s_rect[0]); rc.r1 = (int)to_sgpr_u32(s_rect[1]); rc.c0 = (int)to_sgpr_u32(s_rect[2]); rc.c1 = (int)to_sgpr_u32(s_rect[3]);
+        rc.cstart = (int)to_sgpr_u32(s_rect[4]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rc.id[k] = (int)to_sgpr_u32(s_rect[5 + k]);
+        rc.pad[0] = (int)to_sgpr_u32(s_rect[9]); rc.pad[1] = 0; rc.pad[2] = 0;
         // (Requesting the wave's first row of both bands HERE, before the tables are built, so that its round trip does not open the rows:
         // measured 0.620 ms against 0.600 -- ten more registers live through the prologue, 34 spilled instead of 21.)
         {
@@ -1587,6 +1605,10 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
         }
         __syncthreads();
         if (threadIdx.x == 0) s_next[0] = next_item; // (every thread read the slot before the prologue's barriers; the next read is behind the barrier that ends this item)
+        if (wave == 0) { // (the counter's answer is in thread 0's register: the first wave reads it from there)
+            const int nx = (int)to_sgpr_u32(next_item);
+            if (lane < 12 && nx < a.nrects) rect_word = reinterpret_cast<const uint32_t *>(a.rects + nx)[lane];
+        }
         }
 #ifdef SARPRO_RGB_WG_TIMES
         if (threadIdx.x == 0) { wg_tc = wall_clock64(); wg_t_pro += wg_tc - wg_tb; ++wg_items; }
@@ -1895,6 +1917,7 @@ __device__ __forceinline__ void clahe_rgb_fused_body(const ClaheRgbArgs &a) {
             if (rc.pad[0] & 1) item_rows(std::true_type{}, std::true_type{});
             else item_rows(std::false_type{}, std::true_type{});
         }
+        if (wave == 0 && lane < 12) s_rect[lane] = rect_word; // (every wave read this item's Rect before the prologue's barriers)
     }
     // ---- counts -> workgroup -> device; the workgroup that arrives last decides (as kernel 6, SPEC)
 #ifdef SARPRO_RGB_WG_TIMES
