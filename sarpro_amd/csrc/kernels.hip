@@ -490,6 +490,9 @@ __global__ __launch_bounds__(kBlock) void k_clahe_apply_u16(ClaheApplyArgs a) {
 //     2^-53 below 1, so 1 - dx is exact) and CDFs in [0, 1] every rounded product is <= its weight and the rounded sums <= 1.
 //     Algorithmic traffic: 2 B/px read + 2 B/px written.
 // ------------------------------------------------------------------------------------
+#ifdef SARPRO_RGB_WG_TIMES // instrumented build (tools/rgb_wg_times.py): when each persistent workgroup of the fused CLAHE -> RGB pass (or, KERNEL=clahe_apply_u16, of the exact u16 kernel) started and ended (100 MHz clock)
+__device__ unsigned long long g_rgb_wg_times[1024][8]; // start, end, then thread 0's sums: wait at the item barrier, prologue, rows, items (u16 kernel: rows in extrapolating cells, rows of items with a straddling lane, rows, items, table builds)
+#endif
 constexpr int kCfBlock = 1024, kCfWaves = 16;
 #ifndef SARPRO_CF_ROWS_AHEAD
 #define SARPRO_CF_ROWS_AHEAD 2
@@ -519,9 +522,22 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
     const double max_val = a.max_val;
     const uint32_t in_row_bytes = (uint32_t)a.in_pitch * 2u, out_row_bytes = (uint32_t)a.out_pitch * 2u;
 
+#ifdef SARPRO_RGB_WG_TIMES
+    if (threadIdx.x == 0) g_rgb_wg_times[blockIdx.x & 1023][0] = wall_clock64();
+    unsigned long long cf_n[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
     int have[4] = {-1, -1, -1, -1}; // the tiles whose CDFs the tables hold
     for (int item = first[wg]; item < first[wg + 1]; ++item) {
         const Rect rc = a.rects[item];
+#ifdef SARPRO_RGB_WG_TIMES
+        {
+            const unsigned long long nr = (unsigned long long)(rc.r1 - rc.r0);
+            if (rc.pad[0] & 1) cf_n[0] += nr;
+            if ((rc.c0 - rc.cstart) % 8 != 0 || ((rc.c1 - rc.cstart) % 8 != 0 && rc.c1 - rc.cstart < 512)) cf_n[1] += nr;
+            cf_n[2] += nr; ++cf_n[3];
+            if (rc.id[0] != have[0] || rc.id[1] != have[1] || rc.id[2] != have[2] || rc.id[3] != have[3]) ++cf_n[4];
+        }
+#endif
         // a workgroup's items are vertical neighbours, strip after strip of a cell: the tables change three or four times per launch,
         // and only then do the waves meet -- otherwise each runs on into the next item on its own
         if (rc.id[0] != have[0] || rc.id[1] != have[1] || rc.id[2] != have[2] || rc.id[3] != have[3]) {
@@ -684,6 +700,10 @@ __global__ __launch_bounds__(kCfBlock) void k_clahe_apply_u16_cf(ClaheApplyArgs 
             else item_rows(std::false_type{}, std::false_type{});
         }
     }
+#ifdef SARPRO_RGB_WG_TIMES
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long *o = g_rgb_wg_times[blockIdx.x & 1023]; o[1] = wall_clock64(); for (int k = 0; k < 5; ++k) o[2 + k] = cf_n[k]; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -733,9 +753,6 @@ constexpr float kSpecDeltaEdge = 6.2e-4f, kSpecDeltaInner = 1.6e-4f;
 __device__ __forceinline__ float spec_delta(int pad0) { // the f32 blend's margin for a work item of this kind of cell
     return !(pad0 & 1) ? kSpecDeltaInner : (pad0 & 6) == 2 ? kSpecDeltaEdgeY : (pad0 & 6) == 4 ? kSpecDeltaEdgeX : kSpecDeltaEdge;
 }
-#ifdef SARPRO_RGB_WG_TIMES // instrumented build (tools/rgb_wg_times.py): when each persistent workgroup of the fused CLAHE -> RGB pass started and ended (100 MHz clock)
-__device__ unsigned long long g_rgb_wg_times[1024][8]; // start, end, then thread 0's sums: wait at the item barrier, prologue, rows, items
-#endif
 #ifdef SARPRO_SPEC_MEASURE // instrumented build (tools/spec_margin.py): the largest |y32 - y| the speculative blend produced, per margin class
 __device__ uint32_t g_spec_max_err[4]; // float bits, one per margin of spec_delta: [0] interior cells, [1] dy < 0 only, [2] dx < 0 only, [3] the corner (both)
 __device__ __forceinline__ int spec_class(int pad0) { return !(pad0 & 1) ? 0 : (pad0 & 6) == 2 ? 1 : (pad0 & 6) == 4 ? 2 : 3; }

@@ -17,7 +17,22 @@ with S.Context(0, timing=True) as c:
     for k in range(2):
         c.dev_synth_scene_u16(synth.SEED_SCENE_A, k, q, rows, cols, 0, rows, d[k].data_ptr(), pitch)
     rgb = torch.zeros((rows, pitch * 3), dtype=torch.uint8, device="cuda")
+    which = os.environ.get("KERNEL", "clahe_rgb_fused")  # or dn_hist_u16 (the piece histogram: build with -DSARPRO_PIECE_WG_TIMES, file piece_kernels.hip), or clahe_apply_u16 (config 3's exact kernel)
     for it in range(4):
+        if which == "clahe_apply_u16":  # per workgroup: duration against rows in extrapolating cells / rows of items with a straddling lane / rows / items / table builds
+            c.dev_autoscale_band_u16(d[0].data_ptr(), rows, cols, pitch, St.Clahe, S.BitDepth.U16, d[1].data_ptr(), pitch)
+            t = np.zeros((1024, 8), np.uint64)
+            assert lib.sarpro_hip_debug_rgb_wg_times(t.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0
+            kt = dict(c.last_kernel_times())
+            t = t[:256].astype(np.float64); t0 = t[:, 0].min()
+            st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0
+            X = np.stack([t[:, 4], t[:, 2], t[:, 3], t[:, 5], t[:, 6]], axis=1)  # rows, edge rows, straddle rows, items, builds
+            coef, *_ = np.linalg.lstsq(X, en - st, rcond=None)
+            res = (en - st) - X @ coef
+            print(json.dumps({"kernel_ms": round(kt.get("clahe_apply_u16", 0), 4), "last_end_us": round(float(en.max()), 1), "mean_end_us": round(float(en.mean()), 1), "first_end_us": round(float(en.min()), 1),
+                              "us_per": dict(zip(["row", "edge_row_extra", "straddle_row_extra", "item", "table_build"], [round(float(x), 4) for x in coef])),
+                              "residual_us_rms": round(float(np.sqrt((res ** 2).mean())), 1), "means": [round(float(x), 1) for x in X.mean(axis=0)]}), flush=True)
+            continue
         c.dev_dualpol_synrgb_u16(d[0].data_ptr(), d[1].data_ptr(), rows, cols, pitch, St.Clahe, Mode.Default, rgb.data_ptr(), pitch)
         which = os.environ.get("KERNEL", "clahe_rgb_fused")  # or dn_hist_u16 (the piece histogram: build with -DSARPRO_PIECE_WG_TIMES, file piece_kernels.hip)
         fn = lib.sarpro_hip_debug_rgb_wg_times if which == "clahe_rgb_fused" else lib.sarpro_hip_debug_piece_wg_times
